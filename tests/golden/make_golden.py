@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Generate the golden vectors in tests/golden/*.npz by running the UNMODIFIED
+reference (/root/reference/scintools) in the build container.
+
+    python tests/golden/make_golden.py
+
+astropy and lmfit are not installable here (no network); they are replaced by
+the small stand-ins under tests/golden/refshim (a unit-tracking ndarray
+subclass -- see refshim/astropy/units.py for its numerical contract).  Every
+number written below is produced by the reference's own functions:
+``ththmod.thth_map / thth_redmap / rev_map / modeler / chisq_calc / Eval_calc /
+single_search / fft_axis / min_edges``, ``Dynspec.calc_sspec / calc_acf``,
+``scint_utils.get_window`` and ``scint_sim.Simulation``.
+
+/root/reference does not exist on the GPU box, so nothing in tests/ reads it
+at run time; the tests read the .npz files committed next to this script.
+"""
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import matplotlib  # noqa: E402
+matplotlib.use("Agg")
+import numpy as np  # noqa: E402
+import astropy.units as u  # noqa: E402  (the shim)
+import scintools.ththmod as thth  # noqa: E402
+from scintools.scint_sim import Simulation  # noqa: E402
+from scintools.dynspec import Dynspec  # noqa: E402
+from scintools.scint_utils import get_window  # noqa: E402
+from scintools_amd.synth import arc_dynspec  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, keys={sorted(arrs)}")
+
+
+def V(q):
+    """Strip the shim's unit."""
+    return np.array(getattr(q, "value", q))
+
+
+def cs_of(dspec, npad):
+    pad = np.pad(dspec, ((0, npad * dspec.shape[0]), (0, npad * dspec.shape[1])),
+                 mode="constant", constant_values=dspec.mean())
+    return np.fft.fftshift(np.fft.fft2(pad))
+
+
+# ---------------------------------------------------------------------------
+# 1. small analytic arc: every theta-theta function, element by element
+# ---------------------------------------------------------------------------
+def gen_thth_small():
+    dyn, freqs, times, eta_true = arc_dynspec(64, 48, seed=11, nimg=12)
+    dyn = dyn - dyn.mean()
+    npad = 1
+    fd = thth.fft_axis(times * u.s, u.mHz, npad)
+    tau = thth.fft_axis(freqs * u.MHz, u.us, npad)
+    CS = cs_of(dyn, npad)
+    out = dict(dyn=dyn, freqs=freqs, times=times, npad=npad, fd=V(fd), tau=V(tau), CS=CS,
+               eta_true=eta_true)
+    # (a) edges well inside the CS: no crop; (b) edges reaching past fd.max/2: crop
+    edges_a = np.linspace(-0.45 * V(fd).max(), 0.45 * V(fd).max(), 32)
+    edges_b = np.linspace(-0.8 * V(fd).max(), 0.8 * V(fd).max(), 40)
+    etas = np.array([0.5, 1.0, 1.7]) * eta_true
+    out.update(edges_a=edges_a, edges_b=edges_b, etas=etas)
+    for tag, edges in (("a", edges_a), ("b", edges_b)):
+        for k, eta in enumerate(etas):
+            e = eta * u.s**3
+            ed = edges * u.mHz
+            out[f"map_{tag}{k}"] = thth.thth_map(CS, tau, fd, e, ed)
+            out[f"mapnh_{tag}{k}"] = thth.thth_map(CS, tau, fd, e, ed, hermetian=False)
+            red, edges_red = thth.thth_redmap(CS, tau, fd, e, ed)
+            out[f"red_{tag}{k}"] = red
+            out[f"edgesred_{tag}{k}"] = V(edges_red)
+            out[f"eval_{tag}{k}"] = thth.Eval_calc(CS, tau, fd, e, ed)
+            m = thth.modeler(CS, tau, fd, e, ed)
+            out[f"mod_thth2_{tag}{k}"] = m[1]
+            out[f"mod_recov_{tag}{k}"] = m[2]
+            out[f"mod_model_{tag}{k}"] = m[3]
+            out[f"mod_w_{tag}{k}"] = m[5]
+            out[f"mod_V_{tag}{k}"] = m[6]
+            out[f"rev_{tag}{k}"] = thth.rev_map(red, tau, fd, e, edges_red)
+            out[f"revnh_{tag}{k}"] = thth.rev_map(red, tau, fd, e, edges_red, hermetian=False)
+            out[f"chisq_{tag}{k}"] = thth.chisq_calc(dyn, CS, tau, fd, e, ed, 1.0)
+    out["min_edges"] = V(thth.min_edges(0.4 * fd.max(), fd, tau, eta_true * u.s**3, 2))
+    save("thth_small.npz", **out)
+
+
+# ---------------------------------------------------------------------------
+# 2. the tutorial known answer (docs/source/tutorials/thth_intro.rst:250-308)
+# ---------------------------------------------------------------------------
+def gen_thth_sample():
+    d = np.load("/root/reference/scintools/examples/data/ththsims/Sample_Data.npz")
+    dspec = np.abs(d["Espec"]) ** 2
+    cwf = 64
+    chunk = dspec[:cwf] - dspec[:cwf].mean()
+    freq = d["f_MHz"][:cwf]
+    time = d["t_s"]
+    npad = 3
+    edges = np.linspace(-0.4, 0.4, 256)
+    etas = np.linspace(12.5, 100.0, 100)
+    params = [chunk, freq * u.MHz, time * u.s, etas * u.s**3, edges * u.mHz,
+              None, False, 0.1, npad, True, 0 * u.us, False]
+    eta_fit, eta_sig, fm, tm, eigs = thth.single_search(params)
+    params[9] = False
+    eta_fit_i, eta_sig_i, _, _, eigs_i = thth.single_search(params)
+    fd = thth.fft_axis(time * u.s, u.mHz, npad)
+    tau = thth.fft_axis(freq * u.MHz, u.us, npad)
+    save("thth_sample.npz", chunk=chunk, freq=freq, time=time, npad=npad, edges=edges,
+         etas=etas, eigs=eigs, eta_fit=V(eta_fit), eta_sig=V(eta_sig), fmean=V(fm), tmean=V(tm),
+         eigs_incoh=eigs_i, eta_fit_incoh=V(eta_fit_i), eta_sig_incoh=V(eta_sig_i),
+         fd=V(fd), tau=V(tau))
+
+
+# ---------------------------------------------------------------------------
+# 3. reference Simulation -> Dynspec.calc_sspec / calc_acf, and a sweep with tau_mask
+# ---------------------------------------------------------------------------
+def gen_sim():
+    sim = Simulation(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.03,
+                     freq=1400, dt=30, nx=128, ny=64, nf=96, seed=1234, lamsteps=False)
+    dyn = Dynspec(dyn=sim, process=False, verbose=False)
+    out = dict(dyn=np.array(dyn.dyn), dt=dyn.dt, df=dyn.df, freqs=dyn.freqs, times=dyn.times,
+               sim_eta=sim.eta)
+    for tag, kw in (("default", {}),
+                    ("prewhite", dict(prewhite=True)),
+                    ("full", dict(halve=False)),
+                    ("hamming", dict(window="hamming", window_frac=0.25)),
+                    ("blackman_pw", dict(window="blackman", window_frac=0.3, prewhite=True)),
+                    ("bartlett", dict(window="bartlett", window_frac=0.2)),
+                    ("nowindow", dict(window=None))):
+        fdop, tdel, sec = dyn.calc_sspec(return_sspec=True, **kw)
+        out[f"sec_{tag}"] = sec
+        out[f"fdop_{tag}"] = fdop
+        out[f"tdel_{tag}"] = tdel
+    # odd, non-power-of-two shape through input_dyn
+    sub = np.array(dyn.dyn[:75, :101])
+    fdop, tdel, sec = dyn.calc_sspec(input_dyn=sub, prewhite=True)
+    out.update(sub_sec=sec, sub_fdop=fdop, sub_tdel=tdel)
+    dyn.calc_acf()
+    out["acf"] = dyn.acf
+    for n in ((101, 75), (128, 96), (20, 20)):
+        cw, sw = get_window(n[0], n[1], window="hanning", frac=0.1)
+        out[f"win_t_{n[0]}_{n[1]}"] = cw
+        out[f"win_f_{n[0]}_{n[1]}"] = sw
+    # theta-theta sweep on the simulated chunk, with a delay mask and npad=1
+    d2 = np.array(dyn.dyn) - np.nanmean(dyn.dyn)
+    npad = 1
+    fd = thth.fft_axis(dyn.times * u.s, u.mHz, npad)
+    edges = np.linspace(-V(fd).max() / 2, V(fd).max() / 2, 64)
+    etas = np.geomspace(0.25, 4.0, 24) * sim.eta
+    params = [d2, dyn.freqs * u.MHz, dyn.times * u.s, etas * u.s**3, edges * u.mHz,
+              None, False, 0.3, npad, True, 0.05 * u.us, False]
+    eta_fit, eta_sig, fm, tm, eigs = thth.single_search(params)
+    out.update(sw_edges=edges, sw_etas=etas, sw_eigs=eigs, sw_eta_fit=V(eta_fit),
+               sw_eta_sig=V(eta_sig), sw_npad=npad, sw_tau_mask=0.05, sw_fw=0.3)
+    save("sim_sspec.npz", **out)
+
+
+# ---------------------------------------------------------------------------
+# 4. a medium case: N = 255 eigenvalues + matrix checksums (keeps the file small)
+# ---------------------------------------------------------------------------
+def gen_thth_medium():
+    dyn, freqs, times, eta_true = arc_dynspec(256, 256, seed=5, nimg=48)
+    dyn = dyn - dyn.mean()
+    npad = 0
+    fd = thth.fft_axis(times * u.s, u.mHz, npad)
+    tau = thth.fft_axis(freqs * u.MHz, u.us, npad)
+    CS = cs_of(dyn, npad)
+    edges = np.linspace(-V(fd).max() / 2, V(fd).max() / 2, 256)
+    etas = np.geomspace(0.5, 2.0, 16) * eta_true
+    eigs = np.zeros(len(etas))
+    nred = np.zeros(len(etas), int)
+    csum = np.zeros(len(etas), complex)
+    asum = np.zeros(len(etas))
+    for i, eta in enumerate(etas):
+        red, _ = thth.thth_redmap(CS, tau, fd, eta * u.s**3, edges * u.mHz)
+        nred[i] = red.shape[0]
+        # position-weighted checksum: catches a transposed or shifted gather
+        wgt = np.arange(red.size).reshape(red.shape) % 251 + 1
+        csum[i] = (red * wgt).sum()
+        asum[i] = np.abs(red).sum()
+        eigs[i] = thth.Eval_calc(CS, tau, fd, eta * u.s**3, edges * u.mHz)
+    m = thth.modeler(CS, tau, fd, eta_true * u.s**3, edges * u.mHz)
+    save("thth_medium.npz", seed=5, nf=256, nt=256, nimg=48, npad=npad, edges=edges, etas=etas,
+         eigs=eigs, nred=nred, csum=csum, asum=asum, eta_true=eta_true,
+         mod_w=m[5], mod_V=m[6], mod_model_sum=np.abs(m[3]).sum(),
+         mod_model_row=m[3][17], mod_recov_row=m[2][100],
+         dyn_checksum=np.abs(dyn).sum())
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["small", "sample", "sim", "medium"]
+    if "small" in which:
+        gen_thth_small()
+    if "sample" in which:
+        gen_thth_sample()
+    if "sim" in which:
+        gen_sim()
+    if "medium" in which:
+        gen_thth_medium()

@@ -1,0 +1,149 @@
+"""Pin the CPU oracle against outputs of the unmodified reference
+(tests/golden/*.npz, made by tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import sspec_oracle as so
+from oracle import thth_oracle as to
+
+
+def phase_align(v, ref):
+    return v * np.exp(-1j * np.angle(np.vdot(ref, v)))
+
+
+# ---------------------------------------------------------------- theta-theta
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_small_elementwise(golden, tag, k):
+    g = golden("thth_small.npz")
+    CS, tau, fd = g["CS"], g["tau"], g["fd"]
+    eta = g["etas"][k]
+    edges = g[f"edges_{tag}"]
+    # axes: bit-equal to the reference's fft_axis
+    assert np.array_equal(to.fft_axis(g["times"], 1000.0, int(g["npad"])), fd)
+    assert np.array_equal(to.fft_axis(g["freqs"], 1.0, int(g["npad"])), tau)
+    # gather: bit-equal (a copy times one sqrt)
+    assert np.array_equal(to.thth_map(CS, tau, fd, eta, edges), g[f"map_{tag}{k}"])
+    assert np.array_equal(to.thth_map(CS, tau, fd, eta, edges, hermetian=False),
+                          g[f"mapnh_{tag}{k}"])
+    red, edges_red = to.thth_redmap(CS, tau, fd, eta, edges)
+    assert np.array_equal(red, g[f"red_{tag}{k}"])
+    assert np.array_equal(edges_red, g[f"edgesred_{tag}{k}"])
+    if tag == "b":
+        assert red.shape[0] < edges.shape[0] - 1      # the crop really happened
+    # eigen: same ARPACK call
+    assert to.Eval_calc(CS, tau, fd, eta, edges) == pytest.approx(g[f"eval_{tag}{k}"], rel=1e-12)
+    # scatter
+    np.testing.assert_allclose(to.rev_map(red, tau, fd, eta, edges_red), g[f"rev_{tag}{k}"],
+                               rtol=1e-13, atol=0)
+    np.testing.assert_allclose(to.rev_map(red, tau, fd, eta, edges_red, hermetian=False),
+                               g[f"revnh_{tag}{k}"], rtol=1e-13, atol=0)
+    # model (V has an arbitrary global phase; thth2/recov/model are phase free)
+    m = to.modeler(CS, tau, fd, eta, edges)
+    scale = np.abs(g[f"mod_thth2_{tag}{k}"]).max()
+    np.testing.assert_allclose(m[1], g[f"mod_thth2_{tag}{k}"], rtol=0, atol=1e-9 * scale)
+    np.testing.assert_allclose(m[2], g[f"mod_recov_{tag}{k}"], rtol=0,
+                               atol=1e-9 * np.abs(g[f"mod_recov_{tag}{k}"]).max())
+    np.testing.assert_allclose(m[3], g[f"mod_model_{tag}{k}"], rtol=0,
+                               atol=1e-9 * np.abs(g[f"mod_model_{tag}{k}"]).max())
+    assert m[5] == pytest.approx(g[f"mod_w_{tag}{k}"], rel=1e-12)
+    np.testing.assert_allclose(phase_align(m[6], g[f"mod_V_{tag}{k}"]), g[f"mod_V_{tag}{k}"],
+                               rtol=0, atol=1e-8)
+    assert to.chisq_calc(g["dyn"], CS, tau, fd, eta, edges, 1.0) == pytest.approx(
+        g[f"chisq_{tag}{k}"], rel=1e-9)
+
+
+def test_min_edges(golden):
+    g = golden("thth_small.npz")
+    got = to.min_edges(0.4 * g["fd"].max(), g["fd"], g["tau"], float(g["eta_true"]), 2)
+    assert np.array_equal(got, g["min_edges"])
+
+
+def test_medium_checksums(golden):
+    from scintools_amd.synth import arc_dynspec
+    g = golden("thth_medium.npz")
+    dyn, freqs, times, _ = arc_dynspec(int(g["nf"]), int(g["nt"]), seed=int(g["seed"]),
+                                       nimg=int(g["nimg"]))
+    dyn = dyn - dyn.mean()
+    assert np.abs(dyn).sum() == pytest.approx(float(g["dyn_checksum"]), rel=1e-12)
+    fd = to.fft_axis(times, 1000.0, 0)
+    tau = to.fft_axis(freqs, 1.0, 0)
+    CS = to.conjugate_spectrum(dyn, 0)
+    for i in (0, 7, 15):
+        red, _ = to.thth_redmap(CS, tau, fd, g["etas"][i], g["edges"])
+        assert red.shape[0] == g["nred"][i]
+        wgt = np.arange(red.size).reshape(red.shape) % 251 + 1
+        assert (red * wgt).sum() == pytest.approx(g["csum"][i], rel=1e-9)
+        assert np.abs(red).sum() == pytest.approx(g["asum"][i], rel=1e-10)
+        assert to.Eval_calc(CS, tau, fd, g["etas"][i], g["edges"]) == pytest.approx(
+            g["eigs"][i], rel=1e-10)
+
+
+def test_tutorial_known_answer(golden):
+    """eta ~ 44 s**3 on Sample_Data.npz (thth_intro.rst:101-103) and equality with
+    the reference's own single_search on the same chunk."""
+    g = golden("thth_sample.npz")
+    sel = slice(30, 42)            # the 12 etas around the peak keep this test quick
+    etas = g["etas"][sel]
+    fd = to.fft_axis(g["time"], 1000.0, int(g["npad"]))
+    tau = to.fft_axis(g["freq"], 1.0, int(g["npad"]))
+    assert np.array_equal(fd, g["fd"]) and np.array_equal(tau, g["tau"])
+    CS = to.conjugate_spectrum(g["chunk"], int(g["npad"]), tau, 0.0)
+    eigs = np.array([to.Eval_calc(CS, tau, fd, e, g["edges"]) for e in etas])
+    np.testing.assert_allclose(eigs, g["eigs"][sel], rtol=1e-10)
+    eigs_i = np.array([to.Eval_calc(np.abs(CS), tau, fd, e, g["edges"]) for e in etas[:3]])
+    np.testing.assert_allclose(eigs_i, g["eigs_incoh"][sel][:3], rtol=1e-10)
+    # the fit, fed the reference's full eigenvalue curve
+    eta_fit, eta_sig, _ = to.fit_eig_peak(g["etas"], g["eigs"], 0.1)
+    assert eta_fit == pytest.approx(float(g["eta_fit"]), rel=1e-9)
+    assert eta_sig == pytest.approx(float(g["eta_sig"]), rel=1e-6)
+    assert abs(eta_fit - 44.0) < 0.1 * 44.0
+
+
+def test_sim_sweep_with_tau_mask(golden):
+    g = golden("sim_sspec.npz")
+    dyn = g["dyn"] - np.nanmean(g["dyn"])
+    res = to.single_search(dyn, g["freqs"], g["times"], g["sw_etas"], g["sw_edges"],
+                           fw=float(g["sw_fw"]), npad=int(g["sw_npad"]), coher=True,
+                           tau_mask=float(g["sw_tau_mask"]))
+    np.testing.assert_allclose(res[4], g["sw_eigs"], rtol=1e-10)
+    assert res[0] == pytest.approx(float(g["sw_eta_fit"]), rel=1e-8)
+    assert res[1] == pytest.approx(float(g["sw_eta_sig"]), rel=1e-6)
+
+
+# ---------------------------------------------------------------- secondary spectrum
+SSPEC_CASES = {
+    "default": {},
+    "prewhite": dict(prewhite=True),
+    "full": dict(halve=False),
+    "hamming": dict(window="hamming", window_frac=0.25),
+    "blackman_pw": dict(window="blackman", window_frac=0.3, prewhite=True),
+    "bartlett": dict(window="bartlett", window_frac=0.2),
+    "nowindow": dict(window=None),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(SSPEC_CASES))
+def test_calc_sspec(golden, tag):
+    g = golden("sim_sspec.npz")
+    fdop, tdel, sec = so.calc_sspec(g["dyn"], float(g["dt"]), float(g["df"]), **SSPEC_CASES[tag])
+    assert np.array_equal(fdop, g[f"fdop_{tag}"])
+    assert np.array_equal(tdel, g[f"tdel_{tag}"])
+    assert np.array_equal(sec, g[f"sec_{tag}"])       # same NumPy calls: bit-equal
+
+
+def test_calc_sspec_odd_shape(golden):
+    g = golden("sim_sspec.npz")
+    sub = g["dyn"][:75, :101]
+    fdop, tdel, sec = so.calc_sspec(sub, float(g["dt"]), float(g["df"]), prewhite=True)
+    assert np.array_equal(sec, g["sub_sec"])
+    assert np.array_equal(fdop, g["sub_fdop"]) and np.array_equal(tdel, g["sub_tdel"])
+
+
+def test_window_and_acf(golden):
+    g = golden("sim_sspec.npz")
+    for nt, nf in ((101, 75), (128, 96), (20, 20)):
+        cw, sw = so.get_window(nt, nf)
+        assert np.array_equal(cw, g[f"win_t_{nt}_{nf}"])
+        assert np.array_equal(sw, g[f"win_f_{nt}_{nf}"])
+    assert np.array_equal(so.calc_acf(g["dyn"]), g["acf"])
