@@ -1,0 +1,163 @@
+/*
+ * scint_hip.h -- C ABI of libscint_hip.so: the MI355X (gfx950) implementation of
+ * scintools' secondary-spectrum + theta-theta hot path.
+ *
+ * The reference (danielreardon/scintools) is pure Python and has no FFI; the
+ * boundary below is what a ctypes binding inside the reference would call in
+ * place of the NumPy/SciPy lines cited on every entry point (paths relative to
+ * /root/reference/scintools).  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked HOST;
+ *   - arrays are C-contiguous; complex data is interleaved (re, im) float64,
+ *     i.e. numpy complex128 / HIP double2;
+ *   - sizes are int64_t, flags int32_t, the return value is an int32_t status:
+ *     0 = ok, >0 = SCINT_E_*; the message is available from scint_last_error();
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued on it; only entry points documented as synchronous
+ *     wait for it;
+ *   - no function throws, allocates caller-visible memory, or keeps pointers
+ *     after it returns.  The only persistent state is a mutex-guarded cache of
+ *     FFT twiddle tables.
+ */
+#ifndef SCINT_HIP_H
+#define SCINT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCINT_OK 0
+#define SCINT_E_ARG 1        /* bad size / null pointer / unsupported option   */
+#define SCINT_E_HIP 2        /* a HIP runtime call failed                      */
+#define SCINT_E_WORKSPACE 3  /* workspace too small                            */
+#define SCINT_E_NOCONV 4     /* eigen iteration hit max_iter (per-eta status)  */
+#define SCINT_E_EMPTY 5      /* reduced theta-theta has < 2 points (per-eta)   */
+#define SCINT_E_NONFINITE 6  /* non-finite eigenvalue (per-eta)                */
+
+typedef struct { double re, im; } scint_c128;
+
+/* Geometry of a conjugate spectrum CS[ntau, nfd] and of the theta grid, as the
+ * reference derives it inside thth_map (ththmod.py:83-97) -- computed on the
+ * host by the wrapper with the reference's exact NumPy expressions so that the
+ * floor() in the gather sees bit-identical operands. */
+typedef struct {
+    int64_t ntau, nfd;     /* CS shape: tau is the slow axis                    */
+    double tau0, dtau;     /* tau[0], np.diff(tau).mean()            [us]       */
+    double fd0, dfd;       /* fd[0],  np.diff(fd).mean()             [mHz]      */
+    double tau_max;        /* abs(tau.max())  (crop, ththmod.py:153)            */
+    double fd_max;         /* abs(fd.max())   (crop, ththmod.py:154)            */
+    double tau1_step;      /* tau[1]-tau[0]   (rev_map bin edges, :214-216)     */
+    double fd1_step;       /* fd[1]-fd[0]     (rev_map bin edges, :211-213)     */
+} scint_cs_geom;
+
+/* ---- diagnostics -------------------------------------------------------- */
+int32_t scint_version(void);
+/* HOST buffer; copies the calling thread's last error text. */
+int32_t scint_last_error(char* buf, size_t n);
+/* Number of visible HIP devices (0 if none): lets the wrapper fail loudly. */
+int32_t scint_device_count(void);
+
+/* ---- secondary spectrum: Dynspec.calc_sspec core (dynspec.py:3665-3721) -- */
+/* dyn[nf,nt] -> sec[(halve? nrfft/2 : nrfft), ncfft] in dB, where
+ * nrfft/ncfft = 2*nextpow2(nf/nt) (dynspec.py:3677-3678).
+ * win_t[nt], win_f[nf]: tapers of scint_utils.get_window (:810-832) or NULL.
+ * pd_fd[ncfft], pd_td[nrfft/2]: post-darkening sin^2 vectors (dynspec.py:3706-3711),
+ * required iff prewhite.  Workspace: scint_sspec_workspace_bytes(). */
+int32_t scint_sspec_workspace_bytes(int64_t nf, int64_t nt, size_t* bytes /*HOST*/);
+int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt,
+                    const double* win_t, const double* win_f,
+                    int32_t prewhite, int32_t halve,
+                    const double* pd_fd, const double* pd_td,
+                    double* sec_out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* ---- conjugate spectrum: single_search lines ththmod.py:777-787 ---------- */
+/* CS = fftshift(fft2(pad(dspec, right/bottom by npad*shape, pad_value)));
+ * rows r with mask_lo <= r < mask_hi are zeroed (the |tau| < tauMask rows).
+ * If `incoherent` != 0 the output is abs(CS) + 0j (ththmod.py:801).
+ * cs_out[(npad+1)*nf, (npad+1)*nt].  Any sizes (non powers of two go through a
+ * chirp-z pass).  Workspace: scint_cs_workspace_bytes(). */
+int32_t scint_cs_workspace_bytes(int64_t nf, int64_t nt, int64_t npad, size_t* bytes /*HOST*/);
+int32_t scint_cs(const double* dspec, int64_t nf, int64_t nt, int64_t npad,
+                 double pad_value, int64_t mask_lo, int64_t mask_hi, int32_t incoherent,
+                 scint_c128* cs_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mean of a device array (np.mean of the chunk), synchronous, HOST result. */
+int32_t scint_mean(const double* x, int64_t n, double* mean_out /*HOST*/, void* stream);
+
+/* ---- CS -> theta-theta: thth_map + thth_redmap (ththmod.py:56-173) ------- */
+/* th_cents[M]: bin centres (ththmod.py:83-84).  keep_idx[N]: indices (into
+ * th_cents, ascending) of the centres kept by the crop (:153-155); pass the
+ * identity for plain thth_map.  thth_out[N,N].  hermitian: ththmod.py:108-114. */
+int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
+                       const double* th_cents, int64_t M,
+                       const int32_t* keep_idx, int64_t N,
+                       double eta, int32_t hermitian,
+                       scint_c128* thth_out, void* stream);
+
+/* ---- eta sweep: the Eval_calc loop of single_search (ththmod.py:788-799) -- */
+/* For each eta_i: reduced theta-theta (as above, hermitian) -> dominant
+ * 'largest algebraic' eigenvalue seeded with the middle row (Eval_calc,
+ * ththmod.py:396-401) -> eigs_out[i] = |w|.
+ * keep_idx[neta*M] / keep_n[neta]: per-eta crop (host-computed, device arrays).
+ * status_out[i] != 0 -> the wrapper stores NaN (ththmod.py:795-799).
+ * iters_out[i]: Lanczos steps used (for the roofline accounting); may be NULL.
+ * eigs_out/status_out/iters_out are DEVICE arrays.  Asynchronous. */
+int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                         int32_t max_iter, size_t* bytes /*HOST*/);
+int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
+                         const double* th_cents, int64_t M,
+                         const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
+                         const double* etas /*HOST*/, int64_t neta,
+                         double tol, int32_t max_iter, int64_t batch,
+                         double* eigs_out, int32_t* status_out, int32_t* iters_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- dominant eigenpair of a given Hermitian matrix (eigsh k=1 'LA') ----- */
+/* a[n,n] row-major.  v0[n] start vector or NULL (then a fixed pseudo-random
+ * start, as modeler's eigsh call has no v0, ththmod.py:308).  w_out[1],
+ * vec_out[n] (unit 2-norm) device outputs; status_out[1], iters_out[1]. */
+int32_t scint_eigh_top_workspace_bytes(int64_t n, int32_t max_iter, size_t* bytes /*HOST*/);
+int32_t scint_eigh_top(const scint_c128* a, int64_t n, const scint_c128* v0,
+                       double tol, int32_t max_iter,
+                       double* w_out, scint_c128* vec_out,
+                       int32_t* status_out, int32_t* iters_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- theta-theta -> CS: rev_map (ththmod.py:176-271) --------------------- */
+/* thth[N,N] on centres th_cents[N] (already re-centred) -> recov[ntau,nfd].
+ * If `rank1` != 0, thth is not read: thth = |w| V V^H with V = vec[N], w = *w
+ * (device), which is modeler's thth2_red (ththmod.py:312-313).
+ * norm_ws: 3*ntau*nfd doubles of scratch (weight sums and counts).  The sums use
+ * float64 atomics, so the result is reproducible to rounding, not bit for bit. */
+int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
+                      int32_t rank1, const double* th_cents, int64_t N,
+                      const scint_cs_geom* geom /*HOST*/, double eta, int32_t hermitian,
+                      scint_c128* recov_out, double* norm_ws, void* stream);
+
+/* ---- model dynamic spectrum: ifft2(ifftshift(recov)).real (ththmod.py:322-324) */
+int32_t scint_model_workspace_bytes(int64_t ntau, int64_t nfd, size_t* bytes /*HOST*/);
+int32_t scint_model_from_recov(const scint_c128* recov, int64_t ntau, int64_t nfd,
+                               double* model_out, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/* ---- chi^2: sum((model[:nf,:nt]-dspec)[mask]**2)/N (ththmod.py:364-367) --- */
+/* mask: uint8[nf*nt] or NULL (= isfinite(dspec)).  out: DEVICE double[1]. */
+int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
+                    int64_t nf, int64_t nt, const uint8_t* mask, double noise_n,
+                    double* out, void* stream);
+
+/* ---- plain 2-D complex FFT (forward, numpy sign convention) -------------- */
+/* Exposed for tests: out may alias in. */
+int32_t scint_fft2_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes /*HOST*/);
+int32_t scint_fft2(const scint_c128* in, scint_c128* out, int64_t rows, int64_t cols,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCINT_HIP_H */

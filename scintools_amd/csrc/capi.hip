@@ -1,0 +1,36 @@
+// capi.hip -- error plumbing and diagnostics of the C ABI (include/scint_hip.h).
+#include <stdio.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace scint {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int32_t hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "scint: HIP error %d (%s) in `%s` at %s:%d", (int)e,
+             hipGetErrorString(e), what, file, line);
+    g_last_error = buf;
+    return SCINT_E_HIP;
+}
+
+}  // namespace scint
+
+extern "C" int32_t scint_version(void) { return 100; }
+
+extern "C" int32_t scint_last_error(char* buf, size_t n) {
+    if (!buf || n == 0) return SCINT_E_ARG;
+    strncpy(buf, scint::g_last_error.c_str(), n - 1);
+    buf[n - 1] = '\0';
+    return SCINT_OK;
+}
+
+extern "C" int32_t scint_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}

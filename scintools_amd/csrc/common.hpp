@@ -1,0 +1,95 @@
+// common.hpp -- shared device/host helpers for libscint_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/scint_hip.h"
+
+namespace scint {
+
+// ---- complex128 -------------------------------------------------------------
+struct __attribute__((aligned(16))) cplx {
+    double x, y;
+};
+static_assert(sizeof(cplx) == 16, "cplx must match numpy complex128");
+
+__host__ __device__ inline cplx mk(double x, double y) { cplx r; r.x = x; r.y = y; return r; }
+__host__ __device__ inline cplx operator+(cplx a, cplx b) { return mk(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cplx operator-(cplx a, cplx b) { return mk(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cplx operator*(cplx a, cplx b) {
+    return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__host__ __device__ inline cplx operator*(cplx a, double s) { return mk(a.x * s, a.y * s); }
+__host__ __device__ inline cplx conj(cplx a) { return mk(a.x, -a.y); }
+// a * conj(b)
+__host__ __device__ inline cplx mulc(cplx a, cplx b) {
+    return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+// multiply by -i (forward-FFT quarter turn) and by +i
+__host__ __device__ inline cplx mul_mi(cplx a) { return mk(a.y, -a.x); }
+__host__ __device__ inline cplx mul_pi(cplx a) { return mk(-a.y, a.x); }
+__host__ __device__ inline double norm2(cplx a) { return a.x * a.x + a.y * a.y; }
+
+// ---- wavefront (64 lanes) reductions ------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline cplx wave_sum(cplx v) { return mk(wave_sum(v.x), wave_sum(v.y)); }
+
+// Deterministic block reduction (fixed tree): every thread gets the total.
+// `red` must hold blockDim.x/64 entries.
+template <typename T>
+__device__ inline T block_sum(T v, T* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    T t = red[0];
+    for (int i = 1; i < nw; ++i) t = t + red[i];
+    return t;
+}
+
+// ---- error plumbing -------------------------------------------------------------
+void set_error(const std::string& msg);
+int32_t hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SCINT_HIP(call)                                                         \
+    do {                                                                        \
+        hipError_t _e = (call);                                                 \
+        if (_e != hipSuccess) return ::scint::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define SCINT_LAUNCH_CHECK() SCINT_HIP(hipGetLastError())
+
+#define SCINT_REQUIRE(cond, msg)                                \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            ::scint::set_error(std::string("scint: ") + (msg)); \
+            return SCINT_E_ARG;                                 \
+        }                                                       \
+    } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+inline int ilog2(int64_t n) { int l = 0; while ((int64_t(1) << l) < n) ++l; return l; }
+inline int64_t next_pow2(int64_t n) { return int64_t(1) << ilog2(n); }
+
+// Carve aligned sub-buffers out of the caller's workspace.
+struct Carver {
+    char* base; size_t off; size_t cap;
+    Carver(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes) {}
+    template <typename T> T* take(size_t count) {
+        off = align_up(off, 256);
+        T* r = (T*)(base + off);
+        off += count * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+}  // namespace scint

@@ -1,0 +1,436 @@
+// fft.hpp -- hand-written fp64 complex FFT building blocks for gfx950.
+//
+// Two kernels carry every transform in the library:
+//
+//   fft_rows_kernel   FFT along the CONTIGUOUS axis.  One "slot" (a row, or one
+//                     decimated sub-sequence of a long row) lives in LDS; every
+//                     thread keeps 16 points in registers, Stockham radix-16/8/4/2
+//                     stages exchange through a padded (bank-conflict-free) LDS
+//                     buffer.  The first stage loads straight from global through a
+//                     Loader functor (this is where mean-subtract / window /
+//                     prewhiten / zero-pad are fused), the last stage stores
+//                     straight to global through a Storer functor.
+//
+//   fft_cols_kernel   one decimation-in-frequency radix-R pass along the STRIDED
+//                     axis.  Lanes run along the contiguous axis, so every load and
+//                     store is a coalesced 16 B/lane access whatever the stride;
+//                     each thread holds one radix-R butterfly in registers.  Passes
+//                     are in place; the LAST pass un-scrambles the digit-reversed
+//                     order while storing through a Storer functor (this is where
+//                     fftshift, |.|^2, post-darkening and 10 log10 are fused).
+//
+// All transforms are forward (numpy sign convention, exp(-2 pi i jk/n)); inverse
+// transforms are expressed as conj-forward-conj by the functors.
+#pragma once
+#include <type_traits>
+
+#include "common.hpp"
+
+namespace scint {
+
+// Device table W_n^j = exp(-2 pi i j / n), j = 0..n-1, computed in long double on
+// the host once per n and cached for the life of the process (mutex-guarded).
+// Returns nullptr (and sets the error text) on allocation failure.
+const cplx* twiddle_table(int64_t n);
+
+// ------------------------------------------------------------------------------
+// in-register small FFTs (natural-order output)
+// ------------------------------------------------------------------------------
+__device__ constexpr double kC32[9] = {
+    1.0,
+    0.98078528040323044913,  // cos(2 pi 1/32)
+    0.92387953251128675613,  // cos(2 pi 2/32)
+    0.83146961230254523708,
+    0.70710678118654752440,
+    0.55557023301960222474,
+    0.38268343236508977173,
+    0.19509032201612826785,
+    0.0};
+
+// multiply by W_32^J = exp(-2 pi i J/32), 0 <= J < 16, with the trivial cases folded
+template <int J>
+__device__ inline cplx mul_w32(cplx a) {
+    static_assert(J >= 0 && J < 16, "J range");
+    if constexpr (J == 0) {
+        return a;
+    } else if constexpr (J == 8) {
+        return mul_mi(a);
+    } else if constexpr (J == 4) {
+        return mk((a.x + a.y) * kC32[4], (a.y - a.x) * kC32[4]);
+    } else if constexpr (J == 12) {
+        return mk((a.y - a.x) * kC32[4], -(a.x + a.y) * kC32[4]);
+    } else {
+        constexpr double c = (J <= 8) ? kC32[J] : -kC32[16 - J];
+        constexpr double s = (J <= 8) ? kC32[8 - J] : kC32[J - 8];
+        // (x + iy)(c - is)
+        return mk(a.x * c + a.y * s, a.y * c - a.x * s);
+    }
+}
+
+template <int N>
+struct SmallFFT;
+
+template <>
+struct SmallFFT<1> {
+    __device__ static inline void run(cplx (&)[1]) {}
+};
+template <>
+struct SmallFFT<2> {
+    __device__ static inline void run(cplx (&x)[2]) {
+        cplx a = x[0], b = x[1];
+        x[0] = a + b;
+        x[1] = a - b;
+    }
+};
+template <>
+struct SmallFFT<4> {
+    __device__ static inline void run(cplx (&x)[4]) {
+        cplx t0 = x[0] + x[2], t1 = x[0] - x[2], t2 = x[1] + x[3], t3 = mul_mi(x[1] - x[3]);
+        x[0] = t0 + t2;
+        x[1] = t1 + t3;
+        x[2] = t0 - t2;
+        x[3] = t1 - t3;
+    }
+};
+
+template <int N, int M>
+struct HalfStep {
+    // a[m] = x[m] + x[m+N/2]; b[m] = (x[m] - x[m+N/2]) W_N^m   for m = M..N/2-1
+    __device__ static inline void run(cplx (&x)[N], cplx (&a)[N / 2], cplx (&b)[N / 2]) {
+        if constexpr (M < N / 2) {
+            a[M] = x[M] + x[M + N / 2];
+            b[M] = mul_w32<M*(32 / N)>(x[M] - x[M + N / 2]);
+            HalfStep<N, M + 1>::run(x, a, b);
+        }
+    }
+};
+
+template <int N>
+struct SmallFFT {
+    static_assert(N == 8 || N == 16 || N == 32, "radix");
+    __device__ static inline void run(cplx (&x)[N]) {
+        cplx a[N / 2], b[N / 2];
+        HalfStep<N, 0>::run(x, a, b);
+        SmallFFT<N / 2>::run(a);
+        SmallFFT<N / 2>::run(b);
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            x[2 * k] = a[k];
+            x[2 * k + 1] = b[k];
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------
+// rows: FFT along the contiguous axis, one slot per n/16 threads
+// ------------------------------------------------------------------------------
+constexpr int kEPT = 16;  // points per thread
+
+__device__ inline int lds_pad(int i) { return i + (i >> 4); }  // +1 cplx per 16
+
+struct RowShape {
+    int n;            // FFT length (power of two, 16..8192)
+    int log2n;
+    int threads_per_slot;  // n/16
+    int slots_per_block;
+    int64_t nslots;   // total slots in the launch
+    const cplx* tw;   // W_n table
+};
+
+// One Stockham stage on the registers of a thread.
+//   v[q*R + m], q < 16/R : inputs  in[j_q + m*(n/R)],   j_q = t + q*Tr
+//   outputs out[(j_q/Ns)*Ns*R + (j_q%Ns) + m*Ns]  returned in the same slots.
+template <int R>
+__device__ inline void stockham_compute(cplx (&v)[kEPT], int t, int Tr, int n, int Ns,
+                                        const cplx* __restrict__ tw) {
+    constexpr int NB = kEPT / R;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int j = t + q * Tr;
+        cplx x[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) x[m] = v[q * R + m];
+        if (Ns > 1) {
+            const int k = j & (Ns - 1);
+            const int step = k * (n / (Ns * R));  // index into W_n of W_{Ns R}^k
+#pragma unroll
+            for (int m = 1; m < R; ++m) x[m] = x[m] * tw[(step * m) & (n - 1)];
+        }
+        SmallFFT<R>::run(x);
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[q * R + m] = x[m];
+    }
+}
+
+template <int R>
+__device__ inline int stockham_out_index(int t, int Tr, int Ns, int q, int m) {
+    const int j = t + q * Tr;
+    return (j / Ns) * Ns * R + (j & (Ns - 1)) + m * Ns;
+}
+
+// Stage sequence R0,R1,R2,R3 (1 = unused); product = n.
+template <int R0, int R1, int R2, int R3, class Loader, class Storer>
+__global__ void __launch_bounds__(512)
+fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* smem = reinterpret_cast<cplx*>(smem_raw);
+    const int n = sh.n, Tr = sh.threads_per_slot;
+    const int slot_in_block = threadIdx.x / Tr;
+    const int t = threadIdx.x - slot_in_block * Tr;
+    const int64_t slot = (int64_t)blockIdx.x * sh.slots_per_block + slot_in_block;
+    const bool active = slot < sh.nslots;
+    cplx* lds = smem + (size_t)slot_in_block * lds_pad(n);
+    const cplx* __restrict__ tw = sh.tw;
+
+    cplx v[kEPT];
+    // ---- stage 0: inputs straight from global ---------------------------------
+    {
+        constexpr int NB = kEPT / R0;
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int m = 0; m < R0; ++m) v[q * R0 + m] = ld(slot, t + q * Tr + m * (n / R0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < kEPT; ++e) v[e] = mk(0.0, 0.0);
+        }
+    }
+    int Ns = 1;
+    stockham_compute<R0>(v, t, Tr, n, Ns, tw);
+
+    auto exchange = [&](auto rprev_tag, auto rnext_tag) {
+        constexpr int RP = decltype(rprev_tag)::value;
+        constexpr int RN = decltype(rnext_tag)::value;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kEPT / RP; ++q)
+#pragma unroll
+            for (int m = 0; m < RP; ++m)
+                lds[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kEPT / RN; ++q)
+#pragma unroll
+            for (int m = 0; m < RN; ++m) v[q * RN + m] = lds[lds_pad(t + q * Tr + m * (n / RN))];
+    };
+
+    if constexpr (R1 > 1) {
+        exchange(std::integral_constant<int, R0>{}, std::integral_constant<int, R1>{});
+        Ns *= R0;
+        stockham_compute<R1>(v, t, Tr, n, Ns, tw);
+        if constexpr (R2 > 1) {
+            exchange(std::integral_constant<int, R1>{}, std::integral_constant<int, R2>{});
+            Ns *= R1;
+            stockham_compute<R2>(v, t, Tr, n, Ns, tw);
+            if constexpr (R3 > 1) {
+                exchange(std::integral_constant<int, R2>{}, std::integral_constant<int, R3>{});
+                Ns *= R2;
+                stockham_compute<R3>(v, t, Tr, n, Ns, tw);
+            }
+        }
+    }
+    // ---- last stage: outputs straight to global ---------------------------------
+    constexpr int RL = (R3 > 1) ? R3 : (R2 > 1) ? R2 : (R1 > 1) ? R1 : R0;
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < kEPT / RL; ++q)
+#pragma unroll
+            for (int m = 0; m < RL; ++m)
+                st(slot, stockham_out_index<RL>(t, Tr, Ns, q, m), v[q * RL + m]);
+    }
+}
+
+// Host-side launcher: picks the stage sequence for n and launches.
+template <class Loader, class Storer>
+int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStream_t stream) {
+    SCINT_REQUIRE(is_pow2(n) && n >= 16 && n <= 8192, "fft rows: n must be a power of two in [16, 8192]");
+    if (nslots <= 0) return SCINT_OK;
+    const cplx* tw = twiddle_table(n);
+    if (!tw) return SCINT_E_HIP;
+    RowShape sh;
+    sh.n = (int)n;
+    sh.log2n = ilog2(n);
+    sh.threads_per_slot = (int)(n / kEPT);
+    const int block = sh.threads_per_slot >= 256 ? sh.threads_per_slot : 256;
+    sh.slots_per_block = block / sh.threads_per_slot;
+    sh.nslots = nslots;
+    sh.tw = tw;
+    const int64_t grid = ceil_div(nslots, sh.slots_per_block);
+    const size_t lds = (size_t)sh.slots_per_block * (size_t)(n + n / 16) * sizeof(cplx);
+#define SCINT_ROWS(R0, R1, R2, R3)                                                              \
+    do {                                                                                        \
+        auto k = fft_rows_kernel<R0, R1, R2, R3, Loader, Storer>;                               \
+        if (lds > 64 * 1024)                                                                    \
+            SCINT_HIP(hipFuncSetAttribute((const void*)k,                                       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, sh, ld, st);      \
+    } while (0)
+    switch (sh.log2n) {
+        case 4: SCINT_ROWS(16, 1, 1, 1); break;
+        case 5: SCINT_ROWS(16, 2, 1, 1); break;
+        case 6: SCINT_ROWS(16, 4, 1, 1); break;
+        case 7: SCINT_ROWS(16, 8, 1, 1); break;
+        case 8: SCINT_ROWS(16, 16, 1, 1); break;
+        case 9: SCINT_ROWS(16, 16, 2, 1); break;
+        case 10: SCINT_ROWS(16, 16, 4, 1); break;
+        case 11: SCINT_ROWS(16, 16, 8, 1); break;
+        case 12: SCINT_ROWS(16, 16, 16, 1); break;
+        case 13: SCINT_ROWS(16, 16, 16, 2); break;
+        default: SCINT_REQUIRE(false, "fft rows: unsupported length");
+    }
+#undef SCINT_ROWS
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
+// ------------------------------------------------------------------------------
+// cols: one DIF radix pass along the strided axis
+// ------------------------------------------------------------------------------
+struct ColPass {
+    int64_t ncols;      // contiguous extent handled by lanes
+    int64_t len;        // full FFT length R along the strided axis
+    int64_t block_len;  // Lp: current DIF block length
+    int64_t sub;        // S = Lp / radix
+    const cplx* tw;     // W_len table
+    int64_t tw_mult;    // len / Lp
+    // digit bookkeeping for the last pass: radices of the earlier passes (first pass
+    // = least-significant digit of the output frequency index)
+    int npre;
+    int pre_radix[6];
+    int last;           // 1 if this pass un-scrambles
+};
+
+// Loader: cplx ld(batch, row, col)   (row along the strided axis)
+// Storer: void st(batch, row, col, v)  -- row is the in-place row for inner passes
+//         and the NATURAL frequency index for the last pass.
+template <int R, class Loader, class Storer>
+__global__ void __launch_bounds__(256)
+fft_cols_kernel(ColPass p, Loader ld, Storer st) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= p.ncols) return;
+    const int64_t bf = blockIdx.y;         // butterfly id: b*S + s
+    const int64_t batch = blockIdx.z;
+    const int64_t b = bf / p.sub, s = bf - b * p.sub;
+    const int64_t row0 = b * p.block_len + s;
+    cplx x[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = ld(batch, row0 + m * p.sub, col);
+    SmallFFT<R>::run(x);
+    if (!p.last) {
+        // twiddle W_Lp^{s k} (wave-uniform -> scalar loads), store in place
+        const int64_t step = s * p.tw_mult;
+        st(batch, row0, col, x[0]);
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+            const cplx w = p.tw[step * k];  // s*k < Lp  =>  index < len
+            st(batch, row0 + k * p.sub, col, x[k] * w);
+        }
+    } else {
+        // position digits of b (most significant first) are the earlier passes'
+        // output indices k_1, k_2, ...; natural index = k_1 + R_1 k_2 + ... + (len/R) k_last
+        int64_t rem = b, scale = p.len / R, kbase = 0, weight = 1;
+        // decode from the least-significant position digit (the latest pass) upward
+        int64_t digits[6];
+        for (int i = p.npre - 1; i >= 0; --i) {
+            digits[i] = rem % p.pre_radix[i];
+            rem /= p.pre_radix[i];
+        }
+        for (int i = 0; i < p.npre; ++i) {
+            kbase += digits[i] * weight;
+            weight *= p.pre_radix[i];
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) st(batch, kbase + k * scale, col, x[k]);
+    }
+}
+
+// Plan of column passes for a power-of-two length.
+struct ColPlan {
+    int npass;
+    int radix[6];
+};
+inline ColPlan make_col_plan(int64_t len) {
+    ColPlan pl;
+    pl.npass = 0;
+    int l = ilog2(len);
+    // radix-16 passes first, the remainder (2/4/8) last; a lone remainder of 2 or 4
+    // is merged into the previous pass as radix 32 when possible.
+    while (l >= 4) { pl.radix[pl.npass++] = 16; l -= 4; }
+    if (l > 0) {
+        if (l == 1 && pl.npass > 0) pl.radix[pl.npass - 1] = 32;
+        else pl.radix[pl.npass++] = 1 << l;
+    }
+    if (pl.npass == 0) { pl.radix[0] = 1; pl.npass = 1; }
+    return pl;
+}
+
+template <int R, class Loader, class Storer>
+int32_t launch_cols_pass(const ColPass& p, int64_t batches, Loader ld, Storer st,
+                         hipStream_t stream) {
+    const int block = p.ncols >= 256 ? 256 : (p.ncols >= 128 ? 128 : 64);
+    dim3 grid((unsigned)ceil_div(p.ncols, block), (unsigned)(p.len / R), (unsigned)batches);
+    SCINT_REQUIRE(p.len / R <= 65535 && batches <= 65535, "fft cols: grid too large");
+    hipLaunchKernelGGL((fft_cols_kernel<R, Loader, Storer>), grid, dim3(block), 0, stream, p, ld, st);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
+// Runs all passes of a strided-axis FFT.  `first` loads the first pass, `mid_ld/mid_st`
+// are the plain in-place accessors, `last` stores the final (natural-order) result.
+template <class FirstLoader, class MidLoader, class MidStorer, class LastStorer>
+int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader first,
+                     MidLoader mid_ld, MidStorer mid_st, LastStorer last, hipStream_t stream) {
+    SCINT_REQUIRE(is_pow2(len) && len >= 2, "fft cols: length must be a power of two >= 2");
+    const cplx* tw = twiddle_table(len);
+    if (!tw) return SCINT_E_HIP;
+    ColPlan pl = make_col_plan(len);
+    int64_t Lp = len;
+    ColPass p;
+    p.ncols = ncols;
+    p.len = len;
+    p.tw = tw;
+    p.npre = 0;
+    for (int i = 0; i < pl.npass; ++i) {
+        const int R = pl.radix[i];
+        p.block_len = Lp;
+        p.sub = Lp / R;
+        p.tw_mult = len / Lp;
+        p.last = (i == pl.npass - 1);
+        int32_t rc = SCINT_OK;
+#define SCINT_COLS(RR)                                                                    \
+    if (i == 0 && p.last) rc = launch_cols_pass<RR>(p, batches, first, last, stream);      \
+    else if (i == 0) rc = launch_cols_pass<RR>(p, batches, first, mid_st, stream);         \
+    else if (p.last) rc = launch_cols_pass<RR>(p, batches, mid_ld, last, stream);          \
+    else rc = launch_cols_pass<RR>(p, batches, mid_ld, mid_st, stream);
+        switch (R) {
+            case 2: SCINT_COLS(2) break;
+            case 4: SCINT_COLS(4) break;
+            case 8: SCINT_COLS(8) break;
+            case 16: SCINT_COLS(16) break;
+            case 32: SCINT_COLS(32) break;
+            default: SCINT_REQUIRE(false, "fft cols: bad radix");
+        }
+#undef SCINT_COLS
+        if (rc != SCINT_OK) return rc;
+        p.pre_radix[p.npre++] = R;
+        Lp /= R;
+    }
+    return SCINT_OK;
+}
+
+// ---- plain array accessors ------------------------------------------------------
+struct ArrayLoad {   // a[batch][row][col]
+    const cplx* a; int64_t ld; int64_t batch_stride;
+    __device__ inline cplx operator()(int64_t bt, int64_t r, int64_t c) const {
+        return a[bt * batch_stride + r * ld + c];
+    }
+};
+struct ArrayStore {
+    cplx* a; int64_t ld; int64_t batch_stride;
+    __device__ inline void operator()(int64_t bt, int64_t r, int64_t c, cplx v) const {
+        a[bt * batch_stride + r * ld + c] = v;
+    }
+};
+
+}  // namespace scint

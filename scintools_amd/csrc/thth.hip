@@ -1,0 +1,276 @@
+// thth.hip -- CS -> theta-theta gather (thth_map + thth_redmap, ththmod.py:56-173)
+// and theta-theta -> CS scatter (rev_map, ththmod.py:176-271).
+//
+// This translation unit is compiled with -ffp-contract=off: the bin an element
+// falls in is decided by a floor / an ordered comparison of float64 expressions,
+// and the reference evaluates those expressions with one IEEE rounding per NumPy
+// ufunc.  A fused multiply-add would flip pixels.
+#include <float.h>
+#include <math.h>
+
+#include "thth.hpp"
+
+namespace scint {
+
+// np.floor_divide(a, b) for float64, b > 0.  NumPy (npy_divmod) returns the exact
+// mathematical floor(a/b): fmod is exact and the quotient is snapped to an integer.
+// floor(fl(a/b)) can only be wrong (one too high) when the correctly-rounded quotient
+// landed on an integer from below; the sign of the single-rounded remainder a - q*b
+// detects exactly that case.
+__device__ inline double floor_div_exact(double a, double b) {
+    double q = floor(a / b);
+    if (__builtin_fma(-q, b, a) < 0.0) q -= 1.0;
+    return q;
+}
+
+// np.nan_to_num on one float64
+__device__ inline double nan_to_num(double v) {
+    if (v != v) return 0.0;
+    if (v > DBL_MAX) return DBL_MAX;
+    if (v < -DBL_MAX) return -DBL_MAX;
+    return v;
+}
+
+// theta-theta value at (theta2 = th_i, theta1 = th_j), before any Hermitian forcing
+// (ththmod.py:94-107).
+__device__ inline cplx thth_value(const cplx* __restrict__ cs, const GeomDev& g, double eta,
+                                  double two_eta, double th_i, double th_j) {
+    const double a_tau = ((eta * (th_j * th_j - th_i * th_i)) - g.tau0) + g.half_dtau;
+    const double a_fd = ((th_j - th_i) - g.fd0) + g.half_dfd;
+    const int64_t tau_inv = (int64_t)floor_div_exact(a_tau, g.dtau);
+    int64_t fd_inv = (int64_t)floor_div_exact(a_fd, g.dfd);
+    // pnts = (tau_inv > 0) * (tau_inv < ntau) * (fd_inv < nfd): no lower bound on
+    // fd_inv (ththmod.py:103); NumPy's fancy index wraps a negative one.
+    if (!(tau_inv > 0 && tau_inv < g.ntau && fd_inv < g.nfd)) return mk(0.0, 0.0);
+    if (fd_inv < 0) {
+        fd_inv += g.nfd;
+        if (fd_inv < 0) return mk(nan(""), nan(""));  // NumPy would raise IndexError
+    }
+    const cplx v = cs[tau_inv * g.nfd + fd_inv];
+    const double w = sqrt(fabs(two_eta * (th_i - th_j)));
+    return mk(v.x * w, v.y * w);
+}
+
+constexpr int kTile = 32;
+
+// One 32x32 tile of one job per 256-thread block.  Hermitian jobs compute only tiles on
+// or above the diagonal; the mirrored tile is written through an LDS transpose so that
+// both the (i, j) and the (j, i) stores are coalesced row segments.
+__global__ void __launch_bounds__(256)
+thth_gather_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restrict__ th,
+                   int64_t M, const GatherJob* __restrict__ jobs) {
+    __shared__ cplx tile[kTile][kTile + 1];
+    const GatherJob job = jobs[blockIdx.z];
+    const int N = job.n;
+    const int I0 = blockIdx.y * kTile, J0 = blockIdx.x * kTile;
+    if (I0 >= N || J0 >= N) return;
+    if (job.hermitian && J0 < I0) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int j = J0 + tx;
+    const int kj = j < N ? job.keep[j] : 0;
+    const double th_j = j < N ? th[kj] : 0.0;
+
+    if (!job.hermitian) {
+        for (int r = ty; r < kTile; r += 8) {
+            const int i = I0 + r;
+            if (i < N && j < N)
+                job.out[(int64_t)i * job.ld + j] =
+                    thth_value(cs, g, job.eta, job.two_eta, th[job.keep[i]], th_j);
+        }
+        return;
+    }
+
+    const bool diag_tile = (I0 == J0);
+    for (int r = ty; r < kTile; r += 8) {
+        const int i = I0 + r;
+        cplx v = mk(0.0, 0.0);
+        if (i < N && j < N && i < j) {
+            const int ki = job.keep[i];
+            v = thth_value(cs, g, job.eta, job.two_eta, th[ki], th_j);
+            // anti-diagonal of the FULL matrix is zeroed (ththmod.py:113), then nan_to_num
+            if ((int64_t)ki + kj == M - 1) v = mk(0.0, 0.0);
+            v = mk(nan_to_num(v.x), nan_to_num(v.y));
+        }
+        tile[r][tx] = v;
+        if (!diag_tile && i < N && j < N) job.out[(int64_t)i * job.ld + j] = v;
+    }
+    __syncthreads();
+    if (diag_tile) {
+        for (int r = ty; r < kTile; r += 8) {
+            const int i = I0 + r;
+            if (i < N && j < N) {
+                cplx v = (r < tx) ? tile[r][tx] : (r > tx ? conj(tile[tx][r]) : mk(0.0, 0.0));
+                job.out[(int64_t)i * job.ld + j] = v;
+            }
+        }
+    } else {
+        // mirrored tile: out[J0 + a][I0 + b] = conj(tile[b][a]), b fastest
+        for (int a = ty; a < kTile; a += 8) {
+            const int row = J0 + a, col = I0 + tx;
+            if (row < N && col < N) job.out[(int64_t)row * job.ld + col] = conj(tile[tx][a]);
+        }
+    }
+}
+
+int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
+                      const GatherJob* jobs_dev, int njobs, int nmax, hipStream_t stream) {
+    if (njobs <= 0 || nmax <= 0) return SCINT_OK;
+    const unsigned nt = (unsigned)ceil_div(nmax, kTile);
+    SCINT_REQUIRE(nt <= 65535 && njobs <= 65535, "gather: grid too large");
+    hipLaunchKernelGGL(thth_gather_kernel, dim3(nt, nt, (unsigned)njobs), dim3(256), 0, stream, cs, g,
+                       th_cents, M, jobs_dev);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
+// ------------------------------------------------------------------------------
+// rev_map
+// ------------------------------------------------------------------------------
+// np.histogram2d bin of x on the edges e(k) = (k - 0.5)*step + x0, k = 0..n:
+// searchsorted(edges, x, 'right') - 1, with x == e(n) folded into the last bin
+// (numpy/lib/_histograms_impl.py histogramdd).  Returns -1 for an outlier.
+__host__ __device__ inline int64_t hist_bin(double x, double x0, double step, int64_t n) {
+    if (!(step > 0.0) || x != x) return -1;
+    double guess = floor((x - x0) / step + 0.5);
+    if (guess < -1.0) return -1;
+    if (guess > (double)n + 1.0) return -1;
+    int64_t k = (int64_t)guess;
+    if (k < 0) k = 0;
+    if (k > n) k = n;
+    // largest k in [0, n] with e(k) <= x
+    while (k < n && (((double)(k + 1) - 0.5) * step + x0) <= x) ++k;
+    while (k >= 0 && (((double)k - 0.5) * step + x0) > x) --k;
+    if (k < 0) return -1;
+    if (k == n) return (x == (((double)n - 0.5) * step + x0)) ? n - 1 : -1;
+    return k;
+}
+
+struct RevParams {
+    const cplx* thth; int64_t ld;      // explicit matrix (rank1 == 0)
+    const cplx* vec; const double* w;  // rank-1: |w| v v^H (rank1 == 1)
+    int rank1;
+    const double* th; int N;
+    double eta, two_eta;
+    int hermitian;
+    double* acc_re; double* acc_im; double* norm;  // [ntau*nfd] each
+};
+
+__global__ void __launch_bounds__(256) rev_scatter_kernel(RevParams p, GeomDev g) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= p.N || j >= p.N || i == j) return;  // i == j lands in the poisoned centre bin
+    const double th_i = p.th[i], th_j = p.th[j];
+    const double x = th_j - th_i;                          // fd_map[i, j]   (ththmod.py:207)
+    const double y = p.eta * (th_j * th_j - th_i * th_i);  // tau_map[i, j]  (ththmod.py:208-210)
+    cplx v;
+    if (p.rank1) {
+        // thth2_red = outer(V, conj(V)) * |w|   (ththmod.py:312-313)
+        const cplx o = mulc(p.vec[i], p.vec[j]);
+        const double aw = fabs(p.w[0]);
+        v = mk(o.x * aw, o.y * aw);
+    } else {
+        v = p.thth[(int64_t)i * p.ld + j];
+    }
+    // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
+    const double c = sqrt(fabs(p.two_eta * (th_i - th_j)));
+    const double scl = 1.0 / c;
+    const double wr = v.x * scl, wi = v.y * scl;
+    int64_t bx = hist_bin(x, g.fd0, g.fd1_step, g.nfd);
+    int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau);
+    if (bx >= 0 && by >= 0) {
+        const int64_t o = by * g.nfd + bx;
+        atomicAdd(&p.acc_re[o], wr);
+        atomicAdd(&p.acc_im[o], wi);
+        atomicAdd(&p.norm[o], 1.0);
+    }
+    if (p.hermitian) {
+        bx = hist_bin(-x, g.fd0, g.fd1_step, g.nfd);
+        by = hist_bin(-y, g.tau0, g.tau1_step, g.ntau);
+        if (bx >= 0 && by >= 0) {
+            const int64_t o = by * g.nfd + bx;
+            atomicAdd(&p.acc_re[o], wr);
+            atomicAdd(&p.acc_im[o], -wi);
+            atomicAdd(&p.norm[o], 1.0);
+        }
+    }
+}
+
+// recov = nan_to_num((re + i im) / norm); the bin that receives the i == j terms is
+// NaN in the reference (x/0 weights) and therefore 0 after nan_to_num.
+__global__ void __launch_bounds__(256)
+rev_normalise_kernel(const double* acc_re, const double* acc_im, const double* norm, cplx* recov,
+                     int64_t total, int64_t centre) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    if (o == centre) { recov[o] = mk(0.0, 0.0); return; }
+    const double scl = 1.0 / norm[o];
+    recov[o] = mk(nan_to_num(acc_re[o] * scl), nan_to_num(acc_im[o] * scl));
+}
+
+}  // namespace scint
+
+using namespace scint;
+
+extern "C" int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geom,
+                                  const double* th_cents, int64_t M, const int32_t* keep_idx,
+                                  int64_t N, double eta, int32_t hermitian, scint_c128* thth_out,
+                                  void* stream_) {
+    SCINT_REQUIRE(cs && geom && th_cents && keep_idx && thth_out, "thth_map: null pointer");
+    SCINT_REQUIRE(M >= 1 && N >= 0 && N <= M, "thth_map: bad sizes");
+    SCINT_REQUIRE(geom->dtau > 0 && geom->dfd > 0, "thth_map: tau and fd must be increasing");
+    if (N == 0) return SCINT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    GatherJob job;
+    job.eta = eta;
+    job.two_eta = 2 * eta;
+    job.keep = keep_idx;
+    job.n = (int32_t)N;
+    job.hermitian = hermitian;
+    job.out = (cplx*)thth_out;
+    job.ld = N;
+    GatherJob* jd = nullptr;
+    SCINT_HIP(hipMalloc(&jd, sizeof(GatherJob)));
+    hipError_t e = hipMemcpyAsync(jd, &job, sizeof(job), hipMemcpyHostToDevice, stream);
+    int32_t rc = (e == hipSuccess) ? SCINT_OK : hip_fail(e, "thth_map job upload", __FILE__, __LINE__);
+    if (rc == SCINT_OK) rc = launch_gather((const cplx*)cs, to_dev(*geom), th_cents, M, jd, 1, (int)N, stream);
+    e = hipStreamSynchronize(stream);
+    (void)hipFree(jd);
+    if (rc == SCINT_OK && e != hipSuccess) rc = hip_fail(e, "thth_map sync", __FILE__, __LINE__);
+    return rc;
+}
+
+extern "C" int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
+                                 int32_t rank1, const double* th_cents, int64_t N,
+                                 const scint_cs_geom* geom, double eta, int32_t hermitian,
+                                 scint_c128* recov_out, double* norm_ws, void* stream_) {
+    SCINT_REQUIRE(geom && th_cents && recov_out && norm_ws, "rev_map: null pointer");
+    SCINT_REQUIRE(rank1 ? (vec && w) : (thth != nullptr), "rev_map: missing input");
+    SCINT_REQUIRE(N >= 1, "rev_map: bad N");
+    hipStream_t stream = (hipStream_t)stream_;
+    const GeomDev g = to_dev(*geom);
+    const int64_t total = g.ntau * g.nfd;
+    // workspace planes: [0] = sum of real weights, [1] = imaginary, [2] = counts
+    double* acc_re = norm_ws;
+    double* acc_im = norm_ws + total;
+    double* norm = norm_ws + 2 * total;
+    SCINT_HIP(hipMemsetAsync(norm_ws, 0, sizeof(double) * 3 * (size_t)total, stream));
+    RevParams p;
+    p.thth = (const cplx*)thth; p.ld = N;
+    p.vec = (const cplx*)vec; p.w = w; p.rank1 = rank1;
+    p.th = th_cents; p.N = (int)N;
+    p.eta = eta; p.two_eta = 2 * eta;
+    p.hermitian = hermitian;
+    p.acc_re = acc_re; p.acc_im = acc_im; p.norm = norm;
+    dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(N, 4));
+    SCINT_REQUIRE(grid.y <= 65535, "rev_map: N too large");
+    hipLaunchKernelGGL(rev_scatter_kernel, grid, dim3(256), 0, stream, p, g);
+    SCINT_LAUNCH_CHECK();
+    // the bin the i == j terms fall in (fd_map = 0, tau_map = eta*0)
+    const int64_t cbx = hist_bin(0.0, g.fd0, g.fd1_step, g.nfd);
+    const int64_t cby = hist_bin(eta * 0.0, g.tau0, g.tau1_step, g.ntau);
+    const int64_t centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
+    hipLaunchKernelGGL(rev_normalise_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                       acc_re, acc_im, norm, (cplx*)recov_out, total, centre);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}

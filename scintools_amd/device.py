@@ -1,0 +1,61 @@
+"""Device plumbing: PyTorch-ROCm owns HBM buffers and the HIP stream, nothing else.
+
+No torch op runs inside the hot loop -- tensors are allocated here and their
+``data_ptr()`` is handed to the HIP kernels through the C ABI.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def require_gpu():
+    _lib.require_gpu()
+    if not torch.cuda.is_available():
+        raise _lib.ScintHipError("torch.cuda is not available: scintools_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (kernels and torch copies stay ordered)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def to_device(x, dtype):
+    """NumPy array / torch tensor -> contiguous device tensor of `dtype`."""
+    dev = require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x.to(device=dev, dtype=dtype)
+    else:
+        np_dtype = {torch.float64: np.float64, torch.complex128: np.complex128,
+                    torch.int32: np.int32, torch.uint8: np.uint8}[dtype]
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np_dtype)).to(dev)
+    return t.contiguous()
+
+
+def empty(shape, dtype):
+    return torch.empty(shape, dtype=dtype, device=require_gpu())
+
+
+class Workspace:
+    """Grow-only scratch buffer handed to the library (which never allocates HBM
+    except its cached twiddle tables)."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes):
+        if self._buf is None or self._buf.numel() < nbytes or self._buf.device != require_gpu():
+            self._buf = None
+            self._buf = torch.empty(int(nbytes), dtype=torch.uint8, device=require_gpu())
+        return self._buf
+
+    def release(self):
+        self._buf = None
+
+
+workspace = Workspace()

@@ -1,0 +1,447 @@
+"""Drop-in for the theta-theta functions of ``scintools.ththmod`` on one MI355X.
+
+Same names, argument order and return values as the reference
+(/root/reference/scintools/ththmod.py); the NumPy/SciPy bodies are replaced by
+calls into libscint_hip.so:
+
+=================  =====================  ========================================
+function           reference lines        HIP entry point(s)
+=================  =====================  ========================================
+thth_map           ththmod.py:56-116      scint_thth_map
+thth_redmap        ththmod.py:119-173     scint_thth_map (crop fused)
+rev_map            ththmod.py:176-271     scint_rev_map
+modeler            ththmod.py:274-327     scint_thth_map + scint_eigh_top +
+                                          scint_rev_map + scint_model_from_recov
+chisq_calc         ththmod.py:330-368     ... + scint_chisq
+Eval_calc          ththmod.py:371-401     scint_eval_sweep (one eta)
+single_search      ththmod.py:715-895     scint_cs + scint_eval_sweep (+ SciPy fit)
+eval_sweep         (the loop :788-799)    scint_eval_sweep
+=================  =====================  ========================================
+
+``tau, fd, eta, edges`` may be bare numbers (us, mHz, s**3, mHz) or, when astropy
+is installed, Quantities -- converted exactly as ``unit_checks`` does.  ``CS`` may
+be a NumPy array (uploaded on every call) or a ``torch`` complex128 CUDA tensor
+(kept where it is; use :func:`to_device` once before a loop).  Results are NumPy
+arrays like the reference's.  Grid construction, the crop mask and the parabola
+fit stay on the host in NumPy/SciPy, in the reference's operation order.
+
+There is no CPU fallback: without the HIP library or without a GPU every
+function raises ``ScintHipError``.
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+from scipy.optimize import curve_fit
+
+from . import _lib, units
+from . import device as _dv
+from .device import empty, ptr, require_gpu, stream_ptr, workspace
+
+DEFAULT_TOL = 1e-12       # Ritz-residual tolerance of the Lanczos eigen-solver
+DEFAULT_MAX_ITER = 300    # Lanczos steps (ARPACK needs 30-50 restarts-equivalent mat-vecs)
+DEFAULT_BATCH_BYTES = 8 << 30   # HBM budget for concurrently resident theta-theta matrices
+
+
+# ----------------------------------------------------------------------------
+# small host helpers (reference operation order)
+# ----------------------------------------------------------------------------
+def chi_par(x, A, x0, C):
+    """Parabola for fitting the eigenvalue peak (ththmod.py:38-53)."""
+    return A * (x - x0) ** 2 + C
+
+
+def unit_checks(var, name, desired):
+    """Reference-compatible unit coercion (ththmod.py:1639-1668); needs astropy
+    for anything but bare numbers.  `desired` is an astropy unit."""
+    if not units.HAVE_ASTROPY:
+        raise _lib.ScintHipError("unit_checks with astropy units needs astropy")
+    u = units.u
+    var = var * u.dimensionless_unscaled
+    if u.dimensionless_unscaled.is_equivalent(var.unit):
+        var = var * desired
+        warnings.warn(f"{name} missing units. Assuming {desired}.")
+    elif desired.is_equivalent(var.unit):
+        var = var.to(desired)
+    else:
+        raise u.UnitConversionError(f"{name} units ({var.unit}) not equivalent to {desired}")
+    return var
+
+
+def fft_axis(x, unit=None, pad=0):
+    """Fourier-conjugate axis (ththmod.py:473-493).
+
+    With astropy: same call as the reference (`unit` an astropy unit).  Without:
+    `unit` is the scale factor of the conversion -- 1000.0 for s -> mHz, 1.0 for
+    MHz -> us -- and a bare ndarray is returned.
+    """
+    if units.HAVE_ASTROPY and hasattr(x, "unit"):
+        fx = np.fft.fftshift(np.fft.fftfreq((pad + 1) * x.shape[0], x[1] - x[0]).to_value(unit)) * unit
+        return fx
+    scale = 1.0 if unit is None else float(unit)
+    fx = np.fft.fftfreq((pad + 1) * x.shape[0], x[1] - x[0])
+    if scale != 1.0:
+        fx = fx * scale
+    return np.fft.fftshift(fx)
+
+
+def min_edges(fd_lim, fd, tau, eta, factor=2):
+    """Smallest edges array that oversamples the CS by `factor` (ththmod.py:1671-1705)."""
+    fd_v = units.strip(fd, "fd", "mHz", warn=False)
+    tau_v = units.strip(tau, "tau", "us", warn=False)
+    eta_v = float(units.strip(eta, "eta", "s3", warn=False))
+    lim = float(units.strip(fd_lim, "fD Limit", "mHz", warn=False))
+    dtau_lim = (tau_v[1] - tau_v[0]) / factor
+    dtau_lim /= 2 * eta_v * lim
+    dfd_lim = (fd_v[1] - fd_v[0]) / factor
+    npoints = (2 * lim) // (min(dfd_lim, dtau_lim))
+    npoints += np.mod(npoints, 2)
+    return units.attach(np.linspace(-lim, lim, int(npoints)), "mHz")
+
+
+def _theta_centres(edges):
+    th = (edges[1:] + edges[:-1]) / 2            # ththmod.py:83
+    th -= th[np.abs(th) == np.abs(th).min()]     # ththmod.py:84
+    return th
+
+
+class _Grid:
+    """Plain-float view of (tau, fd, edges) plus everything the kernels need."""
+
+    def __init__(self, tau, fd, edges):
+        self.tau = units.strip(tau, "tau", "us", warn=False)
+        self.fd = units.strip(fd, "fd", "mHz", warn=False)
+        self.edges = np.array(units.strip(edges, "edges", "mHz", warn=False), dtype=float)
+        if self.tau.ndim != 1 or self.fd.ndim != 1 or self.tau.size < 2 or self.fd.size < 2:
+            raise ValueError("tau and fd must be 1-D with at least two points")
+        self.th_cents = _theta_centres(self.edges)
+        g = _lib.CsGeom()
+        g.ntau, g.nfd = self.tau.shape[0], self.fd.shape[0]
+        g.tau0, g.dtau = float(self.tau[0]), float(np.diff(self.tau).mean())   # ththmod.py:90
+        g.fd0, g.dfd = float(self.fd[0]), float(np.diff(self.fd).mean())       # ththmod.py:91
+        g.tau_max = float(np.abs(self.tau.max()))
+        g.fd_max = float(np.abs(self.fd.max()))
+        g.tau1_step = float(self.tau[1] - self.tau[0])
+        g.fd1_step = float(self.fd[1] - self.fd[0])
+        self.geom = g
+        self._th_dev = None
+
+    @property
+    def M(self):
+        return self.th_cents.shape[0]
+
+    def th_dev(self):
+        if self._th_dev is None:
+            self._th_dev = to_device(self.th_cents, torch.float64)
+        return self._th_dev
+
+    def keep(self, eta):
+        """Crop of thth_redmap (ththmod.py:153-155) as ascending indices."""
+        th = self.th_cents
+        pnts = ((th**2) * eta < self.geom.tau_max) * (np.abs(th) < self.geom.fd_max / 2)
+        return np.nonzero(pnts)[0].astype(np.int32)
+
+    def edges_red(self, keep_idx):
+        """edges of the reduced map (ththmod.py:157-172)."""
+        c = self.th_cents[keep_idx]
+        mid = (c[:-1] + c[1:]) / 2
+        step = np.diff(mid).mean()
+        return np.concatenate((np.array([mid[0] - step]), mid, np.array([mid[-1] + step])))
+
+
+def to_device(CS, dtype=torch.complex128):
+    """Upload a conjugate spectrum once; pass the result as ``CS`` to any function here."""
+    return _dv.to_device(CS, dtype)
+
+
+def _cs_dev(CS, grid):
+    t = to_device(CS, torch.complex128)
+    if tuple(t.shape) != (grid.geom.ntau, grid.geom.nfd):
+        raise ValueError(f"CS shape {tuple(t.shape)} does not match (len(tau), len(fd)) = "
+                         f"({grid.geom.ntau}, {grid.geom.nfd})")
+    return t
+
+
+def _eta_float(eta):
+    return float(units.strip(eta, "eta", "s3", warn=False))
+
+
+# ----------------------------------------------------------------------------
+# device-level building blocks (torch tensors in, torch tensors out)
+# ----------------------------------------------------------------------------
+def _thth_dev(cs_t, grid, eta, keep_idx, hermetian):
+    lib = require_gpu() and _lib.load()
+    n = int(keep_idx.shape[0])
+    out = empty((n, n), torch.complex128)
+    if n == 0:
+        return out
+    keep_t = to_device(keep_idx, torch.int32)
+    rc = lib.scint_thth_map(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), grid.M,
+                            ptr(keep_t), n, eta, 1 if hermetian else 0, ptr(out), stream_ptr())
+    _lib.check(rc, "scint_thth_map")
+    if not hermetian and bool(torch.isnan(out.real).any()):
+        # NumPy raises here: a negative fd index below -len(fd) (ththmod.py:104)
+        raise IndexError("theta-theta gather index out of bounds for the conjugate spectrum")
+    return out
+
+
+def _eigh_top_dev(a_t, v0_t=None, want_vec=True, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER):
+    """Top ('LA') eigenpair of a Hermitian device matrix.  Returns (w float, V tensor|None, iters)."""
+    lib = _lib.load()
+    n = int(a_t.shape[0])
+    if n < 2:
+        raise ValueError("eigen-decomposition needs at least a 2x2 theta-theta matrix")
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_eigh_top_workspace_bytes(n, max_iter, ctypes.byref(need)), "eigh_top_workspace_bytes")
+    ws = workspace.get(need.value)
+    w_t = empty((1,), torch.float64)
+    st_t = torch.zeros((2,), dtype=torch.int32, device=a_t.device)
+    vec_t = empty((n,), torch.complex128) if want_vec else None
+    rc = lib.scint_eigh_top(ptr(a_t), n, ptr(v0_t), tol, max_iter, ptr(w_t), ptr(vec_t),
+                            ptr(st_t[0:1]), ptr(st_t[1:2]), ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_eigh_top")
+    status, iters = (int(v) for v in st_t.cpu())
+    if status != _lib.SCINT_OK:
+        raise ArithmeticError(f"top-eigenpair iteration failed (status {status}, {iters} steps)")
+    return float(w_t.cpu()[0]), vec_t, iters
+
+
+def _rev_map_dev(grid_geom, th_t, n, eta, hermetian, thth_t=None, vec_t=None, w_t=None):
+    lib = _lib.load()
+    total = grid_geom.ntau * grid_geom.nfd
+    recov = empty((grid_geom.ntau, grid_geom.nfd), torch.complex128)
+    scratch = workspace.get(3 * total * 8)
+    rank1 = thth_t is None
+    rc = lib.scint_rev_map(ptr(thth_t), ptr(vec_t), ptr(w_t), 1 if rank1 else 0, ptr(th_t), n,
+                           ctypes.byref(grid_geom), eta, 1 if hermetian else 0, ptr(recov),
+                           ptr(scratch), stream_ptr())
+    _lib.check(rc, "scint_rev_map")
+    return recov
+
+
+def _model_dev(recov_t):
+    lib = _lib.load()
+    ntau, nfd = (int(v) for v in recov_t.shape)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_model_workspace_bytes(ntau, nfd, ctypes.byref(need)), "model_workspace_bytes")
+    ws = workspace.get(need.value)
+    model = empty((ntau, nfd), torch.float64)
+    rc = lib.scint_model_from_recov(ptr(recov_t), ntau, nfd, ptr(model), ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_model_from_recov")
+    return model
+
+
+# ----------------------------------------------------------------------------
+# reference API
+# ----------------------------------------------------------------------------
+def thth_map(CS, tau, fd, eta, edges, hermetian=True):
+    """CS -> theta-theta, nearest-bin gather (ththmod.py:56-116)."""
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    keep = np.arange(grid.M, dtype=np.int32)
+    return _thth_dev(cs_t, grid, _eta_float(eta), keep, hermetian).cpu().numpy()
+
+
+def thth_redmap(CS, tau, fd, eta, edges, hermetian=True):
+    """theta-theta for the largest filled-in square within edges (ththmod.py:119-173).
+    Returns (thth_red, edges_red); edges_red carries mHz when astropy is present."""
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    e = _eta_float(eta)
+    keep = grid.keep(e)
+    red = _thth_dev(cs_t, grid, e, keep, hermetian).cpu().numpy()
+    return red, units.attach(grid.edges_red(keep), "mHz")
+
+
+def rev_map(thth, tau, fd, eta, edges, hermetian=True):
+    """theta-theta -> CS weighted-histogram inverse map (ththmod.py:176-271)."""
+    grid = _Grid(tau, fd, edges)
+    e = _eta_float(eta)
+    thth_t = to_device(thth, torch.complex128)
+    n = grid.M
+    if tuple(thth_t.shape) != (n, n):
+        raise ValueError(f"thth shape {tuple(thth_t.shape)} does not match len(edges)-1 = {n}")
+    recov = _rev_map_dev(grid.geom, grid.th_dev(), n, e, hermetian, thth_t=thth_t)
+    return recov.cpu().numpy()
+
+
+def _modeler_dev(cs_t, grid, e):
+    """Device pipeline of modeler; returns tensors (thth_red, V, w float, recov, model, keep)."""
+    keep = grid.keep(e)
+    red_t = _thth_dev(cs_t, grid, e, keep, True)
+    n = int(keep.shape[0])
+    w, V_t, _ = _eigh_top_dev(red_t, None, want_vec=True)
+    # rev_map runs on the REDUCED edges: their centres are re-derived from edges_red
+    # exactly as the reference does (ththmod.py:204-205 applied to :157-172)
+    th_red = _theta_centres(grid.edges_red(keep))
+    th_red_t = to_device(th_red, torch.float64)
+    w_t = to_device(np.array([w]), torch.float64)
+    recov_t = _rev_map_dev(grid.geom, th_red_t, n, e, True, vec_t=V_t, w_t=w_t)
+    model_t = _model_dev(recov_t)
+    return red_t, V_t, w, recov_t, model_t, keep
+
+
+def modeler(CS, tau, fd, eta, edges, hermetian=True):
+    """theta-theta, its rank-1 model, the model CS and model dynamic spectrum
+    (ththmod.py:274-327).  Returns (thth_red, thth2_red, recov, model, edges_red, w, V).
+    V has an arbitrary global phase (as ARPACK's has)."""
+    if not hermetian:
+        # the reference's SVD branch double-indexes U[:, 0][:, 0] and raises (ththmod.py:317-320)
+        raise IndexError("modeler(hermetian=False) raises in the reference (ththmod.py:317-320)")
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    e = _eta_float(eta)
+    red_t, V_t, w, recov_t, model_t, keep = _modeler_dev(cs_t, grid, e)
+    V = V_t.cpu().numpy()
+    thth2_red = np.outer(V, np.conjugate(V))      # ththmod.py:312-313
+    thth2_red *= np.abs(w)
+    return (red_t.cpu().numpy(), thth2_red, recov_t.cpu().numpy(), model_t.cpu().numpy(),
+            units.attach(grid.edges_red(keep), "mHz"), w, V)
+
+
+def chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask=None):
+    """chi**2 of the theta-theta model dynamic spectrum (ththmod.py:330-368)."""
+    lib = _lib.load()
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    _, _, _, _, model_t, _ = _modeler_dev(cs_t, grid, _eta_float(eta))
+    d_t = to_device(dspec, torch.float64)
+    nf, nt = (int(v) for v in d_t.shape)
+    m_t = None if mask is None else to_device(np.asarray(mask, dtype=np.uint8), torch.uint8)
+    out = empty((1,), torch.float64)
+    rc = lib.scint_chisq(ptr(model_t), int(model_t.shape[1]), ptr(d_t), nf, nt, ptr(m_t), float(N),
+                         ptr(out), stream_ptr())
+    _lib.check(rc, "scint_chisq")
+    return float(out.cpu()[0])
+
+
+def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,
+               return_info=False):
+    """Dominant eigenvalue for every curvature in `etas`: the loop of
+    single_search (ththmod.py:788-799) as one batched device call.
+
+    Failed curvatures are NaN, as in the reference.  With `return_info` also
+    returns a dict with per-eta matrix sizes N, Lanczos steps and status."""
+    lib = _lib.load()
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
+    neta, M = etas_v.shape[0], grid.M
+    keep_idx = np.zeros((neta, M), dtype=np.int32)
+    keep_n = np.zeros(neta, dtype=np.int32)
+    for i, e in enumerate(etas_v):
+        k = grid.keep(e)
+        keep_n[i] = k.shape[0]
+        keep_idx[i, : k.shape[0]] = k
+    nmax = max(int(keep_n.max()), 1)
+    if batch is None:
+        batch = max(1, min(neta, 64, DEFAULT_BATCH_BYTES // (16 * nmax * nmax)))
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_eval_sweep_workspace_bytes(M, neta, batch, max_iter, ctypes.byref(need)),
+               "eval_sweep_workspace_bytes")
+    ws = workspace.get(need.value)
+    keep_t = to_device(keep_idx, torch.int32)
+    eigs_t = empty((neta,), torch.float64)
+    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    etas_c = np.ascontiguousarray(etas_v)
+    rc = lib.scint_eval_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
+                              keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                              etas_c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta,
+                              tol, max_iter, batch, ptr(eigs_t), ptr(st_t[0]), ptr(st_t[1]),
+                              ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_eval_sweep")
+    eigs = eigs_t.cpu().numpy()
+    st = st_t.cpu().numpy()
+    eigs[st[0] != 0] = np.nan            # failures -> NaN (ththmod.py:795-799)
+    if return_info:
+        return eigs, {"N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch}
+    return eigs
+
+
+def Eval_calc(CS, tau, fd, eta, edges):
+    """Dominant eigenvalue of the reduced theta-theta at one curvature (ththmod.py:371-401)."""
+    eigs, info = eval_sweep(CS, tau, fd, np.array([_eta_float(eta)]), edges, return_info=True)
+    if info["status"][0] != 0:
+        raise ArithmeticError(f"Eval_calc failed (status {int(info['status'][0])})")
+    return float(eigs[0])
+
+
+def conjugate_spectrum(dspec, npad, tau=None, tau_mask=0.0, coher=True, pad_value=None):
+    """Device conjugate spectrum of a chunk (ththmod.py:777-787): returns a CUDA
+    complex128 tensor [(npad+1)*nf, (npad+1)*nt]."""
+    lib = _lib.load()
+    d_t = to_device(dspec, torch.float64)
+    nf, nt = (int(v) for v in d_t.shape)
+    if pad_value is None:
+        m = ctypes.c_double()
+        _lib.check(lib.scint_mean(ptr(d_t), nf * nt, ctypes.byref(m), stream_ptr()), "scint_mean")
+        pad_value = m.value
+    R = (npad + 1) * nf
+    lo = hi = 0
+    if tau is not None:
+        tau_v = units.strip(tau, "tau", "us", warn=False)
+        sel = np.nonzero(np.abs(tau_v) < float(units.strip(tau_mask, "tauMask", "us", warn=False)))[0]
+        if sel.size:
+            lo, hi = int(sel[0]), int(sel[-1]) + 1
+            if hi - lo != sel.size:
+                raise ValueError("tau mask is not a contiguous block of delays")
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_cs_workspace_bytes(nf, nt, npad, ctypes.byref(need)), "cs_workspace_bytes")
+    ws = workspace.get(need.value)
+    cs_t = empty((R, (npad + 1) * nt), torch.complex128)
+    rc = lib.scint_cs(ptr(d_t), nf, nt, npad, float(pad_value), lo, hi, 0 if coher else 1,
+                      ptr(cs_t), ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_cs")
+    return cs_t
+
+
+def fit_eig_peak(etas, eigs, fw):
+    """Parabola fit around the eigenvalue peak (ththmod.py:814-859), host SciPy.
+    Returns (eta_fit, eta_sig, popt) -- NaN, NaN, None on failure."""
+    try:
+        good = np.isfinite(eigs)
+        etas = etas[good]
+        eigs = eigs[good]
+        sel = np.abs(etas - etas[eigs == eigs.max()]) < fw * etas[eigs == eigs.max()]
+        etas_fit = etas[sel]
+        eigs_fit = eigs[sel]
+        C = eigs_fit.max()
+        x0 = etas_fit[eigs_fit == C][0]
+        if x0 == etas_fit[0]:
+            A = (eigs_fit[-1] - C) / ((etas_fit[-1] - x0) ** 2)
+        else:
+            A = (eigs_fit[0] - C) / ((etas_fit[0] - x0) ** 2)
+        popt, _ = curve_fit(chi_par, etas_fit, eigs_fit, p0=np.array([A, x0, C]))
+        eta_fit = popt[1]
+        eta_sig = np.sqrt((eigs_fit - chi_par(etas_fit, *popt)).std() / np.abs(popt[0]))
+        return eta_fit, eta_sig, popt
+    except Exception:
+        return np.nan, np.nan, None
+
+
+def single_search(params):
+    """Curvature search for one chunk (ththmod.py:715-895).
+
+    params = [dspec2, freq, time, etas, edges, name, plot, fw, npad, coher,
+    tauMask, verbose] as in the reference.  Plotting is not supported (the
+    reference's plot_func is matplotlib-only); `plot=True` is ignored with a
+    warning.  Returns (eta_fit, eta_sig, freq.mean(), time.mean(), eigs).
+    """
+    (dspec2, freq, time, etas, edges, name, plot, fw, npad, coher, tauMask, verbose) = params
+    time_v = units.strip(time, "time", "s", warn=False)
+    freq_v = units.strip(freq, "freq", "MHz", warn=False)
+    etas_v = units.strip(etas, "etas", "s3", warn=False)
+    edges_v = units.strip(edges, "edges", "mHz", warn=False)
+    fd = fft_axis(time_v, 1000.0, npad)          # ththmod.py:773
+    tau = fft_axis(freq_v, 1.0, npad)            # ththmod.py:774
+    cs_t = conjugate_spectrum(dspec2, npad, tau, tauMask, coher)
+    eigs = eval_sweep(cs_t, tau, fd, etas_v, edges_v)
+    eta_fit, eta_sig, _ = fit_eig_peak(etas_v, eigs, fw)
+    if plot:
+        warnings.warn("scintools_amd.single_search does not plot")
+    if verbose:
+        print(f"Chunk completed (eta = {eta_fit} +- {eta_sig} at {freq_v.mean()})", flush=True)
+    if np.isfinite(eta_fit):
+        eta_fit, eta_sig = units.attach(eta_fit, "s3"), units.attach(eta_sig, "s3")
+    return (eta_fit, eta_sig, units.attach(freq_v.mean(), "MHz"), units.attach(time_v.mean(), "s"), eigs)

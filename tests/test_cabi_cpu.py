@@ -1,0 +1,82 @@
+"""CPU-side checks of the boundary: the shared library builds/loads without a GPU and
+exports exactly what include/scint_hip.h declares; argument errors come back as status
+codes with a message; the product refuses to compute without a GPU."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from scintools_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from scintools_amd import build
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    declared = _lib.header_symbols()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(declared) == set(_lib._SIGNATURES)     # the binding covers the whole header
+
+
+def test_version_and_struct_layout(lib):
+    assert lib.scint_version() >= 100
+    assert ctypes.sizeof(_lib.CsGeom) == 2 * 8 + 8 * 8
+
+
+def test_workspace_queries_and_argument_errors(lib):
+    n = ctypes.c_size_t()
+    assert lib.scint_sspec_workspace_bytes(4096, 4096, ctypes.byref(n)) == 0
+    assert n.value >= 8192 * 8192 * 16
+    assert lib.scint_cs_workspace_bytes(64, 32, 3, ctypes.byref(n)) == 0
+    assert n.value >= 256 * 128 * 16
+    assert lib.scint_eval_sweep_workspace_bytes(511, 16, 4, 300, ctypes.byref(n)) == 0
+    assert n.value >= 4 * 511 * 511 * 16
+    # bad arguments: status code + message, no exception, no crash
+    assert lib.scint_sspec_workspace_bytes(0, 10, ctypes.byref(n)) == 1
+    assert "bad shape" in _lib.last_error()
+    assert lib.scint_fft2(None, None, 8, 16, None, 0, None) == 1
+    assert "null" in _lib.last_error()
+    with pytest.raises(_lib.ScintHipError):
+        _lib.check(lib.scint_fft2(None, None, 8, 16, None, 0, None), "scint_fft2")
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from scintools_amd import ththmod
+    from scintools_amd.dynspec import Dynspec
+    x = np.zeros((16, 16))
+    with pytest.raises(_lib.ScintHipError):
+        ththmod.thth_map(x + 0j, np.arange(16.0), np.arange(16.0), 1.0, np.linspace(-1, 1, 8))
+    with pytest.raises(_lib.ScintHipError):
+        ththmod.conjugate_spectrum(x, 0)
+
+    class O:
+        dyn, freqs, times = x, np.arange(16.0), np.arange(16.0)
+    with pytest.raises(_lib.ScintHipError):
+        Dynspec(dyn=O(), verbose=False).calc_sspec()
+
+
+def test_host_grid_matches_oracle(golden):
+    """Host-side grid construction (centres, crop, reduced edges) equals the oracle's."""
+    from oracle import thth_oracle as to
+    from scintools_amd.ththmod import _Grid, fft_axis, min_edges
+    g = golden("thth_small.npz")
+    grid = _Grid(g["tau"], g["fd"], g["edges_b"])
+    assert np.array_equal(grid.th_cents, to.theta_centres(g["edges_b"]))
+    for eta in g["etas"]:
+        keep, th = to.reduced_keep(g["tau"], g["fd"], eta, g["edges_b"])
+        k = grid.keep(eta)
+        assert np.array_equal(k, np.nonzero(keep)[0])
+        assert np.array_equal(grid.edges_red(k), to.reduced_edges(th[keep]))
+    assert np.array_equal(fft_axis(g["times"], 1000.0, 1), g["fd"])
+    assert np.array_equal(fft_axis(g["freqs"], 1.0, 1), g["tau"])
+    me = min_edges(0.4 * g["fd"].max(), g["fd"], g["tau"], float(g["eta_true"]), 2)
+    assert np.array_equal(np.asarray(me), g["min_edges"])
