@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Headline benchmark: eta-curvature-sweep points/s on a 4096x4096 dynamic spectrum.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--neta 256]
+
+One *step* is one pass of the hot path over one observation per GPU: device-resident
+real dynamic spectrum [4096, 4096] -> conjugate spectrum (2-D FFT) -> for each of 256
+curvatures: theta-theta gather (nedge=4096) + dominant 'LA' eigenvalue -> eigs[256] on the
+host -> parabola fit (the body of ththmod.single_search, ththmod.py:773-859).  This is
+BASELINE.json configs[2], the configuration the metric is quoted on.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): the path shards by
+observation -- every rank sweeps its own observation (different seed) and the eigenvalue
+curves are all-gathered at the end of each step.  Per-GPU work is fixed: weak scaling;
+`value` is the whole-job eta-points/s.
+
+Besides the contract fields the JSON line carries
+  roofline      the dominant kernel (eigen mat-vec): algorithmic bytes 16 N^2 per mat-vec
+                per eta summed over every Lanczos step of the timed region,
+                divided by the summed hipEvent time of that kernel's launches;
+  cpu_baseline  the NumPy/SciPy oracle (a restatement of the reference) timed on this host
+                on a 3-eta sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096, help="dynspec is size x size")
+    ap.add_argument("--neta", type=int, default=256)
+    ap.add_argument("--nedge", type=int, default=None, help="default: size")
+    ap.add_argument("--batch", type=int, default=None, help="etas resident per launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=3, help="etas timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def make_workload(size, neta, nedge, seed):
+    from scintools_amd.synth import arc_dynspec
+    from scintools_amd.ththmod import fft_axis
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=seed, nimg=64)
+    dyn -= dyn.mean()                # as Dynspec.fit_thetatheta hands chunks over (dynspec.py:1692)
+    fd = fft_axis(times, 1000.0)     # s -> mHz
+    tau = fft_axis(freqs, 1.0)       # MHz -> us
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge)
+    etas = np.geomspace(0.25, 4.0, neta) * eta_true
+    return dyn, freqs, times, fd, tau, edges, etas, eta_true
+
+
+def cpu_baseline(dyn, tau, fd, edges, etas, nsample):
+    """Oracle (port of the reference) on a bounded sample: `nsample` curvatures spread over
+    the sweep; the FFT is done once and not counted (it is amortised over 256 etas)."""
+    from oracle import thth_oracle
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    CS = thth_oracle.conjugate_spectrum(dyn, 0)
+    idx = np.unique(np.linspace(0, len(etas) - 1, nsample + 2).astype(int)[1:-1])
+    t0 = time.perf_counter()
+    vals = [thth_oracle.Eval_calc(CS, tau, fd, etas[i], edges) for i in idx]
+    dt = time.perf_counter() - t0
+    return {"value": len(idx) / dt, "unit": "eta-points/s", "cores": int(cores), "kind": "port",
+            "sample": f"oracle Eval_calc (NumPy gather + ARPACK eigsh) on {len(idx)} of {len(etas)} etas "
+                      f"(indices {idx.tolist()}) of the same {dyn.shape[0]}x{dyn.shape[1]} workload, "
+                      f"{dt:.1f} s; BLAS threads as shipped; CS FFT excluded"}, dict(zip(idx.tolist(), vals))
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from scintools_amd import _lib, ththmod
+    from scintools_amd.device import require_gpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    require_gpu()
+    lib = _lib.load()
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    size, neta = args.size, args.neta
+    nedge = args.nedge or size
+    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3 + rank)
+    dyn_t = ththmod.to_device(dyn, torch.float64)      # resident in HBM before the clock starts
+    gathered = [torch.empty(neta, dtype=torch.float64, device="cuda") for _ in range(world)]
+
+    def step():
+        # body of single_search (ththmod.py:773-859): CS once, the eta loop, the peak fit
+        cs_t = ththmod.conjugate_spectrum(dyn_t, 0, tau, 0.0, True)
+        eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
+        if world > 1:
+            dist.all_gather(gathered, torch.from_numpy(eigs).cuda())
+        fit = ththmod.fit_eig_peak(etas, eigs, 0.1)
+        return eigs, info, fit
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.scint_profile_begin()
+    t0 = time.perf_counter()
+    alg_bytes = 0.0
+    for _ in range(args.steps):
+        eigs, info, fit = step()
+        alg_bytes += float(np.sum(16.0 * info["N"].astype(float) ** 2 * info["iters"]))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_double * 2)()
+    launches = (ctypes.c_int64 * 2)()
+    lib.scint_profile_end(ms, launches)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        gather_bytes = float(np.sum(24.0 * info["N"].astype(float) ** 2 - 8.0 * info["N"])) * args.steps
+        mv_s = ms[1] / 1e3
+        achieved = alg_bytes / mv_s / 1e9 if mv_s > 0 else 0.0
+        out = {
+            "metric": "eta_curvature_sweep_points_per_sec",
+            "value": world * neta * args.steps / elapsed,
+            "unit": "eta-points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{size}x{size} dynspec, {neta}-eta theta-theta eigenvalue sweep "
+                                   f"(Eval_calc loop of single_search), nedge={nedge}, npad=0, "
+                                   f"one observation per GPU",
+                       "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
+                       "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
+                       "lanczos_steps_mean": float(info["iters"].mean()),
+                       "batch": int(info["batch"]), "failed_etas": int(np.sum(info["status"] != 0)),
+                       "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
+            "roofline": {"kernel": "lanczos_matvec_kernel", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "avg_launch_ms": ms[1] / max(1, launches[1]), "launches": int(launches[1]),
+                         "algorithmic_bytes_per_step": alg_bytes / args.steps,
+                         "share_of_step_time": mv_s / elapsed},
+            "gather": {"kernel": "thth_gather_kernel", "achieved_GBs": gather_bytes / (ms[0] / 1e3) / 1e9
+                       if ms[0] > 0 else 0.0, "avg_launch_ms": ms[0] / max(1, launches[0]),
+                       "launches": int(launches[0]),
+                       "frac": (gather_bytes / (ms[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample)
+            out["cpu_baseline"] = cb
+            out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(
+                max(abs(eigs[i] - v) / abs(v) for i, v in ref_vals.items()))
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

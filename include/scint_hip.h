@@ -61,6 +61,13 @@ int32_t scint_last_error(char* buf, size_t n);
 /* Number of visible HIP devices (0 if none): lets the wrapper fail loudly. */
 int32_t scint_device_count(void);
 
+/* Optional per-kernel timing for the benchmark: between begin and end every launch of
+ * the theta-theta gather kernel ([0]) and of the eigen mat-vec kernel ([1]) is bracketed
+ * by hipEvents on its stream.  end() synchronises the device and returns the summed
+ * milliseconds and launch counts (HOST arrays of 2).  Not thread-safe; off by default. */
+int32_t scint_profile_begin(void);
+int32_t scint_profile_end(double* ms_out /*HOST[2]*/, int64_t* launches_out /*HOST[2]*/);
+
 /* ---- secondary spectrum: Dynspec.calc_sspec core (dynspec.py:3665-3721) -- */
 /* dyn[nf,nt] -> sec[(halve? nrfft/2 : nrfft), ncfft] in dB, where
  * nrfft/ncfft = 2*nextpow2(nf/nt) (dynspec.py:3677-3678).

@@ -2,7 +2,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "common.hpp"
+#include "prof.hpp"
 
 namespace scint {
 
@@ -18,7 +18,31 @@ int32_t hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return SCINT_E_HIP;
 }
 
+Profiler& profiler() {
+    static Profiler p;
+    return p;
+}
+
 }  // namespace scint
+
+extern "C" int32_t scint_profile_begin(void) {
+    scint::Profiler& p = scint::profiler();
+    p.reset();
+    p.enabled = true;
+    return SCINT_OK;
+}
+
+extern "C" int32_t scint_profile_end(double* ms_out, int64_t* launches_out) {
+    scint::Profiler& p = scint::profiler();
+    if (hipDeviceSynchronize() != hipSuccess) return SCINT_E_HIP;
+    p.collect();
+    p.enabled = false;
+    for (int k = 0; k < scint::kProfCount; ++k) {
+        if (ms_out) ms_out[k] = p.ms[k];
+        if (launches_out) launches_out[k] = p.launches[k];
+    }
+    return SCINT_OK;
+}
 
 extern "C" int32_t scint_version(void) { return 100; }
 

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "prof.hpp"
 #include "thth.hpp"
 
 namespace scint {
@@ -383,7 +384,9 @@ static int32_t run_lanczos(const LanczosJob* jobs_dev, const int32_t* states_dev
     while (step < steps_cap) {
         const int upto = std::min(steps_cap, step + chunk);
         for (; step < upto; ++step) {
+            const int slot = profiler().begin(kProfMatvec, stream);
             hipLaunchKernelGGL(lanczos_matvec_kernel, mgrid, dim3(256), lds, stream, jobs_dev, step);
+            profiler().end(kProfMatvec, slot, stream);
             hipLaunchKernelGGL(lanczos_update_kernel, vgrid, dim3(kVecBlock), 0, stream, jobs_dev, step);
         }
         SCINT_LAUNCH_CHECK();
@@ -393,6 +396,7 @@ static int32_t run_lanczos(const LanczosJob* jobs_dev, const int32_t* states_dev
         SCINT_HIP(hipMemcpyAsync(flags_pinned, states_dev, sizeof(int32_t) * 4 * (size_t)njobs,
                                  hipMemcpyDeviceToHost, stream));
         SCINT_HIP(hipStreamSynchronize(stream));
+        if (profiler().enabled) profiler().collect();
         bool all = true;
         for (int i = 0; i < njobs; ++i) all = all && flags_pinned[4 * i] != 0;
         if (all) break;

@@ -4,11 +4,26 @@
 //   scint_cs                conjugate spectrum of a chunk (ththmod.py:777-787)
 //   scint_model_from_recov  ifft2(ifftshift(recov)).real  (ththmod.py:322-324)
 //   scint_mean / scint_chisq  small deterministic reductions
+//
+// Every transform is "source -> row FFT -> column FFT -> sink":
+//   RowSource  produces element (row, j) of the padded real/complex input (this is where
+//              mean-subtract, window, prewhiten stencil, zero/constant padding, ifftshift
+//              are fused -- the padded array is never materialised);
+//   ColSource  feeds the first column pass from the row-FFT result, supplying the rows the
+//              row pass never computed (all-zero or constant padding rows);
+//   ColSink    consumes the final value at natural frequency (k1, k2): fftshift, |.|^2,
+//              post-darkening, 10 log10, delay mask, abs, real-part scaling.
+// The descriptors are plain structs switched at run time (wave-uniform branches) so that the
+// FFT kernels are instantiated once.
+//
+// Axis lengths that are not powers of two go through Bluestein's chirp-z identity
+//   X[k] = w[k] * IFFT_m( FFT_m(x w) * FFT_m(conj w) )[k],   w[j] = exp(-i pi j^2 / n),
+// with m = nextpow2(2n-1); both length-m transforms run on the same two kernels and the
+// chirp multiplications are fused into the sources/sinks.
 #include <math.h>
 
 #include <map>
 #include <mutex>
-#include <type_traits>
 #include <vector>
 
 #include "fft.hpp"
@@ -16,44 +31,118 @@
 namespace scint {
 
 // ------------------------------------------------------------------------------
-// twiddle cache
+// cached device tables
 // ------------------------------------------------------------------------------
-static std::mutex g_tw_mutex;
-static std::map<std::pair<int, int64_t>, cplx*> g_tw_cache;  // (device, n) -> table
+static std::mutex g_tab_mutex;
+static std::map<std::pair<int, int64_t>, cplx*> g_tw_cache;  // (device, n) -> W_n table
+
+static cplx* upload(const std::vector<cplx>& host) {
+    cplx* d = nullptr;
+    if (hipMalloc(&d, sizeof(cplx) * host.size()) != hipSuccess) {
+        set_error("scint: hipMalloc of an FFT table failed");
+        return nullptr;
+    }
+    if (hipMemcpy(d, host.data(), sizeof(cplx) * host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("scint: hipMemcpy of an FFT table failed");
+        (void)hipFree(d);
+        return nullptr;
+    }
+    return d;
+}
+
+static const long double kTwoPiL = 6.283185307179586476925286766559005768L;
 
 const cplx* twiddle_table(int64_t n) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { set_error("scint: hipGetDevice failed"); return nullptr; }
-    std::lock_guard<std::mutex> lock(g_tw_mutex);
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
     auto key = std::make_pair(dev, n);
     auto it = g_tw_cache.find(key);
     if (it != g_tw_cache.end()) return it->second;
     std::vector<cplx> host((size_t)n);
-    const long double two_pi = 6.283185307179586476925286766559005768L;
     for (int64_t j = 0; j < n; ++j) {
-        // exact octant symmetries keep W^{n/4}, W^{n/2}, ... free of rounding noise
-        long double a = two_pi * (long double)j / (long double)n;
+        const long double a = kTwoPiL * (long double)j / (long double)n;
         host[(size_t)j] = mk((double)cosl(a), (double)-sinl(a));
     }
-    if (n % 4 == 0) {
+    if (n % 4 == 0) {  // exact quarter turns
         host[(size_t)(n / 4)] = mk(0.0, -1.0);
         host[(size_t)(n / 2)] = mk(-1.0, 0.0);
         host[(size_t)(3 * n / 4)] = mk(0.0, 1.0);
     } else if (n % 2 == 0) {
         host[(size_t)(n / 2)] = mk(-1.0, 0.0);
     }
-    cplx* d = nullptr;
-    if (hipMalloc(&d, sizeof(cplx) * (size_t)n) != hipSuccess) {
-        set_error("scint: hipMalloc of twiddle table failed");
-        return nullptr;
-    }
-    if (hipMemcpy(d, host.data(), sizeof(cplx) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
-        set_error("scint: hipMemcpy of twiddle table failed");
-        hipFree(d);
-        return nullptr;
-    }
-    g_tw_cache[key] = d;
+    cplx* d = upload(host);
+    if (d) g_tw_cache[key] = d;
     return d;
+}
+
+// Bluestein tables for length n: w[j] = exp(-i pi j^2/n) (j < n) and B = FFT_m(b) with
+// b[l] = conj(w[|l|]) wrapped to length m.  Computed in long double on the host.
+struct Chirp {
+    int64_t n, m;
+    const cplx* w;  // [n]
+    const cplx* B;  // [m]
+};
+static std::map<std::pair<int, int64_t>, Chirp> g_chirp_cache;
+
+static void host_fft_ld(std::vector<long double>& re, std::vector<long double>& im) {
+    const size_t m = re.size();
+    for (size_t i = 1, j = 0; i < m; ++i) {  // bit reversal
+        size_t bit = m >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= m; len <<= 1) {
+        std::vector<long double> wr(len / 2), wi(len / 2);
+        for (size_t k = 0; k < len / 2; ++k) {
+            const long double a = kTwoPiL * (long double)k / (long double)len;
+            wr[k] = cosl(a);
+            wi[k] = -sinl(a);
+        }
+        for (size_t i = 0; i < m; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const size_t a = i + k, b = i + k + len / 2;
+                const long double xr = re[b] * wr[k] - im[b] * wi[k], xi = re[b] * wi[k] + im[b] * wr[k];
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+
+static const Chirp* chirp_table(int64_t n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("scint: hipGetDevice failed"); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto key = std::make_pair(dev, n);
+    auto it = g_chirp_cache.find(key);
+    if (it != g_chirp_cache.end()) return &it->second;
+    const int64_t m = std::max<int64_t>(16, next_pow2(2 * n - 1));
+    std::vector<long double> wr((size_t)n), wi((size_t)n);
+    std::vector<cplx> w((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t q = (j * j) % (2 * n);  // angle pi q / n, reduced exactly in integers
+        const long double a = kTwoPiL / 2 * (long double)q / (long double)n;
+        wr[(size_t)j] = cosl(a);
+        wi[(size_t)j] = -sinl(a);
+        w[(size_t)j] = mk((double)wr[(size_t)j], (double)wi[(size_t)j]);
+    }
+    std::vector<long double> br((size_t)m, 0.0L), bi((size_t)m, 0.0L);
+    for (int64_t l = 0; l < n; ++l) {
+        br[(size_t)l] = wr[(size_t)l];
+        bi[(size_t)l] = -wi[(size_t)l];
+        if (l > 0) { br[(size_t)(m - l)] = wr[(size_t)l]; bi[(size_t)(m - l)] = -wi[(size_t)l]; }
+    }
+    host_fft_ld(br, bi);
+    std::vector<cplx> B((size_t)m);
+    for (int64_t l = 0; l < m; ++l) B[(size_t)l] = mk((double)br[(size_t)l], (double)bi[(size_t)l]);
+    Chirp c;
+    c.n = n; c.m = m;
+    c.w = upload(w);
+    c.B = c.w ? upload(B) : nullptr;
+    if (!c.w || !c.B) return nullptr;
+    auto res = g_chirp_cache.emplace(key, c);
+    return &res.first->second;
 }
 
 // ------------------------------------------------------------------------------
@@ -113,33 +202,146 @@ struct WindowedValue {
 };
 
 // ------------------------------------------------------------------------------
-// generic rows-pass functors
+// sources and sinks
 // ------------------------------------------------------------------------------
-// complex array rows; slot = row
-struct RowLoadC {
-    const cplx* a; int64_t ld;
-    __device__ inline cplx operator()(int64_t slot, int j) const { return a[slot * ld + j]; }
+enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULCONJ = 4 };
+
+// Element (row, j) of the row-FFT input, j in [0, fft length).
+struct RowSource {
+    int mode;
+    int64_t n_in;        // logical row length; j >= n_in reads as 0 (Bluestein/zero padding)
+    const cplx* chirp;   // optional: multiply element j < n_in by chirp[j]
+    // SRC_ARRAY: a[row*ld + j];  SRC_MULCONJ: conj(a[row*ld + j] * b[j])
+    const cplx* a; int64_t ld; const cplx* b;
+    // SRC_SSPEC (dynspec.py:3667-3685)
+    WindowedValue wv; const double* m2; int64_t nt_eff; int prewhite;
+    // SRC_CS: np.pad(dspec, right, constant)  (ththmod.py:777-782): reuses wv.dyn / wv.nt
+    double pad;
+    // SRC_MODEL: conj(ifftshift(recov)) -- real(ifft2(x)) == real(fft2(conj x))/(R C)
+    int64_t R, C;
+
+    __device__ inline double sspec_d(int64_t r, int64_t c) const { return wv.at(r, c) - m2[0]; }
+
+    __device__ inline cplx operator()(int64_t r, int64_t j) const {
+        if (j >= n_in) return mk(0.0, 0.0);
+        cplx v;
+        switch (mode) {
+            case SRC_ARRAY: v = a[r * ld + j]; break;
+            case SRC_MULCONJ: v = conj(a[r * ld + j] * b[j]); break;
+            case SRC_SSPEC:
+                if (j >= nt_eff) v = mk(0.0, 0.0);
+                else if (!prewhite) v = mk(sspec_d(r, j), 0.0);
+                else  // convolve2d([[1,-1],[-1,1]], dyn, 'valid')  (dynspec.py:3681)
+                    v = mk(sspec_d(r + 1, j + 1) - sspec_d(r + 1, j) - sspec_d(r, j + 1) + sspec_d(r, j), 0.0);
+                break;
+            case SRC_CS: v = mk(j < wv.nt ? wv.dyn[r * wv.nt + j] : pad, 0.0); break;
+            default: {  // SRC_MODEL
+                const int64_t sr = (r + R / 2) % R, sc = (j + C / 2) % C;
+                v = conj(a[sr * C + sc]);
+            }
+        }
+        if (chirp) v = v * chirp[j];
+        return v;
+    }
+};
+
+// First column pass: value at (row r, col c) of the row-transformed, padded array.
+struct ColSource {
+    const cplx* a; int64_t ld;  // row-FFT result
+    int64_t nvalid;             // rows computed by the row pass
+    double fill0;               // rows >= nvalid hold fill0 at c == 0, 0 elsewhere
+    int64_t n_in;               // logical column length; r >= n_in reads as 0 (Bluestein padding)
+    const cplx* row_post_w;     // rows went through Bluestein: value = w[c] * conj(a) * row_post_scale
+    double row_post_scale;
+    const cplx* chirp;          // column Bluestein pass 1: multiply by chirp[r]
+    const cplx* mulconj_b;      // column Bluestein pass 2: conj(a * b[r]) (then nothing else applies)
+
+    __device__ inline cplx operator()(int64_t, int64_t r, int64_t c) const {
+        if (mulconj_b) return conj(a[r * ld + c] * mulconj_b[r]);
+        if (r >= n_in) return mk(0.0, 0.0);
+        cplx v;
+        if (r < nvalid) {
+            v = a[r * ld + c];
+            if (row_post_w) { v = row_post_w[c] * conj(v); v = v * row_post_scale; }
+        } else {
+            v = mk(c == 0 ? fill0 : 0.0, 0.0);
+        }
+        if (chirp) v = v * chirp[r];
+        return v;
+    }
+};
+
+enum SinkMode { SINK_ARRAY = 0, SINK_SSPEC = 1, SINK_CS = 2, SINK_MODEL = 3 };
+
+// Final value at natural frequency (k1 along the strided axis, c along the contiguous one).
+struct ColSink {
+    int mode;
+    int64_t R, C;               // logical transform shape
+    const cplx* col_post_w;     // column Bluestein: v = w[k1] * conj(v) * col_post_scale, k1 < R only
+    double col_post_scale;
+    cplx* out_c; int64_t ld;    // SINK_ARRAY / SINK_CS
+    double* out_d;              // SINK_SSPEC / SINK_MODEL
+    int halve, prewhite; const double* pd_fd; const double* pd_td;   // SINK_SSPEC
+    int64_t mask_lo, mask_hi; int incoherent;                        // SINK_CS
+    double scale;                                                    // SINK_MODEL
+
+    __device__ inline void operator()(int64_t, int64_t k1, int64_t c, cplx v) const {
+        if (k1 >= R) return;
+        if (col_post_w) { v = col_post_w[k1] * conj(v); v = v * col_post_scale; }
+        switch (mode) {
+            case SINK_ARRAY: out_c[k1 * ld + c] = v; break;
+            case SINK_SSPEC: {
+                // |.|^2, fftshift, keep tdel >= 0, post-darken, dB (dynspec.py:3686-3721)
+                int64_t orow;
+                if (halve) {
+                    if (k1 >= R / 2) return;
+                    orow = k1;
+                } else {
+                    orow = (k1 + R / 2) % R;
+                }
+                const int64_t ocol = (c + C / 2) % C;
+                double p = v.x * v.x + v.y * v.y;
+                if (prewhite) {
+                    double pd = pd_fd[ocol] * pd_td[orow];
+                    if (ocol == C / 2 || orow == 0) pd = 1.0;
+                    p = p / pd;
+                }
+                out_d[orow * C + ocol] = 10.0 * log10(p);
+                break;
+            }
+            case SINK_CS: {
+                // fftshift on both axes, zero the masked delay rows, optional abs
+                // (ththmod.py:786-787, 801)
+                const int64_t orow = (k1 + R / 2) % R, ocol = (c + C / 2) % C;
+                if (orow >= mask_lo && orow < mask_hi) v = mk(0.0, 0.0);
+                if (incoherent) v = mk(hypot(v.x, v.y), 0.0);
+                out_c[orow * C + ocol] = v;
+                break;
+            }
+            default: out_d[k1 * C + c] = v.x * scale;  // SINK_MODEL
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------
+// row pass (contiguous axis): power-of-two lengths
+// ------------------------------------------------------------------------------
+struct SlotIsRow {
+    RowSource in;
+    __device__ inline cplx operator()(int64_t s, int j) const { return in(s, j); }
 };
 struct RowStoreC {
     cplx* a; int64_t ld;
     __device__ inline void operator()(int64_t slot, int k, cplx v) const { a[slot * ld + k] = v; }
 };
-
-template <class Inner>
-struct SlotIsRow {
-    Inner in;
-    __device__ inline cplx operator()(int64_t s, int j) const { return in(s, j); }
-};
-
 // Decimated long rows (n = n1 * n2): slot = row*n1 + j1, element j2 -> x[row][j1 + n1*j2];
-// result y[j1][k2] * W_n^{j1 k2} -> dst[row][j1*n2 + k2].  `Inner` maps (row, j) -> cplx.
-template <class Inner>
+// result y[j1][k2] * W_n^{j1 k2} -> dst[row][j1*n2 + k2].
 struct DecimLoad {
-    Inner in; int n1;
+    RowSource in; int n1;
     __device__ inline cplx operator()(int64_t slot, int j2) const {
         const int64_t r = slot / n1;
         const int j1 = (int)(slot - r * n1);
-        return in(r, j1 + n1 * j2);
+        return in(r, (int64_t)j1 + (int64_t)n1 * j2);
     }
 };
 struct DecimStore {
@@ -152,72 +354,162 @@ struct DecimStore {
     }
 };
 
-// FFT of length n along the contiguous axis of `nrows` rows produced by `in(row, j)`,
-// written to dst[row][0..n) (row stride ld).  Handles n up to 2^17 by a decimated split.
-template <class Inner>
-static int32_t rows_fft(Inner in, int64_t nrows, int64_t n, cplx* dst, int64_t ld,
-                        hipStream_t stream) {
+// FFT of power-of-two length n of `nrows` rows produced by `in`, into dst[row][0..n)
+// (row stride ld).  dst must not alias what `in` reads when n > 8192.
+static int32_t rows_fft_pow2(const RowSource& in, int64_t nrows, int64_t n, cplx* dst, int64_t ld,
+                             hipStream_t stream) {
     SCINT_REQUIRE(is_pow2(n) && n >= 16, "rows_fft: n must be a power of two >= 16");
-    if (n <= 8192) {
-        return launch_fft_rows(n, nrows, SlotIsRow<Inner>{in}, RowStoreC{dst, ld}, stream);
-    }
+    if (n <= 8192) return launch_fft_rows(n, nrows, SlotIsRow{in}, RowStoreC{dst, ld}, stream);
     const int64_t n2 = 4096, n1 = n / n2;
     SCINT_REQUIRE(n1 <= 32, "rows_fft: n too large (max 131072)");
     const cplx* tw_n = twiddle_table(n);
     if (!tw_n) return SCINT_E_HIP;
-    int32_t rc = launch_fft_rows(n2, nrows * n1, DecimLoad<Inner>{in, (int)n1},
+    int32_t rc = launch_fft_rows(n2, nrows * n1, DecimLoad{in, (int)n1},
                                  DecimStore{dst, ld, (int)n1, (int)n2, tw_n}, stream);
     if (rc != SCINT_OK) return rc;
-    // radix-n1 pass over j1 (stride n2) for every (row, k2): view dst as [nrows][n1][n2]
-    // batches can exceed the 65535 grid.z limit: chunk them
+    // radix-n1 pass over j1 (stride n2) for every (row, k2): view dst as [nrows][n1][n2];
+    // grid.z is limited to 65535, so chunk the rows
     for (int64_t b0 = 0; b0 < nrows; b0 += 32768) {
         const int64_t nb = std::min<int64_t>(32768, nrows - b0);
-        ArrayLoad al2{dst + b0 * ld, n2, ld};
-        ArrayStore as2{dst + b0 * ld, n2, ld};
-        rc = run_cols_fft(n1, n2, nb, al2, al2, as2, as2, stream);
+        ArrayLoad al{dst + b0 * ld, n2, ld};
+        ArrayStore as{dst + b0 * ld, n2, ld};
+        rc = run_cols_fft(n1, n2, nb, al, al, as, as, stream);
         if (rc != SCINT_OK) return rc;
     }
     return SCINT_OK;
 }
 
 // ------------------------------------------------------------------------------
-// scint_fft2
+// generic 2-D driver
 // ------------------------------------------------------------------------------
-struct InnerArray {
-    const cplx* a; int64_t ld;
-    __device__ inline cplx operator()(int64_t r, int j) const { return a[r * ld + j]; }
+struct Fft2Plan {
+    int64_t R, C;        // logical shape
+    int64_t nvalid;      // rows the row pass must transform (the rest: fill0 at col 0)
+    int64_t mR, mC;      // power-of-two working lengths (== R/C when those are powers of two)
+    bool blue_r, blue_c;
+    size_t off_rowA, off_rowB, off_colA, off_colB, total;   // workspace carve (bytes)
 };
 
-static int32_t fft2_pow2(const cplx* in, cplx* out, int64_t rows, int64_t cols, cplx* ws,
-                         hipStream_t stream) {
-    int32_t rc = rows_fft(InnerArray{in, cols}, rows, cols, ws, cols, stream);
-    if (rc != SCINT_OK) return rc;
-    ArrayLoad al{ws, cols, 0};
-    ArrayStore as{ws, cols, 0};
-    ArrayStore fin{out, cols, 0};
-    return run_cols_fft(rows, cols, 1, al, al, as, fin, stream);
+static Fft2Plan make_plan(int64_t R, int64_t C, int64_t nvalid) {
+    Fft2Plan p;
+    p.R = R; p.C = C; p.nvalid = nvalid;
+    p.blue_r = !is_pow2(R);
+    p.blue_c = !(is_pow2(C) && C >= 16);
+    p.mR = p.blue_r ? std::max<int64_t>(16, next_pow2(2 * R - 1)) : R;
+    p.mC = p.blue_c ? std::max<int64_t>(16, next_pow2(2 * C - 1)) : C;
+    size_t off = 0;
+    auto take = [&](size_t elems) { off = align_up(off, 256); size_t o = off; off += elems * sizeof(cplx); return o; };
+    // row result [nvalid][mC]; Bluestein rows need a second buffer of the same size
+    p.off_rowA = take((size_t)nvalid * (size_t)p.mC);
+    p.off_rowB = p.blue_c ? take((size_t)nvalid * (size_t)p.mC) : p.off_rowA;
+    // column working array [mR][C]; Bluestein columns need a second one
+    p.off_colA = take((size_t)p.mR * (size_t)C);
+    p.off_colB = p.blue_r ? take((size_t)p.mR * (size_t)C) : p.off_colA;
+    p.total = align_up(off, 256);
+    return p;
 }
+
+// src: RowSource with mode/payload set (n_in, chirp are managed here).
+// fill0: value at column 0 of the row-FFT for rows >= nvalid (constant-padded rows), else 0.
+// sink: ColSink with mode/payload set (R, C, col_post_* are managed here).
+static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t R, int64_t C,
+                            ColSink sink, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    SCINT_REQUIRE(R >= 1 && C >= 1 && nvalid >= 0 && nvalid <= R, "fft2: bad shape");
+    const Fft2Plan p = make_plan(R, C, nvalid);
+    if (workspace_bytes < p.total) { set_error("scint: fft workspace too small"); return SCINT_E_WORKSPACE; }
+    char* base = (char*)workspace;
+    cplx* rowA = (cplx*)(base + p.off_rowA);
+    cplx* rowB = (cplx*)(base + p.off_rowB);
+    cplx* colA = (cplx*)(base + p.off_colA);
+    cplx* colB = (cplx*)(base + p.off_colB);
+    int32_t rc;
+
+    // ---- rows ---------------------------------------------------------------------
+    ColSource cs;
+    cs.nvalid = nvalid; cs.fill0 = fill0; cs.n_in = R;
+    cs.row_post_w = nullptr; cs.row_post_scale = 1.0; cs.chirp = nullptr; cs.mulconj_b = nullptr;
+    src.n_in = C;
+    src.chirp = nullptr;
+    if (!p.blue_c) {
+        rc = rows_fft_pow2(src, nvalid, C, rowA, C, stream);
+        if (rc != SCINT_OK) return rc;
+        cs.a = rowA; cs.ld = C;
+    } else {
+        const Chirp* ch = chirp_table(C);
+        if (!ch) return SCINT_E_HIP;
+        src.chirp = ch->w;
+        rc = rows_fft_pow2(src, nvalid, p.mC, rowA, p.mC, stream);
+        if (rc != SCINT_OK) return rc;
+        RowSource s2;
+        s2.mode = SRC_MULCONJ; s2.n_in = p.mC; s2.chirp = nullptr;
+        s2.a = rowA; s2.ld = p.mC; s2.b = ch->B;
+        rc = rows_fft_pow2(s2, nvalid, p.mC, rowB, p.mC, stream);
+        if (rc != SCINT_OK) return rc;
+        cs.a = rowB; cs.ld = p.mC;
+        cs.row_post_w = ch->w; cs.row_post_scale = 1.0 / (double)p.mC;
+    }
+
+    // ---- columns ------------------------------------------------------------------
+    sink.R = R; sink.C = C;
+    sink.col_post_w = nullptr; sink.col_post_scale = 1.0;
+    if (R == 1) {  // nothing to transform along the strided axis
+        // a length-1 "FFT": push the row result through the sink with a trivial pass
+        SCINT_REQUIRE(false, "fft2: a single-row transform is not supported");
+    }
+    if (!p.blue_r) {
+        ArrayLoad mid_ld{colA, C, 0};
+        ArrayStore mid_st{colA, C, 0};
+        return run_cols_fft(R, C, 1, cs, mid_ld, mid_st, sink, stream);
+    }
+    const Chirp* ch = chirp_table(R);
+    if (!ch) return SCINT_E_HIP;
+    cs.chirp = ch->w;
+    {   // pass 1: FFT_mR(x w) -> colB (mids in place in colA)
+        ArrayLoad mid_ld{colA, C, 0};
+        ArrayStore mid_st{colA, C, 0};
+        ColSink to_b;
+        to_b.mode = SINK_ARRAY; to_b.R = p.mR; to_b.C = C; to_b.col_post_w = nullptr; to_b.col_post_scale = 1.0;
+        to_b.out_c = colB; to_b.ld = C;
+        rc = run_cols_fft(p.mR, C, 1, cs, mid_ld, mid_st, to_b, stream);
+        if (rc != SCINT_OK) return rc;
+    }
+    {   // pass 2: FFT_mR(conj(A B)) -> w[k] conj(.)/mR -> sink  (mids in place in colB... the
+        // first pass of run_cols_fft reads colB and writes colA, later passes stay in colA)
+        ColSource c2;
+        c2.a = colB; c2.ld = C; c2.nvalid = p.mR; c2.fill0 = 0.0; c2.n_in = p.mR;
+        c2.row_post_w = nullptr; c2.row_post_scale = 1.0; c2.chirp = nullptr; c2.mulconj_b = ch->B;
+        ArrayLoad mid_ld{colA, C, 0};
+        ArrayStore mid_st{colA, C, 0};
+        sink.col_post_w = ch->w; sink.col_post_scale = 1.0 / (double)p.mR;
+        return run_cols_fft(p.mR, C, 1, c2, mid_ld, mid_st, sink, stream);
+    }
+}
+
+static size_t fft2_general_ws(int64_t R, int64_t C, int64_t nvalid) { return make_plan(R, C, nvalid).total; }
 
 }  // namespace scint
 
 using namespace scint;
 
+// ------------------------------------------------------------------------------
+// scint_fft2
+// ------------------------------------------------------------------------------
 extern "C" int32_t scint_fft2_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes) {
     SCINT_REQUIRE(bytes != nullptr, "fft2_workspace_bytes: null output");
-    SCINT_REQUIRE(rows >= 1 && cols >= 1, "fft2_workspace_bytes: bad shape");
-    *bytes = (size_t)rows * (size_t)cols * sizeof(cplx) + 256;
+    SCINT_REQUIRE(rows >= 2 && cols >= 1, "fft2_workspace_bytes: bad shape");
+    *bytes = fft2_general_ws(rows, cols, rows) + 256;
     return SCINT_OK;
 }
 
 extern "C" int32_t scint_fft2(const scint_c128* in, scint_c128* out, int64_t rows, int64_t cols,
                               void* workspace, size_t workspace_bytes, void* stream) {
     SCINT_REQUIRE(in && out && workspace, "fft2: null pointer");
-    SCINT_REQUIRE(is_pow2(rows) && is_pow2(cols) && rows >= 2 && cols >= 16,
-                  "fft2: shape must be powers of two (rows >= 2, cols >= 16)");
-    size_t need = 0;
-    scint_fft2_workspace_bytes(rows, cols, &need);
-    if (workspace_bytes < need) { set_error("scint: fft2 workspace too small"); return SCINT_E_WORKSPACE; }
-    return fft2_pow2((const cplx*)in, (cplx*)out, rows, cols, (cplx*)workspace, (hipStream_t)stream);
+    SCINT_REQUIRE(rows >= 2 && cols >= 1, "fft2: bad shape");
+    RowSource src{};
+    src.mode = SRC_ARRAY; src.a = (const cplx*)in; src.ld = cols;
+    ColSink sink{};
+    sink.mode = SINK_ARRAY; sink.out_c = (cplx*)out; sink.ld = cols;
+    return fft2_general(src, rows, 0.0, rows, cols, sink, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------
@@ -235,67 +527,18 @@ extern "C" int32_t scint_mean(const double* x, int64_t n, double* mean_out, void
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = hip_fail(e, "mean copy-back", __FILE__, __LINE__);
     }
-    hipFree(scratch);
+    (void)hipFree(scratch);
     return rc;
 }
 
 // ------------------------------------------------------------------------------
 // scint_sspec
 // ------------------------------------------------------------------------------
-namespace scint {
-
-// rows-pass input of calc_sspec: the (optionally prewhitened) tapered, twice
-// mean-subtracted dynamic spectrum, zero-padded on the right (dynspec.py:3667-3685)
-struct SspecInner {
-    WindowedValue w; const double* m2; int64_t nf_eff, nt_eff; int prewhite;
-    __device__ inline double d(int64_t r, int64_t c) const { return w.at(r, c) - m2[0]; }
-    __device__ inline cplx operator()(int64_t r, int j) const {
-        if (j >= nt_eff) return mk(0.0, 0.0);
-        if (!prewhite) return mk(d(r, j), 0.0);
-        // convolve2d([[1,-1],[-1,1]], dyn, 'valid')  (dynspec.py:3681)
-        return mk(d(r + 1, j + 1) - d(r + 1, j) - d(r, j + 1) + d(r, j), 0.0);
-    }
-};
-
-// first column pass: rows >= nvalid of the padded array are zero (or a constant-row FFT)
-struct PaddedColLoad {
-    const cplx* a; int64_t ld; int64_t nvalid; double col0_fill;
-    __device__ inline cplx operator()(int64_t, int64_t r, int64_t c) const {
-        if (r < nvalid) return a[r * ld + c];
-        return mk(c == 0 ? col0_fill : 0.0, 0.0);
-    }
-};
-
-// last column pass of calc_sspec: |.|^2, fftshift, keep tdel >= 0, post-darken, dB
-// (dynspec.py:3686-3689, 3704-3721)
-struct SspecStore {
-    double* sec; int64_t R, C; int halve; int prewhite; const double* pd_fd; const double* pd_td;
-    __device__ inline void operator()(int64_t, int64_t k1, int64_t c, cplx v) const {
-        int64_t orow;
-        if (halve) {
-            if (k1 >= R / 2) return;
-            orow = k1;
-        } else {
-            orow = (k1 + R / 2) % R;
-        }
-        const int64_t ocol = (c + C / 2) % C;
-        double p = v.x * v.x + v.y * v.y;
-        if (prewhite) {
-            double pd = pd_fd[ocol] * pd_td[orow];
-            if (ocol == C / 2 || orow == 0) pd = 1.0;
-            p = p / pd;
-        }
-        sec[orow * C + ocol] = 10.0 * log10(p);
-    }
-};
-
-}  // namespace scint
-
 extern "C" int32_t scint_sspec_workspace_bytes(int64_t nf, int64_t nt, size_t* bytes) {
     SCINT_REQUIRE(bytes != nullptr, "sspec_workspace_bytes: null output");
     SCINT_REQUIRE(nf >= 2 && nt >= 2, "sspec_workspace_bytes: bad shape");
-    const int64_t R = 2 * next_pow2(nf), C = 2 * next_pow2(nt);
-    *bytes = (size_t)R * (size_t)C * sizeof(cplx) + sizeof(double) * (kRedBlocks + 8) + 1024;
+    const int64_t R = 2 * next_pow2(nf), C = std::max<int64_t>(16, 2 * next_pow2(nt));
+    *bytes = fft2_general_ws(R, C, nf) + sizeof(double) * (kRedBlocks + 8) + 1024;
     return SCINT_OK;
 }
 
@@ -313,9 +556,9 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
     scint_sspec_workspace_bytes(nf, nt, &need);
     if (workspace_bytes < need) { set_error("scint: sspec workspace too small"); return SCINT_E_WORKSPACE; }
     const int64_t R = 2 * next_pow2(nf), C = 2 * next_pow2(nt);  // dynspec.py:3677-3678
-    SCINT_REQUIRE(C >= 16, "sspec: nt too small");
-    Carver cv(workspace, workspace_bytes);
-    cplx* ws = cv.take<cplx>((size_t)R * (size_t)C);
+    SCINT_REQUIRE(C >= 16, "sspec: nt must be at least 5");
+    const size_t fft_bytes = fft2_general_ws(R, C, nf);
+    Carver cv((char*)workspace + align_up(fft_bytes, 256), workspace_bytes - align_up(fft_bytes, 256));
     double* partial = cv.take<double>(kRedBlocks);
     double* scal = cv.take<double>(8);  // [0] = mean1, [1] = mean2
 
@@ -326,46 +569,23 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
     if (rc != SCINT_OK) return rc;
 
     const int64_t nf_eff = prewhite ? nf - 1 : nf, nt_eff = prewhite ? nt - 1 : nt;
-    SspecInner inner{wv, scal + 1, nf_eff, nt_eff, prewhite};
-    rc = rows_fft(inner, nf_eff, C, ws, C, stream);
-    if (rc != SCINT_OK) return rc;
-    PaddedColLoad first{ws, C, nf_eff, 0.0};
-    ArrayLoad mid_ld{ws, C, 0};
-    ArrayStore mid_st{ws, C, 0};
-    SspecStore last{sec_out, R, C, halve, prewhite, pd_fd, pd_td};
-    return run_cols_fft(R, C, 1, first, mid_ld, mid_st, last, stream);
+    RowSource src{};
+    src.mode = SRC_SSPEC; src.wv = wv; src.m2 = scal + 1; src.nt_eff = nt_eff; src.prewhite = prewhite;
+    ColSink sink{};
+    sink.mode = SINK_SSPEC; sink.out_d = sec_out; sink.halve = halve; sink.prewhite = prewhite;
+    sink.pd_fd = pd_fd; sink.pd_td = pd_td;
+    return fft2_general(src, nf_eff, 0.0, R, C, sink, workspace, fft_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------
 // scint_cs
 // ------------------------------------------------------------------------------
-namespace scint {
-
-struct CsInner {  // np.pad(dspec, right/bottom, constant)  (ththmod.py:777-782)
-    const double* dspec; int64_t nt; double pad;
-    __device__ inline cplx operator()(int64_t r, int j) const {
-        return mk(j < nt ? dspec[r * nt + j] : pad, 0.0);
-    }
-};
-
-// fftshift on both axes, zero the masked delay rows, optional abs (ththmod.py:786-787, 801)
-struct CsStore {
-    cplx* cs; int64_t R, C, mask_lo, mask_hi; int incoherent;
-    __device__ inline void operator()(int64_t, int64_t k1, int64_t c, cplx v) const {
-        const int64_t orow = (k1 + R / 2) % R, ocol = (c + C / 2) % C;
-        if (orow >= mask_lo && orow < mask_hi) v = mk(0.0, 0.0);
-        if (incoherent) v = mk(hypot(v.x, v.y), 0.0);
-        cs[orow * C + ocol] = v;
-    }
-};
-
-}  // namespace scint
-
 extern "C" int32_t scint_cs_workspace_bytes(int64_t nf, int64_t nt, int64_t npad, size_t* bytes) {
     SCINT_REQUIRE(bytes != nullptr, "cs_workspace_bytes: null output");
     SCINT_REQUIRE(nf >= 1 && nt >= 1 && npad >= 0, "cs_workspace_bytes: bad shape");
     const int64_t R = (npad + 1) * nf, C = (npad + 1) * nt;
-    *bytes = (size_t)R * (size_t)C * sizeof(cplx) + 1024;
+    SCINT_REQUIRE(R >= 2, "cs_workspace_bytes: need at least two delay rows");
+    *bytes = fft2_general_ws(R, C, nf) + 1024;
     return SCINT_OK;
 }
 
@@ -377,43 +597,19 @@ extern "C" int32_t scint_cs(const double* dspec, int64_t nf, int64_t nt, int64_t
     SCINT_REQUIRE(nf >= 1 && nt >= 1 && npad >= 0, "cs: bad shape");
     hipStream_t stream = (hipStream_t)stream_;
     const int64_t R = (npad + 1) * nf, C = (npad + 1) * nt;
-    SCINT_REQUIRE(is_pow2(R) && is_pow2(C) && R >= 2 && C >= 16,
-                  "cs: padded shape must be powers of two (rows >= 2, cols >= 16)");
-    size_t need = 0;
-    scint_cs_workspace_bytes(nf, nt, npad, &need);
-    if (workspace_bytes < need) { set_error("scint: cs workspace too small"); return SCINT_E_WORKSPACE; }
-    cplx* ws = (cplx*)workspace;
-    int32_t rc = rows_fft(CsInner{dspec, nt, pad_value}, nf, C, ws, C, stream);
-    if (rc != SCINT_OK) return rc;
-    PaddedColLoad first{ws, C, nf, pad_value * (double)C};
-    ArrayLoad mid_ld{ws, C, 0};
-    ArrayStore mid_st{ws, C, 0};
-    CsStore last{(cplx*)cs_out, R, C, mask_lo, mask_hi, incoherent};
-    return run_cols_fft(R, C, 1, first, mid_ld, mid_st, last, stream);
+    SCINT_REQUIRE(R >= 2, "cs: need at least two delay rows");
+    RowSource src{};
+    src.mode = SRC_CS; src.wv.dyn = dspec; src.wv.nt = nt; src.pad = pad_value;
+    ColSink sink{};
+    sink.mode = SINK_CS; sink.out_c = (cplx*)cs_out; sink.ld = C;
+    sink.mask_lo = mask_lo; sink.mask_hi = mask_hi; sink.incoherent = incoherent;
+    // rows >= nf are constant rows of pad_value: their FFT is C*pad at column 0
+    return fft2_general(src, nf, pad_value * (double)C, R, C, sink, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------
 // scint_model_from_recov
 // ------------------------------------------------------------------------------
-namespace scint {
-
-// conj(ifftshift(recov)): real(ifft2(x)) == real(fft2(conj(x))) / (R C)
-struct ModelInner {
-    const cplx* recov; int64_t R, C;
-    __device__ inline cplx operator()(int64_t r, int j) const {
-        const int64_t sr = (r + R / 2) % R, sc = ((int64_t)j + C / 2) % C;
-        return conj(recov[sr * C + sc]);
-    }
-};
-struct ModelStore {
-    double* model; int64_t C; double scale;
-    __device__ inline void operator()(int64_t, int64_t k1, int64_t c, cplx v) const {
-        model[k1 * C + c] = v.x * scale;
-    }
-};
-
-}  // namespace scint
-
 extern "C" int32_t scint_model_workspace_bytes(int64_t ntau, int64_t nfd, size_t* bytes) {
     return scint_fft2_workspace_bytes(ntau, nfd, bytes);
 }
@@ -422,19 +618,12 @@ extern "C" int32_t scint_model_from_recov(const scint_c128* recov, int64_t ntau,
                                           double* model_out, void* workspace,
                                           size_t workspace_bytes, void* stream_) {
     SCINT_REQUIRE(recov && model_out && workspace, "model: null pointer");
-    SCINT_REQUIRE(is_pow2(ntau) && is_pow2(nfd) && ntau >= 2 && nfd >= 16,
-                  "model: shape must be powers of two (rows >= 2, cols >= 16)");
-    hipStream_t stream = (hipStream_t)stream_;
-    size_t need = 0;
-    scint_fft2_workspace_bytes(ntau, nfd, &need);
-    if (workspace_bytes < need) { set_error("scint: model workspace too small"); return SCINT_E_WORKSPACE; }
-    cplx* ws = (cplx*)workspace;
-    int32_t rc = rows_fft(ModelInner{(const cplx*)recov, ntau, nfd}, ntau, nfd, ws, nfd, stream);
-    if (rc != SCINT_OK) return rc;
-    ArrayLoad al{ws, nfd, 0};
-    ArrayStore as{ws, nfd, 0};
-    ModelStore fin{model_out, nfd, 1.0 / ((double)ntau * (double)nfd)};
-    return run_cols_fft(ntau, nfd, 1, al, al, as, fin, stream);
+    SCINT_REQUIRE(ntau >= 2 && nfd >= 1, "model: bad shape");
+    RowSource src{};
+    src.mode = SRC_MODEL; src.a = (const cplx*)recov; src.R = ntau; src.C = nfd;
+    ColSink sink{};
+    sink.mode = SINK_MODEL; sink.out_d = model_out; sink.scale = 1.0 / ((double)ntau * (double)nfd);
+    return fft2_general(src, ntau, 0.0, ntau, nfd, sink, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 // ------------------------------------------------------------------------------
@@ -464,7 +653,7 @@ extern "C" int32_t scint_chisq(const double* model, int64_t ld_model, const doub
     int32_t rc = launch_reduce(ChisqValue{model, ld_model, dspec, nt, mask}, nf * nt, 1.0 / noise_n,
                                partial, out, stream);
     hipError_t e = hipStreamSynchronize(stream);
-    hipFree(partial);
+    (void)hipFree(partial);
     if (rc == SCINT_OK && e != hipSuccess) rc = hip_fail(e, "chisq sync", __FILE__, __LINE__);
     return rc;
 }

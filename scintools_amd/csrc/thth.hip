@@ -8,6 +8,7 @@
 #include <float.h>
 #include <math.h>
 
+#include "prof.hpp"
 #include "thth.hpp"
 
 namespace scint {
@@ -117,8 +118,10 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
     if (njobs <= 0 || nmax <= 0) return SCINT_OK;
     const unsigned nt = (unsigned)ceil_div(nmax, kTile);
     SCINT_REQUIRE(nt <= 65535 && njobs <= 65535, "gather: grid too large");
+    const int slot = profiler().begin(kProfGather, stream);
     hipLaunchKernelGGL(thth_gather_kernel, dim3(nt, nt, (unsigned)njobs), dim3(256), 0, stream, cs, g,
                        th_cents, M, jobs_dev);
+    profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

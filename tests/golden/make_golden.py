@@ -138,13 +138,18 @@ def gen_sim():
                     ("bartlett", dict(window="bartlett", window_frac=0.2)),
                     ("nowindow", dict(window=None))):
         fdop, tdel, sec = dyn.calc_sspec(return_sspec=True, **kw)
-        out[f"sec_{tag}"] = sec
+        if tag in ("default", "prewhite"):
+            out[f"sec_{tag}"] = sec        # float32-input path (see below)
         out[f"fdop_{tag}"] = fdop
         out[f"tdel_{tag}"] = tdel
+        # Simulation's dyn is float32 and NumPy 2 keeps the FFT in single precision for it;
+        # the same call on a float64 copy pins the double-precision answer
+        out[f"sec64_{tag}"] = dyn.calc_sspec(input_dyn=np.array(dyn.dyn, dtype=np.float64), **kw)[2]
     # odd, non-power-of-two shape through input_dyn
     sub = np.array(dyn.dyn[:75, :101])
     fdop, tdel, sec = dyn.calc_sspec(input_dyn=sub, prewhite=True)
     out.update(sub_sec=sec, sub_fdop=fdop, sub_tdel=tdel)
+    out["sub_sec64"] = dyn.calc_sspec(input_dyn=sub.astype(np.float64), prewhite=True)[2]
     dyn.calc_acf()
     out["acf"] = dyn.acf
     for n in ((101, 75), (128, 96), (20, 20)):

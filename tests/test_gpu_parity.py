@@ -41,7 +41,11 @@ def test_native_library_is_loaded(thth):
 # ------------------------------------------------------------------ FFT
 @pytest.mark.parametrize("shape", [(2, 16), (4, 32), (32, 64), (64, 128), (128, 256), (256, 512),
                                    (512, 1024), (1024, 2048), (16, 4096), (8, 8192), (4, 16384),
-                                   (2048, 16), (4096, 64), (8192, 32)])
+                                   (2048, 16), (4096, 64), (8192, 32),
+                                   # not powers of two: chirp-z on one or both axes
+                                   (2, 1), (3, 5), (7, 16), (16, 7), (75, 101), (128, 96), (96, 128),
+                                   (256, 600), (600, 256), (150, 1024), (1000, 30), (30, 5000),
+                                   (4500, 12)])
 def test_fft2_matches_numpy(thth, shape):
     import ctypes
     import torch
@@ -61,7 +65,8 @@ def test_fft2_matches_numpy(thth, shape):
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("nf,nt,npad", [(64, 64, 0), (64, 32, 1), (32, 128, 3), (256, 256, 0), (16, 16, 0)])
+@pytest.mark.parametrize("nf,nt,npad", [(64, 64, 0), (64, 32, 1), (32, 128, 3), (256, 256, 0), (16, 16, 0),
+                                        (64, 48, 1), (64, 150, 3), (75, 101, 0), (50, 20, 2)])
 @pytest.mark.parametrize("coher", [True, False])
 def test_conjugate_spectrum(thth, to, nf, nt, npad, coher):
     from scintools_amd.synth import arc_dynspec
@@ -179,6 +184,56 @@ def test_rev_map_vs_reference_golden(thth, golden, tag, k):
         assert np.array_equal(got == 0, ref == 0)      # same empty bins
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_modeler_and_chisq_vs_reference_golden(thth, golden, tag, k):
+    g = golden("thth_small.npz")
+    CS, tau, fd, eta, edges = g["CS"], g["tau"], g["fd"], g["etas"][k], g[f"edges_{tag}"]
+    red, thth2, recov, model, edges_red, w, V = thth.modeler(CS, tau, fd, eta, edges)
+    assert np.array_equal(red, g[f"red_{tag}{k}"])
+    assert np.array_equal(np.asarray(edges_red), g[f"edgesred_{tag}{k}"])
+    assert w == pytest.approx(float(g[f"mod_w_{tag}{k}"]), rel=1e-9)
+    Vr = g[f"mod_V_{tag}{k}"]
+    assert 1 - abs(np.vdot(Vr, V)) <= 1e-9
+    for got, key in ((thth2, "mod_thth2"), (recov, "mod_recov"), (model, "mod_model")):
+        ref = g[f"{key}_{tag}{k}"]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max(), key
+    chi = thth.chisq_calc(g["dyn"], CS, tau, fd, eta, edges, 1.0)
+    assert chi == pytest.approx(float(g[f"chisq_{tag}{k}"]), rel=1e-9)
+    mask = np.zeros(g["dyn"].shape, bool)
+    mask[::2, 1::3] = True
+    ref_model = g[f"mod_model_{tag}{k}"][: mask.shape[0], : mask.shape[1]]
+    chi_m = thth.chisq_calc(g["dyn"], CS, tau, fd, eta, edges, 2.5, mask=mask)
+    assert chi_m == pytest.approx(np.sum((ref_model - g["dyn"])[mask] ** 2) / 2.5, rel=1e-9)
+
+
+def test_single_search_end_to_end_vs_reference(thth, golden):
+    """Whole chunk search on the GPU (256 x 600 chirp-z FFT, sweep, fit) against the
+    reference's own single_search on the tutorial chunk and on the simulated chunk."""
+    g = golden("thth_sample.npz")
+    params = [g["chunk"], g["freq"], g["time"], g["etas"], g["edges"], None, False, 0.1,
+              int(g["npad"]), True, 0.0, False]
+    eta_fit, eta_sig, fm, tm, eigs = thth.single_search(params)
+    np.testing.assert_allclose(eigs, g["eigs"], rtol=1e-9)
+    assert float(eta_fit) == pytest.approx(float(g["eta_fit"]), rel=1e-6)
+    assert float(eta_sig) == pytest.approx(float(g["eta_sig"]), rel=1e-4)
+    assert float(fm) == pytest.approx(float(g["fmean"])) and float(tm) == pytest.approx(float(g["tmean"]))
+    params[9] = False
+    res = thth.single_search(params)
+    np.testing.assert_allclose(res[4], g["eigs_incoh"], rtol=1e-9)
+    assert float(res[0]) == pytest.approx(float(g["eta_fit_incoh"]), rel=1e-6)
+
+    s = golden("sim_sspec.npz")
+    dyn = s["dyn"].astype(np.float64)
+    dyn = dyn - np.nanmean(s["dyn"])
+    params = [dyn, s["freqs"], s["times"], s["sw_etas"], s["sw_edges"], None, False, float(s["sw_fw"]),
+              int(s["sw_npad"]), True, float(s["sw_tau_mask"]), False]
+    res = thth.single_search(params)
+    np.testing.assert_allclose(res[4], s["sw_eigs"], rtol=1e-6)     # reference ran on float32 input
+    assert float(res[0]) == pytest.approx(float(s["sw_eta_fit"]), rel=1e-5)
+
+
 def test_sspec_vs_reference_golden(golden):
     from scintools_amd.dynspec import Dynspec
 
@@ -194,7 +249,7 @@ def test_sspec_vs_reference_golden(golden):
              "bartlett": dict(window="bartlett", window_frac=0.2), "nowindow": dict(window=None)}
     for tag, kw in cases.items():
         fdop, tdel, sec = d.calc_sspec(return_sspec=True, **kw)
-        ref = g[f"sec_{tag}"]
+        ref = g[f"sec64_{tag}"]      # the reference run on a float64 copy of the input
         assert np.array_equal(fdop, g[f"fdop_{tag}"]) and np.array_equal(tdel, g[f"tdel_{tag}"])
         assert sec.shape == ref.shape
         # compare in linear power relative to the spectrum's peak: bins at the rounding
@@ -204,7 +259,10 @@ def test_sspec_vs_reference_golden(golden):
         strong = lref > 1e-6 * lref.max()
         assert np.abs(sec - ref)[strong].max() <= 1e-8, tag
     fdop, tdel, sec = d.calc_sspec(input_dyn=g["dyn"][:75, :101], prewhite=True)
-    lin, lref = 10 ** (sec / 10), 10 ** (g["sub_sec"] / 10)
+    lin, lref = 10 ** (sec / 10), 10 ** (g["sub_sec64"] / 10)
     assert np.abs(lin - lref).max() <= 1e-10 * lref.max()
     d.calc_sspec()
     assert d.sspec.shape == g["sec_default"].shape and d.fdop.shape == g["fdop_default"].shape
+    # against the reference's own single-precision result the agreement is float32-level
+    lin, lref = 10 ** (d.sspec / 10), 10 ** (g["sec_default"] / 10)
+    assert np.abs(lin - lref).max() <= 1e-5 * lref.max()

@@ -126,10 +126,17 @@ SSPEC_CASES = {
 @pytest.mark.parametrize("tag", sorted(SSPEC_CASES))
 def test_calc_sspec(golden, tag):
     g = golden("sim_sspec.npz")
-    fdop, tdel, sec = so.calc_sspec(g["dyn"], float(g["dt"]), float(g["df"]), **SSPEC_CASES[tag])
+    # float64 input: the double-precision answer (same NumPy calls: bit-equal)
+    dyn64 = g["dyn"].astype(np.float64)
+    fdop, tdel, sec = so.calc_sspec(dyn64, float(g["dt"]), float(g["df"]), **SSPEC_CASES[tag])
     assert np.array_equal(fdop, g[f"fdop_{tag}"])
     assert np.array_equal(tdel, g[f"tdel_{tag}"])
-    assert np.array_equal(sec, g[f"sec_{tag}"])       # same NumPy calls: bit-equal
+    assert np.array_equal(sec, g[f"sec64_{tag}"])
+    # the Simulation's own float32 dyn: NumPy 2 keeps that FFT in single precision
+    if f"sec_{tag}" in g.files:
+        assert g["dyn"].dtype == np.float32
+        sec32 = so.calc_sspec(g["dyn"], float(g["dt"]), float(g["df"]), **SSPEC_CASES[tag])[2]
+        assert np.array_equal(sec32, g[f"sec_{tag}"])
 
 
 def test_calc_sspec_odd_shape(golden):
@@ -137,6 +144,8 @@ def test_calc_sspec_odd_shape(golden):
     sub = g["dyn"][:75, :101]
     fdop, tdel, sec = so.calc_sspec(sub, float(g["dt"]), float(g["df"]), prewhite=True)
     assert np.array_equal(sec, g["sub_sec"])
+    sec64 = so.calc_sspec(sub.astype(np.float64), float(g["dt"]), float(g["df"]), prewhite=True)[2]
+    assert np.array_equal(sec64, g["sub_sec64"])
     assert np.array_equal(fdop, g["sub_fdop"]) and np.array_equal(tdel, g["sub_tdel"])
 
 
