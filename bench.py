@@ -15,9 +15,11 @@ curves are all-gathered at the end of each step.  Per-GPU work is fixed: weak sc
 `value` is the whole-job eta-points/s.
 
 Besides the contract fields the JSON line carries
-  roofline      the dominant kernel (eigen mat-vec): algorithmic bytes 16 N^2 per mat-vec
-                per eta summed over every Lanczos step of the timed region,
-                divided by the summed hipEvent time of that kernel's launches;
+  roofline      the dominant kernel (eigen mat-vec on the Hermitian tile-packed matrix):
+                algorithmic bytes 8 N (N+1) per mat-vec per eta -- every upper-triangle
+                element once; SURVEY.md 8d's 16 N^2 assumed the full matrix -- summed over
+                every Lanczos step of the timed region, divided by the summed hipEvent time
+                of that kernel's launches;
   cpu_baseline  the NumPy/SciPy oracle (a restatement of the reference) timed on this host
                 on a 3-eta sample of the same workload (rank 0, N=1 only).
 """
@@ -128,7 +130,8 @@ def main():
     alg_bytes = 0.0
     for _ in range(args.steps):
         eigs, info, fit = step()
-        alg_bytes += float(np.sum(16.0 * info["N"].astype(float) ** 2 * info["iters"]))
+        n_ = info["N"].astype(float)
+        alg_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"]))   # Hermitian: upper triangle once
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -142,7 +145,9 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        gather_bytes = float(np.sum(24.0 * info["N"].astype(float) ** 2 - 8.0 * info["N"])) * args.steps
+        n_ = info["N"].astype(float)
+        # packed gather: one CS read per strict-upper element + the upper-triangle tiles written
+        gather_bytes = float(np.sum(8.0 * n_ * (n_ - 1.0) + 8.0 * n_ * (n_ + 1.0))) * args.steps
         mv_s = ms[1] / 1e3
         achieved = alg_bytes / mv_s / 1e9 if mv_s > 0 else 0.0
         out = {
@@ -166,13 +171,13 @@ def main():
                        "lanczos_steps_mean": float(info["iters"].mean()),
                        "batch": int(info["batch"]), "failed_etas": int(np.sum(info["status"] != 0)),
                        "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
-            "roofline": {"kernel": "lanczos_matvec_kernel", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "pk_matvec_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
                          "avg_launch_ms": ms[1] / max(1, launches[1]), "launches": int(launches[1]),
                          "algorithmic_bytes_per_step": alg_bytes / args.steps,
                          "share_of_step_time": mv_s / elapsed},
-            "gather": {"kernel": "thth_gather_kernel", "achieved_GBs": gather_bytes / (ms[0] / 1e3) / 1e9
+            "gather": {"kernel": "thth_gather_packed_kernel", "achieved_GBs": gather_bytes / (ms[0] / 1e3) / 1e9
                        if ms[0] > 0 else 0.0, "avg_launch_ms": ms[0] / max(1, launches[0]),
                        "launches": int(launches[0]),
                        "frac": (gather_bytes / (ms[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else 0.0},

@@ -23,6 +23,7 @@ UNITS = {
     "fft.hip": [],
     "thth.hip": ["-ffp-contract=off"],
     "eigen.hip": [],
+    "eigen_packed.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
@@ -46,16 +47,22 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "scint_hip.h"))
-    objs = []
+    objs, cmds = [], []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers + [__file__]):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            cmds.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
+    if cmds:  # independent translation units: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as pool:
+            list(pool.map(run, cmds))
     if force or _newer(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

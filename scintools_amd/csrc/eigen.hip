@@ -1,5 +1,6 @@
-// eigen.hip -- dominant ('largest algebraic') eigenpair of Hermitian theta-theta
-// matrices, batched over curvatures, and the eta-sweep driver built on it.
+// eigen.hip -- dominant ('largest algebraic') eigenpair of a user-supplied dense Hermitian
+// matrix (scint_eigh_top: the eigsh call of modeler).  The eta sweep itself runs on the
+// tile-packed storage in eigen_packed.hip.
 //
 // Replaces scipy.sparse.linalg.eigsh(thth_red, 1, v0=v0, which="LA") of
 // Eval_calc (ththmod.py:396-401) and modeler (ththmod.py:308).  theta-theta has a
@@ -91,8 +92,8 @@ __global__ void __launch_bounds__(256) lanczos_matvec_kernel(const LanczosJob* j
     const int row_base = blockIdx.x * kRowsPerBlock;
     if (n < 2 || row_base >= n || step >= jb.max_steps || jb.state[0]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const cplx* __restrict__ win = jb.W[step & 1];
-    cplx* __restrict__ wout = jb.W[(step + 1) & 1];
+    const cplx* __restrict__ win = (step & 1) ? jb.W[1] : jb.W[0];
+    cplx* __restrict__ wout = (step & 1) ? jb.W[0] : jb.W[1];
     const int nvb = (n + kVecBlock - 1) / kVecBlock;
     const double beta = sqrt(sum_partials(jb.npart, nvb));   // |w| of the previous step
     const double inv = beta > 0.0 ? 1.0 / beta : 0.0;
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(kVecBlock) lanczos_update_kernel(const Lanczos
     if (n < 2 || blockIdx.x * kVecBlock >= n || step >= jb.max_steps || jb.state[0]) return;
     const int nmb = (n + kRowsPerBlock - 1) / kRowsPerBlock;
     const double alpha = sum_partials(jb.apart, nmb);
-    cplx* __restrict__ w = jb.W[(step + 1) & 1];
+    cplx* __restrict__ w = (step & 1) ? jb.W[0] : jb.W[1];
     const cplx* __restrict__ q = jb.Q + (int64_t)(step % jb.qslots) * n;
     const int r = blockIdx.x * kVecBlock + threadIdx.x;
     double p = 0.0;
@@ -462,98 +463,3 @@ extern "C" int32_t scint_eigh_top(const scint_c128* a, int64_t n, const scint_c1
     return SCINT_OK;
 }
 
-// ------------------------------------------------------------------------------
-// scint_eval_sweep
-// ------------------------------------------------------------------------------
-static size_t sweep_slab_bytes(int64_t M, int steps, size_t* a_off, JobLayout* L) {
-    *L = job_layout(M, steps, 2, true, a_off);
-    return L->total;
-}
-
-extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
-                                                    int32_t max_iter, size_t* bytes) {
-    SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1,
-                  "eval_sweep_workspace_bytes: bad arguments");
-    const int steps = (int)std::min<int64_t>(max_iter, M);
-    size_t a_off; JobLayout L;
-    const size_t slab = sweep_slab_bytes(M, steps, &a_off, &L);
-    const int64_t nb = std::min(batch, neta);
-    *bytes = slab * (size_t)nb + (sizeof(LanczosJob) + sizeof(GatherJob) + 16) * (size_t)nb + 4096;
-    return SCINT_OK;
-}
-
-extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom,
-                                    const double* th_cents, int64_t M, const int32_t* keep_idx,
-                                    const int32_t* keep_n, const double* etas, int64_t neta,
-                                    double tol, int32_t max_iter, int64_t batch, double* eigs_out,
-                                    int32_t* status_out, int32_t* iters_out, void* workspace,
-                                    size_t workspace_bytes, void* stream_) {
-    SCINT_REQUIRE(cs && geom && th_cents && keep_idx && keep_n && etas && eigs_out && status_out && workspace,
-                  "eval_sweep: null pointer");
-    SCINT_REQUIRE(M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && tol > 0, "eval_sweep: bad arguments");
-    SCINT_REQUIRE(geom->dtau > 0 && geom->dfd > 0, "eval_sweep: tau and fd must be increasing");
-    hipStream_t stream = (hipStream_t)stream_;
-    size_t need = 0;
-    scint_eval_sweep_workspace_bytes(M, neta, batch, max_iter, &need);
-    if (workspace_bytes < need) { set_error("scint: eval_sweep workspace too small"); return SCINT_E_WORKSPACE; }
-    const int steps_cap = (int)std::min<int64_t>(max_iter, M);
-    size_t a_off; JobLayout L;
-    const size_t slab = sweep_slab_bytes(M, steps_cap, &a_off, &L);
-    const int64_t nb = std::min(batch, neta);
-    char* base = (char*)workspace;
-    LanczosJob* ljobs_dev = (LanczosJob*)(base + slab * (size_t)nb);
-    GatherJob* gjobs_dev = (GatherJob*)(ljobs_dev + nb);
-    int32_t* states_dev = (int32_t*)(gjobs_dev + nb);
-    const GeomDev g = to_dev(*geom);
-
-    std::vector<LanczosJob> lj((size_t)nb);
-    std::vector<GatherJob> gj((size_t)nb);
-    int32_t* flags = nullptr;
-    SCINT_HIP(hipHostMalloc(&flags, sizeof(int32_t) * 4 * (size_t)nb));
-    int32_t rc = SCINT_OK;
-    for (int64_t e0 = 0; e0 < neta && rc == SCINT_OK; e0 += nb) {
-        const int cnt = (int)std::min<int64_t>(nb, neta - e0);
-        int nmax = 0;
-        for (int s = 0; s < cnt; ++s) {
-            const int64_t e = e0 + s;
-            const int n = keep_n[e];
-            nmax = std::max(nmax, n);
-            char* sl = base + slab * (size_t)s;
-            GatherJob& G = gj[(size_t)s];
-            G.eta = etas[e]; G.two_eta = 2 * etas[e];
-            G.keep = keep_idx + e * M; G.n = n; G.hermitian = 1;
-            G.out = (cplx*)(sl + a_off); G.ld = n;
-            LanczosJob& J = lj[(size_t)s];
-            J.A = G.out; J.ld = n; J.n = n; J.max_steps = std::min(steps_cap, std::max(n, 1));
-            J.W[0] = (cplx*)(sl + L.W0); J.W[1] = (cplx*)(sl + L.W1);
-            J.Q = (cplx*)(sl + L.Q); J.qslots = 2; J.pad0 = 0;
-            J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
-            J.apart = (double*)(sl + L.apart); J.npart = (double*)(sl + L.npart);
-            J.svec = nullptr; J.result = (double*)(sl + L.result); J.state = states_dev + 4 * s;
-            J.eig_out = eigs_out + e; J.status_out = status_out + e;
-            J.iters_out = iters_out ? iters_out + e : nullptr;
-            J.v0 = nullptr; J.tol = tol;
-        }
-        hipError_t he = hipMemcpyAsync(ljobs_dev, lj.data(), sizeof(LanczosJob) * cnt, hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess)
-            he = hipMemcpyAsync(gjobs_dev, gj.data(), sizeof(GatherJob) * cnt, hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(stream);  // lj/gj are reused next batch
-        if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep job upload", __FILE__, __LINE__); break; }
-        if (nmax < 1) {
-            // every job in this batch is empty: flag them from the host side
-            for (int s = 0; s < cnt && rc == SCINT_OK; ++s) {
-                const int32_t st = SCINT_E_EMPTY; const double nanv = nan("");
-                he = hipMemcpyAsync(status_out + e0 + s, &st, sizeof(st), hipMemcpyHostToDevice, stream);
-                if (he == hipSuccess) he = hipMemcpyAsync(eigs_out + e0 + s, &nanv, sizeof(nanv), hipMemcpyHostToDevice, stream);
-                if (he == hipSuccess) he = hipStreamSynchronize(stream);
-                if (he != hipSuccess) rc = hip_fail(he, "eval_sweep empty", __FILE__, __LINE__);
-            }
-            continue;
-        }
-        rc = launch_gather((const cplx*)cs, g, th_cents, M, gjobs_dev, cnt, nmax, stream);
-        if (rc != SCINT_OK) break;
-        rc = run_lanczos(ljobs_dev, states_dev, cnt, nmax, max_iter, flags, stream);
-    }
-    (void)hipHostFree(flags);
-    return rc;
-}

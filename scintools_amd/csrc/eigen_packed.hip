@@ -1,0 +1,514 @@
+// eigen_packed.hip -- the eta sweep: packed gather + batched Hermitian Lanczos on the
+// tile-packed theta-theta matrices (packed.hpp).  This is the headline path
+// (scint_eval_sweep); eigen.hip keeps the full-matrix solver for user-supplied matrices.
+//
+// Per Lanczos step j, for all jobs of a batch at once:
+//
+//   pk_matvec_kernel  one workgroup per strip of <= 8 tiles (I, J0..J1): streams the tiles
+//                     once (16 independent 1-KiB wave loads in flight per wave), forms
+//                     the row-block partial  sum_J A_IJ x_J  (64 lanes stride the columns,
+//                     wave-shuffle reduction at the end of the strip) and, per off-diagonal
+//                     tile, the column-block partial  A_IJ^H x_I  (lane-local over rows,
+//                     4-wave LDS reduction).  x = q_j is never stored normalised: every
+//                     workgroup rebuilds x = (u_{j-1} - alpha_{j-1} q_{j-1}) / beta_{j-1}
+//                     from the previous step's vectors and partial dot products.
+//                     HBM bound: 8 N^2 bytes per job-step (algorithmic = actual).
+//   pk_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials,
+//                     u_j = A q_j - beta_{j-1} q_{j-1}, q_j, and the partials of
+//                     alpha_j = q_j^H u_j and |u_j|^2  (beta_j^2 = |u_j|^2 - alpha_j^2).
+//   pk_check_kernel   (every 4 steps) top two Ritz values of T_k by 64-lane multisection on
+//                     the Sturm count, Ritz residual by the backward recurrence, and the
+//                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
+//
+// Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
+// 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| over the
+// last 4 steps.  No atomics anywhere: results are bit-reproducible and independent of how the
+// etas are batched.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "packed.hpp"
+#include "prof.hpp"
+
+namespace scint {
+
+constexpr int kCheckEvery = 4;
+constexpr int kFirstCheck = 8;
+constexpr int kMaxK = 512;   // upper bound on Lanczos steps held in LDS by the check kernel
+
+// Deterministic sum of p[0..n) by a 256-thread block; every thread gets the total.
+__device__ inline double block_total(const double* __restrict__ p, int n, double* red) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += p[i];
+    return block_sum(acc, red);
+}
+
+struct StepScalars { double alpha, beta, inv; };
+
+// alpha_{j-1}, beta_{j-1} from the partials the previous reduce kernel wrote
+__device__ inline StepScalars step_scalars(const PackedJob& jb, int par, double* red) {
+    StepScalars s;
+    s.alpha = block_total(par ? jb.apart[1] : jb.apart[0], jb.nb, red);
+    const double uu = block_total(par ? jb.upart[1] : jb.upart[0], jb.nb, red);
+    const double b2 = uu - s.alpha * s.alpha;
+    s.beta = b2 > 0.0 ? sqrt(b2) : 0.0;
+    s.inv = s.beta > 0.0 ? 1.0 / s.beta : 0.0;
+    return s;
+}
+
+// Element (row, col) of the packed Hermitian matrix, row != col blocks handled by symmetry.
+__device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
+    const int br = r / kTB, bc = c / kTB;
+    if (bc >= br) return jb.tiles[(tile_offset(jb.nb, br) + (bc - br)) * kTileElems + (r % kTB) * kTB + (c % kTB)];
+    return conj(jb.tiles[(tile_offset(jb.nb, bc) + (br - bc)) * kTileElems + (c % kTB) * kTB + (r % kTB)]);
+}
+
+// u_{-1} := v0 = row n/2 of theta-theta (Eval_calc, ththmod.py:398), q_{-1} := 0
+__global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs) {
+    const PackedJob jb = jobs[blockIdx.y];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (K == 0 && e == 0) { jb.state[0] = 0; jb.state[1] = 0; jb.result[3] = -INFINITY; }
+    if (K >= jb.nb) return;
+    const int r = K * kTB + e;
+    cplx v = mk(0.0, 0.0);
+    if (r < jb.n && jb.n >= 2) v = packed_at(jb, jb.n / 2, r);
+    jb.U[0][r] = v;
+    jb.U[1][r] = mk(0.0, 0.0);
+    jb.Q[0][r] = mk(0.0, 0.0);
+    jb.Q[1][r] = mk(0.0, 0.0);
+    const double p = wave_sum(norm2(v));
+    if (e == 0) {
+        jb.apart[0][K] = 0.0; jb.upart[0][K] = p;
+        jb.apart[1][K] = 0.0; jb.upart[1][K] = 0.0;
+    }
+}
+
+constexpr int kMaxStrip = 16;
+
+__global__ void __launch_bounds__(256) pk_matvec_kernel(const PackedJob* __restrict__ jobs,
+                                                        const Strip* __restrict__ strips, int step) {
+    __shared__ double red[4];
+    __shared__ cplx xI[kTB];
+    __shared__ cplx cred[4][kMaxStrip][kTB];   // per-wave column partials of the strip (32 KiB)
+    const Strip st = strips[blockIdx.x];
+    const PackedJob jb = jobs[st.job];
+    if (jb.n < 2 || step >= jb.max_steps || jb.state[0]) return;
+    const int par = step & 1;
+    const StepScalars sc = step_scalars(jb, par, red);
+    const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
+    const cplx* __restrict__ Qp = par ? jb.Q[0] : jb.Q[1];   // q_{j-1} lives in slot (j-1)&1
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int I = st.I;
+    if (threadIdx.x < kTB) {
+        const cplx u = Up[I * kTB + threadIdx.x], q = Qp[I * kTB + threadIdx.x];
+        xI[threadIdx.x] = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
+    }
+    __syncthreads();
+    cplx accR[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accR[r] = mk(0.0, 0.0);
+    const int64_t t0 = tile_offset(jb.nb, I);
+    const int ntile = st.J1 - st.J0;
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+        const int J = st.J0 + t;
+        const cplx* __restrict__ tile = jb.tiles + (t0 + (J - I)) * kTileElems + (16 * w) * kTB + lane;
+        cplx a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = tile[r * kTB];
+        const cplx uj = Up[J * kTB + lane], qj = Qp[J * kTB + lane];
+        const cplx xJ = mk((uj.x - sc.alpha * qj.x) * sc.inv, (uj.y - sc.alpha * qj.y) * sc.inv);
+        cplx c = mk(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accR[r] = accR[r] + a[r] * xJ;
+            const cplx xi = xI[16 * w + r];   // LDS broadcast
+            // conj(a) * x_I[row]
+            c = mk(c.x + a[r].x * xi.x + a[r].y * xi.y, c.y + a[r].x * xi.y - a[r].y * xi.x);
+        }
+        cred[w][t][lane] = c;   // this wave's own slot: no barrier needed yet
+    }
+    // one cross-wave reduction of the column partials for the whole strip
+    __syncthreads();
+    for (int t = w; t < ntile; t += 4) {
+        const int J = st.J0 + t;
+        if (J != I) {
+            const cplx s = ((cred[0][t][lane] + cred[1][t][lane]) + cred[2][t][lane]) + cred[3][t][lane];
+            jb.colpart[(t0 + (J - I)) * kTB + lane] = s;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const cplx s = wave_sum(accR[r]);
+        if (lane == 0) jb.rowpart[(int64_t)st.index * kTB + 16 * w + r] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restrict__ jobs, int step) {
+    __shared__ double red[4];
+    __shared__ cplx part[4][kTB];
+    const PackedJob jb = jobs[blockIdx.y];
+    const int K = blockIdx.x;
+    if (K >= jb.nb || jb.n < 2 || step >= jb.max_steps || jb.state[0]) return;
+    const int par = step & 1;
+    const StepScalars sc = step_scalars(jb, par, red);
+    const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
+    const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
+    cplx acc = mk(0.0, 0.0);
+    for (int idx = g; idx < nrow + K; idx += 4) {
+        if (idx < nrow) acc = acc + jb.rowpart[(int64_t)(s0 + idx) * kTB + e];
+        else {
+            const int I = idx - nrow;
+            acc = acc + jb.colpart[(tile_offset(jb.nb, I) + (K - I)) * kTB + e];
+        }
+    }
+    part[g][e] = acc;
+    __syncthreads();
+    if (g == 0) {
+        const cplx total = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+        const int r = K * kTB + e;
+        const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
+        const cplx* __restrict__ Qp = par ? jb.Q[0] : jb.Q[1];
+        cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
+        cplx* __restrict__ Qn = par ? jb.Q[1] : jb.Q[0];
+        const cplx up = Up[r], qp = Qp[r];
+        const cplx qn = mk((up.x - sc.alpha * qp.x) * sc.inv, (up.y - sc.alpha * qp.y) * sc.inv);
+        const cplx t = mk(total.x - sc.beta * qp.x, total.y - sc.beta * qp.y);
+        Un[r] = t;
+        Qn[r] = qn;
+        const double pa = wave_sum(qn.x * t.x + qn.y * t.y);   // Re(conj(q) u)
+        const double pu = wave_sum(norm2(t));
+        if (e == 0) {
+            (par ? jb.apart[0] : jb.apart[1])[K] = pa;
+            (par ? jb.upart[0] : jb.upart[1])[K] = pu;
+            if (K == 0) {
+                if (step > 0) jb.alpha[step - 1] = sc.alpha;
+                jb.beta[step] = sc.beta;
+            }
+        }
+    }
+}
+
+// eigenvalues of T_k (diag a[0..k), off-diagonal b[1..k)) strictly below x
+__device__ inline int sturm_count(const double* a, const double* b, int k, double x, double tiny) {
+    int cnt = 0;
+    double d = a[0] - x;
+    if (fabs(d) < tiny) d = -tiny;
+    cnt += d < 0.0;
+    for (int i = 1; i < k; ++i) {
+        d = (a[i] - x) - b[i] * b[i] / d;
+        if (fabs(d) < tiny) d = -tiny;
+        cnt += d < 0.0;
+    }
+    return cnt;
+}
+
+// smallest x in (lo, hi] with count(x) >= target, by 64-lane multisection; requires
+// count(lo) < target <= count(hi).  Returns the midpoint of the final bracket.
+__device__ inline double multisect(const double* a, const double* b, int k, int target, double lo,
+                                   double hi, double tiny, int lane) {
+    for (int round = 0; round < 48; ++round) {
+        const double wdt = hi - lo;
+        if (!(wdt > 0.0)) break;
+        const double x = lo + wdt * ((double)(lane + 1) / 65.0);
+        const int ok = (x > lo && x < hi) ? (sturm_count(a, b, k, x, tiny) >= target) : 0;
+        const unsigned long long m = __ballot(ok);
+        double nlo, nhi;
+        if (m == 0ull) { nlo = __shfl(x, 63, 64); nhi = hi; }
+        else {
+            const int first = __ffsll((long long)m) - 1;
+            nhi = __shfl(x, first, 64);
+            nlo = first > 0 ? __shfl(x, first - 1, 64) : lo;
+        }
+        if (!(nlo > lo) && !(nhi < hi)) break;
+        if (nlo > lo) lo = nlo;
+        if (nhi < hi) hi = nhi;
+        if (hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi))) break;
+    }
+    return 0.5 * (lo + hi);
+}
+
+__global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int k_done, int final_pass) {
+    __shared__ double a[kMaxK + 1];
+    __shared__ double b[kMaxK + 2];
+    const PackedJob jb = jobs[blockIdx.x];
+    if (jb.state[0]) return;
+    const int lane = threadIdx.x;
+    if (jb.n < 2) {
+        if (lane == 0) {
+            jb.state[0] = 1;
+            jb.status_out[0] = SCINT_E_EMPTY;
+            jb.eig_out[0] = nan("");
+            if (jb.iters_out) jb.iters_out[0] = 0;
+        }
+        return;
+    }
+    const int k = min(k_done, jb.max_steps);
+    // alpha_{k-1}, beta_{k-1} are still in the partials of the last reduce kernel
+    const int par = k & 1;
+    double al = 0.0, uu = 0.0;
+    const double* __restrict__ ap = par ? jb.apart[1] : jb.apart[0];
+    const double* __restrict__ upp = par ? jb.upart[1] : jb.upart[0];
+    for (int i = lane; i < jb.nb; i += 64) { al += ap[i]; uu += upp[i]; }
+    al = wave_sum(al);
+    uu = wave_sum(uu);
+    const double b2 = uu - al * al;
+    const double beta_k = b2 > 0.0 ? sqrt(b2) : 0.0;
+    for (int i = lane; i < k - 1; i += 64) a[i] = jb.alpha[i];
+    for (int i = lane + 1; i < k; i += 64) b[i] = jb.beta[i];
+    if (lane == 0) { a[k - 1] = al; b[0] = 0.0; }
+    __syncthreads();
+
+    double lo = INFINITY, hi = -INFINITY, scale = 0.0;
+    for (int i = lane; i < k; i += 64) {
+        const double off = (i > 0 ? fabs(b[i]) : 0.0) + (i + 1 < k ? fabs(b[i + 1]) : 0.0);
+        lo = fmin(lo, a[i] - off);
+        hi = fmax(hi, a[i] + off);
+        scale = fmax(scale, fabs(a[i]) + off);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o, 64));
+        hi = fmax(hi, __shfl_xor(hi, o, 64));
+        scale = fmax(scale, __shfl_xor(scale, o, 64));
+    }
+    const bool finite = isfinite(lo) && isfinite(hi) && isfinite(beta_k);
+    double theta = nan(""), theta2 = -INFINITY, resid = nan(""), err = nan("");
+    if (finite) {
+        const double tiny = scale * 1e-300 + 1e-300;
+        lo = lo - 1e-15 * fabs(lo) - 1e-300;   // count(lo) == 0
+        hi = hi + 1e-15 * fabs(hi) + 1e-300;   // count(hi) == k
+        theta = multisect(a, b, k, k, lo, hi, tiny, lane);
+        if (k >= 2) theta2 = multisect(a, b, k, k - 1, lo, theta, tiny, lane);
+        // Ritz residual beta_k |s_{k-1}|, s = eigenvector of T_k by the backward recurrence
+        if (lane == 0) {
+            double sk = 1.0, skp1 = 0.0, nrm = 1.0, last = 1.0;
+            for (int i = k - 1; i >= 1; --i) {
+                const double bi = b[i];
+                double sm1 = (bi != 0.0) ? ((theta - a[i]) * sk - (i + 1 < k ? b[i + 1] * skp1 : 0.0)) / bi : 0.0;
+                if (!isfinite(sm1)) sm1 = 0.0;
+                if (fabs(sm1) > 1e150) {
+                    const double f = 1e-150;
+                    sm1 *= f; sk *= f; last *= f; nrm *= f * f;
+                }
+                nrm += sm1 * sm1;
+                skp1 = sk;
+                sk = sm1;
+            }
+            resid = beta_k * fabs(last) / sqrt(nrm);
+        }
+        resid = __shfl(resid, 0, 64);
+        const double gap = theta - theta2;
+        err = (gap > resid) ? resid * resid / gap : resid;
+    }
+    if (lane == 0) {
+        const double prev = jb.result[3];
+        const double at = fmax(fabs(theta), 1e-300);
+        const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
+        const bool exact = finite && (k >= jb.n || beta_k == 0.0);
+        const bool conv = finite && ((err <= jb.tol * at && settled) || exact);
+        const bool stop = conv || !finite || k >= jb.max_steps || final_pass;
+        jb.result[0] = theta; jb.result[1] = err; jb.result[2] = resid; jb.result[3] = theta;
+        if (stop) {
+            jb.state[0] = 1;
+            jb.state[1] = k;
+            jb.eig_out[0] = fabs(theta);
+            if (jb.iters_out) jb.iters_out[0] = k;
+            jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------
+struct SlabLayout {
+    size_t tiles, U0, U1, Q0, Q1, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
+        alpha, beta, result, total;
+};
+
+static int max_strips(int nb) {
+    const int S = strip_len_for(nb);
+    int n = 0;
+    for (int I = 0; I < nb; ++I) n += strips_in_row(nb, I, S);
+    return n;
+}
+
+static SlabLayout slab_layout(int nbmax, int max_steps) {
+    SlabLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
+    // the strip count is not monotone in nb across the strip-length thresholds: take the max
+    int smax = 0;
+    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb));
+    L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
+    L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB);
+    L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB);
+    L.Q0 = take(sizeof(cplx) * (size_t)nbmax * kTB);
+    L.Q1 = take(sizeof(cplx) * (size_t)nbmax * kTB);
+    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB);
+    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB);
+    L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
+    L.apart0 = take(sizeof(double) * (size_t)nbmax);
+    L.apart1 = take(sizeof(double) * (size_t)nbmax);
+    L.upart0 = take(sizeof(double) * (size_t)nbmax);
+    L.upart1 = take(sizeof(double) * (size_t)nbmax);
+    L.alpha = take(sizeof(double) * (size_t)(max_steps + 2));
+    L.beta = take(sizeof(double) * (size_t)(max_steps + 3));
+    L.result = take(sizeof(double) * 4);
+    L.total = align_up(off, 256);
+    return L;
+}
+
+struct BatchLayout {
+    SlabLayout slab;
+    int smax;
+    size_t jobs, strips, states, total;
+};
+
+static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch) {
+    BatchLayout B;
+    B.slab = slab_layout(nbmax, max_steps);
+    B.smax = 0;
+    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb));
+    size_t off = B.slab.total * (size_t)nbatch;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
+    B.jobs = take(sizeof(PackedJob) * (size_t)nbatch);
+    B.strips = take(sizeof(Strip) * (size_t)nbatch * (size_t)B.smax);
+    B.states = take(sizeof(int32_t) * 4 * (size_t)nbatch);
+    B.total = align_up(off, 256);
+    return B;
+}
+
+}  // namespace scint
+
+using namespace scint;
+
+extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                                    int32_t max_iter, size_t* bytes) {
+    SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1,
+                  "eval_sweep_workspace_bytes: bad arguments");
+    const int nbmax = (int)ceil_div(M, kTB);
+    const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
+    const int nbatch = (int)std::min(batch, neta);
+    *bytes = batch_layout(nbmax, steps, nbatch).total + 4096;
+    return SCINT_OK;
+}
+
+extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom,
+                                    const double* th_cents, int64_t M, const int32_t* keep_idx,
+                                    const int32_t* keep_n, const double* etas, int64_t neta,
+                                    double tol, int32_t max_iter, int64_t batch, double* eigs_out,
+                                    int32_t* status_out, int32_t* iters_out, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
+    SCINT_REQUIRE(cs && geom && th_cents && keep_idx && keep_n && etas && eigs_out && status_out && workspace,
+                  "eval_sweep: null pointer");
+    SCINT_REQUIRE(M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && tol > 0, "eval_sweep: bad arguments");
+    SCINT_REQUIRE(geom->dtau > 0 && geom->dfd > 0, "eval_sweep: tau and fd must be increasing");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t need = 0;
+    scint_eval_sweep_workspace_bytes(M, neta, batch, max_iter, &need);
+    if (workspace_bytes < need) { set_error("scint: eval_sweep workspace too small"); return SCINT_E_WORKSPACE; }
+    const int nbmax = (int)ceil_div(M, kTB);
+    const int steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
+    const int nbatch = (int)std::min(batch, neta);
+    const BatchLayout BL = batch_layout(nbmax, steps_cap, nbatch);
+    const SlabLayout& L = BL.slab;
+    char* base = (char*)workspace;
+    PackedJob* jobs_dev = (PackedJob*)(base + BL.jobs);
+    Strip* strips_dev = (Strip*)(base + BL.strips);
+    int32_t* states_dev = (int32_t*)(base + BL.states);
+    const GeomDev g = to_dev(*geom);
+
+    std::vector<PackedJob> jobs((size_t)nbatch);
+    std::vector<Strip> strips;
+    std::vector<int32_t> rs_all((size_t)nbatch * (size_t)(nbmax + 1));
+    int32_t* flags = nullptr;
+    SCINT_HIP(hipHostMalloc(&flags, sizeof(int32_t) * 4 * (size_t)nbatch));
+    int32_t rc = SCINT_OK;
+    for (int64_t e0 = 0; e0 < neta && rc == SCINT_OK; e0 += nbatch) {
+        const int cnt = (int)std::min<int64_t>(nbatch, neta - e0);
+        strips.clear();
+        int nb_hi = 0, n_hi = 0;
+        hipError_t he = hipSuccess;
+        for (int s = 0; s < cnt; ++s) {
+            const int64_t e = e0 + s;
+            const int n = keep_n[e];
+            const int nb = (int)ceil_div(std::max(n, 1), kTB);
+            nb_hi = std::max(nb_hi, nb);
+            n_hi = std::max(n_hi, n);
+            char* sl = base + L.total * (size_t)s;
+            PackedJob& J = jobs[(size_t)s];
+            J.eta = etas[e]; J.two_eta = 2 * etas[e];
+            J.keep = keep_idx + e * M; J.n = n; J.nb = nb;
+            J.tiles = (cplx*)(sl + L.tiles);
+            J.max_steps = std::min(steps_cap, std::max(n, 1));
+            J.strip_len = strip_len_for(nb);
+            J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
+            J.Q[0] = (cplx*)(sl + L.Q0); J.Q[1] = (cplx*)(sl + L.Q1);
+            J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
+            J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
+            J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
+            J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
+            J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
+            J.result = (double*)(sl + L.result); J.state = states_dev + 4 * s;
+            J.eig_out = eigs_out + e; J.status_out = status_out + e;
+            J.iters_out = iters_out ? iters_out + e : nullptr;
+            J.tol = tol;
+            // strips of this job, block row by block row
+            int32_t* rs0 = rs_all.data() + (size_t)s * (size_t)(nbmax + 1);   // alive until the sync below
+            int idx = 0;
+            for (int I = 0; I < nb; ++I) {
+                rs0[(size_t)I] = idx;
+                for (int J0 = I; J0 < nb; J0 += J.strip_len) {
+                    Strip st;
+                    st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(nb, J0 + J.strip_len); st.index = idx++;
+                    strips.push_back(st);
+                }
+            }
+            rs0[(size_t)nb] = idx;
+            he = hipMemcpyAsync(sl + L.row_strip0, rs0, sizeof(int32_t) * (size_t)(nb + 1),
+                                hipMemcpyHostToDevice, stream);
+            if (he != hipSuccess) break;
+        }
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(PackedJob) * cnt, hipMemcpyHostToDevice, stream);
+        if (he == hipSuccess && !strips.empty())
+            he = hipMemcpyAsync(strips_dev, strips.data(), sizeof(Strip) * strips.size(), hipMemcpyHostToDevice, stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(stream);
+        if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep job upload", __FILE__, __LINE__); break; }
+
+        rc = launch_gather_packed((const cplx*)cs, g, th_cents, M, jobs_dev, cnt, nb_hi, stream);
+        if (rc != SCINT_OK) break;
+        hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_hi, (unsigned)cnt), dim3(64), 0, stream, jobs_dev);
+        const int nstrips = (int)strips.size();
+        const int cap = std::min(steps_cap, std::max(n_hi, 1));
+        int step = 0;
+        while (true) {
+            const int next_check = step < kFirstCheck ? kFirstCheck : step + kCheckEvery;
+            const int upto = std::min(cap, next_check);
+            for (; step < upto; ++step) {
+                const int slot = profiler().begin(kProfMatvec, stream);
+                hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, jobs_dev,
+                                   strips_dev, step);
+                profiler().end(kProfMatvec, slot, stream);
+                hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_hi, (unsigned)cnt), dim3(256), 0, stream,
+                                   jobs_dev, step);
+            }
+            hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, jobs_dev, step,
+                               step >= cap ? 1 : 0);
+            he = hipGetLastError();
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(flags, states_dev, sizeof(int32_t) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(stream);
+            if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep step", __FILE__, __LINE__); break; }
+            if (profiler().enabled) profiler().collect();
+            bool all = true;
+            for (int i = 0; i < cnt; ++i) all = all && flags[4 * i] != 0;
+            if (all || step >= cap) break;
+        }
+    }
+    (void)hipHostFree(flags);
+    return rc;
+}

@@ -1,0 +1,66 @@
+// packed.hpp -- Hermitian tile-packed theta-theta storage used by the eta sweep.
+//
+// The sweep never returns the matrix, and theta-theta is Hermitian with a zero diagonal
+// (ththmod.py:108-114), so only the tiles on or above the block diagonal are stored:
+//
+//   n  x n matrix -> nb = ceil(n/64) block rows; tile (I, J), J >= I, is a dense
+//   row-major 64 x 64 complex128 block (64 KiB, contiguous) at tile index
+//   tile_offset(nb, I) + (J - I); rows/cols >= n are zero.  Diagonal tiles hold the full
+//   Hermitian block (both triangles) so that one code path multiplies every tile.
+//
+// This halves the HBM bytes of both the gather (writes) and every Lanczos mat-vec
+// (reads): 8 N^2 instead of 16 N^2, and at N = 4095 the whole matrix (136 MB) fits the
+// 256 MiB Infinity Cache.  y = A x is computed tile by tile -- y_I += A_IJ x_J and, for
+// J > I, y_J += A_IJ^H x_I -- into per-strip / per-tile partial vectors that a second
+// kernel sums in a fixed order, so the result is bit-reproducible (no atomics).
+#pragma once
+#include "thth.hpp"
+
+namespace scint {
+
+constexpr int kTB = 64;                       // tile edge
+constexpr int kTileElems = kTB * kTB;         // 4096 complex = 64 KiB
+
+__host__ __device__ inline int64_t tile_offset(int nb, int I) {
+    return (int64_t)I * nb - (int64_t)I * (I - 1) / 2;
+}
+__host__ __device__ inline int64_t tile_count(int nb) { return (int64_t)nb * (nb + 1) / 2; }
+
+// strips: consecutive tiles (I, J0..J1) of one block row handled by one workgroup
+// (long strips amortise the per-workgroup prologue/epilogue; the length depends on nb only, so
+// the summation order -- and every bit of the result -- is independent of the batch)
+inline int strip_len_for(int nb) { return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1))); }
+inline int strips_in_row(int nb, int I, int S) { return (nb - I + S - 1) / S; }
+
+struct PackedJob {
+    // ---- gather ----------------------------------------------------------------
+    double eta, two_eta;
+    const int32_t* keep;    // [n] indices into th_cents
+    int32_t n, nb;
+    cplx* tiles;            // [tile_count(nb)][64][64]
+    // ---- Lanczos state -----------------------------------------------------------
+    int32_t max_steps, strip_len;
+    cplx* U[2];             // u_{j-1} / u_j                     [nb*64] each
+    cplx* Q[2];             // q ring                            [nb*64] each
+    cplx* rowpart;          // [nstrips][64]   row-block partial sums per strip
+    cplx* colpart;          // [ntiles][64]    column-block partial sums per off-diagonal tile
+    const int32_t* row_strip0;  // [nb+1] first strip index of each block row
+    double* apart[2];       // [nb] partial q_j^H u_j      (ping-pong by step parity)
+    double* upart[2];       // [nb] partial |u_j|^2
+    double* alpha;          // [max_steps + 1]
+    double* beta;           // [max_steps + 2]   beta[i] couples i-1 and i
+    double* result;         // [4] theta, err estimate, resid, theta2
+    int32_t* state;         // [4] done, steps, -, -
+    double* eig_out; int32_t* status_out; int32_t* iters_out;
+    double tol;             // target relative accuracy of the eigenvalue
+};
+
+struct Strip {
+    int32_t job, I, J0, J1;   // tiles (I, J0 .. J1-1)
+    int32_t index;            // strip index inside the job (row of rowpart)
+};
+
+int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
+                             const PackedJob* jobs_dev, int njobs, int nbmax, hipStream_t stream);
+
+}  // namespace scint

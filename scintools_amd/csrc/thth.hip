@@ -8,49 +8,11 @@
 #include <float.h>
 #include <math.h>
 
+#include "packed.hpp"
 #include "prof.hpp"
 #include "thth.hpp"
 
 namespace scint {
-
-// np.floor_divide(a, b) for float64, b > 0.  NumPy (npy_divmod) returns the exact
-// mathematical floor(a/b): fmod is exact and the quotient is snapped to an integer.
-// floor(fl(a/b)) can only be wrong (one too high) when the correctly-rounded quotient
-// landed on an integer from below; the sign of the single-rounded remainder a - q*b
-// detects exactly that case.
-__device__ inline double floor_div_exact(double a, double b) {
-    double q = floor(a / b);
-    if (__builtin_fma(-q, b, a) < 0.0) q -= 1.0;
-    return q;
-}
-
-// np.nan_to_num on one float64
-__device__ inline double nan_to_num(double v) {
-    if (v != v) return 0.0;
-    if (v > DBL_MAX) return DBL_MAX;
-    if (v < -DBL_MAX) return -DBL_MAX;
-    return v;
-}
-
-// theta-theta value at (theta2 = th_i, theta1 = th_j), before any Hermitian forcing
-// (ththmod.py:94-107).
-__device__ inline cplx thth_value(const cplx* __restrict__ cs, const GeomDev& g, double eta,
-                                  double two_eta, double th_i, double th_j) {
-    const double a_tau = ((eta * (th_j * th_j - th_i * th_i)) - g.tau0) + g.half_dtau;
-    const double a_fd = ((th_j - th_i) - g.fd0) + g.half_dfd;
-    const int64_t tau_inv = (int64_t)floor_div_exact(a_tau, g.dtau);
-    int64_t fd_inv = (int64_t)floor_div_exact(a_fd, g.dfd);
-    // pnts = (tau_inv > 0) * (tau_inv < ntau) * (fd_inv < nfd): no lower bound on
-    // fd_inv (ththmod.py:103); NumPy's fancy index wraps a negative one.
-    if (!(tau_inv > 0 && tau_inv < g.ntau && fd_inv < g.nfd)) return mk(0.0, 0.0);
-    if (fd_inv < 0) {
-        fd_inv += g.nfd;
-        if (fd_inv < 0) return mk(nan(""), nan(""));  // NumPy would raise IndexError
-    }
-    const cplx v = cs[tau_inv * g.nfd + fd_inv];
-    const double w = sqrt(fabs(two_eta * (th_i - th_j)));
-    return mk(v.x * w, v.y * w);
-}
 
 constexpr int kTile = 32;
 
@@ -121,6 +83,50 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
     const int slot = profiler().begin(kProfGather, stream);
     hipLaunchKernelGGL(thth_gather_kernel, dim3(nt, nt, (unsigned)njobs), dim3(256), 0, stream, cs, g,
                        th_cents, M, jobs_dev);
+    profiler().end(kProfGather, slot, stream);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
+// ------------------------------------------------------------------------------
+// packed gather (eta sweep): only tiles on/above the block diagonal, 64 KiB contiguous each
+// ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+thth_gather_packed_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restrict__ th,
+                          int64_t M, const PackedJob* __restrict__ jobs) {
+    const PackedJob job = jobs[blockIdx.z];
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (I >= job.nb || J >= job.nb || J < I) return;
+    const int n = job.n;
+    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = J * kTB + tx;
+    const int kj = j < n ? job.keep[j] : 0;
+    const double th_j = j < n ? th[kj] : 0.0;
+    cplx* __restrict__ tile = job.tiles + (tile_offset(job.nb, I) + (J - I)) * kTileElems;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int rr = 16 * w + r;
+        const int i = I * kTB + rr;
+        cplx v = mk(0.0, 0.0);
+        if (i < n && j < n && i != j) {
+            const int ki = job.keep[i];
+            const double th_i = th[ki];
+            if (i < j) v = thth_value(cs, g, job.eta, job.two_eta, th_i, th_j);
+            else v = conj(thth_value(cs, g, job.eta, job.two_eta, th_j, th_i));  // diagonal tile, lower half
+            if ((int64_t)ki + kj == M - 1) v = mk(0.0, 0.0);   // anti-diagonal (ththmod.py:113)
+            v = mk(nan_to_num(v.x), nan_to_num(v.y));
+        }
+        tile[rr * kTB + tx] = v;
+    }
+}
+
+int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
+                             const PackedJob* jobs_dev, int njobs, int nbmax, hipStream_t stream) {
+    if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
+    SCINT_REQUIRE(nbmax <= 65535 && njobs <= 65535, "gather: grid too large");
+    const int slot = profiler().begin(kProfGather, stream);
+    hipLaunchKernelGGL(thth_gather_packed_kernel, dim3((unsigned)nbmax, (unsigned)nbmax, (unsigned)njobs),
+                       dim3(256), 0, stream, cs, g, th_cents, M, jobs_dev);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;

@@ -1,5 +1,8 @@
 // thth.hpp -- CS <-> theta-theta maps (ththmod.py:56-271) as gfx950 kernels.
 #pragma once
+#include <float.h>
+#include <math.h>
+
 #include "common.hpp"
 
 namespace scint {
@@ -20,6 +23,47 @@ inline GeomDev to_dev(const scint_cs_geom& g) {
     d.fd0 = g.fd0; d.dfd = g.dfd; d.half_dfd = g.dfd / 2;
     d.tau1_step = g.tau1_step; d.fd1_step = g.fd1_step;
     return d;
+}
+
+// ---- element math shared by the gather kernels ---------------------------------------
+// (the translation units that CALL these are compiled with -ffp-contract=off)
+// np.floor_divide(a, b) for float64, b > 0.  NumPy (npy_divmod) returns the exact
+// mathematical floor(a/b): fmod is exact and the quotient is snapped to an integer.
+// floor(fl(a/b)) can only be wrong (one too high) when the correctly-rounded quotient
+// landed on an integer from below; the sign of the single-rounded remainder a - q*b
+// detects exactly that case.
+__device__ inline double floor_div_exact(double a, double b) {
+    double q = floor(a / b);
+    if (__builtin_fma(-q, b, a) < 0.0) q -= 1.0;
+    return q;
+}
+
+// np.nan_to_num on one float64
+__device__ inline double nan_to_num(double v) {
+    if (v != v) return 0.0;
+    if (v > DBL_MAX) return DBL_MAX;
+    if (v < -DBL_MAX) return -DBL_MAX;
+    return v;
+}
+
+// theta-theta value at (theta2 = th_i, theta1 = th_j), before any Hermitian forcing
+// (ththmod.py:94-107).
+__device__ inline cplx thth_value(const cplx* __restrict__ cs, const GeomDev& g, double eta,
+                                  double two_eta, double th_i, double th_j) {
+    const double a_tau = ((eta * (th_j * th_j - th_i * th_i)) - g.tau0) + g.half_dtau;
+    const double a_fd = ((th_j - th_i) - g.fd0) + g.half_dfd;
+    const int64_t tau_inv = (int64_t)floor_div_exact(a_tau, g.dtau);
+    int64_t fd_inv = (int64_t)floor_div_exact(a_fd, g.dfd);
+    // pnts = (tau_inv > 0) * (tau_inv < ntau) * (fd_inv < nfd): no lower bound on
+    // fd_inv (ththmod.py:103); NumPy's fancy index wraps a negative one.
+    if (!(tau_inv > 0 && tau_inv < g.ntau && fd_inv < g.nfd)) return mk(0.0, 0.0);
+    if (fd_inv < 0) {
+        fd_inv += g.nfd;
+        if (fd_inv < 0) return mk(nan(""), nan(""));  // NumPy would raise IndexError
+    }
+    const cplx v = cs[tau_inv * g.nfd + fd_inv];
+    const double w = sqrt(fabs(two_eta * (th_i - th_j)));
+    return mk(v.x * w, v.y * w);
 }
 
 // One theta-theta matrix to build: curvature, crop and destination.

@@ -316,6 +316,17 @@ def chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask=None):
     return float(out.cpu()[0])
 
 
+def default_batch(nmax, neta):
+    """Curvatures resident per launch: enough tile strips (one workgroup each) to fill the
+    256 CUs several times over, within the HBM budget for the packed matrices (8 N^2 bytes)."""
+    nb = -(-nmax // 64)
+    strip = 16 if nb >= 32 else (8 if nb >= 16 else (4 if nb >= 8 else (2 if nb >= 4 else 1)))
+    strips = sum(-(-(nb - i) // strip) for i in range(nb))
+    want = -(-4096 // max(strips, 1))
+    cap = max(1, DEFAULT_BATCH_BYTES // (8 * (nb * 64) ** 2 + 1))
+    return int(max(1, min(neta, 256, want, cap)))
+
+
 def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,
                return_info=False):
     """Dominant eigenvalue for every curvature in `etas`: the loop of
@@ -336,7 +347,7 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
         keep_idx[i, : k.shape[0]] = k
     nmax = max(int(keep_n.max()), 1)
     if batch is None:
-        batch = max(1, min(neta, 64, DEFAULT_BATCH_BYTES // (16 * nmax * nmax)))
+        batch = default_batch(nmax, neta)
     need = ctypes.c_size_t()
     _lib.check(lib.scint_eval_sweep_workspace_bytes(M, neta, batch, max_iter, ctypes.byref(need)),
                "eval_sweep_workspace_bytes")

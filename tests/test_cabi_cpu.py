@@ -36,7 +36,7 @@ def test_workspace_queries_and_argument_errors(lib):
     assert lib.scint_cs_workspace_bytes(64, 32, 3, ctypes.byref(n)) == 0
     assert n.value >= 256 * 128 * 16
     assert lib.scint_eval_sweep_workspace_bytes(511, 16, 4, 300, ctypes.byref(n)) == 0
-    assert n.value >= 4 * 511 * 511 * 16
+    assert n.value >= 4 * 511 * 511 * 8      # Hermitian tile-packed: 8 N^2 per resident eta
     # bad arguments: status code + message, no exception, no crash
     assert lib.scint_sspec_workspace_bytes(0, 10, ctypes.byref(n)) == 1
     assert "bad shape" in _lib.last_error()
