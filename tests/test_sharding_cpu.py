@@ -1,0 +1,90 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU sharding logic.  The per-rank compute is
+the oracle here (local_fn), so this checks partitioning + all-gather, not kernels: the
+gathered result must equal the single-process result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    from oracle import thth_oracle as to
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(64, 64, seed=21, nimg=10)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    CS = to.conjugate_spectrum(dyn, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 40)
+    etas = np.geomspace(0.5, 2.0, 7) * eta_true          # 7: uneven split over 2 ranks
+    return to, CS, tau, fd, etas, edges
+
+
+def _oracle_sweep(CS, tau, fd, etas, edges):
+    from oracle import thth_oracle as to
+    return np.array([to.Eval_calc(CS, tau, fd, e, edges) for e in etas])
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from scintools_amd import sweep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    to, CS, tau, fd, etas, edges = _problem()
+    full = sweep.sharded_eval_sweep(CS, tau, fd, etas, edges, local_fn=_oracle_sweep)
+
+    def one_obs(i):
+        return _oracle_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges)
+    obs = sweep.sharded_observations(5, one_obs, 3)
+    q.put((rank, full, obs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_bounds_cover_everything():
+    from scintools_amd.sweep import block_bounds
+    for n in (0, 1, 7, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [block_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_world2_gloo_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    to, CS, tau, fd, etas, edges = _problem()
+    ref = _oracle_sweep(CS, tau, fd, etas, edges)
+    ref_obs = np.stack([_oracle_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges) for i in range(5)])
+    for rank, full, obs in results:
+        assert np.array_equal(full, ref), rank          # same bits on every rank
+        assert np.array_equal(obs, ref_obs), rank
+
+
+def test_single_process_path_needs_no_process_group():
+    from scintools_amd import sweep
+    to, CS, tau, fd, etas, edges = _problem()
+    got = sweep.sharded_eval_sweep(CS, tau, fd, etas[:2], edges, local_fn=_oracle_sweep)
+    assert np.array_equal(got, _oracle_sweep(CS, tau, fd, etas[:2], edges))
