@@ -20,6 +20,12 @@
 //                     the Sturm count, Ritz residual by the backward recurrence, and the
 //                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
+// Scheduling: `batch` slots are kept full -- as soon as a curvature converges (flags are read
+// back every 4 launches) its slot is re-filled with the next eta of the sweep: gather + init
+// for the new slots only, then the common step launches continue.  Every job carries the launch
+// index it started at, so jobs at different Lanczos steps share one launch (continuous
+// batching); per-job arithmetic does not depend on the schedule.
+//
 // Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
 // 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| over the
 // last 4 steps.  No atomics anywhere: results are bit-reproducible and independent of how the
@@ -38,25 +44,7 @@ constexpr int kCheckEvery = 4;
 constexpr int kFirstCheck = 8;
 constexpr int kMaxK = 512;   // upper bound on Lanczos steps held in LDS by the check kernel
 
-// Deterministic sum of p[0..n) by a 256-thread block; every thread gets the total.
-__device__ inline double block_total(const double* __restrict__ p, int n, double* red) {
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += p[i];
-    return block_sum(acc, red);
-}
-
 struct StepScalars { double alpha, beta, inv; };
-
-// alpha_{j-1}, beta_{j-1} from the partials the previous reduce kernel wrote
-__device__ inline StepScalars step_scalars(const PackedJob& jb, int par, double* red) {
-    StepScalars s;
-    s.alpha = block_total(par ? jb.apart[1] : jb.apart[0], jb.nb, red);
-    const double uu = block_total(par ? jb.upart[1] : jb.upart[0], jb.nb, red);
-    const double b2 = uu - s.alpha * s.alpha;
-    s.beta = b2 > 0.0 ? sqrt(b2) : 0.0;
-    s.inv = s.beta > 0.0 ? 1.0 / s.beta : 0.0;
-    return s;
-}
 
 // Element (row, col) of the packed Hermitian matrix, row != col blocks handled by symmetry.
 __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
@@ -66,8 +54,8 @@ __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
 }
 
 // u_{-1} := v0 = row n/2 of theta-theta (Eval_calc, ththmod.py:398), q_{-1} := 0
-__global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs) {
-    const PackedJob jb = jobs[blockIdx.y];
+__global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs, const int32_t* slots) {
+    const PackedJob jb = jobs[slots[blockIdx.y]];
     const int K = blockIdx.x, e = threadIdx.x;
     if (K == 0 && e == 0) { jb.state[0] = 0; jb.state[1] = 0; jb.result[3] = -INFINITY; }
     if (K >= jb.nb) return;
@@ -87,74 +75,110 @@ __global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs) {
 
 constexpr int kMaxStrip = 16;
 
-__global__ void __launch_bounds__(256) pk_matvec_kernel(const PackedJob* __restrict__ jobs,
-                                                        const Strip* __restrict__ strips, int step) {
-    __shared__ double red[4];
+// alpha_{j-1}, beta_{j-1} by ONE wavefront (no barriers): nb <= 64*k entries, fixed order
+__device__ inline StepScalars step_scalars_wave(const double* __restrict__ ap, const double* __restrict__ up,
+                                                int nb, int lane) {
+    double a = 0.0, uu = 0.0;
+    for (int i = lane; i < nb; i += 64) { a += ap[i]; uu += up[i]; }
+    StepScalars s;
+    s.alpha = wave_sum(a);
+    uu = wave_sum(uu);
+    const double b2 = uu - s.alpha * s.alpha;
+    s.beta = b2 > 0.0 ? sqrt(b2) : 0.0;
+    s.inv = s.beta > 0.0 ? 1.0 / s.beta : 0.0;
+    return s;
+}
+
+__global__ void __launch_bounds__(256, 2)
+pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
     __shared__ cplx xI[kTB];
-    __shared__ cplx cred[4][kMaxStrip][kTB];   // per-wave column partials of the strip (32 KiB)
+    __shared__ cplx cred[4][kMaxStrip][kTB];   // per-wave column partials of the strip (64 KiB)
     const Strip st = strips[blockIdx.x];
-    const PackedJob jb = jobs[st.job];
-    if (jb.n < 2 || step >= jb.max_steps || jb.state[0]) return;
+    const PackedJob* __restrict__ jp = jobs + st.job;
+    const int step = launch - jp->start;
+    if (jp->n < 2 || step < 0 || step >= jp->max_steps || jp->state[0]) return;
     const int par = step & 1;
-    const StepScalars sc = step_scalars(jb, par, red);
-    const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
-    const cplx* __restrict__ Qp = par ? jb.Q[0] : jb.Q[1];   // q_{j-1} lives in slot (j-1)&1
+    const int nb = jp->nb;
+    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
+    const cplx* __restrict__ Qp = par ? jp->Q[0] : jp->Q[1];   // q_{j-1} lives in slot (j-1)&1
+    const cplx* __restrict__ tiles = jp->tiles;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int I = st.I;
-    if (threadIdx.x < kTB) {
-        const cplx u = Up[I * kTB + threadIdx.x], q = Qp[I * kTB + threadIdx.x];
-        xI[threadIdx.x] = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
+    const int64_t t0 = tile_offset(nb, I);
+    const int ntile = st.J1 - st.J0;
+    // Software pipeline over half tiles (8 rows x 64 columns = 8 KiB per wave): the next half
+    // tile's loads are always in flight while the current one is consumed.  The first loads go
+    // out before anything else -- they do not depend on the step scalars.
+    const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
+    cplx a0[8], a1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a0[r] = tp[r * kTB];
+    const StepScalars sc = step_scalars_wave(par ? jp->apart[1] : jp->apart[0],
+                                             par ? jp->upart[1] : jp->upart[0], nb, lane);
+    if (w == 0) {
+        const cplx u = Up[I * kTB + lane], q = Qp[I * kTB + lane];
+        xI[lane] = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
     }
     __syncthreads();
     cplx accR[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) accR[r] = mk(0.0, 0.0);
-    const int64_t t0 = tile_offset(jb.nb, I);
-    const int ntile = st.J1 - st.J0;
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
         const int J = st.J0 + t;
-        const cplx* __restrict__ tile = jb.tiles + (t0 + (J - I)) * kTileElems + (16 * w) * kTB + lane;
-        cplx a[16];
+        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = tile[r * kTB];
+        for (int r = 0; r < 8; ++r) a1[r] = tc[(8 + r) * kTB];          // second half of this tile
         const cplx uj = Up[J * kTB + lane], qj = Qp[J * kTB + lane];
         const cplx xJ = mk((uj.x - sc.alpha * qj.x) * sc.inv, (uj.y - sc.alpha * qj.y) * sc.inv);
         cplx c = mk(0.0, 0.0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            accR[r] = accR[r] + a[r] * xJ;
+        for (int r = 0; r < 8; ++r) {
+            accR[r] = accR[r] + a0[r] * xJ;
             const cplx xi = xI[16 * w + r];   // LDS broadcast
-            // conj(a) * x_I[row]
-            c = mk(c.x + a[r].x * xi.x + a[r].y * xi.y, c.y + a[r].x * xi.y - a[r].y * xi.x);
+            c = mk(c.x + a0[r].x * xi.x + a0[r].y * xi.y, c.y + a0[r].x * xi.y - a0[r].y * xi.x);   // conj(a) x_I
+        }
+        if (t + 1 < ntile) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a0[r] = tc[kTileElems + r * kTB];   // first half of the next tile
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            accR[8 + r] = accR[8 + r] + a1[r] * xJ;
+            const cplx xi = xI[16 * w + 8 + r];
+            c = mk(c.x + a1[r].x * xi.x + a1[r].y * xi.y, c.y + a1[r].x * xi.y - a1[r].y * xi.x);
         }
         cred[w][t][lane] = c;   // this wave's own slot: no barrier needed yet
     }
     // one cross-wave reduction of the column partials for the whole strip
     __syncthreads();
+    cplx* __restrict__ colpart = jp->colpart;
     for (int t = w; t < ntile; t += 4) {
         const int J = st.J0 + t;
         if (J != I) {
             const cplx s = ((cred[0][t][lane] + cred[1][t][lane]) + cred[2][t][lane]) + cred[3][t][lane];
-            jb.colpart[(t0 + (J - I)) * kTB + lane] = s;
+            colpart[(t0 + (J - I)) * kTB + lane] = s;
         }
     }
+    cplx* __restrict__ rowpart = jp->rowpart;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const cplx s = wave_sum(accR[r]);
-        if (lane == 0) jb.rowpart[(int64_t)st.index * kTB + 16 * w + r] = s;
+        if (lane == 0) rowpart[(int64_t)st.index * kTB + 16 * w + r] = s;
     }
 }
 
-__global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restrict__ jobs, int step) {
-    __shared__ double red[4];
+__global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     __shared__ cplx part[4][kTB];
     const PackedJob jb = jobs[blockIdx.y];
     const int K = blockIdx.x;
-    if (K >= jb.nb || jb.n < 2 || step >= jb.max_steps || jb.state[0]) return;
+    const int step = launch - jb.start;
+    if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || jb.state[0]) return;
     const int par = step & 1;
-    const StepScalars sc = step_scalars(jb, par, red);
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
+    // every wavefront evaluates the same fixed-order sums as the mat-vec kernel did
+    const StepScalars sc = step_scalars_wave(par ? jb.apart[1] : jb.apart[0],
+                                             par ? jb.upart[1] : jb.upart[0], jb.nb, e);
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc = mk(0.0, 0.0);
     for (int idx = g; idx < nrow + K; idx += 4) {
@@ -230,12 +254,13 @@ __device__ inline double multisect(const double* a, const double* b, int k, int 
     return 0.5 * (lo + hi);
 }
 
-__global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int k_done, int final_pass) {
+__global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int launches_done) {
     __shared__ double a[kMaxK + 1];
     __shared__ double b[kMaxK + 2];
     const PackedJob jb = jobs[blockIdx.x];
     if (jb.state[0]) return;
     const int lane = threadIdx.x;
+    const int k_done = launches_done - jb.start;   // Lanczos steps this job has completed
     if (jb.n < 2) {
         if (lane == 0) {
             jb.state[0] = 1;
@@ -245,6 +270,7 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
         }
         return;
     }
+    if (k_done < kFirstCheck && k_done < jb.max_steps) return;
     const int k = min(k_done, jb.max_steps);
     // alpha_{k-1}, beta_{k-1} are still in the partials of the last reduce kernel
     const int par = k & 1;
@@ -308,7 +334,7 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
         const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
         const bool exact = finite && (k >= jb.n || beta_k == 0.0);
         const bool conv = finite && ((err <= jb.tol * at && settled) || exact);
-        const bool stop = conv || !finite || k >= jb.max_steps || final_pass;
+        const bool stop = conv || !finite || k >= jb.max_steps;
         jb.result[0] = theta; jb.result[1] = err; jb.result[2] = resid; jb.result[3] = theta;
         if (stop) {
             jb.state[0] = 1;
@@ -364,7 +390,7 @@ static SlabLayout slab_layout(int nbmax, int max_steps) {
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, states, total;
+    size_t jobs, strips, states, slots, total;
 };
 
 static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch) {
@@ -377,6 +403,7 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch) {
     B.jobs = take(sizeof(PackedJob) * (size_t)nbatch);
     B.strips = take(sizeof(Strip) * (size_t)nbatch * (size_t)B.smax);
     B.states = take(sizeof(int32_t) * 4 * (size_t)nbatch);
+    B.slots = take(sizeof(int32_t) * (size_t)nbatch);
     B.total = align_up(off, 256);
     return B;
 }
@@ -412,101 +439,132 @@ extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* g
     if (workspace_bytes < need) { set_error("scint: eval_sweep workspace too small"); return SCINT_E_WORKSPACE; }
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
-    const int nbatch = (int)std::min(batch, neta);
-    const BatchLayout BL = batch_layout(nbmax, steps_cap, nbatch);
+    const int nslots = (int)std::min(batch, neta);
+    const BatchLayout BL = batch_layout(nbmax, steps_cap, nslots);
     const SlabLayout& L = BL.slab;
     char* base = (char*)workspace;
     PackedJob* jobs_dev = (PackedJob*)(base + BL.jobs);
     Strip* strips_dev = (Strip*)(base + BL.strips);
     int32_t* states_dev = (int32_t*)(base + BL.states);
+    int32_t* slots_dev = (int32_t*)(base + BL.slots);
     const GeomDev g = to_dev(*geom);
 
-    std::vector<PackedJob> jobs((size_t)nbatch);
+    std::vector<PackedJob> jobs((size_t)nslots);
+    std::vector<int64_t> slot_eta((size_t)nslots, -1);   // eta index running in each slot, -1 = idle
     std::vector<Strip> strips;
-    std::vector<int32_t> rs_all((size_t)nbatch * (size_t)(nbmax + 1));
+    std::vector<int32_t> rs_all((size_t)nslots * (size_t)(nbmax + 1));
+    std::vector<int32_t> fresh;                           // slots (re)filled in this round
     int32_t* flags = nullptr;
-    SCINT_HIP(hipHostMalloc(&flags, sizeof(int32_t) * 4 * (size_t)nbatch));
+    SCINT_HIP(hipHostMalloc(&flags, sizeof(int32_t) * 4 * (size_t)nslots));
+    for (int s = 0; s < nslots; ++s) {                    // static part of every slot
+        char* sl = base + L.total * (size_t)s;
+        PackedJob& J = jobs[(size_t)s];
+        J.tiles = (cplx*)(sl + L.tiles);
+        J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
+        J.Q[0] = (cplx*)(sl + L.Q0); J.Q[1] = (cplx*)(sl + L.Q1);
+        J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
+        J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
+        J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
+        J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
+        J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
+        J.result = (double*)(sl + L.result); J.state = states_dev + 4 * s;
+        J.tol = tol; J.pad0 = 0;
+        J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
+        J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
+        J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
+    }
+
     int32_t rc = SCINT_OK;
-    for (int64_t e0 = 0; e0 < neta && rc == SCINT_OK; e0 += nbatch) {
-        const int cnt = (int)std::min<int64_t>(nbatch, neta - e0);
-        strips.clear();
-        int nb_hi = 0, n_hi = 0;
-        hipError_t he = hipSuccess;
-        for (int s = 0; s < cnt; ++s) {
-            const int64_t e = e0 + s;
-            const int n = keep_n[e];
-            const int nb = (int)ceil_div(std::max(n, 1), kTB);
-            nb_hi = std::max(nb_hi, nb);
-            n_hi = std::max(n_hi, n);
-            char* sl = base + L.total * (size_t)s;
+    int64_t next_eta = 0;
+    int launch = 0;          // global launch counter: a job's Lanczos step = launch - job.start
+    int active = 0;
+    hipError_t he = hipSuccess;
+    while (rc == SCINT_OK) {
+        // ---- (re)fill idle slots with the next curvatures ---------------------------------
+        fresh.clear();
+        for (int s = 0; s < nslots && next_eta < neta; ++s) {
+            if (slot_eta[(size_t)s] >= 0) continue;
+            const int64_t e = next_eta++;
+            slot_eta[(size_t)s] = e;
+            ++active;
             PackedJob& J = jobs[(size_t)s];
+            const int n = keep_n[e];
             J.eta = etas[e]; J.two_eta = 2 * etas[e];
-            J.keep = keep_idx + e * M; J.n = n; J.nb = nb;
-            J.tiles = (cplx*)(sl + L.tiles);
+            J.keep = keep_idx + e * M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
             J.max_steps = std::min(steps_cap, std::max(n, 1));
-            J.strip_len = strip_len_for(nb);
-            J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
-            J.Q[0] = (cplx*)(sl + L.Q0); J.Q[1] = (cplx*)(sl + L.Q1);
-            J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
-            J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
-            J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
-            J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
-            J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
-            J.result = (double*)(sl + L.result); J.state = states_dev + 4 * s;
+            J.strip_len = strip_len_for(J.nb);
+            J.start = launch;
             J.eig_out = eigs_out + e; J.status_out = status_out + e;
             J.iters_out = iters_out ? iters_out + e : nullptr;
-            J.tol = tol;
-            // strips of this job, block row by block row
-            int32_t* rs0 = rs_all.data() + (size_t)s * (size_t)(nbmax + 1);   // alive until the sync below
-            int idx = 0;
-            for (int I = 0; I < nb; ++I) {
-                rs0[(size_t)I] = idx;
-                for (int J0 = I; J0 < nb; J0 += J.strip_len) {
-                    Strip st;
-                    st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(nb, J0 + J.strip_len); st.index = idx++;
-                    strips.push_back(st);
-                }
-            }
-            rs0[(size_t)nb] = idx;
-            he = hipMemcpyAsync(sl + L.row_strip0, rs0, sizeof(int32_t) * (size_t)(nb + 1),
-                                hipMemcpyHostToDevice, stream);
-            if (he != hipSuccess) break;
+            fresh.push_back(s);
         }
-        if (he == hipSuccess)
-            he = hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(PackedJob) * cnt, hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess && !strips.empty())
-            he = hipMemcpyAsync(strips_dev, strips.data(), sizeof(Strip) * strips.size(), hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(stream);
-        if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep job upload", __FILE__, __LINE__); break; }
-
-        rc = launch_gather_packed((const cplx*)cs, g, th_cents, M, jobs_dev, cnt, nb_hi, stream);
-        if (rc != SCINT_OK) break;
-        hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_hi, (unsigned)cnt), dim3(64), 0, stream, jobs_dev);
-        const int nstrips = (int)strips.size();
-        const int cap = std::min(steps_cap, std::max(n_hi, 1));
-        int step = 0;
-        while (true) {
-            const int next_check = step < kFirstCheck ? kFirstCheck : step + kCheckEvery;
-            const int upto = std::min(cap, next_check);
-            for (; step < upto; ++step) {
-                const int slot = profiler().begin(kProfMatvec, stream);
-                hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, jobs_dev,
-                                   strips_dev, step);
-                profiler().end(kProfMatvec, slot, stream);
-                hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_hi, (unsigned)cnt), dim3(256), 0, stream,
-                                   jobs_dev, step);
+        if (active == 0) break;
+        if (!fresh.empty()) {
+            // strips of every running job, block row by block row (rebuilt: slots changed size)
+            strips.clear();
+            int nb_fresh = 0;
+            for (int s = 0; s < nslots; ++s) {
+                if (slot_eta[(size_t)s] < 0) continue;
+                const PackedJob& J = jobs[(size_t)s];
+                int32_t* rs0 = rs_all.data() + (size_t)s * (size_t)(nbmax + 1);
+                int idx = 0;
+                for (int I = 0; I < J.nb; ++I) {
+                    rs0[I] = idx;
+                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
+                        Strip st;
+                        st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
+                        strips.push_back(st);
+                    }
+                }
+                rs0[J.nb] = idx;
             }
-            hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)cnt), dim3(64), 0, stream, jobs_dev, step,
-                               step >= cap ? 1 : 0);
-            he = hipGetLastError();
+            for (int s : fresh) {
+                const PackedJob& J = jobs[(size_t)s];
+                nb_fresh = std::max(nb_fresh, J.nb);
+                he = hipMemcpyAsync(base + L.total * (size_t)s + L.row_strip0,
+                                    rs_all.data() + (size_t)s * (size_t)(nbmax + 1),
+                                    sizeof(int32_t) * (size_t)(J.nb + 1), hipMemcpyHostToDevice, stream);
+                if (he != hipSuccess) break;
+            }
             if (he == hipSuccess)
-                he = hipMemcpyAsync(flags, states_dev, sizeof(int32_t) * 4 * (size_t)cnt, hipMemcpyDeviceToHost, stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(stream);
-            if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep step", __FILE__, __LINE__); break; }
-            if (profiler().enabled) profiler().collect();
-            bool all = true;
-            for (int i = 0; i < cnt; ++i) all = all && flags[4 * i] != 0;
-            if (all || step >= cap) break;
+                he = hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(strips_dev, strips.data(), sizeof(Strip) * strips.size(), hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(slots_dev, fresh.data(), sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(stream);   // host vectors are reused
+            if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep job upload", __FILE__, __LINE__); break; }
+            rc = launch_gather_packed((const cplx*)cs, g, th_cents, M, jobs_dev, slots_dev, (int)fresh.size(),
+                                      nb_fresh, stream);
+            if (rc != SCINT_OK) break;
+            hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0,
+                               stream, jobs_dev, slots_dev);
+        }
+        // ---- kCheckEvery common Lanczos steps, then look at the Ritz pairs -------------------
+        int nb_run = 1;
+        for (int s = 0; s < nslots; ++s)
+            if (slot_eta[(size_t)s] >= 0) nb_run = std::max(nb_run, jobs[(size_t)s].nb);
+        const unsigned nstrips = (unsigned)strips.size();
+        for (int i = 0; i < kCheckEvery; ++i, ++launch) {
+            const int slot = profiler().begin(kProfMatvec, stream);
+            hipLaunchKernelGGL(pk_matvec_kernel, dim3(nstrips), dim3(256), 0, stream, jobs_dev, strips_dev, launch);
+            profiler().end(kProfMatvec, slot, stream);
+            hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(256), 0, stream,
+                               jobs_dev, launch);
+        }
+        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, jobs_dev, launch);
+        he = hipGetLastError();
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(flags, states_dev, sizeof(int32_t) * 4 * (size_t)nslots, hipMemcpyDeviceToHost, stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(stream);
+        if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep step", __FILE__, __LINE__); break; }
+        if (profiler().enabled) profiler().collect();
+        for (int s = 0; s < nslots; ++s) {
+            if (slot_eta[(size_t)s] >= 0 && flags[4 * s] != 0) {
+                slot_eta[(size_t)s] = -1;     // finished: results were written by the check kernel
+                jobs[(size_t)s].n = 0;        // an idle slot's kernels exit at once
+                --active;
+            }
         }
     }
     (void)hipHostFree(flags);

@@ -14,6 +14,8 @@
 // J > I, y_J += A_IJ^H x_I -- into per-strip / per-tile partial vectors that a second
 // kernel sums in a fixed order, so the result is bit-reproducible (no atomics).
 #pragma once
+#include <stdlib.h>
+
 #include "thth.hpp"
 
 namespace scint {
@@ -29,7 +31,11 @@ __host__ __device__ inline int64_t tile_count(int nb) { return (int64_t)nb * (nb
 // strips: consecutive tiles (I, J0..J1) of one block row handled by one workgroup
 // (long strips amortise the per-workgroup prologue/epilogue; the length depends on nb only, so
 // the summation order -- and every bit of the result -- is independent of the batch)
-inline int strip_len_for(int nb) { return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1))); }
+inline int strip_len_for(int nb) {
+    static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced > 16 ? 16 : forced;   // experiments only
+    return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
+}
 inline int strips_in_row(int nb, int I, int S) { return (nb - I + S - 1) / S; }
 
 struct PackedJob {
@@ -40,6 +46,7 @@ struct PackedJob {
     cplx* tiles;            // [tile_count(nb)][64][64]
     // ---- Lanczos state -----------------------------------------------------------
     int32_t max_steps, strip_len;
+    int32_t start, pad0;    // launch index of this job's Lanczos step 0
     cplx* U[2];             // u_{j-1} / u_j                     [nb*64] each
     cplx* Q[2];             // q ring                            [nb*64] each
     cplx* rowpart;          // [nstrips][64]   row-block partial sums per strip
@@ -60,7 +67,9 @@ struct Strip {
     int32_t index;            // strip index inside the job (row of rowpart)
 };
 
+// Gather for the jobs in slots[0..njobs) (device array of indices into jobs_dev).
 int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
-                             const PackedJob* jobs_dev, int njobs, int nbmax, hipStream_t stream);
+                             const PackedJob* jobs_dev, const int32_t* slots_dev, int njobs, int nbmax,
+                             hipStream_t stream);
 
 }  // namespace scint

@@ -93,8 +93,9 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 // ------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 thth_gather_packed_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restrict__ th,
-                          int64_t M, const PackedJob* __restrict__ jobs) {
-    const PackedJob job = jobs[blockIdx.z];
+                          int64_t M, const PackedJob* __restrict__ jobs,
+                          const int32_t* __restrict__ slots) {
+    const PackedJob job = jobs[slots[blockIdx.z]];
     const int I = blockIdx.y, J = blockIdx.x;
     if (I >= job.nb || J >= job.nb || J < I) return;
     const int n = job.n;
@@ -121,12 +122,13 @@ thth_gather_packed_kernel(const cplx* __restrict__ cs, GeomDev g, const double* 
 }
 
 int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
-                             const PackedJob* jobs_dev, int njobs, int nbmax, hipStream_t stream) {
+                             const PackedJob* jobs_dev, const int32_t* slots_dev, int njobs, int nbmax,
+                             hipStream_t stream) {
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
     SCINT_REQUIRE(nbmax <= 65535 && njobs <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
     hipLaunchKernelGGL(thth_gather_packed_kernel, dim3((unsigned)nbmax, (unsigned)nbmax, (unsigned)njobs),
-                       dim3(256), 0, stream, cs, g, th_cents, M, jobs_dev);
+                       dim3(256), 0, stream, cs, g, th_cents, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;

@@ -1,0 +1,130 @@
+"""Full-size (BASELINE.json configs 2-5) checks on the GPU.  Where the CPU oracle finishes in
+seconds the comparison is direct; otherwise size-independent properties are used: Parseval and
+Hermitian symmetry of the conjugate spectrum, exact Hermitian symmetry / zero diagonal of
+theta-theta, the eigen-residual |A v - w v| of the returned pair (checked with an independent
+NumPy mat-vec), agreement between the packed sweep and the dense solver, linearity."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import thth_oracle as to
+    from scintools_amd import ththmod as thth
+    from scintools_amd.device import require_gpu
+    from scintools_amd.synth import arc_dynspec
+    require_gpu()
+    return thth, to, arc_dynspec
+
+
+def _setup(env, size, seed, nedge=None):
+    thth, to, arc = env
+    dyn, freqs, times, eta_true = arc(size, size, seed=seed, nimg=64)
+    dyn -= dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge or size)
+    return dyn, fd, tau, edges, eta_true
+
+
+def test_cs_4096_parseval_symmetry_linearity(env):
+    thth, to, _ = env
+    dyn, fd, tau, edges, _ = _setup(env, 4096, 3)
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0).cpu().numpy()
+    assert cs.shape == (4096, 4096)
+    # Parseval
+    assert np.sum(np.abs(cs) ** 2) == pytest.approx(dyn.size * np.sum(dyn**2), rel=1e-12)
+    # real input: CS[-tau, -fd] = conj(CS[tau, fd]) (fftshifted: index n - i, for i >= 1)
+    a = cs[1:, 1:]
+    assert np.abs(a - np.conj(a[::-1, ::-1])).max() <= 1e-9 * np.abs(cs).max()
+    # a few rows against NumPy directly (full 2-D transform of 4096^2 is cheap enough on the host)
+    ref = np.fft.fftshift(np.fft.fft2(dyn))
+    assert np.abs(cs - ref).max() <= 1e-12 * np.abs(ref).max()
+    # linearity
+    cs2 = thth.conjugate_spectrum(2.5 * dyn, 0, pad_value=0.0).cpu().numpy()
+    assert np.abs(cs2 - 2.5 * cs).max() <= 1e-12 * np.abs(cs2).max()
+
+
+def test_sspec_4096_vs_oracle(env):
+    import torch
+    from oracle import sspec_oracle as so
+    from scintools_amd.dynspec import sspec_device
+    thth, to, _ = env
+    dyn, *_ = _setup(env, 4096, 3)
+    for kw in (dict(), dict(prewhite=True)):
+        sec = sspec_device(thth.to_device(dyn, torch.float64), **kw).cpu().numpy()
+        ref = so.calc_sspec(dyn, 30.0, 0.1, **kw)[2]
+        assert sec.shape == ref.shape == (4096, 8192)
+        lin, lref = 10 ** (sec / 10), 10 ** (ref / 10)
+        assert np.abs(lin - lref).max() <= 1e-10 * lref.max()
+        strong = lref > 1e-6 * lref.max()
+        assert np.abs(sec - ref)[strong].max() <= 1e-8
+
+
+@pytest.mark.parametrize("size,seed", [(2048, 2), (4096, 3)])
+def test_thth_hermitian_and_eigpair_residual(env, size, seed):
+    thth, to, _ = env
+    dyn, fd, tau, edges, eta_true = _setup(env, size, seed)
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
+    eta = 0.84 * eta_true
+    red, edges_red = thth.thth_redmap(cs, tau, fd, eta, edges)
+    n = red.shape[0]
+    assert n == size - 1
+    assert np.array_equal(red, red.conj().T)                 # exactly Hermitian
+    assert not np.any(np.diag(red)) and not np.any(np.diag(red[::-1]))
+    assert np.count_nonzero(red) > 0.5 * n * n
+    # dense solver: eigenpair residual with an independent mat-vec
+    from scintools_amd.ththmod import _eigh_top_dev
+    w, V, iters = _eigh_top_dev(thth.to_device(red))
+    V = V.cpu().numpy()
+    assert np.linalg.norm(red @ V - w * V) <= 1e-9 * abs(w)
+    assert abs(np.linalg.norm(V) - 1) <= 1e-12
+    # packed sweep agrees with the dense solver and with Eval_calc's definition |w|
+    eig = thth.eval_sweep(cs, tau, fd, np.array([eta]), edges)[0]
+    assert eig == pytest.approx(abs(w), rel=1e-10)
+    # Rayleigh quotient can only underestimate the top eigenvalue
+    x = np.random.default_rng(0).standard_normal(n) + 0j
+    assert (np.vdot(x, red @ x).real / np.vdot(x, x).real) <= w * (1 + 1e-12)
+
+
+def test_gather_4096_spot_rows_vs_oracle(env):
+    """Bit-equality of whole rows of the 4095 x 4095 map against the oracle's index math,
+    evaluated row-wise on the host (the full oracle map needs ~1 GB of temporaries per array)."""
+    thth, to, _ = env
+    dyn, fd, tau, edges, eta_true = _setup(env, 4096, 3)
+    CS = np.fft.fftshift(np.fft.fft2(dyn))
+    red, _ = thth.thth_redmap(CS, tau, fd, eta_true, edges)
+    th = to.theta_centres(edges)
+    dtau, dfd = np.diff(tau).mean(), np.diff(fd).mean()
+    M = th.shape[0]
+    for i in (0, 1, 777, 2047, 3000, 4093):
+        th1, th2 = th, th[i]
+        tau_inv = (((eta_true * (th1**2 - th2**2)) - tau[0] + dtau / 2) // dtau).astype(int)
+        fd_inv = (((th1 - th2) - fd[0] + dfd / 2) // dfd).astype(int)
+        pnts = (tau_inv > 0) * (tau_inv < tau.shape[0]) * (fd_inv < fd.shape[0])
+        row = np.zeros(M, complex)
+        row[pnts] = CS[tau_inv[pnts], fd_inv[pnts]]
+        row *= np.sqrt(np.abs(2 * eta_true * (th2 - th1)))
+        row[: i + 1] = 0                       # strictly upper part of row i
+        row[M - 1 - i] = 0                     # anti-diagonal
+        got = red[i].copy()
+        got[: i + 1] = 0
+        assert np.array_equal(got, np.nan_to_num(row)), i
+
+
+def test_config5_8192_eigen_and_fit_vs_oracle(env):
+    """BASELINE config 5: 8192^2, N = 8191, fp64 eigenvalue tolerance-checked against the
+    reference algorithm (oracle gather + ARPACK) at the curvature of the arc, and the fitted
+    curvature of a 33-eta sweep around it against the injected one."""
+    thth, to, _ = env
+    dyn, fd, tau, edges, eta_true = _setup(env, 8192, 5)
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
+    etas = np.linspace(0.9, 1.1, 33) * eta_true
+    eigs, info = thth.eval_sweep(cs, tau, fd, etas, edges, return_info=True)
+    assert np.all(info["status"] == 0) and info["N"].max() == 8191
+    eta_fit, eta_sig, _ = thth.fit_eig_peak(etas, eigs, 0.1)
+    assert eta_fit == pytest.approx(eta_true, rel=2e-2)
+    CS = cs.cpu().numpy()
+    ref = to.Eval_calc(CS, tau, fd, etas[16], edges)
+    assert eigs[16] == pytest.approx(ref, rel=1e-9)
