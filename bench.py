@@ -39,6 +39,19 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def pmc_traffic_ratio():
+    """HBM bytes / algorithmic bytes of the dominant kernel, from the committed PMC summary
+    (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same script, gfx950
+    FETCH x2 correction -- tools/pmc_summary.py).  None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        k = json.load(fh)["kernels"].get("scint::pk_matvec_kernel", {})
+    return k.get("traffic_over_algorithmic"), os.path.relpath(files[-1], REPO)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +163,8 @@ def main():
         gather_bytes = float(np.sum(8.0 * n_ * (n_ - 1.0) + 8.0 * n_ * (n_ + 1.0))) * args.steps
         mv_s = ms[1] / 1e3
         achieved = alg_bytes / mv_s / 1e9 if mv_s > 0 else 0.0
+        ratio, ratio_src = pmc_traffic_ratio()
+        alg_per_launch = alg_bytes / max(1, launches[1])
         out = {
             "metric": "eta_curvature_sweep_points_per_sec",
             "value": world * neta * args.steps / elapsed,
@@ -173,7 +188,11 @@ def main():
                        "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
             "roofline": {"kernel": "pk_matvec_kernel", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_per_launch,
+                         "traffic": (ratio * alg_per_launch) if ratio else None,
+                         "traffic_note": (f"HBM bytes per launch = {ratio:.3f} x algorithmic bytes; ratio measured "
+                                          f"with rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
+                                          f"separate passes), {ratio_src}") if ratio else None,
                          "avg_launch_ms": ms[1] / max(1, launches[1]), "launches": int(launches[1]),
                          "algorithmic_bytes_per_step": alg_bytes / args.steps,
                          "share_of_step_time": mv_s / elapsed},
