@@ -91,33 +91,62 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 // ------------------------------------------------------------------------------
 // packed gather (eta sweep): only tiles on/above the block diagonal, 64 KiB contiguous each
 // ------------------------------------------------------------------------------
+// One 32 x 32 quadrant of a 64 x 64 packed tile per 256-thread block (32 lanes x 8 rows, four
+// rows per thread): the quadrant's footprint in the CS is a compact patch (~16 f_D bins wide),
+// which keeps the scattered 16-B reads inside few cache lines per wave.
 __global__ void __launch_bounds__(256)
 thth_gather_packed_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restrict__ th,
                           int64_t M, const PackedJob* __restrict__ jobs,
                           const int32_t* __restrict__ slots) {
-    const PackedJob job = jobs[slots[blockIdx.z]];
-    const int I = blockIdx.y, J = blockIdx.x;
-    if (I >= job.nb || J >= job.nb || J < I) return;
-    const int n = job.n;
-    const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int j = J * kTB + tx;
-    const int kj = j < n ? job.keep[j] : 0;
+    const PackedJob* __restrict__ jp = jobs + slots[blockIdx.z];
+    const int I = blockIdx.y >> 1, J = blockIdx.x >> 1;       // 64-tile coordinates
+    const int qi = blockIdx.y & 1, qj = blockIdx.x & 1;       // quadrant inside the tile
+    const int nb = jp->nb, n = jp->n;
+    if (I >= nb || J >= nb || J < I) return;
+    const int32_t* __restrict__ keep = jp->keep;
+    const double eta = jp->eta, two_eta = jp->two_eta;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int cj = qj * 32 + tx;                              // column inside the 64-tile
+    const int j = J * kTB + cj;
+    const int kj = j < n ? keep[j] : 0;
     const double th_j = j < n ? th[kj] : 0.0;
-    cplx* __restrict__ tile = job.tiles + (tile_offset(job.nb, I) + (J - I)) * kTileElems;
-#pragma unroll 4
-    for (int r = 0; r < 16; ++r) {
-        const int rr = 16 * w + r;
-        const int i = I * kTB + rr;
-        cplx v = mk(0.0, 0.0);
+    cplx* __restrict__ tile = jp->tiles + (tile_offset(nb, I) + (J - I)) * kTileElems;
+    // Three phases so that a lane's scattered CS reads are all in flight together:
+    // (1) index math, (2) the loads, (3) weights and stores.
+    int64_t off[4];
+    double wgt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ri = qi * 32 + ty + 8 * r;
+        const int i = I * kTB + ri;
+        off[r] = -1;
+        wgt[r] = 0.0;
         if (i < n && j < n && i != j) {
-            const int ki = job.keep[i];
+            const int ki = keep[i];
             const double th_i = th[ki];
-            if (i < j) v = thth_value(cs, g, job.eta, job.two_eta, th_i, th_j);
-            else v = conj(thth_value(cs, g, job.eta, job.two_eta, th_j, th_i));  // diagonal tile, lower half
-            if ((int64_t)ki + kj == M - 1) v = mk(0.0, 0.0);   // anti-diagonal (ththmod.py:113)
+            // upper element (i < j) reads (theta2 = th_i, theta1 = th_j); the lower half of a
+            // diagonal tile is the conjugate of the mirrored upper element
+            const double t2 = i < j ? th_i : th_j, t1 = i < j ? th_j : th_i;
+            int64_t o = thth_offset(g, eta, t2, t1);
+            if ((int64_t)ki + kj == M - 1) o = -1;          // anti-diagonal (ththmod.py:113)
+            off[r] = o;
+            wgt[r] = sqrt(fabs(two_eta * (t2 - t1)));
+            if (i > j) wgt[r] = -wgt[r];                    // sign carries "conjugate"
+        }
+    }
+    cplx val[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) val[r] = cs[off[r] >= 0 ? off[r] : 0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cplx v = mk(0.0, 0.0);
+        if (off[r] >= 0) {
+            const double aw = fabs(wgt[r]);
+            v = mk(val[r].x * aw, val[r].y * aw);
+            if (wgt[r] < 0.0) v = conj(v);
             v = mk(nan_to_num(v.x), nan_to_num(v.y));
         }
-        tile[rr * kTB + tx] = v;
+        tile[(qi * 32 + ty + 8 * r) * kTB + cj] = v;
     }
 }
 
@@ -125,9 +154,9 @@ int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_
                              const PackedJob* jobs_dev, const int32_t* slots_dev, int njobs, int nbmax,
                              hipStream_t stream) {
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
-    SCINT_REQUIRE(nbmax <= 65535 && njobs <= 65535, "gather: grid too large");
+    SCINT_REQUIRE(nbmax <= 32767 && njobs <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
-    hipLaunchKernelGGL(thth_gather_packed_kernel, dim3((unsigned)nbmax, (unsigned)nbmax, (unsigned)njobs),
+    hipLaunchKernelGGL(thth_gather_packed_kernel, dim3(2u * (unsigned)nbmax, 2u * (unsigned)nbmax, (unsigned)njobs),
                        dim3(256), 0, stream, cs, g, th_cents, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();

@@ -66,6 +66,21 @@ __device__ inline cplx thth_value(const cplx* __restrict__ cs, const GeomDev& g,
     return mk(v.x * w, v.y * w);
 }
 
+// Index half of thth_value: linear offset into CS of the pixel feeding (theta2 = th_i,
+// theta1 = th_j), -1 if the point is outside the CS (value 0), -2 if NumPy would raise.
+__device__ inline int64_t thth_offset(const GeomDev& g, double eta, double th_i, double th_j) {
+    const double a_tau = ((eta * (th_j * th_j - th_i * th_i)) - g.tau0) + g.half_dtau;
+    const double a_fd = ((th_j - th_i) - g.fd0) + g.half_dfd;
+    const int64_t tau_inv = (int64_t)floor_div_exact(a_tau, g.dtau);
+    int64_t fd_inv = (int64_t)floor_div_exact(a_fd, g.dfd);
+    if (!(tau_inv > 0 && tau_inv < g.ntau && fd_inv < g.nfd)) return -1;
+    if (fd_inv < 0) {
+        fd_inv += g.nfd;
+        if (fd_inv < 0) return -2;
+    }
+    return tau_inv * g.nfd + fd_inv;
+}
+
 // One theta-theta matrix to build: curvature, crop and destination.
 struct GatherJob {
     double eta, two_eta;     // eta and 2*eta (ththmod.py:95, 107)
