@@ -1,10 +1,17 @@
-"""Drop-in for the secondary-spectrum entry point of ``scintools.dynspec.Dynspec``.
+"""Drop-in for the hot-path entry points of ``scintools.dynspec.Dynspec``.
 
 Only what the hot path needs is here: a ``Dynspec`` that is built from an object
-carrying the reference's attributes (a ``scint_sim.Simulation``, a reference
-``Dynspec``, or plain arrays) and its ``calc_sspec`` with the reference's
-signature (dynspec.py:3584-3748) running as HIP kernels (``scint_sspec``).  File
-I/O, cleaning, fitting and plotting are out of scope.
+carrying the reference's attributes (a ``scint_sim.Simulation``, a ``BasicDyn``, a
+reference ``Dynspec``, or plain arrays) with
+
+* ``calc_sspec`` (dynspec.py:3584-3748) -> HIP kernels (``scint_sspec``);
+* ``prep_thetatheta`` / ``thetatheta_single`` / ``fit_thetatheta``
+  (dynspec.py:1348-1763): the chunked curvature search -- chunking, eta grids, edges and
+  the global eta ~ nu**-2 fit stay on the host exactly as in the reference, every
+  chunk's conjugate spectrum + eta sweep runs on the GPU (``ththmod.single_search``).
+
+File I/O, cleaning, arc fitting from the secondary spectrum (``fit_arc``), phase
+retrieval and plotting are out of scope.
 """
 import ctypes
 
@@ -12,7 +19,8 @@ import numpy as np
 import scipy.constants as sc
 import torch
 
-from . import _lib
+from . import _lib, units
+from . import ththmod as thth
 from .device import empty, ptr, require_gpu, stream_ptr, to_device, workspace
 
 _WINDOWS = {"hanning": np.hanning, "hamming": np.hamming,
@@ -131,3 +139,155 @@ class Dynspec:
             self.tdel = tdel
             return None
         return fdop, tdel, sec
+
+    # ------------------------------------------------------------------ theta-theta
+    def prep_thetatheta(self, fw=.1, npad=3, verbose=False, fitting_proc='standard', **kwargs):
+        """Set the theta-theta search parameters (dynspec.py:1348-1537).
+
+        Same keywords as the reference: cwf, cwt, fref, eta_min, eta_max, nedge, edges_lim,
+        tau_lim, tau_mask (bare numbers in s**3 / mHz / us / MHz, or astropy Quantities).
+        ``eta_min`` and ``eta_max`` are required: the reference falls back to ``fit_arc``
+        (a Hough transform of the secondary spectrum) for them, which is outside the
+        accelerated hot path.  The 'thin' procedure (rectangular theta-theta + SVD) is out
+        of scope as well.
+        """
+        fitting_procs = ['standard', 'thin', 'incoherent']
+        assert fitting_proc in fitting_procs, f'fitting_proc must be one of {fitting_procs}'
+        if fitting_proc == 'thin':
+            raise NotImplementedError("fitting_proc='thin' (two-curvature SVD) is outside the hot path")
+        if not ('eta_min' in kwargs and 'eta_max' in kwargs):
+            raise NotImplementedError("give eta_min and eta_max: the reference's fit_arc fallback "
+                                      "(dynspec.py:1458-1473) is outside the accelerated hot path")
+        val = lambda key, unit, name: float(units.strip(kwargs[key], name, unit, warn=False))
+        self.thetatheta_proc = fitting_proc
+        self.npad = npad
+        self.fw = fw
+        if 'cwf' in kwargs:
+            self.cwf = 2 * (kwargs['cwf'] // 2)
+            self.ncf_fit = self.dyn.shape[0] // self.cwf
+            self.ncf_ret = (self.dyn.shape[0] // (self.cwf // 2)) - 1
+        else:
+            self.cwf, self.ncf_fit, self.ncf_ret = self.dyn.shape[0], 1, 1
+        if 'cwt' in kwargs:
+            self.cwt = 2 * (kwargs['cwt'] // 2)
+            self.nct_fit = self.dyn.shape[1] // self.cwt
+            self.nct_ret = (self.dyn.shape[1] // (self.cwt // 2)) - 1
+        else:
+            self.cwt, self.nct_fit, self.nct_ret = self.dyn.shape[1], 1, 1
+        tau_lim = val('tau_lim', 'us', 'Tau Limit') if 'tau_lim' in kwargs else None
+        self.fref = val('fref', 'MHz', 'reference frequency') if 'fref' in kwargs else self.freqs.mean()
+
+        fd = thth.fft_axis(self.times[:self.cwt], 1000.0)       # mHz   (dynspec.py:1445)
+        tau = thth.fft_axis(self.freqs[:self.cwf], 1.0)         # us    (dynspec.py:1446)
+        eta_min = 4 * (tau[1] - tau[0]) / fd.max()**2            # dynspec.py:1448-1451
+        eta_max = tau.max() / (fd[1] - fd[0])**2
+        eta_min *= (self.freqs.max() / self.fref)**2
+        eta_max *= (self.freqs.min() / self.fref)**2
+        self.eta_min = max((val('eta_min', 's3', 'eta_min'), eta_min))
+        self.eta_max = min((val('eta_max', 's3', 'eta_max'), eta_max))
+        l0, l1 = np.log10(self.eta_min), np.log10(self.eta_max)
+        self.neta = int(1 + (l1 - l0) / np.log10(1 + self.fw / 10))     # dynspec.py:1478
+        fd_cut = (fd.max() / 2) * (self.fref / self.freqs.max())
+        edges_lim = min((val('edges_lim', 'mHz', 'edges limit'), fd_cut)) if 'edges_lim' in kwargs else fd_cut
+        if tau_lim is not None:
+            edges_lim = min((edges_lim, np.sqrt(tau_lim / self.eta_max)))
+        if 'nedge' in kwargs:
+            assert np.mod(kwargs['nedge'], 2) == 0, 'nedge must be even!'
+            self.edges = np.linspace(-edges_lim, edges_lim, kwargs['nedge'])
+        else:                                                     # dynspec.py:1500-1503
+            self.edges = np.asarray(thth.min_edges(edges_lim, fd, tau,
+                                                   self.eta_max * (self.fref / self.freqs.min()), 2)) \
+                * (self.freqs.min() / self.fref)
+            if units.HAVE_ASTROPY:
+                self.edges = np.asarray(getattr(self.edges, "value", self.edges))
+        self.thth_tau_mask = val('tau_mask', 'us', 'tau_mask') if 'tau_mask' in kwargs else 0.0
+        if verbose:
+            print("\n\t THETA-THETA PROPERTIES\n")
+            print(f'Channels per chunk: {self.cwf}')
+            print(f'Time bins per chunk: {self.cwt}')
+            print(f'Number of fitting chunks: {self.ncf_fit}x{self.nct_fit}')
+            print(f'Reference Frequency: {self.fref} MHz')
+            print(f'Eta range: {self.eta_min} to {self.eta_max} s3 with {self.neta} points')
+            print(f'Edges has {self.edges.shape[0]} point out to {self.edges[-1]} mHz')
+            print(f'Fractional fitting width: {self.fw}')
+            print(f'Zero paddings: {self.npad}')
+            print(f'Fitting Procedure: {self.thetatheta_proc}')
+            print(f'Masking |tau| < {self.thth_tau_mask} us')
+
+    def _chunk(self, cf, ct):
+        fs = slice(cf * self.cwf, (cf + 1) * self.cwf)
+        ts = slice(ct * self.cwt, (ct + 1) * self.cwt)
+        return fs, ts
+
+    def _chunk_etas(self, freq2):
+        return np.logspace(np.log10(self.eta_min), np.log10(self.eta_max), self.neta) \
+            * (self.fref / freq2.mean())**2
+
+    def thetatheta_single(self, cf=0, ct=0, fname=None, verbose=False, plot=False, arrays=True):
+        """theta-theta curvature search on one chunk (dynspec.py:1539-1655); returns
+        (etas, eigs, popt).  No diagnostic plot (plotting is out of scope)."""
+        if not hasattr(self, 'cwf'):
+            raise RuntimeError("call prep_thetatheta(eta_min=..., eta_max=..., ...) first")
+        cf, ct = min(cf, self.ncf_fit - 1), min(ct, self.nct_fit - 1)
+        fs, ts = self._chunk(cf, ct)
+        time2, freq2 = self.times[ts], self.freqs[fs]
+        tau = thth.fft_axis(freq2, 1.0, self.npad)
+        fd = thth.fft_axis(time2, 1000.0, self.npad)
+        dspec2 = np.copy(self.dyn[fs, ts])
+        dspec2 -= np.nanmean(dspec2)
+        cs = thth.conjugate_spectrum(np.nan_to_num(dspec2), self.npad, tau, self.thth_tau_mask,
+                                     self.thetatheta_proc != 'incoherent', pad_value=0.0)
+        etas = self._chunk_etas(freq2)
+        edges = self.edges * (freq2.mean() / self.fref)
+        eigs = thth.eval_sweep(cs, tau, fd, etas, edges)
+        _, _, popt = thth.fit_eig_peak(etas, eigs, self.fw)
+        if arrays:
+            return etas, eigs, popt
+
+    def fit_thetatheta(self, verbose=False, plot=False, pool=None, time_avg=False):
+        """Curvature search over all fitting chunks and the global eta ~ nu**-2 fit
+        (dynspec.py:1657-1763).  Sets eta_evo, eta_evo_err, f0s, t0s, ththeta, ththetaerr
+        (plain floats: s**3, MHz, s).  `pool` is accepted for signature compatibility; the
+        chunks run one after another on the GPU."""
+        if not hasattr(self, 'cwf'):
+            raise RuntimeError("call prep_thetatheta(eta_min=..., eta_max=..., ...) first")
+        self.eta_evo = np.zeros((self.ncf_fit, self.nct_fit))
+        self.eta_evo_err = np.zeros((self.ncf_fit, self.nct_fit))
+        self.f0s = np.zeros(self.ncf_fit)
+        self.t0s = np.zeros(self.nct_fit)
+        self.thth_eigs = np.zeros((self.ncf_fit, self.nct_fit, self.neta))
+        coher = (self.thetatheta_proc != 'incoherent')
+        for cf in range(self.ncf_fit):
+            freq2 = np.copy(self.freqs[cf * self.cwf:(cf + 1) * self.cwf])
+            self.f0s[cf] = freq2.mean()
+            etas = self._chunk_etas(freq2)
+            for ct in range(self.nct_fit):
+                fs, ts = self._chunk(cf, ct)
+                time2 = np.copy(self.times[ts])
+                self.t0s[ct] = time2.mean()
+                dspec2 = np.copy(self.dyn[fs, ts])
+                dspec2 -= np.nanmean(dspec2)
+                dspec2 = np.nan_to_num(dspec2)
+                params = [dspec2, freq2, time2, etas, self.edges * (freq2.mean() / self.fref), None, False,
+                          self.fw, self.npad, coher, self.thth_tau_mask, verbose]
+                res = thth.single_search(params)
+                self.eta_evo[cf, ct] = float(getattr(res[0], "value", res[0]))
+                self.eta_evo_err[cf, ct] = float(getattr(res[1], "value", res[1]))
+                self.thth_eigs[cf, ct] = res[4]
+        f0 = self.f0s[:, np.newaxis]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            if time_avg:                                                   # dynspec.py:1724-1732
+                eta_avg = np.nanmean(self.eta_evo, 1)
+                eta_count = np.nansum(self.eta_evo, 1) / eta_avg
+                avg_err = np.nanstd(self.eta_evo, 1) / np.sqrt(eta_count - 1)
+                tofit = np.isfinite(eta_avg) * np.isfinite(avg_err)
+                A = (np.sum(eta_avg[tofit] / (self.f0s * avg_err)[tofit] ** 2) /
+                     np.sum(1 / (self.f0s**2 * avg_err)[tofit] ** 2))
+                A_err = np.sqrt(1 / np.sum(2 / ((self.f0s**2) * avg_err)[tofit] ** 2))
+            else:                                                          # dynspec.py:1734-1742
+                tofit = np.isfinite(self.eta_evo) * np.isfinite(self.eta_evo_err)
+                A = (np.sum(self.eta_evo[tofit] / (f0 * self.eta_evo_err)[tofit] ** 2) /
+                     np.sum(1 / ((f0**2) * self.eta_evo_err)[tofit] ** 2))
+                A_err = np.sqrt(1 / np.sum(2 / ((f0**2) * self.eta_evo_err)[tofit] ** 2))
+        self.ththeta = A / self.fref**2
+        self.ththetaerr = A_err / self.fref**2

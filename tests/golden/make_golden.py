@@ -202,8 +202,30 @@ def gen_thth_medium():
          dyn_checksum=np.abs(dyn).sum())
 
 
+# ---------------------------------------------------------------------------
+# 5. the Dynspec path of the tutorial (docs/source/tutorials/dynspec_thth.rst:86-170)
+# ---------------------------------------------------------------------------
+def gen_fit_thetatheta():
+    from scintools.dynspec import BasicDyn
+    d = np.load("/root/reference/scintools/examples/data/ththsims/Sample_Data.npz")
+    dspec = np.abs(d["Espec"]) ** 2
+    freq, tme = d["f_MHz"], d["t_s"]
+    b = BasicDyn(name="Sample Data", header=["Sample Data"], times=tme, freqs=freq, dyn=dspec,
+                 nsub=tme.shape[0], nchan=freq.shape[0], dt=(tme[1] - tme[0]), df=(freq[1] - freq[0]))
+    dyn = Dynspec(dyn=b, process=False, verbose=False)
+    dyn.prep_thetatheta(verbose=False, cwf=64, edges_lim=.3, eta_min=30 * u.s**3, eta_max=50 * u.s**3)
+    etas0, eigs0, popt0 = dyn.thetatheta_single(cf=0, ct=0, plot=False, arrays=True)
+    dyn.fit_thetatheta(verbose=False)
+    save("fit_thetatheta.npz", dspec=dspec, freq=freq, time=tme, dt=b.dt, df=b.df,
+         edges=V(dyn.edges), neta=dyn.neta, npad=dyn.npad, fw=dyn.fw, fref=V(dyn.fref),
+         eta_min=V(dyn.eta_min), eta_max=V(dyn.eta_max), cwf=dyn.cwf, cwt=dyn.cwt,
+         single_etas=V(etas0), single_eigs=eigs0, single_popt=np.array(popt0),
+         eta_evo=V(dyn.eta_evo), eta_evo_err=V(dyn.eta_evo_err), f0s=V(dyn.f0s), t0s=V(dyn.t0s),
+         ththeta=V(dyn.ththeta), ththetaerr=V(dyn.ththetaerr))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "sample", "sim", "medium"]
+    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit"]
     if "small" in which:
         gen_thth_small()
     if "sample" in which:
@@ -212,3 +234,5 @@ if __name__ == "__main__":
         gen_sim()
     if "medium" in which:
         gen_thth_medium()
+    if "fit" in which:
+        gen_fit_thetatheta()

@@ -205,6 +205,11 @@ class Quantity(np.ndarray):
             out = self._wrap(out)
         return out
 
+    def __setitem__(self, key, value):
+        if isinstance(value, Quantity):
+            value = value.to_value(self._unit)
+        self.view(np.ndarray)[key] = value
+
     def __iter__(self):
         if self.ndim == 0:
             raise TypeError("scalar quantity is not iterable")

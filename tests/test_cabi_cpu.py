@@ -80,3 +80,24 @@ def test_host_grid_matches_oracle(golden):
     assert np.array_equal(fft_axis(g["freqs"], 1.0, 1), g["tau"])
     me = min_edges(0.4 * g["fd"].max(), g["fd"], g["tau"], float(g["eta_true"]), 2)
     assert np.array_equal(np.asarray(me), g["min_edges"])
+
+
+def test_prep_thetatheta_host_logic_matches_reference(golden):
+    """Chunking, eta grid and edges of Dynspec.prep_thetatheta are pure host logic: they must
+    equal what the reference derived for the tutorial recipe (dynspec_thth.rst:146-170)."""
+    from scintools_amd.dynspec import Dynspec
+    g = golden("fit_thetatheta.npz")
+
+    class B:
+        dyn, freqs, times, dt, df = g["dspec"], g["freq"], g["time"], float(g["dt"]), float(g["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50)
+    assert (d.cwf, d.cwt, d.ncf_fit, d.nct_fit) == (int(g["cwf"]), int(g["cwt"]), 16, 1)
+    assert d.neta == int(g["neta"]) and d.npad == int(g["npad"]) and d.fw == float(g["fw"])
+    assert d.fref == float(g["fref"])
+    assert d.eta_min == float(g["eta_min"]) and d.eta_max == float(g["eta_max"])
+    assert np.array_equal(d.edges, g["edges"])
+    with pytest.raises(NotImplementedError):
+        d.prep_thetatheta(cwf=64, edges_lim=.3)            # needs fit_arc in the reference
+    with pytest.raises(AssertionError):
+        d.prep_thetatheta(eta_min=30, eta_max=50, nedge=301)

@@ -266,3 +266,27 @@ def test_sspec_vs_reference_golden(golden):
     # against the reference's own single-precision result the agreement is float32-level
     lin, lref = 10 ** (d.sspec / 10), 10 ** (g["sec_default"] / 10)
     assert np.abs(lin - lref).max() <= 1e-5 * lref.max()
+
+
+def test_fit_thetatheta_vs_reference_golden(golden):
+    """The Dynspec entry point of the tutorial (dynspec_thth.rst:146-170): 16 chunks of 64
+    channels, 52 curvatures each, npad=3, auto-sized edges -- against the reference's own
+    fit_thetatheta run (tests/golden/make_golden.py::gen_fit_thetatheta)."""
+    from scintools_amd.dynspec import Dynspec
+    g = golden("fit_thetatheta.npz")
+
+    class B:
+        dyn, freqs, times, dt, df = g["dspec"], g["freq"], g["time"], float(g["dt"]), float(g["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50)
+    etas, eigs, popt = d.thetatheta_single(cf=0, ct=0)
+    assert np.array_equal(etas, g["single_etas"])
+    np.testing.assert_allclose(eigs, g["single_eigs"], rtol=1e-9)
+    np.testing.assert_allclose(popt, g["single_popt"], rtol=1e-6)
+    d.fit_thetatheta()
+    assert np.array_equal(d.f0s, g["f0s"])
+    np.testing.assert_allclose(d.eta_evo, g["eta_evo"], rtol=1e-6)
+    np.testing.assert_allclose(d.eta_evo_err, g["eta_evo_err"], rtol=1e-4)
+    assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-6)
+    assert d.ththetaerr == pytest.approx(float(g["ththetaerr"]), rel=1e-4)
+    assert abs(d.ththeta - 44.0 * (1332.0 + 64.0) ** 0 ) < 10     # same arc as the known answer
