@@ -9,7 +9,9 @@
 //                     the row-block partial  sum_J A_IJ x_J  (64 lanes stride the columns,
 //                     wave-shuffle reduction at the end of the strip) and, per off-diagonal
 //                     tile, the column-block partial  A_IJ^H x_I  (lane-local over rows,
-//                     4-wave LDS reduction).  x = q_j is never stored normalised: every
+//                     4-wave LDS reduction every 4 tiles; x_I is broadcast with v_readlane).
+//                     The loop is software-pipelined over half tiles so that >= 8 KiB per
+//                     wave is always in flight.  x = q_j is never stored normalised: every
 //                     workgroup rebuilds x = (u_{j-1} - alpha_{j-1} q_{j-1}) / beta_{j-1}
 //                     from the previous step's vectors and partial dot products.
 //                     HBM bound: 8 N^2 bytes per job-step (algorithmic = actual).
@@ -74,6 +76,7 @@ __global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs, cons
 }
 
 constexpr int kMaxStrip = 16;
+constexpr int kFlush = 4;      // column partials are reduced across the 4 waves every kFlush tiles
 
 // alpha_{j-1}, beta_{j-1} by ONE wavefront (no barriers): nb <= 64*k entries, fixed order
 __device__ inline StepScalars step_scalars_wave(const double* __restrict__ ap, const double* __restrict__ up,
@@ -89,10 +92,16 @@ __device__ inline StepScalars step_scalars_wave(const double* __restrict__ ap, c
     return s;
 }
 
+// wave-uniform broadcast of lane `src`'s double through the scalar unit (no LDS, no VGPR)
+__device__ inline double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(256, 2)
 pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx xI[kTB];
-    __shared__ cplx cred[4][kMaxStrip][kTB];   // per-wave column partials of the strip (64 KiB)
+    __shared__ cplx cred[4][kFlush][kTB];      // per-wave column partials of kFlush tiles (16 KiB)
     const Strip st = strips[blockIdx.x];
     const PackedJob* __restrict__ jp = jobs + st.job;
     const int step = launch - jp->start;
@@ -115,14 +124,16 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
     for (int r = 0; r < 8; ++r) a0[r] = tp[r * kTB];
     const StepScalars sc = step_scalars_wave(par ? jp->apart[1] : jp->apart[0],
                                              par ? jp->upart[1] : jp->upart[0], nb, lane);
-    if (w == 0) {
+    // lane l of every wave holds x_I[l]; rows read it back with v_readlane (scalar broadcast)
+    cplx xIr;
+    {
         const cplx u = Up[I * kTB + lane], q = Qp[I * kTB + lane];
-        xI[lane] = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
+        xIr = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
     }
-    __syncthreads();
     cplx accR[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) accR[r] = mk(0.0, 0.0);
+    cplx* __restrict__ colpart = jp->colpart;
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
         const int J = st.J0 + t;
@@ -135,7 +146,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             accR[r] = accR[r] + a0[r] * xJ;
-            const cplx xi = xI[16 * w + r];   // LDS broadcast
+            const cplx xi = mk(readlane_f64(xIr.x, 16 * w + r), readlane_f64(xIr.y, 16 * w + r));
             c = mk(c.x + a0[r].x * xi.x + a0[r].y * xi.y, c.y + a0[r].x * xi.y - a0[r].y * xi.x);   // conj(a) x_I
         }
         if (t + 1 < ntile) {
@@ -145,19 +156,23 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             accR[8 + r] = accR[8 + r] + a1[r] * xJ;
-            const cplx xi = xI[16 * w + 8 + r];
+            const cplx xi = mk(readlane_f64(xIr.x, 16 * w + 8 + r), readlane_f64(xIr.y, 16 * w + 8 + r));
             c = mk(c.x + a1[r].x * xi.x + a1[r].y * xi.y, c.y + a1[r].x * xi.y - a1[r].y * xi.x);
         }
-        cred[w][t][lane] = c;   // this wave's own slot: no barrier needed yet
-    }
-    // one cross-wave reduction of the column partials for the whole strip
-    __syncthreads();
-    cplx* __restrict__ colpart = jp->colpart;
-    for (int t = w; t < ntile; t += 4) {
-        const int J = st.J0 + t;
-        if (J != I) {
-            const cplx s = ((cred[0][t][lane] + cred[1][t][lane]) + cred[2][t][lane]) + cred[3][t][lane];
-            colpart[(t0 + (J - I)) * kTB + lane] = s;
+        cred[w][t & (kFlush - 1)][lane] = c;   // this wave's own slot
+        if ((t & (kFlush - 1)) == kFlush - 1 || t + 1 == ntile) {
+            // cross-wave reduction of the last <= kFlush tiles' column partials: wave w takes tile w
+            __syncthreads();
+            const int tb = t & ~(kFlush - 1);
+            const int tt = tb + w;
+            if (tt <= t) {
+                const int Jt = st.J0 + tt;
+                if (Jt != I) {
+                    const cplx s = ((cred[0][w][lane] + cred[1][w][lane]) + cred[2][w][lane]) + cred[3][w][lane];
+                    colpart[(t0 + (Jt - I)) * kTB + lane] = s;
+                }
+            }
+            __syncthreads();
         }
     }
     cplx* __restrict__ rowpart = jp->rowpart;
@@ -518,6 +533,11 @@ extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* g
                 }
                 rs0[J.nb] = idx;
             }
+            // longest strips first: the short ones of the last block rows then fill the tail
+            // of the launch (dispatch order only; the arithmetic does not depend on it)
+            std::stable_sort(strips.begin(), strips.end(), [](const Strip& a, const Strip& b) {
+                return (a.J1 - a.J0) > (b.J1 - b.J0);
+            });
             for (int s : fresh) {
                 const PackedJob& J = jobs[(size_t)s];
                 nb_fresh = std::max(nb_fresh, J.nb);

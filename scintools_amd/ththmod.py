@@ -322,7 +322,7 @@ def default_batch(nmax, neta):
     nb = -(-nmax // 64)
     strip = 16 if nb >= 32 else (8 if nb >= 16 else (4 if nb >= 8 else (2 if nb >= 4 else 1)))
     strips = sum(-(-(nb - i) // strip) for i in range(nb))
-    want = -(-5000 // max(strips, 1))
+    want = -(-7500 // max(strips, 1))
     cap = max(1, DEFAULT_BATCH_BYTES // (8 * (nb * 64) ** 2 + 1))
     return int(max(1, min(neta, 256, want, cap)))
 
