@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--neta", type=int, default=256)
     ap.add_argument("--nedge", type=int, default=None, help="default: size")
     ap.add_argument("--batch", type=int, default=None, help="etas resident per launch")
+    ap.add_argument("--objective", choices=["eig", "chisq"], default="eig",
+                    help="eig: Eval_calc sweep of single_search (headline); chisq: modeler/chisq_calc sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="etas timed on the CPU oracle")
     return ap.parse_args()
@@ -127,6 +129,12 @@ def main():
     def step():
         # body of single_search (ththmod.py:773-859): CS once, the eta loop, the peak fit
         cs_t = ththmod.conjugate_spectrum(dyn_t, 0, tau, 0.0, True)
+        if args.objective == "chisq":
+            # the other objective of BASELINE config 3: chisq_calc(modeler(...)) for every eta
+            chis, info = ththmod.chisq_sweep(dyn_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
+            if world > 1:
+                dist.all_gather(gathered, torch.from_numpy(chis).cuda())
+            return chis, info, (etas[np.nanargmin(chis)], np.nan, None)
         eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
         if world > 1:
             dist.all_gather(gathered, torch.from_numpy(eigs).cuda())
@@ -178,9 +186,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{size}x{size} dynspec, {neta}-eta theta-theta eigenvalue sweep "
-                                   f"(Eval_calc loop of single_search), nedge={nedge}, npad=0, "
-                                   f"one observation per GPU",
+            "config": {"workload": (f"{size}x{size} dynspec, {neta}-eta theta-theta eigenvalue sweep "
+                                    f"(Eval_calc loop of single_search), nedge={nedge}, npad=0, "
+                                    f"one observation per GPU") if args.objective == "eig" else
+                                   (f"{size}x{size} dynspec, {neta}-eta modeler/chisq_calc sweep, nedge={nedge}, "
+                                    f"npad=0, one observation per GPU"),
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
@@ -201,7 +211,7 @@ def main():
                        "launches": int(launches[0]),
                        "frac": (gather_bytes / (ms[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else 0.0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
             cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample)
             out["cpu_baseline"] = cb
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(

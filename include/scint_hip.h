@@ -124,6 +124,20 @@ int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*
                          double* eigs_out, int32_t* status_out, int32_t* iters_out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same sweep, but returning the eigenpair (signed w and unit eigenvector) of every eta: the
+ * eigsh call of modeler (ththmod.py:308) for a whole curvature sweep.  vec_out[neta, vec_stride]
+ * (vec_stride >= M; row i holds keep_n[i] entries).  Stops on the Ritz residual (tol). */
+int32_t scint_eigvec_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                           int32_t max_iter, size_t* bytes /*HOST*/);
+int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
+                           const double* th_cents, int64_t M,
+                           const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
+                           const double* etas /*HOST*/, int64_t neta,
+                           double tol, int32_t max_iter, int64_t batch,
+                           double* w_out, scint_c128* vec_out, int64_t vec_stride,
+                           int32_t* status_out, int32_t* iters_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- dominant eigenpair of a given Hermitian matrix (eigsh k=1 'LA') ----- */
 /* a[n,n] row-major.  v0[n] start vector or NULL (then a fixed pseudo-random
  * start, as modeler's eigsh call has no v0, ththmod.py:308).  w_out[1],
@@ -153,7 +167,7 @@ int32_t scint_model_from_recov(const scint_c128* recov, int64_t ntau, int64_t nf
                                void* stream);
 
 /* ---- chi^2: sum((model[:nf,:nt]-dspec)[mask]**2)/N (ththmod.py:364-367) --- */
-/* mask: uint8[nf*nt] or NULL (= isfinite(dspec)).  out: DEVICE double[1]. */
+/* mask: uint8[nf*nt] or NULL (= isfinite(dspec)).  out: DEVICE double[1].  Asynchronous. */
 int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
                     int64_t nf, int64_t nt, const uint8_t* mask, double noise_n,
                     double* out, void* stream);

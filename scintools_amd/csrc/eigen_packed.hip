@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs, cons
     if (r < jb.n && jb.n >= 2) v = packed_at(jb, jb.n / 2, r);
     jb.U[0][r] = v;
     jb.U[1][r] = mk(0.0, 0.0);
-    jb.Q[0][r] = mk(0.0, 0.0);
-    jb.Q[1][r] = mk(0.0, 0.0);
+    jb.Q[(int64_t)(jb.qslots - 1) * jb.qstride + r] = mk(0.0, 0.0);   // "q_{-1}" = 0
+    jb.Q[r] = mk(0.0, 0.0);
     const double p = wave_sum(norm2(v));
     if (e == 0) {
         jb.apart[0][K] = 0.0; jb.upart[0][K] = p;
@@ -109,7 +109,8 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
     const int par = step & 1;
     const int nb = jp->nb;
     const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
-    const cplx* __restrict__ Qp = par ? jp->Q[0] : jp->Q[1];   // q_{j-1} lives in slot (j-1)&1
+    const int qs = jp->qslots;
+    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride;   // q_{j-1}
     const cplx* __restrict__ tiles = jp->tiles;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int I = st.I;
@@ -209,9 +210,9 @@ __global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restr
         const cplx total = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
         const int r = K * kTB + e;
         const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
-        const cplx* __restrict__ Qp = par ? jb.Q[0] : jb.Q[1];
+        const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + jb.qslots - 1) % jb.qslots) * jb.qstride;
         cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
-        cplx* __restrict__ Qn = par ? jb.Q[1] : jb.Q[0];
+        cplx* __restrict__ Qn = jb.Q + (int64_t)(step % jb.qslots) * jb.qstride;
         const cplx up = Up[r], qp = Qp[r];
         const cplx qn = mk((up.x - sc.alpha * qp.x) * sc.inv, (up.y - sc.alpha * qp.y) * sc.inv);
         const cplx t = mk(total.x - sc.beta * qp.x, total.y - sc.beta * qp.y);
@@ -324,7 +325,9 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
         if (k >= 2) theta2 = multisect(a, b, k, k - 1, lo, theta, tiny, lane);
         // Ritz residual beta_k |s_{k-1}|, s = eigenvector of T_k by the backward recurrence
         if (lane == 0) {
+            double* __restrict__ sv = jb.want_vec ? jb.svec : nullptr;
             double sk = 1.0, skp1 = 0.0, nrm = 1.0, last = 1.0;
+            if (sv) sv[k - 1] = 1.0;
             for (int i = k - 1; i >= 1; --i) {
                 const double bi = b[i];
                 double sm1 = (bi != 0.0) ? ((theta - a[i]) * sk - (i + 1 < k ? b[i + 1] * skp1 : 0.0)) / bi : 0.0;
@@ -332,12 +335,16 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
                 if (fabs(sm1) > 1e150) {
                     const double f = 1e-150;
                     sm1 *= f; sk *= f; last *= f; nrm *= f * f;
+                    if (sv) for (int t = i; t < k; ++t) sv[t] *= f;
                 }
+                if (sv) sv[i - 1] = sm1;
                 nrm += sm1 * sm1;
                 skp1 = sk;
                 sk = sm1;
             }
-            resid = beta_k * fabs(last) / sqrt(nrm);
+            const double inv = 1.0 / sqrt(nrm);
+            if (sv) for (int t = 0; t < k; ++t) sv[t] *= inv;
+            resid = beta_k * fabs(last) * inv;
         }
         resid = __shfl(resid, 0, 64);
         const double gap = theta - theta2;
@@ -348,25 +355,66 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
         const double at = fmax(fabs(theta), 1e-300);
         const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
         const bool exact = finite && (k >= jb.n || beta_k == 0.0);
-        const bool conv = finite && ((err <= jb.tol * at && settled) || exact);
+        // eigenvalue only: a-posteriori bound on theta; eigenvector wanted: the Ritz residual
+        // itself (vector error ~ resid / gap)
+        const bool ok = jb.want_vec ? (resid <= jb.tol * at) : (err <= jb.tol * at && settled);
+        const bool conv = finite && (ok || exact);
         const bool stop = conv || !finite || k >= jb.max_steps;
         jb.result[0] = theta; jb.result[1] = err; jb.result[2] = resid; jb.result[3] = theta;
         if (stop) {
             jb.state[0] = 1;
             jb.state[1] = k;
-            jb.eig_out[0] = fabs(theta);
+            jb.eig_out[0] = jb.want_vec ? theta : fabs(theta);   // modeler keeps the sign of w
             if (jb.iters_out) jb.iters_out[0] = k;
             jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
         }
     }
 }
 
+// Ritz vector of finished jobs: y = sum_j s_j q_j, then normalised (fixed-order reductions).
+// grid (nb, njobs); vec_out rows are `vstride` apart and indexed by the job's eta index.
+__global__ void __launch_bounds__(64) pk_ritz_kernel(const PackedJob* jobs, const int32_t* slots,
+                                                     const int64_t* eta_index, cplx* vec_out,
+                                                     int64_t vstride) {
+    const PackedJob jb = jobs[slots[blockIdx.y]];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (K >= jb.nb) return;
+    const int k = jb.state[1];
+    const int r = K * kTB + e;
+    cplx y = mk(0.0, 0.0);
+    for (int j = 0; j < k; ++j) {
+        const cplx q = jb.Q[(int64_t)j * jb.qstride + r];
+        const double s = jb.svec[j];
+        y = mk(y.x + s * q.x, y.y + s * q.y);
+    }
+    cplx* out = vec_out + eta_index[blockIdx.y] * vstride;
+    if (r < jb.n) out[r] = y;
+    const double p = wave_sum(r < jb.n ? norm2(y) : 0.0);
+    if (e == 0) jb.upart[0][K] = p;   // the job is finished: its partial arrays are free
+}
+
+__global__ void __launch_bounds__(64) pk_ritz_scale_kernel(const PackedJob* jobs, const int32_t* slots,
+                                                           const int64_t* eta_index, cplx* vec_out,
+                                                           int64_t vstride) {
+    const PackedJob jb = jobs[slots[blockIdx.y]];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (K >= jb.nb) return;
+    double t = 0.0;
+    for (int i = e; i < jb.nb; i += 64) t += jb.upart[0][i];
+    t = wave_sum(t);
+    const double inv = t > 0.0 ? 1.0 / sqrt(t) : 0.0;
+    const int r = K * kTB + e;
+    cplx* out = vec_out + eta_index[blockIdx.y] * vstride;
+    if (r < jb.n) out[r] = mk(out[r].x * inv, out[r].y * inv);
+}
+
 // ------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------
 struct SlabLayout {
-    size_t tiles, U0, U1, Q0, Q1, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
+    size_t tiles, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
         alpha, beta, result, total;
+    int qslots;
 };
 
 static int max_strips(int nb) {
@@ -376,7 +424,7 @@ static int max_strips(int nb) {
     return n;
 }
 
-static SlabLayout slab_layout(int nbmax, int max_steps) {
+static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     SlabLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
@@ -386,8 +434,9 @@ static SlabLayout slab_layout(int nbmax, int max_steps) {
     L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB);
-    L.Q0 = take(sizeof(cplx) * (size_t)nbmax * kTB);
-    L.Q1 = take(sizeof(cplx) * (size_t)nbmax * kTB);
+    L.qslots = want_vec ? max_steps + 1 : 2;
+    L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots);
+    L.svec = take(sizeof(double) * (size_t)(max_steps + 2));
     L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB);
     L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
@@ -405,12 +454,12 @@ static SlabLayout slab_layout(int nbmax, int max_steps) {
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, states, slots, total;
+    size_t jobs, strips, states, slots, fin_slots, fin_eta, total;
 };
 
-static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch) {
+static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec) {
     BatchLayout B;
-    B.slab = slab_layout(nbmax, max_steps);
+    B.slab = slab_layout(nbmax, max_steps, want_vec);
     B.smax = 0;
     for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb));
     size_t off = B.slab.total * (size_t)nbatch;
@@ -419,49 +468,53 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch) {
     B.strips = take(sizeof(Strip) * (size_t)nbatch * (size_t)B.smax);
     B.states = take(sizeof(int32_t) * 4 * (size_t)nbatch);
     B.slots = take(sizeof(int32_t) * (size_t)nbatch);
+    B.fin_slots = take(sizeof(int32_t) * (size_t)nbatch);
+    B.fin_eta = take(sizeof(int64_t) * (size_t)nbatch);
     B.total = align_up(off, 256);
     return B;
 }
 
-}  // namespace scint
 
-using namespace scint;
-
-extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
-                                                    int32_t max_iter, size_t* bytes) {
+static int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,
+                                     bool want_vec, size_t* bytes) {
     SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1,
-                  "eval_sweep_workspace_bytes: bad arguments");
+                  "sweep_workspace_bytes: bad arguments");
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec).total + 4096;
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom,
-                                    const double* th_cents, int64_t M, const int32_t* keep_idx,
-                                    const int32_t* keep_n, const double* etas, int64_t neta,
-                                    double tol, int32_t max_iter, int64_t batch, double* eigs_out,
-                                    int32_t* status_out, int32_t* iters_out, void* workspace,
-                                    size_t workspace_bytes, void* stream_) {
+// Shared driver of scint_eval_sweep (eigenvalues) and scint_eigvec_sweep (eigenpairs).
+static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const double* th_cents,
+                         int64_t M, const int32_t* keep_idx, const int32_t* keep_n, const double* etas,
+                         int64_t neta, double tol, int32_t max_iter, int64_t batch, double* eigs_out,
+                         int32_t* status_out, int32_t* iters_out, bool want_vec, cplx* vec_out,
+                         int64_t vstride, void* workspace, size_t workspace_bytes, void* stream_) {
     SCINT_REQUIRE(cs && geom && th_cents && keep_idx && keep_n && etas && eigs_out && status_out && workspace,
-                  "eval_sweep: null pointer");
-    SCINT_REQUIRE(M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && tol > 0, "eval_sweep: bad arguments");
-    SCINT_REQUIRE(geom->dtau > 0 && geom->dfd > 0, "eval_sweep: tau and fd must be increasing");
+                  "sweep: null pointer");
+    SCINT_REQUIRE(M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && tol > 0, "sweep: bad arguments");
+    SCINT_REQUIRE(geom->dtau > 0 && geom->dfd > 0, "sweep: tau and fd must be increasing");
+    SCINT_REQUIRE(!want_vec || (vec_out && vstride >= M), "sweep: bad eigenvector output");
     hipStream_t stream = (hipStream_t)stream_;
     size_t need = 0;
-    scint_eval_sweep_workspace_bytes(M, neta, batch, max_iter, &need);
-    if (workspace_bytes < need) { set_error("scint: eval_sweep workspace too small"); return SCINT_E_WORKSPACE; }
+    sweep_workspace_bytes(M, neta, batch, max_iter, want_vec, &need);
+    if (workspace_bytes < need) { set_error("scint: sweep workspace too small"); return SCINT_E_WORKSPACE; }
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nslots = (int)std::min(batch, neta);
-    const BatchLayout BL = batch_layout(nbmax, steps_cap, nslots);
+    const BatchLayout BL = batch_layout(nbmax, steps_cap, nslots, want_vec);
     const SlabLayout& L = BL.slab;
     char* base = (char*)workspace;
     PackedJob* jobs_dev = (PackedJob*)(base + BL.jobs);
     Strip* strips_dev = (Strip*)(base + BL.strips);
     int32_t* states_dev = (int32_t*)(base + BL.states);
     int32_t* slots_dev = (int32_t*)(base + BL.slots);
+    int32_t* fin_slots_dev = (int32_t*)(base + BL.fin_slots);
+    int64_t* fin_eta_dev = (int64_t*)(base + BL.fin_eta);
+    std::vector<int32_t> fin_slots;
+    std::vector<int64_t> fin_eta;
     const GeomDev g = to_dev(*geom);
 
     std::vector<PackedJob> jobs((size_t)nslots);
@@ -476,7 +529,8 @@ extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* g
         PackedJob& J = jobs[(size_t)s];
         J.tiles = (cplx*)(sl + L.tiles);
         J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
-        J.Q[0] = (cplx*)(sl + L.Q0); J.Q[1] = (cplx*)(sl + L.Q1);
+        J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)nbmax * kTB; J.qslots = L.qslots;
+        J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
         J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
         J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
         J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
@@ -579,14 +633,76 @@ extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* g
         if (he == hipSuccess) he = hipStreamSynchronize(stream);
         if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep step", __FILE__, __LINE__); break; }
         if (profiler().enabled) profiler().collect();
+        fin_slots.clear();
+        fin_eta.clear();
+        int nb_fin = 1;
         for (int s = 0; s < nslots; ++s) {
             if (slot_eta[(size_t)s] >= 0 && flags[4 * s] != 0) {
+                if (want_vec && jobs[(size_t)s].n >= 2) {
+                    fin_slots.push_back(s);
+                    fin_eta.push_back(slot_eta[(size_t)s]);
+                    nb_fin = std::max(nb_fin, jobs[(size_t)s].nb);
+                }
                 slot_eta[(size_t)s] = -1;     // finished: results were written by the check kernel
-                jobs[(size_t)s].n = 0;        // an idle slot's kernels exit at once
+                jobs[(size_t)s].n = 0;        // an idle slot's kernels exit at once (host copy only)
                 --active;
             }
+        }
+        if (!fin_slots.empty()) {
+            // export the Ritz vectors before the slots are re-used (the device job table still
+            // describes the finished jobs: it is only rewritten at the next refill)
+            he = hipMemcpyAsync(fin_slots_dev, fin_slots.data(), sizeof(int32_t) * fin_slots.size(),
+                                hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(fin_eta_dev, fin_eta.data(), sizeof(int64_t) * fin_eta.size(),
+                                    hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess) {
+                const dim3 grid((unsigned)nb_fin, (unsigned)fin_slots.size());
+                hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, jobs_dev, fin_slots_dev, fin_eta_dev,
+                                   vec_out, vstride);
+                hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, jobs_dev, fin_slots_dev,
+                                   fin_eta_dev, vec_out, vstride);
+                he = hipGetLastError();
+            }
+            if (he == hipSuccess) he = hipStreamSynchronize(stream);
+            if (he != hipSuccess) { rc = hip_fail(he, "sweep ritz vectors", __FILE__, __LINE__); break; }
         }
     }
     (void)hipHostFree(flags);
     return rc;
+}
+
+}  // namespace scint
+
+using namespace scint;
+
+extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                                    int32_t max_iter, size_t* bytes) {
+    return sweep_workspace_bytes(M, neta, batch, max_iter, false, bytes);
+}
+
+extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom,
+                                    const double* th_cents, int64_t M, const int32_t* keep_idx,
+                                    const int32_t* keep_n, const double* etas, int64_t neta,
+                                    double tol, int32_t max_iter, int64_t batch, double* eigs_out,
+                                    int32_t* status_out, int32_t* iters_out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return run_sweep(cs, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, eigs_out,
+                     status_out, iters_out, false, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t scint_eigvec_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                                      int32_t max_iter, size_t* bytes) {
+    return sweep_workspace_bytes(M, neta, batch, max_iter, true, bytes);
+}
+
+extern "C" int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom* geom,
+                                      const double* th_cents, int64_t M, const int32_t* keep_idx,
+                                      const int32_t* keep_n, const double* etas, int64_t neta,
+                                      double tol, int32_t max_iter, int64_t batch, double* w_out,
+                                      scint_c128* vec_out, int64_t vec_stride, int32_t* status_out,
+                                      int32_t* iters_out, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    return run_sweep(cs, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,
+                     status_out, iters_out, true, (cplx*)vec_out, vec_stride, workspace, workspace_bytes, stream);
 }

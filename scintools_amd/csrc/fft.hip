@@ -182,6 +182,24 @@ static int32_t launch_reduce(F f, int64_t n, double scale, double* partial /*kRe
     return SCINT_OK;
 }
 
+// Per-device scratch for the two-stage reductions (cached like the FFT tables; calls on one
+// device are expected to be stream-ordered, as everywhere in this library).
+static std::map<int, double*> g_red_scratch;
+static double* reduce_scratch() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("scint: hipGetDevice failed"); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    auto it = g_red_scratch.find(dev);
+    if (it != g_red_scratch.end()) return it->second;
+    double* d = nullptr;
+    if (hipMalloc(&d, sizeof(double) * (kRedBlocks + 8)) != hipSuccess) {
+        set_error("scint: hipMalloc of reduction scratch failed");
+        return nullptr;
+    }
+    g_red_scratch[dev] = d;
+    return d;
+}
+
 struct PlainValue {
     const double* x;
     __device__ inline double operator()(int64_t i) const { return x[i]; }
@@ -518,8 +536,8 @@ extern "C" int32_t scint_fft2(const scint_c128* in, scint_c128* out, int64_t row
 extern "C" int32_t scint_mean(const double* x, int64_t n, double* mean_out, void* stream_) {
     SCINT_REQUIRE(x && mean_out && n > 0, "mean: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
-    double* scratch = nullptr;
-    SCINT_HIP(hipMalloc(&scratch, sizeof(double) * (kRedBlocks + 1)));
+    double* scratch = reduce_scratch();
+    if (!scratch) return SCINT_E_HIP;
     int32_t rc = launch_reduce(PlainValue{x}, n, 1.0 / (double)n, scratch, scratch + kRedBlocks, stream);
     if (rc == SCINT_OK) {
         hipError_t e = hipMemcpyAsync(mean_out, scratch + kRedBlocks, sizeof(double),
@@ -527,7 +545,6 @@ extern "C" int32_t scint_mean(const double* x, int64_t n, double* mean_out, void
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) rc = hip_fail(e, "mean copy-back", __FILE__, __LINE__);
     }
-    (void)hipFree(scratch);
     return rc;
 }
 
@@ -648,12 +665,8 @@ extern "C" int32_t scint_chisq(const double* model, int64_t ld_model, const doub
                                double* out, void* stream_) {
     SCINT_REQUIRE(model && dspec && out && nf > 0 && nt > 0, "chisq: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
-    double* partial = nullptr;
-    SCINT_HIP(hipMalloc(&partial, sizeof(double) * kRedBlocks));
-    int32_t rc = launch_reduce(ChisqValue{model, ld_model, dspec, nt, mask}, nf * nt, 1.0 / noise_n,
-                               partial, out, stream);
-    hipError_t e = hipStreamSynchronize(stream);
-    (void)hipFree(partial);
-    if (rc == SCINT_OK && e != hipSuccess) rc = hip_fail(e, "chisq sync", __FILE__, __LINE__);
-    return rc;
+    double* partial = reduce_scratch();
+    if (!partial) return SCINT_E_HIP;
+    return launch_reduce(ChisqValue{model, ld_model, dspec, nt, mask}, nf * nt, 1.0 / noise_n, partial, out,
+                         stream);
 }

@@ -48,7 +48,11 @@ struct PackedJob {
     int32_t max_steps, strip_len;
     int32_t start, pad0;    // launch index of this job's Lanczos step 0
     cplx* U[2];             // u_{j-1} / u_j                     [nb*64] each
-    cplx* Q[2];             // q ring                            [nb*64] each
+    cplx* Q;                // q vectors: slot (j % qslots) holds q_j, slots are qstride apart
+    int64_t qstride;        // elements between slots (>= nb*64)
+    int32_t qslots;         // 2 = ring (eigenvalue only); max_steps+1 = keep all (Ritz vector wanted)
+    int32_t want_vec;       // 1: stop on the Ritz residual and export the eigenvector of T_k
+    double* svec;           // [max_steps + 1] eigenvector of T_k (want_vec)
     cplx* rowpart;          // [nstrips][64]   row-block partial sums per strip
     cplx* colpart;          // [ntiles][64]    column-block partial sums per off-diagonal tile
     const int32_t* row_strip0;  // [nb+1] first strip index of each block row

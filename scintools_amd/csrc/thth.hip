@@ -199,6 +199,11 @@ __global__ void __launch_bounds__(256) rev_scatter_kernel(RevParams p, GeomDev g
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (i >= p.N || j >= p.N || i == j) return;  // i == j lands in the poisoned centre bin
+    // rank-1 Hermitian model (modeler): element (j, i) is the exact conjugate of (i, j) and maps
+    // to the exactly negated (fd, tau), i.e. it repeats what the mirrored pass adds for (i, j).
+    // Scattering only i < j halves the atomics; sums and counts are both halved, so every
+    // recov = sum / count is unchanged (a power-of-two scaling is exact).
+    if (p.rank1 && p.hermitian && i > j) return;
     const double th_i = p.th[i], th_j = p.th[j];
     const double x = th_j - th_i;                          // fd_map[i, j]   (ththmod.py:207)
     const double y = p.eta * (th_j * th_j - th_i * th_i);  // tau_map[i, j]  (ththmod.py:208-210)

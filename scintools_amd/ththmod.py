@@ -13,6 +13,7 @@ rev_map            ththmod.py:176-271     scint_rev_map
 modeler            ththmod.py:274-327     scint_thth_map + scint_eigh_top +
                                           scint_rev_map + scint_model_from_recov
 chisq_calc         ththmod.py:330-368     ... + scint_chisq
+chisq_sweep        (a loop of chisq_calc) scint_eigvec_sweep + scint_rev_map + ...
 Eval_calc          ththmod.py:371-401     scint_eval_sweep (one eta)
 single_search      ththmod.py:715-895     scint_cs + scint_eval_sweep (+ SciPy fit)
 eval_sweep         (the loop :788-799)    scint_eval_sweep
@@ -339,12 +340,7 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
     cs_t = _cs_dev(CS, grid)
     etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
     neta, M = etas_v.shape[0], grid.M
-    keep_idx = np.zeros((neta, M), dtype=np.int32)
-    keep_n = np.zeros(neta, dtype=np.int32)
-    for i, e in enumerate(etas_v):
-        k = grid.keep(e)
-        keep_n[i] = k.shape[0]
-        keep_idx[i, : k.shape[0]] = k
+    keep_idx, keep_n = _sweep_inputs(grid, etas_v)
     nmax = max(int(keep_n.max()), 1)
     if batch is None:
         batch = default_batch(nmax, neta)
@@ -368,6 +364,93 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
     if return_info:
         return eigs, {"N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch}
     return eigs
+
+
+def _sweep_inputs(grid, etas_v):
+    neta, M = etas_v.shape[0], grid.M
+    keep_idx = np.zeros((neta, M), dtype=np.int32)
+    keep_n = np.zeros(neta, dtype=np.int32)
+    for i, e in enumerate(etas_v):
+        k = grid.keep(e)
+        keep_n[i] = k.shape[0]
+        keep_idx[i, : k.shape[0]] = k
+    return keep_idx, keep_n
+
+
+def eigvec_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None):
+    """Dominant eigenpair of the reduced theta-theta for every curvature: modeler's
+    ``eigsh(thth_red, 1, which="LA")`` (ththmod.py:308) as one batched device call.
+
+    Returns (w[neta] float64 signed, V device tensor [neta, M] complex128 -- row i holds
+    N_i = len(keep_i) entries, unit norm, arbitrary phase --, info dict)."""
+    lib = _lib.load()
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
+    neta, M = etas_v.shape[0], grid.M
+    keep_idx, keep_n = _sweep_inputs(grid, etas_v)
+    nmax = max(int(keep_n.max()), 1)
+    if batch is None:
+        batch = default_batch(nmax, neta)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_eigvec_sweep_workspace_bytes(M, neta, batch, max_iter, ctypes.byref(need)),
+               "eigvec_sweep_workspace_bytes")
+    ws = workspace.get(need.value)
+    keep_t = _dv.to_device(keep_idx, torch.int32)
+    w_t = empty((neta,), torch.float64)
+    V_t = torch.zeros((neta, M), dtype=torch.complex128, device=cs_t.device)
+    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    etas_c = np.ascontiguousarray(etas_v)
+    rc = lib.scint_eigvec_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
+                                keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                etas_c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta,
+                                tol, max_iter, batch, ptr(w_t), ptr(V_t), M, ptr(st_t[0]), ptr(st_t[1]),
+                                ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_eigvec_sweep")
+    st = st_t.cpu().numpy()
+    w = w_t.cpu().numpy()
+    w[st[0] != 0] = np.nan
+    info = {"N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch,
+            "keep_idx": keep_idx, "w_dev": w_t}
+    return w, V_t, info
+
+
+def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False):
+    """chi**2 of the theta-theta model for every curvature: the loop
+    ``[chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask) for eta in etas]``
+    (ththmod.py:330-368) with the eigenpairs of all curvatures found in one batched call and
+    the per-eta rank-1 back-map, inverse FFT and reduction chained on the device."""
+    lib = _lib.load()
+    grid = _Grid(tau, fd, edges)
+    cs_t = _cs_dev(CS, grid)
+    etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
+    w, V_t, info = eigvec_sweep(cs_t, grid.tau, grid.fd, etas_v, grid.edges)
+    d_t = _dv.to_device(dspec, torch.float64)
+    nf, nt = (int(v) for v in d_t.shape)
+    m_t = None if mask is None else _dv.to_device(np.asarray(mask, dtype=np.uint8), torch.uint8)
+    neta = etas_v.shape[0]
+    out = torch.full((neta,), float("nan"), dtype=torch.float64, device=cs_t.device)
+    # centres of the reduced edges, re-derived as rev_map does (ththmod.py:204-205 on :157-172)
+    th_red = np.zeros((neta, grid.M))
+    for i in range(neta):
+        n = int(info["N"][i])
+        if n >= 2:
+            th_red[i, :n] = _theta_centres(grid.edges_red(info["keep_idx"][i, :n]))
+    th_red_t = _dv.to_device(th_red, torch.float64)
+    for i in range(neta):
+        n = int(info["N"][i])
+        if info["status"][i] != 0 or n < 2:
+            continue
+        recov_t = _rev_map_dev(grid.geom, th_red_t[i], n, float(etas_v[i]), True, vec_t=V_t[i],
+                               w_t=info["w_dev"][i:i + 1])
+        model_t = _model_dev(recov_t)
+        rc = lib.scint_chisq(ptr(model_t), int(model_t.shape[1]), ptr(d_t), nf, nt, ptr(m_t), float(N),
+                             ptr(out[i:i + 1]), stream_ptr())
+        _lib.check(rc, "scint_chisq")
+    chis = out.cpu().numpy()
+    if return_info:
+        return chis, {"w": w, **{k: info[k] for k in ("N", "iters", "status", "batch")}}
+    return chis
 
 
 def Eval_calc(CS, tau, fd, eta, edges):

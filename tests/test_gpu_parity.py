@@ -290,3 +290,26 @@ def test_fit_thetatheta_vs_reference_golden(golden):
     assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-6)
     assert d.ththetaerr == pytest.approx(float(g["ththetaerr"]), rel=1e-4)
     assert abs(d.ththeta - 44.0 * (1332.0 + 64.0) ** 0 ) < 10     # same arc as the known answer
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_eigvec_and_chisq_sweep_vs_reference_golden(thth, golden, tag):
+    """The batched modeler sweep (eigenpairs of all etas in one call, then per-eta back-map,
+    inverse FFT, chi^2) against the reference's modeler / chisq_calc goldens."""
+    g = golden("thth_small.npz")
+    CS, tau, fd, etas, edges = g["CS"], g["tau"], g["fd"], g["etas"], g[f"edges_{tag}"]
+    w, V, info = thth.eigvec_sweep(CS, tau, fd, etas, edges)
+    assert np.all(info["status"] == 0)
+    V = V.cpu().numpy()
+    for k in range(3):
+        n = int(info["N"][k])
+        assert w[k] == pytest.approx(float(g[f"mod_w_{tag}{k}"]), rel=1e-9)
+        Vr = g[f"mod_V_{tag}{k}"]
+        assert n == Vr.shape[0]
+        assert abs(np.linalg.norm(V[k, :n]) - 1) <= 1e-12 and not np.any(V[k, n:])
+        assert 1 - abs(np.vdot(Vr, V[k, :n])) <= 1e-9
+    chis = thth.chisq_sweep(g["dyn"], CS, tau, fd, etas, edges, 1.0)
+    for k in range(3):
+        assert chis[k] == pytest.approx(float(g[f"chisq_{tag}{k}"]), rel=1e-9)
+    single = [thth.chisq_calc(g["dyn"], CS, tau, fd, e, edges, 1.0) for e in etas]
+    np.testing.assert_allclose(chis, single, rtol=1e-9)

@@ -28,3 +28,15 @@ for rep in range(2):
     recov = thth._rev_map_dev(grid.geom, th_t, len(keep), e, True, vec_t=V, w_t=w_t); sync(); t.append(time.perf_counter())
     model = thth._model_dev(recov); sync(); t.append(time.perf_counter())
 print('gather %.2f  eigh %.2f (%d it)  rev_map %.2f  model %.2f ms' % (*(1e3*np.diff(t)), it))
+
+etas = np.geomspace(0.5, 2.0, 32) * eta_true
+for rep in range(2):
+    sync(); t0 = time.perf_counter()
+    chis, info = thth.chisq_sweep(d_t, cs, tau, fd, etas, edges, 1.0, return_info=True)
+    sync(); t1 = time.perf_counter()
+print('chisq_sweep per eta ms', 1e3*(t1-t0)/len(etas), 'iters mean', info['iters'].mean(), chis[:3], 'argmin eta/eta_true', etas[np.nanargmin(chis)]/eta_true)
+for rep in range(2):
+    sync(); t0 = time.perf_counter()
+    w, V, info = thth.eigvec_sweep(cs, tau, fd, etas, edges)
+    sync(); t1 = time.perf_counter()
+print('eigvec_sweep per eta ms', 1e3*(t1-t0)/len(etas))
