@@ -317,7 +317,10 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
     }
     const bool finite = isfinite(lo) && isfinite(hi) && isfinite(beta_k);
     double theta = nan(""), theta2 = -INFINITY, resid = nan(""), err = nan("");
-    if (finite) {
+    if (finite && scale == 0.0 && beta_k == 0.0) {
+        // T_k = 0: an all-zero theta-theta (e.g. every delay masked); ARPACK returns 0 as well
+        theta = 0.0; theta2 = 0.0; resid = 0.0; err = 0.0;
+    } else if (finite) {
         const double tiny = scale * 1e-300 + 1e-300;
         lo = lo - 1e-15 * fabs(lo) - 1e-300;   // count(lo) == 0
         hi = hi + 1e-15 * fabs(hi) + 1e-300;   // count(hi) == k

@@ -1,0 +1,119 @@
+"""Edge cases of the domain on the GPU path: empty / 1x1 reduced maps, an all-masked conjugate
+spectrum, tiny matrices, non-finite input, dtype/contiguity of inputs, the non-Hermitian
+wrap-around, and schedule invariance of the sweep."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import thth_oracle as to
+    from scintools_amd import ththmod as thth
+    from scintools_amd.device import require_gpu
+    from scintools_amd.synth import arc_dynspec
+    require_gpu()
+    dyn, freqs, times, eta_true = arc_dynspec(128, 128, seed=4, nimg=16)
+    dyn -= dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    CS = to.conjugate_spectrum(dyn, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 96)
+    return thth, to, dict(dyn=dyn, fd=fd, tau=tau, CS=CS, edges=edges, eta=eta_true)
+
+
+def test_crop_to_nothing_gives_nan_like_the_reference(env):
+    thth, to, p = env
+    # eta so large that theta^2 eta < tau_max keeps only the theta = 0 centre (or nothing)
+    etas = np.array([p["eta"], 1e6 * p["eta"], 1e9 * p["eta"]])
+    eigs, info = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
+    assert np.isfinite(eigs[0]) and info["status"][0] == 0
+    assert info["N"][1] <= 1 and info["N"][2] <= 1
+    assert np.isnan(eigs[1]) and np.isnan(eigs[2])          # reference: exception -> nan
+    for e in etas[1:]:
+        with pytest.raises(Exception):
+            to.Eval_calc(p["CS"], p["tau"], p["fd"], e, p["edges"])
+    fit = thth.fit_eig_peak(etas, eigs, 0.1)                 # NaNs are dropped before the fit
+    assert fit[2] is None or np.isfinite(fit[0])
+
+
+def test_all_masked_cs_gives_zero(env):
+    thth, to, p = env
+    eigs = thth.eval_sweep(np.zeros_like(p["CS"]), p["tau"], p["fd"], np.array([p["eta"]]), p["edges"])
+    assert eigs[0] == 0.0
+    red, _ = thth.thth_redmap(np.zeros_like(p["CS"]), p["tau"], p["fd"], p["eta"], p["edges"])
+    assert not np.any(red)
+
+
+def test_tiny_reduced_matrices_against_lapack(env):
+    thth, to, p = env
+    for nedge in (4, 6, 8, 10, 34):
+        edges = np.linspace(-p["fd"].max() / 2, p["fd"].max() / 2, nedge)
+        red, _ = to.thth_redmap(p["CS"], p["tau"], p["fd"], p["eta"], edges)
+        eig, info = thth.eval_sweep(p["CS"], p["tau"], p["fd"], np.array([p["eta"]]), edges, return_info=True)
+        assert info["N"][0] == red.shape[0] == nedge - 1
+        assert eig[0] == pytest.approx(abs(np.linalg.eigvalsh(red)[-1]), rel=1e-10, abs=1e-9)
+
+
+def test_inputs_float32_noncontiguous_and_nan(env):
+    thth, to, p = env
+    # complex64 / Fortran-ordered CS are converted, result as for the converted array
+    cs32 = p["CS"].astype(np.complex64)
+    a = thth.thth_redmap(np.asfortranarray(cs32), p["tau"], p["fd"], p["eta"], p["edges"])[0]
+    b = to.thth_redmap(cs32.astype(np.complex128), p["tau"], p["fd"], p["eta"], p["edges"])[0]
+    assert np.array_equal(a, b)
+    # NaN pixels in the CS: the Hermitian branch turns them into zeros (nan_to_num, ththmod.py:114)
+    cs = p["CS"].copy()
+    cs[70, 80] = np.nan + 1j * np.nan
+    cs[75, 90] = np.inf
+    a = thth.thth_redmap(cs, p["tau"], p["fd"], p["eta"], p["edges"])[0]
+    b = to.thth_redmap(cs, p["tau"], p["fd"], p["eta"], p["edges"])[0]
+    assert np.all(np.isfinite(a))
+    ok = np.isfinite(b.real) & np.isfinite(b.imag) & (np.abs(b) < 1e300) & (np.abs(a) < 1e300)
+    assert np.array_equal(a[ok], b[ok])
+
+
+def test_nonhermitian_wraparound_and_indexerror(env):
+    thth, to, p = env
+    # edges wider than the CS: negative fd indices wrap like NumPy's fancy indexing ...
+    edges = np.linspace(-0.9 * p["fd"].max(), 0.9 * p["fd"].max(), 64)
+    ref = to.thth_map(p["CS"], p["tau"], p["fd"], p["eta"], edges, hermetian=False)
+    got = thth.thth_map(p["CS"], p["tau"], p["fd"], p["eta"], edges, hermetian=False)
+    assert np.array_equal(got, ref)
+    # ... and raise once they fall below -len(fd), exactly where NumPy raises
+    edges = np.linspace(-1.6 * p["fd"].max(), 1.6 * p["fd"].max(), 64)
+    with pytest.raises(IndexError):
+        to.thth_map(p["CS"], p["tau"], p["fd"], 0.01 * p["eta"], edges, hermetian=False)
+    with pytest.raises(IndexError):
+        thth.thth_map(p["CS"], p["tau"], p["fd"], 0.01 * p["eta"], edges, hermetian=False)
+
+
+def test_sweep_is_schedule_invariant(env):
+    """Continuous batching must not change a bit: any batch size, any eta order."""
+    thth, to, p = env
+    etas = np.geomspace(0.3, 3.0, 23) * p["eta"]
+    ref = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=23)
+    for b in (1, 2, 7):
+        assert np.array_equal(thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=b), ref)
+    perm = np.random.default_rng(0).permutation(len(etas))
+    got = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas[perm], p["edges"], batch=5)
+    assert np.array_equal(got, ref[perm])
+    one = np.array([thth.Eval_calc(p["CS"], p["tau"], p["fd"], e, p["edges"]) for e in etas[:4]])
+    assert np.array_equal(one, ref[:4])
+
+
+def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
+    from scintools_amd.dynspec import Dynspec
+    thth, to, p = env
+    dyn = p["dyn"] + 50.0
+    dyn[5, 7] = np.nan
+    dyn[40:42, 100] = np.nan
+
+    class B:
+        pass
+    b = B()
+    b.dyn, b.freqs, b.times = dyn, 1400.0 + 0.05 * np.arange(128), 30.0 * np.arange(128)
+    d = Dynspec(dyn=b, verbose=False)
+    d.prep_thetatheta(cwf=64, cwt=128, eta_min=0.5 * p["eta"], eta_max=2 * p["eta"], nedge=64, npad=1, fw=0.3)
+    d.fit_thetatheta()
+    assert d.eta_evo.shape == (2, 1) and np.all(np.isfinite(d.thth_eigs))
