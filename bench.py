@@ -110,11 +110,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SCINT_BENCH_BACKEND", "nccl")   # "gloo": 2 ranks on one GPU (tests only)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
     require_gpu()
     lib = _lib.load()
     if args.gpus != world and rank == 0 and world > 1:
@@ -124,7 +130,7 @@ def main():
     nedge = args.nedge or size
     dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3 + rank)
     dyn_t = ththmod.to_device(dyn, torch.float64)      # resident in HBM before the clock starts
-    gathered = [torch.empty(neta, dtype=torch.float64, device="cuda") for _ in range(world)]
+    gathered = [torch.empty(neta, dtype=torch.float64, device=comm_dev) for _ in range(world)]
 
     def step():
         # body of single_search (ththmod.py:773-859): CS once, the eta loop, the peak fit
@@ -133,11 +139,11 @@ def main():
             # the other objective of BASELINE config 3: chisq_calc(modeler(...)) for every eta
             chis, info = ththmod.chisq_sweep(dyn_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
             if world > 1:
-                dist.all_gather(gathered, torch.from_numpy(chis).cuda())
+                dist.all_gather(gathered, torch.from_numpy(chis).to(comm_dev))
             return chis, info, (etas[np.nanargmin(chis)], np.nan, None)
         eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
         if world > 1:
-            dist.all_gather(gathered, torch.from_numpy(eigs).cuda())
+            dist.all_gather(gathered, torch.from_numpy(eigs).to(comm_dev))
         fit = ththmod.fit_eig_peak(etas, eigs, 0.1)
         return eigs, info, fit
 
@@ -161,7 +167,7 @@ def main():
     launches = (ctypes.c_int64 * 2)()
     lib.scint_profile_end(ms, launches)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
