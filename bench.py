@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--neta", type=int, default=256)
     ap.add_argument("--nedge", type=int, default=None, help="default: size")
     ap.add_argument("--batch", type=int, default=None, help="etas resident per launch")
+    ap.add_argument("--npad", type=int, default=0, help="zero-padding multiple of the CS (reference default 3)")
+    ap.add_argument("--obs", type=int, default=1,
+                    help="observations swept per GPU per step (BASELINE config 4: --size 2048 --obs 8 on 8 GPUs)")
     ap.add_argument("--objective", choices=["eig", "chisq"], default="eig",
                     help="eig: Eval_calc sweep of single_search (headline); chisq: modeler/chisq_calc sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -68,19 +71,19 @@ def parse():
     return ap.parse_args()
 
 
-def make_workload(size, neta, nedge, seed):
+def make_workload(size, neta, nedge, seed, npad=0):
     from scintools_amd.synth import arc_dynspec
     from scintools_amd.ththmod import fft_axis
     dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=seed, nimg=64)
     dyn -= dyn.mean()                # as Dynspec.fit_thetatheta hands chunks over (dynspec.py:1692)
-    fd = fft_axis(times, 1000.0)     # s -> mHz
-    tau = fft_axis(freqs, 1.0)       # MHz -> us
+    fd = fft_axis(times, 1000.0, npad)     # s -> mHz
+    tau = fft_axis(freqs, 1.0, npad)       # MHz -> us
     edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge)
     etas = np.geomspace(0.25, 4.0, neta) * eta_true
     return dyn, freqs, times, fd, tau, edges, etas, eta_true
 
 
-def cpu_baseline(dyn, tau, fd, edges, etas, nsample):
+def cpu_baseline(dyn, tau, fd, edges, etas, nsample, npad=0):
     """Oracle (port of the reference) on a bounded sample: `nsample` curvatures spread over
     the sweep; the FFT is done once and not counted (it is amortised over 256 etas)."""
     from oracle import thth_oracle
@@ -89,7 +92,7 @@ def cpu_baseline(dyn, tau, fd, edges, etas, nsample):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    CS = thth_oracle.conjugate_spectrum(dyn, 0)
+    CS = thth_oracle.conjugate_spectrum(dyn, npad)
     idx = np.unique(np.linspace(0, len(etas) - 1, nsample + 2).astype(int)[1:-1])
     t0 = time.perf_counter()
     vals = [thth_oracle.Eval_calc(CS, tau, fd, etas[i], edges) for i in idx]
@@ -128,13 +131,19 @@ def main():
 
     size, neta = args.size, args.neta
     nedge = args.nedge or size
-    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3 + rank)
+    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3 + rank, npad=args.npad)
     dyn_t = ththmod.to_device(dyn, torch.float64)      # resident in HBM before the clock starts
+    extra_obs = [ththmod.to_device(make_workload(size, neta, nedge, seed=1000 + 97 * rank + k, npad=args.npad)[0], torch.float64)
+                 for k in range(1, args.obs)]
     gathered = [torch.empty(neta, dtype=torch.float64, device=comm_dev) for _ in range(world)]
 
     def step():
+        for other in extra_obs:                      # further observations of this rank's share
+            cs_o = ththmod.conjugate_spectrum(other, args.npad, tau, 0.0, True)
+            e_o = ththmod.eval_sweep(cs_o, tau, fd, etas, edges, batch=args.batch)
+            ththmod.fit_eig_peak(etas, e_o, 0.1)
         # body of single_search (ththmod.py:773-859): CS once, the eta loop, the peak fit
-        cs_t = ththmod.conjugate_spectrum(dyn_t, 0, tau, 0.0, True)
+        cs_t = ththmod.conjugate_spectrum(dyn_t, args.npad, tau, 0.0, True)
         if args.objective == "chisq":
             # the other objective of BASELINE config 3: chisq_calc(modeler(...)) for every eta
             chis, info = ththmod.chisq_sweep(dyn_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
@@ -158,7 +167,7 @@ def main():
     for _ in range(args.steps):
         eigs, info, fit = step()
         n_ = info["N"].astype(float)
-        alg_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"]))   # Hermitian: upper triangle once
+        alg_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"])) * args.obs   # Hermitian: upper triangle once
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,7 +190,7 @@ def main():
         alg_per_launch = alg_bytes / max(1, launches[1])
         out = {
             "metric": "eta_curvature_sweep_points_per_sec",
-            "value": world * neta * args.steps / elapsed,
+            "value": world * args.obs * neta * args.steps / elapsed,
             "unit": "eta-points/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -193,10 +202,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": (f"{size}x{size} dynspec, {neta}-eta theta-theta eigenvalue sweep "
-                                    f"(Eval_calc loop of single_search), nedge={nedge}, npad=0, "
+                                    f"(Eval_calc loop of single_search), nedge={nedge}, npad={args.npad}, "
                                     f"one observation per GPU") if args.objective == "eig" else
                                    (f"{size}x{size} dynspec, {neta}-eta modeler/chisq_calc sweep, nedge={nedge}, "
-                                    f"npad=0, one observation per GPU"),
+                                    f"npad={args.npad}, one observation per GPU"),
+                       "observations_per_gpu_per_step": args.obs,
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
@@ -218,7 +228,7 @@ def main():
                        "frac": (gather_bytes / (ms[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
-            cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample)
+            cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad)
             out["cpu_baseline"] = cb
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(
                 max(abs(eigs[i] - v) / abs(v) for i, v in ref_vals.items()))
