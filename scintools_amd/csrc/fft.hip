@@ -303,9 +303,17 @@ struct ColSink {
     int64_t mask_lo, mask_hi; int incoherent;                        // SINK_CS
     double scale;                                                    // SINK_MODEL
 
+    int half;                   // real input: only columns 0..C/2 are transformed; the rest is
+                                // X[(R-k1)%R, C-c] = conj X[k1, c]
+
     __device__ inline void operator()(int64_t, int64_t k1, int64_t c, cplx v) const {
         if (k1 >= R) return;
         if (col_post_w) { v = col_post_w[k1] * conj(v); v = v * col_post_scale; }
+        emit(k1, c, v);
+        if (half && c > 0 && c < C / 2) emit(k1 == 0 ? 0 : R - k1, C - c, conj(v));
+    }
+
+    __device__ inline void emit(int64_t k1, int64_t c, cplx v) const {
         switch (mode) {
             case SINK_ARRAY: out_c[k1 * ld + c] = v; break;
             case SINK_SSPEC: {
@@ -349,8 +357,31 @@ struct SlotIsRow {
     __device__ inline cplx operator()(int64_t s, int j) const { return in(s, j); }
 };
 struct RowStoreC {
+    static constexpr bool kPair = false;
     cplx* a; int64_t ld;
     __device__ inline void operator()(int64_t slot, int k, cplx v) const { a[slot * ld + k] = v; }
+};
+// Real input, two rows per slot: slot s carries rows 2s and 2s+1 as z = x_{2s} + i x_{2s+1}.
+struct PairLoad {
+    RowSource in; int64_t nrows;
+    __device__ inline cplx operator()(int64_t s, int j) const {
+        const int64_t r0 = 2 * s, r1 = 2 * s + 1;
+        return mk(in(r0, j).x, r1 < nrows ? in(r1, j).x : 0.0);
+    }
+};
+// X1[k] = (Z[k] + conj Z[n-k]) / 2,  X2[k] = (Z[k] - conj Z[n-k]) / (2i);  half-width rows
+struct PairStore {
+    static constexpr bool kPair = true;
+    cplx* a; int64_t ld; int64_t nrows;
+    __device__ inline void operator()(int64_t, int, cplx) const {}
+    __device__ inline void pair(int64_t s, int k, cplx zk, cplx zm) const {
+        const cplx zc = conj(zm);
+        const cplx x1 = mk(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+        const cplx d = mk(zk.x - zc.x, zk.y - zc.y);
+        const cplx x2 = mk(0.5 * d.y, -0.5 * d.x);   // d / (2i)
+        a[(2 * s) * ld + k] = x1;
+        if (2 * s + 1 < nrows) a[(2 * s + 1) * ld + k] = x2;
+    }
 };
 // Decimated long rows (n = n1 * n2): slot = row*n1 + j1, element j2 -> x[row][j1 + n1*j2];
 // result y[j1][k2] * W_n^{j1 k2} -> dst[row][j1*n2 + k2].
@@ -363,6 +394,7 @@ struct DecimLoad {
     }
 };
 struct DecimStore {
+    static constexpr bool kPair = false;
     cplx* dst; int64_t ld; int n1; int n2; const cplx* tw_n;  // W_n, n = n1*n2
     __device__ inline void operator()(int64_t slot, int k2, cplx v) const {
         const int64_t r = slot / n1;
@@ -429,9 +461,13 @@ static Fft2Plan make_plan(int64_t R, int64_t C, int64_t nvalid) {
 
 // src: RowSource with mode/payload set (n_in, chirp are managed here).
 // fill0: value at column 0 of the row-FFT for rows >= nvalid (constant-padded rows), else 0.
-// sink: ColSink with mode/payload set (R, C, col_post_* are managed here).
+// sink: ColSink with mode/payload set (R, C, col_post_*, half are managed here).
+// real_input: the source is real -> real-to-complex path when both lengths are powers of two:
+//   two rows per row-FFT, only columns 0..C/2 go through the column passes, and the sink emits
+//   each value together with its conjugate-symmetric partner.
 static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t R, int64_t C,
-                            ColSink sink, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                            ColSink sink, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                            bool real_input = false) {
     SCINT_REQUIRE(R >= 1 && C >= 1 && nvalid >= 0 && nvalid <= R, "fft2: bad shape");
     const Fft2Plan p = make_plan(R, C, nvalid);
     if (workspace_bytes < p.total) { set_error("scint: fft workspace too small"); return SCINT_E_WORKSPACE; }
@@ -441,6 +477,21 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
     cplx* colA = (cplx*)(base + p.off_colA);
     cplx* colB = (cplx*)(base + p.off_colB);
     int32_t rc;
+    sink.half = 0;
+    if (real_input && !p.blue_r && !p.blue_c && C <= 8192 && R >= 2) {
+        const int64_t Ch = C / 2 + 1;
+        src.n_in = C;
+        src.chirp = nullptr;
+        rc = launch_fft_rows(C, (nvalid + 1) / 2, PairLoad{src, nvalid}, PairStore{rowA, Ch, nvalid}, stream);
+        if (rc != SCINT_OK) return rc;
+        ColSource hs;
+        hs.a = rowA; hs.ld = Ch; hs.nvalid = nvalid; hs.fill0 = fill0; hs.n_in = R;
+        hs.row_post_w = nullptr; hs.row_post_scale = 1.0; hs.chirp = nullptr; hs.mulconj_b = nullptr;
+        sink.R = R; sink.C = C; sink.col_post_w = nullptr; sink.col_post_scale = 1.0; sink.half = 1;
+        ArrayLoad mid_ld{colA, Ch, 0};
+        ArrayStore mid_st{colA, Ch, 0};
+        return run_cols_fft(R, Ch, 1, hs, mid_ld, mid_st, sink, stream);
+    }
 
     // ---- rows ---------------------------------------------------------------------
     ColSource cs;
@@ -487,6 +538,7 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
         ArrayStore mid_st{colA, C, 0};
         ColSink to_b;
         to_b.mode = SINK_ARRAY; to_b.R = p.mR; to_b.C = C; to_b.col_post_w = nullptr; to_b.col_post_scale = 1.0;
+        to_b.half = 0;
         to_b.out_c = colB; to_b.ld = C;
         rc = run_cols_fft(p.mR, C, 1, cs, mid_ld, mid_st, to_b, stream);
         if (rc != SCINT_OK) return rc;
@@ -591,7 +643,7 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
     ColSink sink{};
     sink.mode = SINK_SSPEC; sink.out_d = sec_out; sink.halve = halve; sink.prewhite = prewhite;
     sink.pd_fd = pd_fd; sink.pd_td = pd_td;
-    return fft2_general(src, nf_eff, 0.0, R, C, sink, workspace, fft_bytes, stream);
+    return fft2_general(src, nf_eff, 0.0, R, C, sink, workspace, fft_bytes, stream, /*real_input=*/true);
 }
 
 // ------------------------------------------------------------------------------
@@ -621,7 +673,8 @@ extern "C" int32_t scint_cs(const double* dspec, int64_t nf, int64_t nt, int64_t
     sink.mode = SINK_CS; sink.out_c = (cplx*)cs_out; sink.ld = C;
     sink.mask_lo = mask_lo; sink.mask_hi = mask_hi; sink.incoherent = incoherent;
     // rows >= nf are constant rows of pad_value: their FFT is C*pad at column 0
-    return fft2_general(src, nf, pad_value * (double)C, R, C, sink, workspace, workspace_bytes, stream);
+    return fft2_general(src, nf, pad_value * (double)C, R, C, sink, workspace, workspace_bytes, stream,
+                        /*real_input=*/true);
 }
 
 // ------------------------------------------------------------------------------

@@ -232,12 +232,29 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
     }
     // ---- last stage: outputs straight to global ---------------------------------
     constexpr int RL = (R3 > 1) ? R3 : (R2 > 1) ? R2 : (R1 > 1) ? R1 : R0;
-    if (active) {
+    if constexpr (Storer::kPair) {
+        // Two real rows were transformed as one complex sequence z = x1 + i x2.  Put Z back
+        // into LDS in natural order and let the storer separate X1[k], X2[k] from Z[k] and
+        // Z[n-k] for k = 0 .. n/2 (the other half follows from conjugate symmetry).
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < kEPT / RL; ++q)
 #pragma unroll
             for (int m = 0; m < RL; ++m)
-                st(slot, stockham_out_index<RL>(t, Tr, Ns, q, m), v[q * RL + m]);
+                lds[lds_pad(stockham_out_index<RL>(t, Tr, Ns, q, m))] = v[q * RL + m];
+        __syncthreads();
+        if (active) {
+            for (int k = t; k <= n / 2; k += Tr)
+                st.pair(slot, k, lds[lds_pad(k)], lds[lds_pad((n - k) & (n - 1))]);
+        }
+    } else {
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < kEPT / RL; ++q)
+#pragma unroll
+                for (int m = 0; m < RL; ++m)
+                    st(slot, stockham_out_index<RL>(t, Tr, Ns, q, m), v[q * RL + m]);
+        }
     }
 }
 
