@@ -124,6 +124,22 @@ int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*
                          double* eigs_out, int32_t* status_out, int32_t* iters_out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same sweep over MANY conjugate spectra of one shape in a single batched call -- the
+ * chunk loop of Dynspec.fit_thetatheta (dynspec.py:1681-1719), where every chunk has its own
+ * CS, eta grid and (frequency-scaled) edges.  cs_stack[ncs][ntau][nfd] with cs_stride elements
+ * between spectra; geoms[ncs] (HOST); th_stack[ncs][M]; curvature e reads spectrum
+ * cs_index[e] (HOST) and keeps keep_idx[e*M ..] of th_stack[cs_index[e]]. */
+int32_t scint_eval_sweep_multi_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                               int32_t max_iter, int64_t ncs, size_t* bytes /*HOST*/);
+int32_t scint_eval_sweep_multi(const scint_c128* cs_stack, int64_t ncs, int64_t cs_stride,
+                               const int32_t* cs_index /*HOST*/, const scint_cs_geom* geoms /*HOST*/,
+                               const double* th_stack, int64_t M,
+                               const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
+                               const double* etas /*HOST*/, int64_t neta,
+                               double tol, int32_t max_iter, int64_t batch,
+                               double* eigs_out, int32_t* status_out, int32_t* iters_out,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same sweep, but returning the eigenpair (signed w and unit eigenvector) of every eta: the
  * eigsh call of modeler (ththmod.py:308) for a whole curvature sweep.  vec_out[neta, vec_stride]
  * (vec_stride >= M; row i holds keep_n[i] entries).  Stops on the Ritz residual (tol). */

@@ -457,10 +457,10 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, states, slots, fin_slots, fin_eta, total;
+    size_t jobs, strips, states, slots, fin_slots, fin_eta, geoms, total;
 };
 
-static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec) {
+static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs) {
     BatchLayout B;
     B.slab = slab_layout(nbmax, max_steps, want_vec);
     B.smax = 0;
@@ -473,24 +473,29 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_
     B.slots = take(sizeof(int32_t) * (size_t)nbatch);
     B.fin_slots = take(sizeof(int32_t) * (size_t)nbatch);
     B.fin_eta = take(sizeof(int64_t) * (size_t)nbatch);
+    B.geoms = take(sizeof(GeomDev) * (size_t)ncs);
     B.total = align_up(off, 256);
     return B;
 }
 
 
 static int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,
-                                     bool want_vec, size_t* bytes) {
-    SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1,
+                                     bool want_vec, int64_t ncs, size_t* bytes) {
+    SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && ncs >= 1,
                   "sweep_workspace_bytes: bad arguments");
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch, want_vec).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs).total + 4096;
     return SCINT_OK;
 }
 
-// Shared driver of scint_eval_sweep (eigenvalues) and scint_eigvec_sweep (eigenpairs).
-static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const double* th_cents,
+// Shared driver of scint_eval_sweep (eigenvalues), scint_eigvec_sweep (eigenpairs) and
+// scint_eval_sweep_multi.  `ncs` conjugate spectra of one shape live `cs_stride` elements apart
+// from `cs`, each with its own geometry geom[c] and theta grid th_cents + c*M; curvature e reads
+// spectrum cs_index[e] (nullptr: all read spectrum 0).
+static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const int32_t* cs_index,
+                         const scint_cs_geom* geom, const double* th_cents,
                          int64_t M, const int32_t* keep_idx, const int32_t* keep_n, const double* etas,
                          int64_t neta, double tol, int32_t max_iter, int64_t batch, double* eigs_out,
                          int32_t* status_out, int32_t* iters_out, bool want_vec, cplx* vec_out,
@@ -498,16 +503,21 @@ static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const 
     SCINT_REQUIRE(cs && geom && th_cents && keep_idx && keep_n && etas && eigs_out && status_out && workspace,
                   "sweep: null pointer");
     SCINT_REQUIRE(M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && tol > 0, "sweep: bad arguments");
-    SCINT_REQUIRE(geom->dtau > 0 && geom->dfd > 0, "sweep: tau and fd must be increasing");
+    SCINT_REQUIRE(ncs >= 1 && (ncs == 1 || cs_index), "sweep: bad spectrum table");
+    for (int64_t c = 0; c < ncs; ++c) {
+        SCINT_REQUIRE(geom[c].dtau > 0 && geom[c].dfd > 0, "sweep: tau and fd must be increasing");
+        SCINT_REQUIRE(geom[c].ntau == geom[0].ntau && geom[c].nfd == geom[0].nfd,
+                      "sweep: all conjugate spectra must have one shape");
+    }
     SCINT_REQUIRE(!want_vec || (vec_out && vstride >= M), "sweep: bad eigenvector output");
     hipStream_t stream = (hipStream_t)stream_;
     size_t need = 0;
-    sweep_workspace_bytes(M, neta, batch, max_iter, want_vec, &need);
+    sweep_workspace_bytes(M, neta, batch, max_iter, want_vec, ncs, &need);
     if (workspace_bytes < need) { set_error("scint: sweep workspace too small"); return SCINT_E_WORKSPACE; }
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nslots = (int)std::min(batch, neta);
-    const BatchLayout BL = batch_layout(nbmax, steps_cap, nslots, want_vec);
+    const BatchLayout BL = batch_layout(nbmax, steps_cap, nslots, want_vec, ncs);
     const SlabLayout& L = BL.slab;
     char* base = (char*)workspace;
     PackedJob* jobs_dev = (PackedJob*)(base + BL.jobs);
@@ -518,7 +528,12 @@ static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const 
     int64_t* fin_eta_dev = (int64_t*)(base + BL.fin_eta);
     std::vector<int32_t> fin_slots;
     std::vector<int64_t> fin_eta;
-    const GeomDev g = to_dev(*geom);
+    GeomDev* geoms_dev = (GeomDev*)(base + BL.geoms);
+    std::vector<GeomDev> geoms_host((size_t)ncs);
+    for (int64_t c = 0; c < ncs; ++c) geoms_host[(size_t)c] = to_dev(geom[c]);
+    SCINT_HIP(hipMemcpyAsync(geoms_dev, geoms_host.data(), sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice,
+                             stream));
+    SCINT_HIP(hipStreamSynchronize(stream));
 
     std::vector<PackedJob> jobs((size_t)nslots);
     std::vector<int64_t> slot_eta((size_t)nslots, -1);   // eta index running in each slot, -1 = idle
@@ -543,6 +558,7 @@ static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const 
         J.tol = tol; J.pad0 = 0;
         J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
         J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
+        J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
         J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
     }
 
@@ -562,6 +578,8 @@ static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const 
             PackedJob& J = jobs[(size_t)s];
             const int n = keep_n[e];
             J.eta = etas[e]; J.two_eta = 2 * etas[e];
+            const int64_t c = cs_index ? cs_index[e] : 0;
+            J.cs = (const cplx*)cs + c * cs_stride; J.th = th_cents + c * M; J.geom = (int32_t)c;
             J.keep = keep_idx + e * M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
             J.max_steps = std::min(steps_cap, std::max(n, 1));
             J.strip_len = strip_len_for(J.nb);
@@ -611,8 +629,7 @@ static int32_t run_sweep(const scint_c128* cs, const scint_cs_geom* geom, const 
                 he = hipMemcpyAsync(slots_dev, fresh.data(), sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
             if (he == hipSuccess) he = hipStreamSynchronize(stream);   // host vectors are reused
             if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep job upload", __FILE__, __LINE__); break; }
-            rc = launch_gather_packed((const cplx*)cs, g, th_cents, M, jobs_dev, slots_dev, (int)fresh.size(),
-                                      nb_fresh, stream);
+            rc = launch_gather_packed(geoms_dev, M, jobs_dev, slots_dev, (int)fresh.size(), nb_fresh, stream);
             if (rc != SCINT_OK) break;
             hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0,
                                stream, jobs_dev, slots_dev);
@@ -681,7 +698,7 @@ using namespace scint;
 
 extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
                                                     int32_t max_iter, size_t* bytes) {
-    return sweep_workspace_bytes(M, neta, batch, max_iter, false, bytes);
+    return sweep_workspace_bytes(M, neta, batch, max_iter, false, 1, bytes);
 }
 
 extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom,
@@ -690,13 +707,31 @@ extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* g
                                     double tol, int32_t max_iter, int64_t batch, double* eigs_out,
                                     int32_t* status_out, int32_t* iters_out, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-    return run_sweep(cs, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, eigs_out,
-                     status_out, iters_out, false, nullptr, 0, workspace, workspace_bytes, stream);
+    return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch,
+                     eigs_out, status_out, iters_out, false, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int32_t scint_eval_sweep_multi_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                                          int32_t max_iter, int64_t ncs, size_t* bytes) {
+    return sweep_workspace_bytes(M, neta, batch, max_iter, false, ncs, bytes);
+}
+
+extern "C" int32_t scint_eval_sweep_multi(const scint_c128* cs_stack, int64_t ncs, int64_t cs_stride,
+                                          const int32_t* cs_index, const scint_cs_geom* geoms,
+                                          const double* th_stack, int64_t M, const int32_t* keep_idx,
+                                          const int32_t* keep_n, const double* etas, int64_t neta,
+                                          double tol, int32_t max_iter, int64_t batch, double* eigs_out,
+                                          int32_t* status_out, int32_t* iters_out, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    SCINT_REQUIRE(cs_index != nullptr || ncs == 1, "eval_sweep_multi: cs_index required");
+    return run_sweep(cs_stack, ncs, cs_stride, cs_index, geoms, th_stack, M, keep_idx, keep_n, etas, neta, tol,
+                     max_iter, batch, eigs_out, status_out, iters_out, false, nullptr, 0, workspace,
+                     workspace_bytes, stream);
 }
 
 extern "C" int32_t scint_eigvec_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
                                                       int32_t max_iter, size_t* bytes) {
-    return sweep_workspace_bytes(M, neta, batch, max_iter, true, bytes);
+    return sweep_workspace_bytes(M, neta, batch, max_iter, true, 1, bytes);
 }
 
 extern "C" int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom* geom,
@@ -706,6 +741,7 @@ extern "C" int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom*
                                       scint_c128* vec_out, int64_t vec_stride, int32_t* status_out,
                                       int32_t* iters_out, void* workspace, size_t workspace_bytes,
                                       void* stream) {
-    return run_sweep(cs, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,
-                     status_out, iters_out, true, (cplx*)vec_out, vec_stride, workspace, workspace_bytes, stream);
+    return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch,
+                     w_out, status_out, iters_out, true, (cplx*)vec_out, vec_stride, workspace, workspace_bytes,
+                     stream);
 }

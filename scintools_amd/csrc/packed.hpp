@@ -41,7 +41,10 @@ inline int strips_in_row(int nb, int I, int S) { return (nb - I + S - 1) / S; }
 struct PackedJob {
     // ---- gather ----------------------------------------------------------------
     double eta, two_eta;
-    const int32_t* keep;    // [n] indices into th_cents
+    const cplx* cs;         // conjugate spectrum this job reads (one per chunk/observation)
+    const double* th;       // [M] theta centres of that chunk
+    int32_t geom, pad1;     // index into the launch's GeomDev table
+    const int32_t* keep;    // [n] indices into th
     int32_t n, nb;
     cplx* tiles;            // [tile_count(nb)][64][64]
     // ---- Lanczos state -----------------------------------------------------------
@@ -71,9 +74,9 @@ struct Strip {
     int32_t index;            // strip index inside the job (row of rowpart)
 };
 
-// Gather for the jobs in slots[0..njobs) (device array of indices into jobs_dev).
-int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
-                             const PackedJob* jobs_dev, const int32_t* slots_dev, int njobs, int nbmax,
-                             hipStream_t stream);
+// Gather for the jobs in slots[0..njobs) (device array of indices into jobs_dev); every job
+// names its own CS, theta grid and geometry (geoms_dev[job.geom]).
+int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
+                             const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream);
 
 }  // namespace scint

@@ -95,10 +95,12 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 // rows per thread): the quadrant's footprint in the CS is a compact patch (~16 f_D bins wide),
 // which keeps the scattered 16-B reads inside few cache lines per wave.
 __global__ void __launch_bounds__(256)
-thth_gather_packed_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restrict__ th,
-                          int64_t M, const PackedJob* __restrict__ jobs,
-                          const int32_t* __restrict__ slots) {
+thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
+                          const PackedJob* __restrict__ jobs, const int32_t* __restrict__ slots) {
     const PackedJob* __restrict__ jp = jobs + slots[blockIdx.z];
+    const cplx* __restrict__ cs = jp->cs;
+    const double* __restrict__ th = jp->th;
+    const GeomDev g = geoms[jp->geom];
     const int I = blockIdx.y >> 1, J = blockIdx.x >> 1;       // 64-tile coordinates
     const int qi = blockIdx.y & 1, qj = blockIdx.x & 1;       // quadrant inside the tile
     const int nb = jp->nb, n = jp->n;
@@ -150,14 +152,13 @@ thth_gather_packed_kernel(const cplx* __restrict__ cs, GeomDev g, const double* 
     }
 }
 
-int32_t launch_gather_packed(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
-                             const PackedJob* jobs_dev, const int32_t* slots_dev, int njobs, int nbmax,
-                             hipStream_t stream) {
+int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
+                             const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream) {
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
     SCINT_REQUIRE(nbmax <= 32767 && njobs <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
     hipLaunchKernelGGL(thth_gather_packed_kernel, dim3(2u * (unsigned)nbmax, 2u * (unsigned)nbmax, (unsigned)njobs),
-                       dim3(256), 0, stream, cs, g, th_cents, M, jobs_dev, slots_dev);
+                       dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;

@@ -257,23 +257,35 @@ class Dynspec:
         self.t0s = np.zeros(self.nct_fit)
         self.thth_eigs = np.zeros((self.ncf_fit, self.nct_fit, self.neta))
         coher = (self.thetatheta_proc != 'incoherent')
-        for cf in range(self.ncf_fit):
-            freq2 = np.copy(self.freqs[cf * self.cwf:(cf + 1) * self.cwf])
-            self.f0s[cf] = freq2.mean()
-            etas = self._chunk_etas(freq2)
-            for ct in range(self.nct_fit):
+        # Every chunk's conjugate spectrum goes into one device stack and ALL (chunk, eta) pairs
+        # run as one continuously-batched sweep; chunks are grouped so that a stack stays
+        # below ~8 GiB.
+        R, C = (self.npad + 1) * self.cwf, (self.npad + 1) * self.cwt
+        per_group = max(1, int((8 << 30) // (16 * R * C)))
+        chunks = [(cf, ct) for cf in range(self.ncf_fit) for ct in range(self.nct_fit)]
+        for g0 in range(0, len(chunks), per_group):
+            group = chunks[g0:g0 + per_group]
+            stack = empty((len(group), R, C), torch.complex128)
+            grids, etas_list = [], []
+            for k, (cf, ct) in enumerate(group):
                 fs, ts = self._chunk(cf, ct)
-                time2 = np.copy(self.times[ts])
+                freq2, time2 = np.copy(self.freqs[fs]), np.copy(self.times[ts])
+                self.f0s[cf] = freq2.mean()
                 self.t0s[ct] = time2.mean()
                 dspec2 = np.copy(self.dyn[fs, ts])
                 dspec2 -= np.nanmean(dspec2)
                 dspec2 = np.nan_to_num(dspec2)
-                params = [dspec2, freq2, time2, etas, self.edges * (freq2.mean() / self.fref), None, False,
-                          self.fw, self.npad, coher, self.thth_tau_mask, verbose]
-                res = thth.single_search(params)
-                self.eta_evo[cf, ct] = float(getattr(res[0], "value", res[0]))
-                self.eta_evo_err[cf, ct] = float(getattr(res[1], "value", res[1]))
-                self.thth_eigs[cf, ct] = res[4]
+                fd = thth.fft_axis(time2, 1000.0, self.npad)          # ththmod.py:773
+                tau = thth.fft_axis(freq2, 1.0, self.npad)            # ththmod.py:774
+                thth.conjugate_spectrum(dspec2, self.npad, tau, self.thth_tau_mask, coher, out=stack[k])
+                grids.append((tau, fd, self.edges * (freq2.mean() / self.fref)))
+                etas_list.append(self._chunk_etas(freq2))
+            eig_list = thth.eval_sweep_multi(stack, grids, etas_list)
+            for (cf, ct), etas, eigs in zip(group, etas_list, eig_list):
+                eta_fit, eta_sig, _ = thth.fit_eig_peak(etas, eigs, self.fw)   # ththmod.py:814-859
+                self.eta_evo[cf, ct] = eta_fit
+                self.eta_evo_err[cf, ct] = eta_sig
+                self.thth_eigs[cf, ct] = eigs
         f0 = self.f0s[:, np.newaxis]
         with np.errstate(divide='ignore', invalid='ignore'):
             if time_avg:                                                   # dynspec.py:1724-1732

@@ -461,9 +461,66 @@ def Eval_calc(CS, tau, fd, eta, edges):
     return float(eigs[0])
 
 
-def conjugate_spectrum(dspec, npad, tau=None, tau_mask=0.0, coher=True, pad_value=None):
+def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,
+                     return_info=False):
+    """Eigenvalue curves of MANY chunks in one batched device call -- the chunk loop of
+    Dynspec.fit_thetatheta (dynspec.py:1681-1719).
+
+    cs_stack: CUDA complex128 tensor [nchunk, ntau, nfd]; grids: one (tau, fd, edges) triple per
+    chunk (all conjugate spectra one shape, all edges one length); etas_list: per-chunk eta
+    arrays.  Returns a list of eigenvalue arrays (NaN where a curvature failed)."""
+    lib = _lib.load()
+    G = [g if isinstance(g, _Grid) else _Grid(*g) for g in grids]
+    ncs = len(G)
+    cs_t = _dv.to_device(cs_stack, torch.complex128)
+    if cs_t.dim() != 3 or cs_t.shape[0] != ncs:
+        raise ValueError("cs_stack must be [nchunk, ntau, nfd] with one spectrum per grid")
+    M = G[0].M
+    if any(g.M != M or (g.geom.ntau, g.geom.nfd) != tuple(cs_t.shape[1:]) for g in G):
+        raise ValueError("all chunks must share the CS shape and the number of edges")
+    etas_all, cs_index, keep_rows, keep_n = [], [], [], []
+    for c, (g, et) in enumerate(zip(G, etas_list)):
+        et = np.atleast_1d(units.strip(et, "etas", "s3", warn=False)).astype(float)
+        ki, kn = _sweep_inputs(g, et)
+        etas_all.append(et); keep_rows.append(ki); keep_n.append(kn)
+        cs_index.append(np.full(et.shape[0], c, dtype=np.int32))
+    etas_v = np.ascontiguousarray(np.concatenate(etas_all))
+    cs_idx = np.ascontiguousarray(np.concatenate(cs_index))
+    keep_idx = np.ascontiguousarray(np.concatenate(keep_rows, axis=0))
+    keep_cnt = np.ascontiguousarray(np.concatenate(keep_n))
+    neta = etas_v.shape[0]
+    if batch is None:
+        batch = default_batch(max(int(keep_cnt.max()), 1), neta)
+    geoms = (_lib.CsGeom * ncs)(*[g.geom for g in G])
+    th_stack = _dv.to_device(np.stack([g.th_cents for g in G]), torch.float64)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_eval_sweep_multi_workspace_bytes(M, neta, batch, max_iter, ncs, ctypes.byref(need)),
+               "eval_sweep_multi_workspace_bytes")
+    ws = workspace.get(need.value)
+    keep_t = _dv.to_device(keep_idx, torch.int32)
+    eigs_t = empty((neta,), torch.float64)
+    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    rc = lib.scint_eval_sweep_multi(ptr(cs_t), ncs, int(cs_t.shape[1] * cs_t.shape[2]),
+                                    cs_idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), geoms,
+                                    ptr(th_stack), M, ptr(keep_t),
+                                    keep_cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                    etas_v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta,
+                                    tol, max_iter, batch, ptr(eigs_t), ptr(st_t[0]), ptr(st_t[1]),
+                                    ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_eval_sweep_multi")
+    eigs = eigs_t.cpu().numpy()
+    st = st_t.cpu().numpy()
+    eigs[st[0] != 0] = np.nan
+    bounds = np.cumsum([0] + [e.shape[0] for e in etas_all])
+    out = [eigs[bounds[i]:bounds[i + 1]] for i in range(ncs)]
+    if return_info:
+        return out, {"N": keep_cnt, "iters": st[1], "status": st[0], "batch": batch}
+    return out
+
+
+def conjugate_spectrum(dspec, npad, tau=None, tau_mask=0.0, coher=True, pad_value=None, out=None):
     """Device conjugate spectrum of a chunk (ththmod.py:777-787): returns a CUDA
-    complex128 tensor [(npad+1)*nf, (npad+1)*nt]."""
+    complex128 tensor [(npad+1)*nf, (npad+1)*nt] (written into `out` when given)."""
     lib = _lib.load()
     d_t = to_device(dspec, torch.float64)
     nf, nt = (int(v) for v in d_t.shape)
@@ -483,7 +540,9 @@ def conjugate_spectrum(dspec, npad, tau=None, tau_mask=0.0, coher=True, pad_valu
     need = ctypes.c_size_t()
     _lib.check(lib.scint_cs_workspace_bytes(nf, nt, npad, ctypes.byref(need)), "cs_workspace_bytes")
     ws = workspace.get(need.value)
-    cs_t = empty((R, (npad + 1) * nt), torch.complex128)
+    cs_t = empty((R, (npad + 1) * nt), torch.complex128) if out is None else out
+    if tuple(cs_t.shape) != (R, (npad + 1) * nt) or cs_t.dtype != torch.complex128 or not cs_t.is_contiguous():
+        raise ValueError("conjugate_spectrum: `out` must be a contiguous complex128 tensor of the padded shape")
     rc = lib.scint_cs(ptr(d_t), nf, nt, npad, float(pad_value), lo, hi, 0 if coher else 1,
                       ptr(cs_t), ptr(ws), ws.numel(), stream_ptr())
     _lib.check(rc, "scint_cs")

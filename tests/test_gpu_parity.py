@@ -313,3 +313,24 @@ def test_eigvec_and_chisq_sweep_vs_reference_golden(thth, golden, tag):
         assert chis[k] == pytest.approx(float(g[f"chisq_{tag}{k}"]), rel=1e-9)
     single = [thth.chisq_calc(g["dyn"], CS, tau, fd, e, edges, 1.0) for e in etas]
     np.testing.assert_allclose(chis, single, rtol=1e-9)
+
+
+def test_eval_sweep_multi_equals_per_chunk_sweeps(thth, to):
+    """One batched call over several conjugate spectra == the per-chunk calls, bit for bit."""
+    import torch
+    from scintools_amd.device import empty
+    from scintools_amd.synth import arc_dynspec
+    stack = empty((3, 64, 128), torch.complex128)
+    grids, etas_list, singles = [], [], []
+    for k in range(3):
+        dyn, freqs, times, eta_true = arc_dynspec(64, 128, seed=30 + k, nimg=10, f0=1300.0 + 40 * k)
+        dyn -= dyn.mean()
+        tau, fd = to.fft_axis(freqs, 1.0, 0), to.fft_axis(times, 1000.0, 0)
+        thth.conjugate_spectrum(dyn, 0, tau, 0.0, True, out=stack[k])
+        edges = np.linspace(-fd.max() / 2, fd.max() / 2, 48) * (1.0 + 0.01 * k)
+        etas = np.geomspace(0.5, 2.0, 5 + 2 * k) * eta_true
+        grids.append((tau, fd, edges)); etas_list.append(etas)
+        singles.append(thth.eval_sweep(stack[k], tau, fd, etas, edges))
+    multi = thth.eval_sweep_multi(stack, grids, etas_list, batch=4)
+    for a, b in zip(multi, singles):
+        assert np.array_equal(a, b)
