@@ -88,6 +88,10 @@ def load():
         raise ScintHipError(
             f"{LIB_PATH} is missing: build it with `python -m scintools_amd.build` "
             "(there is no CPU fallback)")
+    # PyTorch-ROCm ships its own HIP runtime; it must be in the process BEFORE our library is
+    # loaded so that both bind the same runtime (loading ours first leaves the process with two
+    # runtimes and ours then sees no device).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (argtypes, restype) in _SIGNATURES.items():
         fn = getattr(lib, name)
