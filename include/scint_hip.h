@@ -182,6 +182,22 @@ int32_t scint_model_from_recov(const scint_c128* recov, int64_t ntau, int64_t nf
                                double* model_out, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* ---- complex inverse: scale * ifft2(ifftshift(x))[:crop_rows, :crop_cols] ----------------
+ * The wavefield step of single_chunk_retrieval (ththmod.py:1465-1468).  out[crop_rows, crop_cols]. */
+int32_t scint_ifft2_shifted(const scint_c128* in, int64_t rows, int64_t cols, double scale,
+                            int64_t crop_rows, int64_t crop_cols, scint_c128* out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Gerchberg-Saxton iterations of Dynspec.gerchberg_saxton (dynspec.py:1868-1875) -------
+ * wavefield[rows, cols] in place.  Per iteration: fft2, zero the natural-order delay rows
+ * zero_lo <= k < zero_hi (the tau < 0 half), ifft2, then where pos != 0 replace the amplitude
+ * by amp (= sqrt(dyn)) keeping the phase.  Workspace: scint_gs_workspace_bytes(). */
+int32_t scint_gs_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes /*HOST*/);
+int32_t scint_gerchberg_saxton(scint_c128* wavefield, int64_t rows, int64_t cols,
+                               const double* amp, const uint8_t* pos,
+                               int64_t zero_lo, int64_t zero_hi, int32_t niter,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- chi^2: sum((model[:nf,:nt]-dspec)[mask]**2)/N (ththmod.py:364-367) --- */
 /* mask: uint8[nf*nt] or NULL (= isfinite(dspec)).  out: DEVICE double[1].  Asynchronous. */
 int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,

@@ -234,3 +234,64 @@ def single_search(dspec, freq, time, etas, edges, fw=0.1, npad=3, coher=True, ta
             eigs[i] = np.nan
     eta_fit, eta_sig, _ = fit_eig_peak(etas, eigs, fw)
     return eta_fit, eta_sig, freq.mean(), time.mean(), eigs
+
+
+# --------------------------------------------------------------------------
+# phase retrieval
+# --------------------------------------------------------------------------
+def single_chunk_retrieval(dspec2, edges, time, freq, eta, npad, tau_mask=0.0):
+    """Wavefield of one chunk (ththmod.py:1390-1476), without the try/except."""
+    fd = fft_axis(time, 1000.0, npad)
+    tau = fft_axis(freq, 1.0, npad)
+    CS = conjugate_spectrum(dspec2, npad, tau, tau_mask)
+    thth_red, thth2_red, recov, model, edges_red, w, V = modeler(CS, tau, fd, eta, edges)
+    ththE_red = thth_red * 0
+    ththE_red[ththE_red.shape[0] // 2, :] = np.conjugate(V) * np.sqrt(w)
+    recov_E = rev_map(ththE_red, tau, fd, eta, edges_red, hermetian=False)
+    model_E = np.fft.ifft2(np.fft.ifftshift(recov_E))[: dspec2.shape[0], : dspec2.shape[1]]
+    model_E *= dspec2.shape[0] * dspec2.shape[1] / 4
+    return model_E
+
+
+def mask_func(w):
+    """ththmod.py:1479-1489."""
+    x = np.linspace(0, w - 1, w)
+    return np.sin((np.pi / 2) * x / w) ** 2
+
+
+def mosaic(chunks):
+    """ththmod.py:1492-1554."""
+    ncf, nct, cwf, cwt = chunks.shape
+    E_recov = np.zeros(((ncf - 1) * (cwf // 2) + cwf, (nct - 1) * (cwt // 2) + cwt), dtype=complex)
+    for cf in range(ncf):
+        for ct in range(nct):
+            chunk_new = chunks[cf, ct, :, :]
+            chunk_old = E_recov[cf * cwf // 2: cf * cwf // 2 + cwf, ct * cwt // 2: ct * cwt // 2 + cwt]
+            mask = np.ones(chunk_new.shape)
+            if cf > 0:
+                mask[: cwf // 2, :] *= mask_func(cwf // 2)[:, np.newaxis]
+            if cf < ncf - 1:
+                mask[cwf // 2:, :] *= 1 - mask_func(cwf // 2)[:, np.newaxis]
+            if ct > 0:
+                mask[:, : cwt // 2] *= mask_func(cwt // 2)
+            if ct < nct - 1:
+                mask[:, cwt // 2:] *= 1 - mask_func(cwt // 2)
+            rot = np.angle((chunk_old * np.conjugate(chunk_new) * mask).mean())
+            E_recov[cf * cwf // 2: cf * cwf // 2 + cwf, ct * cwt // 2: ct * cwt // 2 + cwt] += (
+                chunk_new * mask * np.exp(1j * rot))
+    return E_recov
+
+
+def gerchberg_saxton(wavefield, dyn, tau, niter=1):
+    """Dynspec.gerchberg_saxton after calc_wavefield (dynspec.py:1858-1875)."""
+    wavefield = np.array(wavefield, dtype=complex)
+    d = dyn[: wavefield.shape[0], : wavefield.shape[1]]
+    posdspec = np.isfinite(d) * (d > 0)
+    wavefield *= np.sqrt(d[posdspec].mean() / np.abs(wavefield[posdspec] ** 2).mean())
+    wavefield[posdspec] = np.sqrt(d[posdspec]) * np.exp(1j * np.angle(wavefield[posdspec]))
+    for _ in range(niter):
+        CWF = np.fft.fftshift(np.fft.fft2(wavefield))
+        CWF[tau < 0] = 0
+        wavefield = np.fft.ifft2(np.fft.ifftshift(CWF))
+        wavefield[posdspec] = np.sqrt(d[posdspec]) * np.exp(1j * np.angle(wavefield[posdspec]))
+    return wavefield

@@ -222,7 +222,7 @@ struct WindowedValue {
 // ------------------------------------------------------------------------------
 // sources and sinks
 // ------------------------------------------------------------------------------
-enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULCONJ = 4 };
+enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULCONJ = 4, SRC_CONJ = 5 };
 
 // Element (row, j) of the row-FFT input, j in [0, fft length).
 struct RowSource {
@@ -246,6 +246,7 @@ struct RowSource {
         switch (mode) {
             case SRC_ARRAY: v = a[r * ld + j]; break;
             case SRC_MULCONJ: v = conj(a[r * ld + j] * b[j]); break;
+            case SRC_CONJ: v = conj(a[r * ld + j]); break;
             case SRC_SSPEC:
                 if (j >= nt_eff) v = mk(0.0, 0.0);
                 else if (!prewhite) v = mk(sspec_d(r, j), 0.0);
@@ -289,7 +290,8 @@ struct ColSource {
     }
 };
 
-enum SinkMode { SINK_ARRAY = 0, SINK_SSPEC = 1, SINK_CS = 2, SINK_MODEL = 3 };
+enum SinkMode { SINK_ARRAY = 0, SINK_SSPEC = 1, SINK_CS = 2, SINK_MODEL = 3, SINK_CONJ = 4, SINK_GS_FWD = 5,
+                SINK_GS_INV = 6 };
 
 // Final value at natural frequency (k1 along the strided axis, c along the contiguous one).
 struct ColSink {
@@ -301,7 +303,10 @@ struct ColSink {
     double* out_d;              // SINK_SSPEC / SINK_MODEL
     int halve, prewhite; const double* pd_fd; const double* pd_td;   // SINK_SSPEC
     int64_t mask_lo, mask_hi; int incoherent;                        // SINK_CS
-    double scale;                                                    // SINK_MODEL
+    double scale;                                                    // SINK_MODEL / SINK_CONJ / SINK_GS_INV
+    int64_t crop_r, crop_c;                                          // SINK_CONJ: keep [0,crop_r) x [0,crop_c)
+    int64_t zero_lo, zero_hi;                                        // SINK_GS_FWD: natural rows to zero
+    const double* amp; const uint8_t* pos;                           // SINK_GS_INV: sqrt(dyn), posdspec
 
     int half;                   // real input: only columns 0..C/2 are transformed; the rest is
                                 // X[(R-k1)%R, C-c] = conj X[k1, c]
@@ -344,7 +349,24 @@ struct ColSink {
                 out_c[orow * C + ocol] = v;
                 break;
             }
-            default: out_d[k1 * C + c] = v.x * scale;  // SINK_MODEL
+            case SINK_MODEL: out_d[k1 * C + c] = v.x * scale; break;
+            case SINK_CONJ:   // complex inverse transform: ifft2(x) = conj(fft2(conj x)) / (R C), cropped
+                if (k1 < crop_r && c < crop_c) out_c[k1 * ld + c] = mk(v.x * scale, -v.y * scale);
+                break;
+            case SINK_GS_FWD:  // CWF[tau < 0] = 0 in natural frequency order (dynspec.py:1869-1870)
+                if (k1 >= zero_lo && k1 < zero_hi) v = mk(0.0, 0.0);
+                out_c[k1 * ld + c] = v;
+                break;
+            default: {         // SINK_GS_INV: inverse transform + amplitude constraint (dynspec.py:1871-1875)
+                cplx wv = mk(v.x * scale, -v.y * scale);
+                const int64_t o = k1 * ld + c;
+                if (pos[o]) {
+                    // sqrt(dyn) * exp(1j * angle(w)); angle(0) = 0 in NumPy
+                    const double m = hypot(wv.x, wv.y);
+                    wv = (m > 0.0) ? mk(amp[o] * (wv.x / m), amp[o] * (wv.y / m)) : mk(amp[o], 0.0);
+                }
+                out_c[o] = wv;
+            }
         }
     }
 };
@@ -722,4 +744,62 @@ extern "C" int32_t scint_chisq(const double* model, int64_t ld_model, const doub
     if (!partial) return SCINT_E_HIP;
     return launch_reduce(ChisqValue{model, ld_model, dspec, nt, mask}, nf * nt, 1.0 / noise_n, partial, out,
                          stream);
+}
+
+// ------------------------------------------------------------------------------
+// scint_ifft2_shifted: complex ifft2(ifftshift(x)), optionally cropped and scaled
+// (single_chunk_retrieval, ththmod.py:1465-1468)
+// ------------------------------------------------------------------------------
+extern "C" int32_t scint_ifft2_shifted(const scint_c128* in, int64_t rows, int64_t cols, double scale,
+                                       int64_t crop_rows, int64_t crop_cols, scint_c128* out,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    SCINT_REQUIRE(in && out && workspace, "ifft2_shifted: null pointer");
+    SCINT_REQUIRE(rows >= 2 && cols >= 1 && crop_rows >= 1 && crop_rows <= rows && crop_cols >= 1 && crop_cols <= cols,
+                  "ifft2_shifted: bad shape");
+    RowSource src{};
+    src.mode = SRC_MODEL; src.a = (const cplx*)in; src.R = rows; src.C = cols;   // conj(ifftshift(x))
+    ColSink sink{};
+    sink.mode = SINK_CONJ; sink.out_c = (cplx*)out; sink.ld = crop_cols;
+    sink.scale = scale / ((double)rows * (double)cols);
+    sink.crop_r = crop_rows; sink.crop_c = crop_cols;
+    return fft2_general(src, rows, 0.0, rows, cols, sink, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+// ------------------------------------------------------------------------------
+// scint_gerchberg_saxton: Dynspec.gerchberg_saxton iterations (dynspec.py:1868-1875)
+// ------------------------------------------------------------------------------
+extern "C" int32_t scint_gs_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes) {
+    SCINT_REQUIRE(bytes && rows >= 2 && cols >= 1, "gs_workspace_bytes: bad shape");
+    *bytes = fft2_general_ws(rows, cols, rows) + sizeof(cplx) * (size_t)rows * (size_t)cols + 1024;
+    return SCINT_OK;
+}
+
+extern "C" int32_t scint_gerchberg_saxton(scint_c128* wavefield, int64_t rows, int64_t cols,
+                                          const double* amp, const uint8_t* pos, int64_t zero_lo,
+                                          int64_t zero_hi, int32_t niter, void* workspace,
+                                          size_t workspace_bytes, void* stream_) {
+    SCINT_REQUIRE(wavefield && amp && pos && workspace, "gerchberg_saxton: null pointer");
+    SCINT_REQUIRE(rows >= 2 && cols >= 1 && niter >= 0, "gerchberg_saxton: bad arguments");
+    size_t need = 0;
+    scint_gs_workspace_bytes(rows, cols, &need);
+    if (workspace_bytes < need) { set_error("scint: gerchberg_saxton workspace too small"); return SCINT_E_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t fft_bytes = align_up(fft2_general_ws(rows, cols, rows), 256);
+    cplx* cwf = (cplx*)((char*)workspace + fft_bytes);
+    for (int it = 0; it < niter; ++it) {
+        RowSource f{};
+        f.mode = SRC_ARRAY; f.a = (const cplx*)wavefield; f.ld = cols;
+        ColSink fs{};
+        fs.mode = SINK_GS_FWD; fs.out_c = cwf; fs.ld = cols; fs.zero_lo = zero_lo; fs.zero_hi = zero_hi;
+        int32_t rc = fft2_general(f, rows, 0.0, rows, cols, fs, workspace, fft_bytes, stream);
+        if (rc != SCINT_OK) return rc;
+        RowSource b{};
+        b.mode = SRC_CONJ; b.a = cwf; b.ld = cols;
+        ColSink bs{};
+        bs.mode = SINK_GS_INV; bs.out_c = (cplx*)wavefield; bs.ld = cols;
+        bs.scale = 1.0 / ((double)rows * (double)cols); bs.amp = amp; bs.pos = pos;
+        rc = fft2_general(b, rows, 0.0, rows, cols, bs, workspace, fft_bytes, stream);
+        if (rc != SCINT_OK) return rc;
+    }
+    return SCINT_OK;
 }

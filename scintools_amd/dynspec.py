@@ -303,3 +303,43 @@ class Dynspec:
                 A_err = np.sqrt(1 / np.sum(2 / ((f0**2) * self.eta_evo_err)[tofit] ** 2))
         self.ththeta = A / self.fref**2
         self.ththetaerr = A_err / self.fref**2
+
+    # ------------------------------------------------------------------ phase retrieval
+    def thetatheta_chunks(self, verbose=False, pool=None, memmap=False):
+        """theta-theta phase retrieval on all half-overlapping chunks (dynspec.py:1765-1826):
+        fills ``self.chunks[ncf_ret, nct_ret, cwf, cwt]``.  `pool` / `memmap` are accepted for
+        signature compatibility; chunks run one after another on the GPU."""
+        if not hasattr(self, "ththeta"):
+            self.fit_thetatheta(verbose=verbose, pool=pool)
+        self.chunks = np.zeros((self.ncf_ret, self.nct_ret, self.cwf, self.cwt), dtype=complex)
+        for cf in range(self.ncf_ret):
+            fs = slice(cf * (self.cwf // 2), cf * (self.cwf // 2) + self.cwf)
+            freq2 = np.copy(self.freqs[fs])
+            freq = freq2.mean()
+            eta = self.ththeta * (self.fref / freq)**2
+            for ct in range(self.nct_ret):
+                ts = slice(ct * (self.cwt // 2), ct * (self.cwt // 2) + self.cwt)
+                time2 = np.copy(self.times[ts])
+                dspec2 = np.copy(self.dyn[fs, ts])
+                dspec2 -= np.nanmean(dspec2)
+                dspec2 = np.nan_to_num(dspec2)
+                params = (dspec2, self.edges * (freq / self.fref), time2, freq2, eta, ct, cf, self.npad,
+                          self.thth_tau_mask, verbose)
+                res = thth.single_chunk_retrieval(params)
+                self.chunks[cf, ct, :, :] = res[0]
+
+    def calc_wavefield(self, verbose=False, pool=None, gs=False, memmap=False, niter=1):
+        """Mosaic the chunks into the final wavefield (dynspec.py:1828-1856)."""
+        if not hasattr(self, "chunks"):
+            self.thetatheta_chunks(verbose=verbose, pool=pool, memmap=memmap)
+        self.wavefield = thth.mosaic(self.chunks)
+        if gs:
+            self.gerchberg_saxton(verbose=verbose, pool=pool, niter=niter)
+
+    def gerchberg_saxton(self, niter=1, verbose=False, pool=None):
+        """Gerchberg-Saxton: enforce the measured amplitudes and causality (tau >= 0)
+        (dynspec.py:1858-1875); the FFT <-> projection iterations run on the GPU."""
+        self.calc_wavefield(verbose=verbose, pool=pool)
+        F = self.wavefield.shape[0]
+        tau = thth.fft_axis(self.freqs[:F], 1.0)
+        self.wavefield = thth.gerchberg_saxton_device(self.wavefield, self.dyn, tau, niter=niter)

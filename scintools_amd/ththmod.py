@@ -598,3 +598,118 @@ def single_search(params):
     if np.isfinite(eta_fit):
         eta_fit, eta_sig = units.attach(eta_fit, "s3"), units.attach(eta_sig, "s3")
     return (eta_fit, eta_sig, units.attach(freq_v.mean(), "MHz"), units.attach(time_v.mean(), "s"), eigs)
+
+
+# ----------------------------------------------------------------------------
+# phase retrieval
+# ----------------------------------------------------------------------------
+def _ifft2_shifted_dev(x_t, scale=1.0, crop=None):
+    """scale * ifft2(ifftshift(x))[:crop[0], :crop[1]] on the device (complex128)."""
+    lib = _lib.load()
+    rows, cols = (int(v) for v in x_t.shape)
+    cr, cc = crop if crop is not None else (rows, cols)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_fft2_workspace_bytes(rows, cols, ctypes.byref(need)), "fft2_workspace_bytes")
+    ws = workspace.get(need.value)
+    out = empty((cr, cc), torch.complex128)
+    rc = lib.scint_ifft2_shifted(ptr(x_t), rows, cols, float(scale), cr, cc, ptr(out), ptr(ws), ws.numel(),
+                                 stream_ptr())
+    _lib.check(rc, "scint_ifft2_shifted")
+    return out
+
+
+def single_chunk_retrieval(params):
+    """Phase retrieval on one time/frequency chunk (ththmod.py:1390-1476).
+
+    params = (dspec2, edges, time, freq, eta, idx_t, idx_f, npad, tauMask, verbose) as in the
+    reference.  Returns (model_E[nf, nt] complex, idx_f, idx_t); on failure a zero array, as
+    the reference does.  The wavefield carries the arbitrary global phase of the eigenvector."""
+    dspec2, edges, time, freq, eta, idx_t, idx_f, npad, tauMask, verbose = params
+    time_v = units.strip(time, "time2", "s", warn=False)
+    freq_v = units.strip(freq, "freq2", "MHz", warn=False)
+    e = _eta_float(eta)
+    edges_v = units.strip(edges, "edges", "mHz", warn=False)
+    dspec2 = np.asarray(dspec2, dtype=float)
+    fd = fft_axis(time_v, 1000.0, npad)
+    tau = fft_axis(freq_v, 1.0, npad)
+    try:
+        cs_t = conjugate_spectrum(dspec2, npad, tau, tauMask, True)
+        grid = _Grid(tau, fd, edges_v)
+        red_t, V_t, w, _, _, keep = _modeler_dev(cs_t, grid, e)
+        n = int(keep.shape[0])
+        # ththE_red: only the theta_2 = 0 row is filled, with conj(V) sqrt(w)   (ththmod.py:1459-1461)
+        E_t = torch.zeros((n, n), dtype=torch.complex128, device=cs_t.device)
+        E_t[n // 2, :] = torch.conj(V_t) * float(np.sqrt(w))
+        th_red = _theta_centres(grid.edges_red(keep))
+        recov_E = _rev_map_dev(grid.geom, _dv.to_device(th_red, torch.float64), n, e, False, thth_t=E_t)
+        nf, nt = dspec2.shape
+        model_E = _ifft2_shifted_dev(recov_E, scale=nf * nt / 4, crop=(nf, nt)).cpu().numpy()
+        if verbose:
+            print("Chunk %s-%s success" % (idx_f, idx_t), flush=True)
+    except Exception as exc:   # the reference keeps going with a zero chunk
+        print(exc, flush=True)
+        model_E = np.zeros(dspec2.shape, dtype=complex)
+    return (model_E, idx_f, idx_t)
+
+
+def mask_func(w):
+    """Mask for combining chunks (ththmod.py:1479-1489)."""
+    x = np.linspace(0, w - 1, w)
+    return np.sin((np.pi / 2) * x / w) ** 2
+
+
+def mosaic(chunks):
+    """Stack half-overlapping wavefield chunks after removing their relative phase
+    (ththmod.py:1492-1554).  Host NumPy: one pass over the output, sequentially dependent."""
+    nct, ncf, cwf, cwt = chunks.shape[1], chunks.shape[0], chunks.shape[2], chunks.shape[3]
+    E_recov = np.zeros(((ncf - 1) * (cwf // 2) + cwf, (nct - 1) * (cwt // 2) + cwt), dtype=complex)
+    for cf in range(ncf):
+        for ct in range(nct):
+            chunk_new = chunks[cf, ct, :, :]
+            sl = (slice(cf * cwf // 2, cf * cwf // 2 + cwf), slice(ct * cwt // 2, ct * cwt // 2 + cwt))
+            chunk_old = E_recov[sl]
+            mask = np.ones(chunk_new.shape)
+            if cf > 0:
+                mask[: cwf // 2, :] *= mask_func(cwf // 2)[:, np.newaxis]
+            if cf < ncf - 1:
+                mask[cwf // 2:, :] *= 1 - mask_func(cwf // 2)[:, np.newaxis]
+            if ct > 0:
+                mask[:, : cwt // 2] *= mask_func(cwt // 2)
+            if ct < nct - 1:
+                mask[:, cwt // 2:] *= 1 - mask_func(cwt // 2)
+            rot = np.angle((chunk_old * np.conjugate(chunk_new) * mask).mean())
+            E_recov[sl] += chunk_new * mask * np.exp(1j * rot)
+    return E_recov
+
+
+def gerchberg_saxton_device(wavefield, dyn, tau, niter=1):
+    """Gerchberg-Saxton clean-up of a wavefield (Dynspec.gerchberg_saxton, dynspec.py:1858-1875):
+    host normalisation + first amplitude projection, then `niter` device iterations of
+    fft2 -> zero tau < 0 -> ifft2 -> amplitude projection.  Returns the new wavefield (NumPy)."""
+    lib = _lib.load()
+    wf = np.array(wavefield, dtype=complex)
+    F, T = wf.shape
+    d = np.asarray(dyn, dtype=float)[:F, :T]
+    posdspec = np.isfinite(d) * (d > 0)
+    wf *= np.sqrt(d[posdspec].mean() / np.abs(wf[posdspec] ** 2).mean())
+    wf[posdspec] = np.sqrt(d[posdspec]) * np.exp(1j * np.angle(wf[posdspec]))
+    if niter <= 0:
+        return wf
+    tau_v = units.strip(tau, "tau", "us", warn=False)
+    neg = np.nonzero(tau_v < 0)[0]                      # rows of the fftshifted CWF to clear
+    nat = np.sort((neg - F // 2) % F)                    # the same rows in natural FFT order
+    if nat.size and (nat[-1] - nat[0] + 1 != nat.size):
+        raise ValueError("tau < 0 is not a contiguous block of delays")
+    lo, hi = (int(nat[0]), int(nat[-1]) + 1) if nat.size else (0, 0)
+    amp = np.zeros((F, T))
+    amp[posdspec] = np.sqrt(d[posdspec])
+    wf_t = _dv.to_device(wf, torch.complex128)
+    amp_t = _dv.to_device(amp, torch.float64)
+    pos_t = _dv.to_device(posdspec.astype(np.uint8), torch.uint8)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_gs_workspace_bytes(F, T, ctypes.byref(need)), "gs_workspace_bytes")
+    ws = workspace.get(need.value)
+    rc = lib.scint_gerchberg_saxton(ptr(wf_t), F, T, ptr(amp_t), ptr(pos_t), lo, hi, int(niter), ptr(ws),
+                                    ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_gerchberg_saxton")
+    return wf_t.cpu().numpy()

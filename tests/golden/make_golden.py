@@ -224,8 +224,33 @@ def gen_fit_thetatheta():
          ththeta=V(dyn.ththeta), ththetaerr=V(dyn.ththetaerr))
 
 
+# ---------------------------------------------------------------------------
+# 6. phase retrieval: thetatheta_chunks -> mosaic -> Gerchberg-Saxton (dynspec.py:1765-1875)
+# ---------------------------------------------------------------------------
+def gen_retrieval():
+    from scintools.dynspec import BasicDyn
+    d = np.load("/root/reference/scintools/examples/data/ththsims/Sample_Data.npz")
+    nchan = 256
+    dspec = (np.abs(d["Espec"]) ** 2)[:nchan]
+    freq, tme = d["f_MHz"][:nchan], d["t_s"]
+    b = BasicDyn(name="Sample Data", header=["Sample Data"], times=tme, freqs=freq, dyn=dspec,
+                 nsub=tme.shape[0], nchan=freq.shape[0], dt=(tme[1] - tme[0]), df=(freq[1] - freq[0]))
+    dyn = Dynspec(dyn=b, process=False, verbose=False)
+    dyn.prep_thetatheta(verbose=False, cwf=64, edges_lim=.3, eta_min=30 * u.s**3, eta_max=50 * u.s**3,
+                        nedge=128)
+    dyn.fit_thetatheta(verbose=False)
+    dyn.calc_wavefield()
+    wavefield = np.array(dyn.wavefield)
+    chunks = np.array(dyn.chunks)
+    dyn.gerchberg_saxton(niter=2)
+    save("retrieval.npz", nchan=nchan, edges=V(dyn.edges), neta=dyn.neta, fref=V(dyn.fref),
+         ththeta=V(dyn.ththeta), ththetaerr=V(dyn.ththetaerr), eta_evo=V(dyn.eta_evo),
+         chunk0=chunks[0, 0], chunk3=chunks[3, 0],
+         wavefield=wavefield, wavefield_gs=np.array(dyn.wavefield))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit"]
+    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval"]
     if "small" in which:
         gen_thth_small()
     if "sample" in which:
@@ -236,3 +261,5 @@ if __name__ == "__main__":
         gen_thth_medium()
     if "fit" in which:
         gen_fit_thetatheta()
+    if "retrieval" in which:
+        gen_retrieval()

@@ -334,3 +334,57 @@ def test_eval_sweep_multi_equals_per_chunk_sweeps(thth, to):
     multi = thth.eval_sweep_multi(stack, grids, etas_list, batch=4)
     for a, b in zip(multi, singles):
         assert np.array_equal(a, b)
+
+
+def _align(a, ref):
+    return a * np.exp(-1j * np.angle(np.vdot(ref, a)))
+
+
+def test_phase_retrieval_vs_reference_golden(thth, golden):
+    """thetatheta_chunks -> mosaic -> Gerchberg-Saxton on the GPU against the reference's run
+    (tests/golden/make_golden.py::gen_retrieval); wavefields compared up to a global phase."""
+    from scintools_amd.dynspec import Dynspec
+    g = golden("retrieval.npz")
+    f = golden("fit_thetatheta.npz")
+    n = int(g["nchan"])
+
+    class B:
+        dyn, freqs, times, dt, df = f["dspec"][:n], f["freq"][:n], f["time"], float(f["dt"]), float(f["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50, nedge=128)
+    assert np.array_equal(d.edges, g["edges"]) and d.neta == int(g["neta"])
+    d.calc_wavefield()
+    assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-6)
+    np.testing.assert_allclose(d.eta_evo, g["eta_evo"], rtol=1e-6)
+    assert d.chunks.shape == (7, 1, 64, 150)
+    for cf, key in ((0, "chunk0"), (3, "chunk3")):
+        ref = g[key]
+        assert np.abs(_align(d.chunks[cf, 0], ref) - ref).max() <= 1e-6 * np.abs(ref).max()
+    ref = g["wavefield"]
+    assert d.wavefield.shape == ref.shape
+    assert np.abs(_align(d.wavefield, ref) - ref).max() <= 1e-6 * np.abs(ref).max()
+    d.gerchberg_saxton(niter=2)
+    ref = g["wavefield_gs"]
+    assert np.abs(_align(d.wavefield, ref) - ref).max() <= 1e-6 * np.abs(ref).max()
+    # the constraints GS enforces: measured amplitudes, and causality after the last projection
+    pos = B.dyn[: ref.shape[0]] > 0
+    np.testing.assert_allclose(np.abs(d.wavefield[pos]) ** 2, B.dyn[: ref.shape[0]][pos], rtol=1e-9)
+
+
+def test_ifft2_shifted_and_gs_kernels_vs_numpy(thth):
+    import torch
+    from scintools_amd.ththmod import _ifft2_shifted_dev, gerchberg_saxton_device
+    from oracle import thth_oracle as to
+    rng = np.random.default_rng(8)
+    for shape in ((64, 32), (96, 150), (33, 17)):
+        x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+        ref = np.fft.ifft2(np.fft.ifftshift(x))[: shape[0] // 2, : shape[1] - 3] * 2.5
+        got = _ifft2_shifted_dev(thth.to_device(x), scale=2.5, crop=(shape[0] // 2, shape[1] - 3)).cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        dyn = np.abs(rng.standard_normal(shape)) + 0.1
+        dyn[3, 5] = -1.0
+        dyn[7, 2] = np.nan
+        tau = np.fft.fftshift(np.fft.fftfreq(shape[0], 0.1))
+        ref = to.gerchberg_saxton(x, dyn, tau, niter=3)
+        got = gerchberg_saxton_device(x, dyn, tau, niter=3)
+        assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()

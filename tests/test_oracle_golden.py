@@ -156,3 +156,40 @@ def test_window_and_acf(golden):
         assert np.array_equal(cw, g[f"win_t_{nt}_{nf}"])
         assert np.array_equal(sw, g[f"win_f_{nt}_{nf}"])
     assert np.array_equal(so.calc_acf(g["dyn"]), g["acf"])
+
+
+# ---------------------------------------------------------------- phase retrieval
+def _align(a, ref):
+    """Remove the arbitrary global phase (the eigenvector's) before comparing wavefields."""
+    return a * np.exp(-1j * np.angle(np.vdot(ref, a)))
+
+
+def test_retrieval_chunks_mosaic_gs(golden):
+    """single_chunk_retrieval / mosaic / gerchberg_saxton of the oracle against the reference's
+    Dynspec.thetatheta_chunks + calc_wavefield + gerchberg_saxton run (first 256 channels of
+    Sample_Data.npz).  Wavefields are defined up to one global phase."""
+    g = golden("retrieval.npz")
+    f = golden("fit_thetatheta.npz")
+    n = int(g["nchan"])
+    dspec, freq, time = f["dspec"][:n], f["freq"][:n], f["time"]
+    cwf, npad = 64, 3
+    fref, ththeta, edges = float(g["fref"]), float(g["ththeta"]), g["edges"]
+    ncf = n // (cwf // 2) - 1
+    chunks = np.zeros((ncf, 1, cwf, time.shape[0]), dtype=complex)
+    for cf in range(ncf):
+        fs = slice(cf * (cwf // 2), cf * (cwf // 2) + cwf)
+        d2 = np.copy(dspec[fs])
+        d2 -= np.nanmean(d2)
+        fm = freq[fs].mean()
+        chunks[cf, 0] = to.single_chunk_retrieval(np.nan_to_num(d2), edges * (fm / fref), time, freq[fs],
+                                                  ththeta * (fref / fm) ** 2, npad)
+    for cf, key in ((0, "chunk0"), (3, "chunk3")):
+        ref = g[key]
+        assert np.abs(_align(chunks[cf, 0], ref) - ref).max() <= 1e-7 * np.abs(ref).max()
+    wf = to.mosaic(chunks)
+    ref = g["wavefield"]
+    assert wf.shape == ref.shape
+    assert np.abs(_align(wf, ref) - ref).max() <= 1e-7 * np.abs(ref).max()
+    gs = to.gerchberg_saxton(wf, dspec, to.fft_axis(freq[: wf.shape[0]], 1.0), niter=2)
+    ref = g["wavefield_gs"]
+    assert np.abs(_align(gs, ref) - ref).max() <= 1e-7 * np.abs(ref).max()
