@@ -198,6 +198,14 @@ int32_t scint_gerchberg_saxton(scint_c128* wavefield, int64_t rows, int64_t cols
                                int64_t zero_lo, int64_t zero_hi, int32_t niter,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- autocovariance: Dynspec.calc_acf(method='direct') (dynspec.py:3780-3797) ------------
+ * acf_out[2nf, 2nt] = real(fftshift(ifft2(|fft2(dyn - mean, s=[2nf, 2nt])|^2))), / max if
+ * normalise; the mean is subtracted only if subtract_mean (the reference skips it for
+ * input_dyn).  dyn must be finite (the reference takes the mean of the valid pixels only). */
+int32_t scint_acf_workspace_bytes(int64_t nf, int64_t nt, size_t* bytes /*HOST*/);
+int32_t scint_acf(const double* dyn, int64_t nf, int64_t nt, int32_t subtract_mean, int32_t normalise,
+                  double* acf_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- chi^2: sum((model[:nf,:nt]-dspec)[mask]**2)/N (ththmod.py:364-367) --- */
 /* mask: uint8[nf*nt] or NULL (= isfinite(dspec)).  out: DEVICE double[1].  Asynchronous. */
 int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,

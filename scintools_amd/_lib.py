@@ -65,6 +65,8 @@ _SIGNATURES = {
     "scint_ifft2_shifted": ([_P, c_int64, c_int64, c_double, c_int64, c_int64, _P, _P, c_size_t, _P], c_int32),
     "scint_gs_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_gerchberg_saxton": ([_P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int32, _P, c_size_t, _P], c_int32),
+    "scint_acf_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
+    "scint_acf": ([_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P], c_int32),
     "scint_chisq": ([_P, c_int64, _P, c_int64, c_int64, _P, c_double, _P, _P], c_int32),
     "scint_fft2_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_fft2": ([_P, _P, c_int64, c_int64, _P, c_size_t, _P], c_int32),

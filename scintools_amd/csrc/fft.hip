@@ -222,7 +222,8 @@ struct WindowedValue {
 // ------------------------------------------------------------------------------
 // sources and sinks
 // ------------------------------------------------------------------------------
-enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULCONJ = 4, SRC_CONJ = 5 };
+enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULCONJ = 4, SRC_CONJ = 5,
+               SRC_ACF_IN = 6, SRC_POWER = 7 };
 
 // Element (row, j) of the row-FFT input, j in [0, fft length).
 struct RowSource {
@@ -247,6 +248,14 @@ struct RowSource {
             case SRC_ARRAY: v = a[r * ld + j]; break;
             case SRC_MULCONJ: v = conj(a[r * ld + j] * b[j]); break;
             case SRC_CONJ: v = conj(a[r * ld + j]); break;
+            case SRC_ACF_IN:   // (dyn - mean) zero-padded on the right (dynspec.py:3783-3790)
+                v = mk(j < wv.nt ? wv.dyn[r * wv.nt + j] - wv.m1[0] : 0.0, 0.0);
+                break;
+            case SRC_POWER: {  // |X|^2 (dynspec.py:3791-3792); real, so no conjugation is needed
+                const cplx x = a[r * ld + j];
+                v = mk(x.x * x.x + x.y * x.y, 0.0);
+                break;
+            }
             case SRC_SSPEC:
                 if (j >= nt_eff) v = mk(0.0, 0.0);
                 else if (!prewhite) v = mk(sspec_d(r, j), 0.0);
@@ -291,7 +300,7 @@ struct ColSource {
 };
 
 enum SinkMode { SINK_ARRAY = 0, SINK_SSPEC = 1, SINK_CS = 2, SINK_MODEL = 3, SINK_CONJ = 4, SINK_GS_FWD = 5,
-                SINK_GS_INV = 6 };
+                SINK_GS_INV = 6, SINK_ACF = 7 };
 
 // Final value at natural frequency (k1 along the strided axis, c along the contiguous one).
 struct ColSink {
@@ -353,6 +362,11 @@ struct ColSink {
             case SINK_CONJ:   // complex inverse transform: ifft2(x) = conj(fft2(conj x)) / (R C), cropped
                 if (k1 < crop_r && c < crop_c) out_c[k1 * ld + c] = mk(v.x * scale, -v.y * scale);
                 break;
+            case SINK_ACF: {   // real(fftshift(ifft2(.)))  (dynspec.py:3793-3795)
+                const int64_t orow = (k1 + R / 2) % R, ocol = (c + C / 2) % C;
+                out_d[orow * C + ocol] = v.x * scale;
+                break;
+            }
             case SINK_GS_FWD:  // CWF[tau < 0] = 0 in natural frequency order (dynspec.py:1869-1870)
                 if (k1 >= zero_lo && k1 < zero_hi) v = mk(0.0, 0.0);
                 out_c[k1 * ld + c] = v;
@@ -801,5 +815,79 @@ extern "C" int32_t scint_gerchberg_saxton(scint_c128* wavefield, int64_t rows, i
         rc = fft2_general(b, rows, 0.0, rows, cols, bs, workspace, fft_bytes, stream);
         if (rc != SCINT_OK) return rc;
     }
+    return SCINT_OK;
+}
+
+// ------------------------------------------------------------------------------
+// scint_acf: Dynspec.calc_acf(method='direct') (dynspec.py:3780-3797)
+// ------------------------------------------------------------------------------
+namespace scint {
+struct MaxAbsValue {   // arr /= np.max(arr): the maximum of a real array via two-stage max
+    const double* x;
+};
+__global__ void __launch_bounds__(256) max_partial_kernel(const double* x, int64_t n, double* partial) {
+    __shared__ double red[4];
+    double m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, x[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__global__ void __launch_bounds__(256) scale_by_max_kernel(double* x, int64_t n, const double* partial, int np) {
+    double m = -INFINITY;
+    for (int i = 0; i < np; ++i) m = fmax(m, partial[i]);
+    const double inv = 1.0 / m;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = x[i] / m;
+    (void)inv;
+}
+}  // namespace scint
+
+extern "C" int32_t scint_acf_workspace_bytes(int64_t nf, int64_t nt, size_t* bytes) {
+    SCINT_REQUIRE(bytes && nf >= 1 && nt >= 1, "acf_workspace_bytes: bad shape");
+    const int64_t R = 2 * nf, C = 2 * nt;
+    *bytes = fft2_general_ws(R, C, R) + sizeof(cplx) * (size_t)R * (size_t)C + sizeof(double) * (kRedBlocks + 8) + 1024;
+    return SCINT_OK;
+}
+
+extern "C" int32_t scint_acf(const double* dyn, int64_t nf, int64_t nt, int32_t subtract_mean,
+                             int32_t normalise, double* acf_out, void* workspace, size_t workspace_bytes,
+                             void* stream_) {
+    SCINT_REQUIRE(dyn && acf_out && workspace, "acf: null pointer");
+    SCINT_REQUIRE(nf >= 1 && nt >= 1, "acf: bad shape");
+    size_t need = 0;
+    scint_acf_workspace_bytes(nf, nt, &need);
+    if (workspace_bytes < need) { set_error("scint: acf workspace too small"); return SCINT_E_WORKSPACE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t R = 2 * nf, C = 2 * nt;
+    const size_t fft_bytes = align_up(fft2_general_ws(R, C, R), 256);
+    cplx* spec = (cplx*)((char*)workspace + fft_bytes);
+    Carver cv((char*)workspace + fft_bytes + sizeof(cplx) * (size_t)R * (size_t)C,
+              workspace_bytes - fft_bytes - sizeof(cplx) * (size_t)R * (size_t)C);
+    double* partial = cv.take<double>(kRedBlocks);
+    double* scal = cv.take<double>(8);
+    int32_t rc = SCINT_OK;
+    if (subtract_mean) rc = launch_reduce(PlainValue{dyn}, nf * nt, 1.0 / (double)(nf * nt), partial, scal, stream);
+    else SCINT_HIP(hipMemsetAsync(scal, 0, sizeof(double), stream));
+    if (rc != SCINT_OK) return rc;
+    RowSource f{};
+    f.mode = SRC_ACF_IN; f.wv.dyn = dyn; f.wv.nt = nt; f.wv.m1 = scal;
+    ColSink fs{};
+    fs.mode = SINK_ARRAY; fs.out_c = spec; fs.ld = C;
+    rc = fft2_general(f, nf, 0.0, R, C, fs, workspace, fft_bytes, stream, /*real_input=*/true);
+    if (rc != SCINT_OK) return rc;
+    RowSource b{};
+    b.mode = SRC_POWER; b.a = spec; b.ld = C;
+    ColSink bs{};
+    bs.mode = SINK_ACF; bs.out_d = acf_out; bs.scale = 1.0 / ((double)R * (double)C);
+    // the power spectrum is real and even, so fft2 and ifft2 of it coincide up to the 1/(RC) factor
+    rc = fft2_general(b, R, 0.0, R, C, bs, workspace, fft_bytes, stream, /*real_input=*/true);
+    if (rc != SCINT_OK || !normalise) return rc;
+    const int blocks = (int)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, ceil_div(R * C, 1024)));
+    hipLaunchKernelGGL(max_partial_kernel, dim3(blocks), dim3(256), 0, stream, acf_out, R * C, partial);
+    hipLaunchKernelGGL(scale_by_max_kernel, dim3(blocks), dim3(256), 0, stream, acf_out, R * C, partial, blocks);
+    SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

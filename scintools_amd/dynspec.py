@@ -140,6 +140,34 @@ class Dynspec:
             return None
         return fdop, tdel, sec
 
+    def calc_acf(self, method='direct', input_dyn=None, normalise=True, window_frac=0.1):
+        """Autocovariance function (dynspec.py:3750-3814), 'direct' method on the GPU:
+        zero-padded fft2 -> |.|^2 -> ifft2 -> fftshift -> real (-> / max).  Sets ``self.acf`` or,
+        with ``input_dyn``, returns it.  Non-finite pixels are not supported here (the reference
+        only excludes them from the mean); method='sspec' is outside the hot path."""
+        if method != 'direct':
+            raise NotImplementedError("calc_acf(method='sspec') is outside the accelerated hot path")
+        lib = _lib.load()
+        require_gpu()
+        dyn = self.dyn if input_dyn is None else np.asarray(input_dyn)
+        if not np.all(np.isfinite(dyn)):
+            raise ValueError("calc_acf on the GPU needs a finite dynamic spectrum (run refill first)")
+        dyn_t = to_device(dyn, torch.float64)
+        nf, nt = (int(v) for v in dyn_t.shape)
+        need = ctypes.c_size_t()
+        _lib.check(lib.scint_acf_workspace_bytes(nf, nt, ctypes.byref(need)), "acf_workspace_bytes")
+        ws = workspace.get(need.value)
+        out = empty((2 * nf, 2 * nt), torch.float64)
+        # with input_dyn the reference does NOT subtract the mean (dynspec.py:3786-3789)
+        rc = lib.scint_acf(ptr(dyn_t), nf, nt, 1 if input_dyn is None else 0, 1 if normalise else 0, ptr(out),
+                           ptr(ws), ws.numel(), stream_ptr())
+        _lib.check(rc, "scint_acf")
+        arr = out.cpu().numpy()
+        if input_dyn is None:
+            self.acf = arr
+            return None
+        return arr
+
     # ------------------------------------------------------------------ theta-theta
     def prep_thetatheta(self, fw=.1, npad=3, verbose=False, fitting_proc='standard', **kwargs):
         """Set the theta-theta search parameters (dynspec.py:1348-1537).

@@ -388,3 +388,23 @@ def test_ifft2_shifted_and_gs_kernels_vs_numpy(thth):
         ref = to.gerchberg_saxton(x, dyn, tau, niter=3)
         got = gerchberg_saxton_device(x, dyn, tau, niter=3)
         assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_calc_acf_vs_oracle_and_reference_golden(golden):
+    """BASELINE config 1's other half: Dynspec.calc_acf (direct method)."""
+    from oracle import sspec_oracle as so
+    from scintools_amd.dynspec import Dynspec
+    g = golden("sim_sspec.npz")
+
+    class O:
+        dyn, freqs, times, dt, df = g["dyn"].astype(np.float64), g["freqs"], g["times"], float(g["dt"]), float(g["df"])
+    d = Dynspec(dyn=O(), verbose=False)
+    d.calc_acf()
+    ref64 = so.calc_acf(O.dyn)
+    assert d.acf.shape == ref64.shape == (192, 256)
+    assert np.abs(d.acf - ref64).max() <= 1e-12
+    assert np.abs(d.acf - g["acf"]).max() <= 1e-5          # the reference ran on its float32 dyn
+    raw = d.calc_acf(input_dyn=O.dyn[:75, :101], normalise=False)   # odd sizes, no mean subtraction
+    x = np.fft.fft2(O.dyn[:75, :101], s=[150, 202])
+    ref = np.real(np.fft.fftshift(np.fft.ifft2(np.abs(x) ** 2)))
+    assert np.abs(raw - ref).max() <= 1e-12 * np.abs(ref).max()
