@@ -31,6 +31,25 @@ __host__ __device__ inline cplx mul_mi(cplx a) { return mk(a.y, -a.x); }
 __host__ __device__ inline cplx mul_pi(cplx a) { return mk(-a.y, a.x); }
 __host__ __device__ inline double norm2(cplx a) { return a.x * a.x + a.y * a.y; }
 
+// ---- explicit global-memory accesses ------------------------------------------------
+// Pointers that are LOADED from a job table are generic to the compiler, which then emits
+// flat_load/flat_store: those count on both vmcnt and lgkmcnt, so every wait becomes
+// "wait for everything" and software pipelining is lost.  These helpers assert the global
+// address space (global_load_dwordx4 / global_store_dwordx4, counted on vmcnt only).
+typedef double v2d __attribute__((ext_vector_type(2)));
+#define SCINT_GLOBAL __attribute__((address_space(1)))
+__device__ inline cplx gload(const cplx* p) {
+    const v2d v = *(const SCINT_GLOBAL v2d*)p;
+    return mk(v.x, v.y);
+}
+__device__ inline double gload(const double* p) { return *(const SCINT_GLOBAL double*)p; }
+__device__ inline int32_t gload(const int32_t* p) { return *(const SCINT_GLOBAL int32_t*)p; }
+__device__ inline void gstore(cplx* p, cplx v) {
+    v2d t; t.x = v.x; t.y = v.y;
+    *(SCINT_GLOBAL v2d*)p = t;
+}
+__device__ inline void gstore(double* p, double v) { *(SCINT_GLOBAL double*)p = v; }
+
 // ---- wavefront (64 lanes) reductions ------------------------------------------
 __device__ inline double wave_sum(double v) {
 #pragma unroll

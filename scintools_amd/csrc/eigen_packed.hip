@@ -82,7 +82,7 @@ constexpr int kFlush = 4;      // column partials are reduced across the 4 waves
 __device__ inline StepScalars step_scalars_wave(const double* __restrict__ ap, const double* __restrict__ up,
                                                 int nb, int lane) {
     double a = 0.0, uu = 0.0;
-    for (int i = lane; i < nb; i += 64) { a += ap[i]; uu += up[i]; }
+    for (int i = lane; i < nb; i += 64) { a += gload(ap + i); uu += gload(up + i); }
     StepScalars s;
     s.alpha = wave_sum(a);
     uu = wave_sum(uu);
@@ -122,13 +122,13 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
     const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
     cplx a0[8], a1[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = tp[r * kTB];
+    for (int r = 0; r < 8; ++r) a0[r] = gload(tp + r * kTB);
     const StepScalars sc = step_scalars_wave(par ? jp->apart[1] : jp->apart[0],
                                              par ? jp->upart[1] : jp->upart[0], nb, lane);
     // lane l of every wave holds x_I[l]; rows read it back with v_readlane (scalar broadcast)
     cplx xIr;
     {
-        const cplx u = Up[I * kTB + lane], q = Qp[I * kTB + lane];
+        const cplx u = gload(Up + I * kTB + lane), q = gload(Qp + I * kTB + lane);
         xIr = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
     }
     cplx accR[16];
@@ -140,8 +140,8 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
         const int J = st.J0 + t;
         const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a1[r] = tc[(8 + r) * kTB];          // second half of this tile
-        const cplx uj = Up[J * kTB + lane], qj = Qp[J * kTB + lane];
+        for (int r = 0; r < 8; ++r) a1[r] = gload(tc + (8 + r) * kTB);   // second half of this tile
+        const cplx uj = gload(Up + J * kTB + lane), qj = gload(Qp + J * kTB + lane);
         const cplx xJ = mk((uj.x - sc.alpha * qj.x) * sc.inv, (uj.y - sc.alpha * qj.y) * sc.inv);
         cplx c = mk(0.0, 0.0);
 #pragma unroll
@@ -152,7 +152,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
         }
         if (t + 1 < ntile) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a0[r] = tc[kTileElems + r * kTB];   // first half of the next tile
+            for (int r = 0; r < 8; ++r) a0[r] = gload(tc + kTileElems + r * kTB);   // first half of the next tile
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -170,7 +170,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
                 const int Jt = st.J0 + tt;
                 if (Jt != I) {
                     const cplx s = ((cred[0][w][lane] + cred[1][w][lane]) + cred[2][w][lane]) + cred[3][w][lane];
-                    colpart[(t0 + (Jt - I)) * kTB + lane] = s;
+                    gstore(colpart + (t0 + (Jt - I)) * kTB + lane, s);
                 }
             }
             __syncthreads();
@@ -180,7 +180,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const cplx s = wave_sum(accR[r]);
-        if (lane == 0) rowpart[(int64_t)st.index * kTB + 16 * w + r] = s;
+        if (lane == 0) gstore(rowpart + (int64_t)st.index * kTB + 16 * w + r, s);
     }
 }
 
@@ -198,10 +198,10 @@ __global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restr
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc = mk(0.0, 0.0);
     for (int idx = g; idx < nrow + K; idx += 4) {
-        if (idx < nrow) acc = acc + jb.rowpart[(int64_t)(s0 + idx) * kTB + e];
+        if (idx < nrow) acc = acc + gload(jb.rowpart + (int64_t)(s0 + idx) * kTB + e);
         else {
             const int I = idx - nrow;
-            acc = acc + jb.colpart[(tile_offset(jb.nb, I) + (K - I)) * kTB + e];
+            acc = acc + gload(jb.colpart + (tile_offset(jb.nb, I) + (K - I)) * kTB + e);
         }
     }
     part[g][e] = acc;
@@ -490,6 +490,26 @@ static int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int
     return SCINT_OK;
 }
 
+// Pinned read-back buffer for the per-slot state words, kept per host thread and grown on
+// demand (a hipHostMalloc per sweep call costs more than a small sweep).
+static int32_t* pinned_flags(size_t count) {
+    thread_local int32_t* buf = nullptr;
+    thread_local size_t cap = 0;
+    if (count > cap) {
+        if (buf) (void)hipHostFree(buf);
+        buf = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(count, 1024);
+        if (hipHostMalloc(&buf, sizeof(int32_t) * want) != hipSuccess) {
+            set_error("scint: hipHostMalloc of the flag buffer failed");
+            buf = nullptr;
+            return nullptr;
+        }
+        cap = want;
+    }
+    return buf;
+}
+
 // Shared driver of scint_eval_sweep (eigenvalues), scint_eigvec_sweep (eigenpairs) and
 // scint_eval_sweep_multi.  `ncs` conjugate spectra of one shape live `cs_stride` elements apart
 // from `cs`, each with its own geometry geom[c] and theta grid th_cents + c*M; curvature e reads
@@ -540,8 +560,8 @@ static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, c
     std::vector<Strip> strips;
     std::vector<int32_t> rs_all((size_t)nslots * (size_t)(nbmax + 1));
     std::vector<int32_t> fresh;                           // slots (re)filled in this round
-    int32_t* flags = nullptr;
-    SCINT_HIP(hipHostMalloc(&flags, sizeof(int32_t) * 4 * (size_t)nslots));
+    int32_t* flags = pinned_flags((size_t)nslots * 4);
+    if (!flags) return SCINT_E_HIP;
     for (int s = 0; s < nslots; ++s) {                    // static part of every slot
         char* sl = base + L.total * (size_t)s;
         PackedJob& J = jobs[(size_t)s];
@@ -688,7 +708,6 @@ static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, c
             if (he != hipSuccess) { rc = hip_fail(he, "sweep ritz vectors", __FILE__, __LINE__); break; }
         }
     }
-    (void)hipHostFree(flags);
     return rc;
 }
 

@@ -110,8 +110,8 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int cj = qj * 32 + tx;                              // column inside the 64-tile
     const int j = J * kTB + cj;
-    const int kj = j < n ? keep[j] : 0;
-    const double th_j = j < n ? th[kj] : 0.0;
+    const int kj = j < n ? gload(keep + j) : 0;
+    const double th_j = j < n ? gload(th + kj) : 0.0;
     cplx* __restrict__ tile = jp->tiles + (tile_offset(nb, I) + (J - I)) * kTileElems;
     // Three phases so that a lane's scattered CS reads are all in flight together:
     // (1) index math, (2) the loads, (3) weights and stores.
@@ -124,8 +124,8 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
         off[r] = -1;
         wgt[r] = 0.0;
         if (i < n && j < n && i != j) {
-            const int ki = keep[i];
-            const double th_i = th[ki];
+            const int ki = gload(keep + i);
+            const double th_i = gload(th + ki);
             // upper element (i < j) reads (theta2 = th_i, theta1 = th_j); the lower half of a
             // diagonal tile is the conjugate of the mirrored upper element
             const double t2 = i < j ? th_i : th_j, t1 = i < j ? th_j : th_i;
@@ -138,7 +138,7 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
     }
     cplx val[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) val[r] = cs[off[r] >= 0 ? off[r] : 0];
+    for (int r = 0; r < 4; ++r) val[r] = gload(cs + (off[r] >= 0 ? off[r] : 0));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         cplx v = mk(0.0, 0.0);
@@ -148,7 +148,7 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
             if (wgt[r] < 0.0) v = conj(v);
             v = mk(nan_to_num(v.x), nan_to_num(v.y));
         }
-        tile[(qi * 32 + ty + 8 * r) * kTB + cj] = v;
+        gstore(tile + (qi * 32 + ty + 8 * r) * kTB + cj, v);
     }
 }
 

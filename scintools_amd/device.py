@@ -3,6 +3,8 @@
 No torch op runs inside the hot loop -- tensors are allocated here and their
 ``data_ptr()`` is handed to the HIP kernels through the C ABI.
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -58,4 +60,23 @@ class Workspace:
         self._buf = None
 
 
-workspace = Workspace()
+class _PerThreadWorkspace:
+    """One grow-only scratch buffer per Python thread (each thread drives its own stream)."""
+
+    def __init__(self):
+        self._local = threading.local()
+
+    def _ws(self):
+        ws = getattr(self._local, "ws", None)
+        if ws is None:
+            ws = self._local.ws = Workspace()
+        return ws
+
+    def get(self, nbytes):
+        return self._ws().get(nbytes)
+
+    def release(self):
+        self._ws().release()
+
+
+workspace = _PerThreadWorkspace()
