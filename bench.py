@@ -68,6 +68,9 @@ def parse():
                     help="eig: Eval_calc sweep of single_search (headline); chisq: modeler/chisq_calc sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="etas timed on the CPU oracle")
+    ap.add_argument("--cpu-pool", type=int, default=8,
+                    help="also time the oracle eta-parallel with multiprocessing.Pool(P), one BLAS thread "
+                         "per worker (how a user parallelises the reference, dynspec.py:1715-1719); 0 = skip")
     return ap.parse_args()
 
 
@@ -101,6 +104,49 @@ def cpu_baseline(dyn, tau, fd, edges, etas, nsample, npad=0):
             "sample": f"oracle Eval_calc (NumPy gather + ARPACK eigsh) on {len(idx)} of {len(etas)} etas "
                       f"(indices {idx.tolist()}) of the same {dyn.shape[0]}x{dyn.shape[1]} workload, "
                       f"{dt:.1f} s; BLAS threads as shipped; CS FFT excluded"}, dict(zip(idx.tolist(), vals))
+
+
+def _pool_worker(job):
+    """One eta of the oracle sweep in a worker process (spawned: no GPU state is inherited)."""
+    path, i = job
+    import numpy as _np
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:
+        ctx = None
+    from oracle import thth_oracle
+    z = _np.load(path, mmap_mode="r")
+    meta = _np.load(path.replace("_cs.npy", "_meta.npz"))
+    val = thth_oracle.Eval_calc(_np.asarray(z), meta["tau"], meta["fd"], float(meta["etas"][i]), meta["edges"])
+    del ctx
+    return i, val
+
+
+def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
+    """eta-parallel oracle: Pool(nproc).map over 2*nproc curvatures spread over the sweep."""
+    import multiprocessing as mp
+    import tempfile
+    from oracle import thth_oracle
+    CS = thth_oracle.conjugate_spectrum(dyn, npad)
+    tmp = tempfile.mkdtemp(prefix="scint_bench_")
+    path = os.path.join(tmp, "w_cs.npy")
+    np.save(path, CS)
+    np.savez(path.replace("_cs.npy", "_meta.npz"), tau=tau, fd=fd, etas=etas, edges=edges)
+    idx = np.unique(np.linspace(0, len(etas) - 1, 2 * nproc + 2).astype(int)[1:-1]).tolist()
+    ctx = mp.get_context("spawn")
+    try:
+        with ctx.Pool(nproc) as pool:
+            pool.map(_pool_worker, [(path, idx[0])] * nproc)          # warm the workers (imports, page cache)
+            t0 = time.perf_counter()
+            res = pool.map_async(_pool_worker, [(path, i) for i in idx]).get(timeout=600)
+            dt = time.perf_counter() - t0
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": len(idx) / dt, "unit": "eta-points/s", "cores": int(nproc), "kind": "port",
+            "sample": f"oracle Eval_calc over multiprocessing.Pool({nproc}) (spawn, 1 BLAS thread per worker) on "
+                      f"{len(idx)} of {len(etas)} etas, {dt:.1f} s"}
 
 
 def main():
@@ -233,6 +279,29 @@ def main():
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(
                 max(abs(eigs[i] - v) / abs(v) for i, v in ref_vals.items()))
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            if args.cpu_pool > 0:
+                try:
+                    out["cpu_baseline_pool"] = cpu_baseline_pool(dyn, tau, fd, edges, etas, args.cpu_pool, args.npad)
+                    out["speedup_vs_cpu_baseline_pool"] = out["value"] / out["cpu_baseline_pool"]["value"]
+                except Exception as exc:          # a baseline must never take the benchmark down
+                    out["cpu_baseline_pool"] = {"error": repr(exc)}
+            # practical read ceiling of this GPU for the roofline context (a 2 GiB torch.sum; not
+            # part of the timed region, not part of the product path)
+            try:
+                probe = torch.empty(2**28, dtype=torch.float64, device="cuda").normal_()
+                for _ in range(2):
+                    probe.sum()
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for _ in range(5):
+                    probe.sum()
+                torch.cuda.synchronize()
+                ceil_gbs = probe.numel() * 8 * 5 / (time.perf_counter() - tp) / 1e9
+                out["roofline"]["measured_read_ceiling_GBs"] = ceil_gbs
+                out["roofline"]["frac_of_measured_read_ceiling"] = achieved / ceil_gbs
+                del probe
+            except Exception:
+                pass
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -184,20 +184,24 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
     }
 }
 
-__global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
-    __shared__ cplx part[4][kTB];
+constexpr int kRedGroups = 16;   // wavefronts per reduce block: each sums every 16th partial vector
+
+__global__ void __launch_bounds__(64 * kRedGroups)
+pk_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
+    __shared__ cplx part[kRedGroups][kTB];
     const PackedJob jb = jobs[blockIdx.y];
     const int K = blockIdx.x;
     const int step = launch - jb.start;
     if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || jb.state[0]) return;
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
-    // every wavefront evaluates the same fixed-order sums as the mat-vec kernel did
-    const StepScalars sc = step_scalars_wave(par ? jb.apart[1] : jb.apart[0],
-                                             par ? jb.upart[1] : jb.upart[0], jb.nb, e);
+    // fixed summation order: group g adds entries g, g+16, g+32, ... of the list
+    // [row-strip partials of block row K, then column partials of tiles (0..K-1, K)];
+    // the 16 group sums are then added in group order.  Few entries per group keeps the
+    // dependent-load chain short.
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc = mk(0.0, 0.0);
-    for (int idx = g; idx < nrow + K; idx += 4) {
+    for (int idx = g; idx < nrow + K; idx += kRedGroups) {
         if (idx < nrow) acc = acc + gload(jb.rowpart + (int64_t)(s0 + idx) * kTB + e);
         else {
             const int I = idx - nrow;
@@ -207,17 +211,22 @@ __global__ void __launch_bounds__(256) pk_reduce_kernel(const PackedJob* __restr
     part[g][e] = acc;
     __syncthreads();
     if (g == 0) {
-        const cplx total = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+        // the same fixed-order scalar sums the mat-vec kernel evaluated
+        const StepScalars sc = step_scalars_wave(par ? jb.apart[1] : jb.apart[0],
+                                                 par ? jb.upart[1] : jb.upart[0], jb.nb, e);
+        cplx total = part[0][e];
+#pragma unroll
+        for (int k = 1; k < kRedGroups; ++k) total = total + part[k][e];
         const int r = K * kTB + e;
         const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
         const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + jb.qslots - 1) % jb.qslots) * jb.qstride;
         cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
         cplx* __restrict__ Qn = jb.Q + (int64_t)(step % jb.qslots) * jb.qstride;
-        const cplx up = Up[r], qp = Qp[r];
+        const cplx up = gload(Up + r), qp = gload(Qp + r);
         const cplx qn = mk((up.x - sc.alpha * qp.x) * sc.inv, (up.y - sc.alpha * qp.y) * sc.inv);
         const cplx t = mk(total.x - sc.beta * qp.x, total.y - sc.beta * qp.y);
-        Un[r] = t;
-        Qn[r] = qn;
+        gstore(Un + r, t);
+        gstore(Qn + r, qn);
         const double pa = wave_sum(qn.x * t.x + qn.y * t.y);   // Re(conj(q) u)
         const double pu = wave_sum(norm2(t));
         if (e == 0) {
@@ -663,7 +672,7 @@ static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, c
             const int slot = profiler().begin(kProfMatvec, stream);
             hipLaunchKernelGGL(pk_matvec_kernel, dim3(nstrips), dim3(256), 0, stream, jobs_dev, strips_dev, launch);
             profiler().end(kProfMatvec, slot, stream);
-            hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(256), 0, stream,
+            hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0, stream,
                                jobs_dev, launch);
         }
         hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, jobs_dev, launch);
