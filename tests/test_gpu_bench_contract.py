@@ -1,0 +1,45 @@
+"""The driver-facing contract: bench.py prints one JSON line with the agreed fields (plus the
+roofline and cpu_baseline objects), and __graft_entry__.smoke() passes.  Small sizes: this is a
+contract check, not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--size", "512", "--neta", "16",
+                          "--steps", "2", "--warmup", "1", "--cpu-sample", "1", "--cpu-pool", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["scaling"] == "weak"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and d["config"]["failed_etas"] == 0
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] == "port" and c["max_rel_diff_vs_gpu"] < 1e-9
+
+
+def test_graft_entry_smoke():
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "smoke ok" in out.stdout
