@@ -21,9 +21,8 @@ constexpr int kTile = 32;
 // both the (i, j) and the (j, i) stores are coalesced row segments.
 __global__ void __launch_bounds__(256)
 thth_gather_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restrict__ th,
-                   int64_t M, const GatherJob* __restrict__ jobs) {
+                   int64_t M, GatherJob job) {
     __shared__ cplx tile[kTile][kTile + 1];
-    const GatherJob job = jobs[blockIdx.z];
     const int N = job.n;
     const int I0 = blockIdx.y * kTile, J0 = blockIdx.x * kTile;
     if (I0 >= N || J0 >= N) return;
@@ -76,13 +75,12 @@ thth_gather_kernel(const cplx* __restrict__ cs, GeomDev g, const double* __restr
 }
 
 int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
-                      const GatherJob* jobs_dev, int njobs, int nmax, hipStream_t stream) {
-    if (njobs <= 0 || nmax <= 0) return SCINT_OK;
-    const unsigned nt = (unsigned)ceil_div(nmax, kTile);
-    SCINT_REQUIRE(nt <= 65535 && njobs <= 65535, "gather: grid too large");
+                      const GatherJob& job, hipStream_t stream) {
+    if (job.n <= 0) return SCINT_OK;
+    const unsigned nt = (unsigned)ceil_div(job.n, kTile);
+    SCINT_REQUIRE(nt <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
-    hipLaunchKernelGGL(thth_gather_kernel, dim3(nt, nt, (unsigned)njobs), dim3(256), 0, stream, cs, g,
-                       th_cents, M, jobs_dev);
+    hipLaunchKernelGGL(thth_gather_kernel, dim3(nt, nt, 1), dim3(256), 0, stream, cs, g, th_cents, M, job);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
@@ -274,15 +272,7 @@ extern "C" int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geo
     job.hermitian = hermitian;
     job.out = (cplx*)thth_out;
     job.ld = N;
-    GatherJob* jd = nullptr;
-    SCINT_HIP(hipMalloc(&jd, sizeof(GatherJob)));
-    hipError_t e = hipMemcpyAsync(jd, &job, sizeof(job), hipMemcpyHostToDevice, stream);
-    int32_t rc = (e == hipSuccess) ? SCINT_OK : hip_fail(e, "thth_map job upload", __FILE__, __LINE__);
-    if (rc == SCINT_OK) rc = launch_gather((const cplx*)cs, to_dev(*geom), th_cents, M, jd, 1, (int)N, stream);
-    e = hipStreamSynchronize(stream);
-    (void)hipFree(jd);
-    if (rc == SCINT_OK && e != hipSuccess) rc = hip_fail(e, "thth_map sync", __FILE__, __LINE__);
-    return rc;
+    return launch_gather((const cplx*)cs, to_dev(*geom), th_cents, M, job, stream);
 }
 
 extern "C" int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,

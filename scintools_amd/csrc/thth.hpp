@@ -91,8 +91,8 @@ struct GatherJob {
     int64_t ld;
 };
 
-// Enqueue the gather for `njobs` jobs (device array) on `stream`; `nmax` = max N.
+// Enqueue the full-matrix gather of one job on `stream` (asynchronous).
 int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
-                      const GatherJob* jobs_dev, int njobs, int nmax, hipStream_t stream);
+                      const GatherJob& job, hipStream_t stream);
 
 }  // namespace scint

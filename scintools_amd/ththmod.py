@@ -172,7 +172,8 @@ def _eta_float(eta):
 # device-level building blocks (torch tensors in, torch tensors out)
 # ----------------------------------------------------------------------------
 def _thth_dev(cs_t, grid, eta, keep_idx, hermetian):
-    lib = require_gpu() and _lib.load()
+    require_gpu()
+    lib = _lib.load()
     n = int(keep_idx.shape[0])
     out = empty((n, n), torch.complex128)
     if n == 0:
