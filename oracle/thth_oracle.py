@@ -295,3 +295,16 @@ def gerchberg_saxton(wavefield, dyn, tau, niter=1):
         wavefield = np.fft.ifft2(np.fft.ifftshift(CWF))
         wavefield[posdspec] = np.sqrt(d[posdspec]) * np.exp(1j * np.angle(wavefield[posdspec]))
     return wavefield
+
+
+def calc_asymmetry(dspec2, edges, time, freq, eta, npad):
+    """Arc asymmetry from the theta-theta eigenvector (ththmod.py:2385-2463), no try/except."""
+    fd = fft_axis(time, 1000.0, npad)
+    tau = fft_axis(freq, 1.0, npad)
+    CS = conjugate_spectrum(dspec2, npad)
+    thth_red, thth2_red, recov, model, edges_red, w, V = modeler(CS, tau, fd, eta, edges)
+    cents = (edges_red[1:] + edges_red[:-1]) / 2
+    leftV = V[: (cents.shape[0] - 1) // 2]
+    rightV = V[1 + (cents.shape[0] - 1) // 2:]
+    return (np.sum(np.abs(leftV) ** 2) - np.sum(np.abs(rightV) ** 2)) / (
+        np.sum(np.abs(leftV) ** 2) + np.sum(np.abs(rightV) ** 2))

@@ -371,3 +371,23 @@ class Dynspec:
         F = self.wavefield.shape[0]
         tau = thth.fft_axis(self.freqs[:F], 1.0)
         self.wavefield = thth.gerchberg_saxton_device(self.wavefield, self.dyn, tau, niter=niter)
+
+    def calc_asymmetry(self, verbose=False, pool=None):
+        """Arc asymmetry of every fitting chunk (dynspec.py:1877-1906), including the
+        reference's time slice ``ct*cwt//2 : (ct+1)*cwt``."""
+        if not hasattr(self, "ththeta"):
+            self.fit_thetatheta(verbose=verbose, pool=pool)
+        self.asymmetry = np.zeros((self.ncf_fit, self.nct_fit), dtype=complex)
+        for cf in range(self.ncf_fit):
+            fs = slice(cf * self.cwf, (cf + 1) * self.cwf)
+            freq2 = np.copy(self.freqs[fs])
+            freq = freq2.mean()
+            eta = self.ththeta * (self.fref / freq)**2
+            for ct in range(self.nct_fit):
+                ts = slice(ct * self.cwt // 2, (ct + 1) * self.cwt)
+                time2 = np.copy(self.times[ts])
+                dspec2 = np.copy(self.dyn[fs, ts])
+                dspec2 -= np.nanmean(dspec2)
+                dspec2 = np.nan_to_num(dspec2)
+                params = (dspec2, self.edges * (freq / self.fref), time2, freq2, eta, ct, cf, self.npad, verbose)
+                self.asymmetry[cf, ct] = thth.calc_asymmetry(params)[0]

@@ -714,3 +714,35 @@ def gerchberg_saxton_device(wavefield, dyn, tau, niter=1):
                                     ws.numel(), stream_ptr())
     _lib.check(rc, "scint_gerchberg_saxton")
     return wf_t.cpu().numpy()
+
+
+def calc_asymmetry(params):
+    """Arc asymmetry of one chunk from the dominant theta-theta eigenvector
+    (ththmod.py:2385-2463): (sum|V_left|^2 - sum|V_right|^2) / (sum|V_left|^2 + sum|V_right|^2).
+
+    params = (dspec2, edges, time, freq, eta, idx_t, idx_f, npad, verbose).  Only the
+    eigenvector of the reduced theta-theta is needed, so the model/back-map steps of the
+    reference's modeler call are skipped.  Returns (asymm, idx_f, idx_t); NaN on failure."""
+    dspec2, edges, time, freq, eta, idx_t, idx_f, npad, verbose = params
+    time_v = units.strip(time, "time2", "s", warn=False)
+    freq_v = units.strip(freq, "freq2", "MHz", warn=False)
+    e = _eta_float(eta)
+    edges_v = units.strip(edges, "edges", "mHz", warn=False)
+    fd = fft_axis(time_v, 1000.0, npad)
+    tau = fft_axis(freq_v, 1.0, npad)
+    try:
+        cs_t = conjugate_spectrum(np.asarray(dspec2, dtype=float), npad)
+        w, V_t, info = eigvec_sweep(cs_t, tau, fd, np.array([e]), edges_v)
+        if info["status"][0] != 0:
+            raise ArithmeticError(f"eigenpair iteration failed (status {int(info['status'][0])})")
+        n = int(info["N"][0])
+        p = (torch.abs(V_t[0, :n]) ** 2).cpu().numpy()
+        half = (n - 1) // 2                     # cents.shape[0] == n  (ththmod.py:2447-2449)
+        left, right = p[:half].sum(), p[1 + half:].sum()
+        asymm = (left - right) / (left + right)
+        if verbose:
+            print("Chunk %s-%s success" % (idx_f, idx_t), flush=True)
+    except Exception as exc:
+        print(exc, flush=True)
+        asymm = np.nan
+    return (asymm, idx_f, idx_t)

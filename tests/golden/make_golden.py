@@ -243,7 +243,8 @@ def gen_retrieval():
     wavefield = np.array(dyn.wavefield)
     chunks = np.array(dyn.chunks)
     dyn.gerchberg_saxton(niter=2)
-    save("retrieval.npz", nchan=nchan, edges=V(dyn.edges), neta=dyn.neta, fref=V(dyn.fref),
+    dyn.calc_asymmetry()
+    save("retrieval.npz", asymmetry=np.array(dyn.asymmetry), nchan=nchan, edges=V(dyn.edges), neta=dyn.neta, fref=V(dyn.fref),
          ththeta=V(dyn.ththeta), ththetaerr=V(dyn.ththetaerr), eta_evo=V(dyn.eta_evo),
          chunk0=chunks[0, 0], chunk3=chunks[3, 0],
          wavefield=wavefield, wavefield_gs=np.array(dyn.wavefield))

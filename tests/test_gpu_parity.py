@@ -408,3 +408,18 @@ def test_calc_acf_vs_oracle_and_reference_golden(golden):
     x = np.fft.fft2(O.dyn[:75, :101], s=[150, 202])
     ref = np.real(np.fft.fftshift(np.fft.ifft2(np.abs(x) ** 2)))
     assert np.abs(raw - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_calc_asymmetry_vs_reference_golden(golden):
+    from scintools_amd.dynspec import Dynspec
+    g = golden("retrieval.npz")
+    f = golden("fit_thetatheta.npz")
+    n = int(g["nchan"])
+
+    class B:
+        dyn, freqs, times, dt, df = f["dspec"][:n], f["freq"][:n], f["time"], float(f["dt"]), float(f["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50, nedge=128)
+    d.calc_asymmetry()
+    assert d.asymmetry.shape == g["asymmetry"].shape
+    np.testing.assert_allclose(d.asymmetry.real, g["asymmetry"].real, rtol=1e-6, atol=1e-8)

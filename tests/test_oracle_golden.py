@@ -193,3 +193,18 @@ def test_retrieval_chunks_mosaic_gs(golden):
     gs = to.gerchberg_saxton(wf, dspec, to.fft_axis(freq[: wf.shape[0]], 1.0), niter=2)
     ref = g["wavefield_gs"]
     assert np.abs(_align(gs, ref) - ref).max() <= 1e-7 * np.abs(ref).max()
+
+
+def test_calc_asymmetry(golden):
+    g = golden("retrieval.npz")
+    f = golden("fit_thetatheta.npz")
+    n = int(g["nchan"])
+    dspec, freq, time = f["dspec"][:n], f["freq"][:n], f["time"]
+    fref, ththeta, edges = float(g["fref"]), float(g["ththeta"]), g["edges"]
+    for cf in range(n // 64):
+        fs = slice(cf * 64, (cf + 1) * 64)
+        d2 = np.copy(dspec[fs])
+        d2 -= np.nanmean(d2)
+        fm = freq[fs].mean()
+        a = to.calc_asymmetry(np.nan_to_num(d2), edges * (fm / fref), time, freq[fs], ththeta * (fref / fm) ** 2, 3)
+        assert a == pytest.approx(g["asymmetry"][cf, 0].real, rel=1e-7, abs=1e-9)
