@@ -14,6 +14,7 @@ File I/O, cleaning, arc fitting from the secondary spectrum (``fit_arc``), phase
 retrieval and plotting are out of scope.
 """
 import ctypes
+import os
 
 import numpy as np
 import scipy.constants as sc
@@ -77,14 +78,111 @@ class Dynspec:
 
     def __init__(self, filename=None, dyn=None, verbose=True, process=False, lamsteps=False,
                  remove_short_subs=True, subint_thresh=2.33, mjd=None):
-        if filename:
-            raise NotImplementedError("psrflux file I/O is outside the accelerated hot path")
-        if dyn is None:
-            raise ValueError("Error: No dynamic spectrum file or object")
         if process:
             raise NotImplementedError("process=True: cleaning is outside the accelerated hot path "
                                       "(and calls a missing method in the reference, dynspec.py:416)")
-        self.load_dyn_obj(dyn, verbose=verbose, lamsteps=lamsteps)
+        if filename:
+            self.load_file(filename, verbose=verbose, lamsteps=lamsteps, subint_thresh=subint_thresh,
+                           remove_short_subs=remove_short_subs, mjd=mjd)
+        elif dyn is not None:
+            self.load_dyn_obj(dyn, verbose=verbose, lamsteps=lamsteps)
+        else:
+            raise ValueError("Error: No dynamic spectrum file or object")
+
+    # ------------------------------------------------------------------ psrflux text I/O (host)
+    def load_file(self, filename, verbose=True, process=False, lamsteps=False, remove_short_subs=True,
+                  subint_thresh=2.33, mjd=None):
+        """Load a psrflux-format dynamic spectrum (dynspec.py:144-230): header lines start with
+        '#', data columns are ``isub ichan time(min) freq(MHz) flux flux_err``.  Host-side text
+        parsing; same attribute conventions as the reference (times from 0, ascending freqs)."""
+        if process:
+            raise NotImplementedError("process=True: cleaning is outside the accelerated hot path")
+        if verbose:
+            print("LOADING {0}...".format(filename))
+        head = []
+        with open(filename, "r") as fh:
+            for line in fh:
+                if line.startswith("#"):
+                    headline = str.strip(line[1:])
+                    head.append(headline)
+                    if str.split(headline) != [] and str.split(headline)[0] == 'MJD0:' \
+                            and not hasattr(self, 'mjd'):
+                        self.mjd = float(str.split(headline)[1])
+        self.name = os.path.basename(filename)
+        self.filename = filename
+        self.header = head
+        rawdata = np.loadtxt(filename).transpose()
+        self.times = np.unique(rawdata[2] * 60)
+        if mjd is not None:
+            self.mjd = mjd
+        else:
+            self.mjd = self.mjd + self.times[0] / 86400
+        self.times = self.times - self.times[0]
+        self.freqs = rawdata[3]
+        fluxes = rawdata[4]
+        self.nchan = int(np.max(rawdata[1])) + 1
+        self.bw = self.freqs[-1] - self.freqs[0]
+        self.df = round(self.bw / self.nchan, 5)
+        self.bw = round(self.bw + self.df, 2)
+        self.nsub = int(np.max(rawdata[0])) + 1
+        self.dt = np.mean(np.diff(self.times))
+        self.tobs = np.max(self.times) + self.dt
+        self.freqs = np.unique(self.freqs)
+        self.freq = round(np.mean(self.freqs), 2)
+        fluxes = fluxes.reshape([self.nsub, self.nchan]).transpose()
+        if self.df < 0:   # descending channels in the file: flip to match the ascending freqs
+            self.df = -self.df
+            self.bw = -self.bw
+            fluxes = np.flip(fluxes, 0)
+        self.dyn = fluxes
+        if remove_short_subs and np.std(np.diff(self.times)) != 0:
+            self.remove_short_subs(threshold=subint_thresh)
+        self.lamsteps = lamsteps
+
+    def remove_short_subs(self, threshold=2.33):
+        """Drop short sub-integrations at the start of the observation (dynspec.py:232-258)."""
+        dt0 = np.abs(np.diff(self.times))[0]
+        dt = np.mean(np.abs(np.diff(self.times))[1:])
+        sdt = np.std(np.abs(np.diff(self.times))[1:])
+        while dt0 - dt <= -threshold * sdt and sdt >= 0:
+            self.dyn = np.delete(self.dyn, (0), axis=1)
+            self.times = np.delete(self.times, (0))
+            dt0 = np.abs(np.diff(self.times))[0]
+            dt = np.mean(np.abs(np.diff(self.times))[1:])
+            sdt = np.std(np.abs(np.diff(self.times))[1:])
+        self.mjd += np.min(self.times) / 86400
+        self.times -= np.min(self.times)
+        self.nsub = len(self.times)
+        self.dt = round(np.mean(np.diff(self.times)), 3)
+        self.tobs = round(max(self.times) + self.dt, 3)
+
+    def write_file(self, filename=None, verbose=True, note=None):
+        """Write the dynamic spectrum in psrflux format (dynspec.py:330-376)."""
+        if filename is None:
+            ext = self.filename.split('.')[-1]
+            fname = '.'.join(self.filename.split('.')[0:-1]) + '.processed.' + ext
+        else:
+            fname = filename
+        with open(fname, 'w') as fn:
+            fn.write("# Scintools-modified dynamic spectrum in psrflux format\n")
+            fn.write("# Created using write_file method in Dynspec class\n")
+            if note is not None:
+                fn.write("# Note: {0}\n".format(note))
+            fn.write("# MJD0: {0}\n".format(self.mjd))
+            fn.write("# Original header begins below:\n")
+            isub = False
+            for line in self.header:
+                fn.write("# {} \n".format(line))
+                if 'isub' in line:
+                    isub = True
+            if not isub:
+                fn.write('# isub ichan time(min) freq(MHz) flux flux_err\n')
+            for i in range(len(self.times)):
+                ti = self.times[i] / 60
+                for j in range(len(self.freqs)):
+                    fn.write("{0} {1} {2} {3} {4} {5}\n".format(i, j, ti, self.freqs[j], self.dyn[j, i], 0))
+        if verbose:
+            print("Wrote dynamic spectrum file as {}".format(fname))
 
     def load_dyn_obj(self, dyn, verbose=True, process=False, lamsteps=False):
         """Copy the reference's attribute set from any object that has it (dynspec.py:378-419)."""

@@ -250,8 +250,36 @@ def gen_retrieval():
          wavefield=wavefield, wavefield_gs=np.array(dyn.wavefield))
 
 
+# ---------------------------------------------------------------------------
+# 7. psrflux text I/O (dynspec.py:144-258, 330-376): a small synthetic file, as the reference parses it
+# ---------------------------------------------------------------------------
+def gen_psrflux():
+    rng = np.random.default_rng(12)
+    nsub, nchan = 24, 40
+    path = os.path.join(HERE, "synthetic.dynspec")
+    t_min = 0.05 + 0.5 * np.arange(nsub)        # minutes, leading edges
+    t_min[0] = t_min[1] - 0.12                  # a short first sub-integration (gets removed)
+    freqs = 1500.0 - 0.78125 * np.arange(nchan)  # descending, as psrflux writes them
+    flux = rng.standard_normal((nsub, nchan)) + 5
+    with open(path, "w") as fh:
+        fh.write("# Dynamic spectrum computed by psrflux\n# Data file: synthetic\n# MJD0: 58000.25\n")
+        fh.write("# Data columns:\n# isub ichan time(min) freq(MHz) flux flux_err\n")
+        for i in range(nsub):
+            for j in range(nchan):
+                fh.write(f"{i:4d} {j:4d} {t_min[i]:10.4f} {freqs[j]:12.6f} {flux[i, j]:+e} {0.1:+e}\n")
+    d = Dynspec(filename=path, verbose=False, process=False)
+    out = dict(dyn=np.array(d.dyn), times=d.times, freqs=d.freqs, nchan=d.nchan, nsub=d.nsub, bw=d.bw,
+               df=d.df, freq=d.freq, dt=d.dt, tobs=d.tobs, mjd=d.mjd, nheader=len(d.header))
+    wpath = os.path.join(HERE, "_rewritten.dynspec")
+    d.write_file(filename=wpath, verbose=False, note="roundtrip")
+    d2 = Dynspec(filename=wpath, verbose=False, process=False)
+    os.remove(wpath)
+    out.update(rt_dyn=np.array(d2.dyn), rt_times=d2.times, rt_freqs=d2.freqs, rt_mjd=d2.mjd)
+    save("psrflux.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval"]
+    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval", "psrflux"]
     if "small" in which:
         gen_thth_small()
     if "sample" in which:
@@ -264,3 +292,5 @@ if __name__ == "__main__":
         gen_fit_thetatheta()
     if "retrieval" in which:
         gen_retrieval()
+    if "psrflux" in which:
+        gen_psrflux()

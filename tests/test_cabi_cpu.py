@@ -101,3 +101,23 @@ def test_prep_thetatheta_host_logic_matches_reference(golden):
         d.prep_thetatheta(cwf=64, edges_lim=.3)            # needs fit_arc in the reference
     with pytest.raises(AssertionError):
         d.prep_thetatheta(eta_min=30, eta_max=50, nedge=301)
+
+
+def test_psrflux_io_matches_reference(golden, tmp_path):
+    """Host-side text I/O: the reference's own parse of tests/golden/synthetic.dynspec
+    (descending channels, a short first sub-integration) and a write/read round trip."""
+    import os
+    from scintools_amd.dynspec import Dynspec
+    g = golden("psrflux.npz")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic.dynspec")
+    d = Dynspec(filename=here, verbose=False)
+    assert np.array_equal(d.dyn, g["dyn"]) and np.array_equal(d.times, g["times"])
+    assert np.array_equal(d.freqs, g["freqs"])
+    for key in ("nchan", "nsub", "bw", "df", "freq", "dt", "tobs", "mjd"):
+        assert getattr(d, key) == g[key], key
+    assert len(d.header) == int(g["nheader"]) and d.nsub == 23          # first sub-integration removed
+    out = str(tmp_path / "rt.dynspec")
+    d.write_file(filename=out, verbose=False, note="roundtrip")
+    d2 = Dynspec(filename=out, verbose=False)
+    assert np.array_equal(d2.dyn, g["rt_dyn"]) and np.array_equal(d2.times, g["rt_times"])
+    assert np.array_equal(d2.freqs, g["rt_freqs"]) and d2.mjd == float(g["rt_mjd"])
