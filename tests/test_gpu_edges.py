@@ -117,3 +117,43 @@ def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
     d.prep_thetatheta(cwf=64, cwt=128, eta_min=0.5 * p["eta"], eta_max=2 * p["eta"], nedge=64, npad=1, fw=0.3)
     d.fit_thetatheta()
     assert d.eta_evo.shape == (2, 1) and np.all(np.isfinite(d.thth_eigs))
+
+
+def test_non_default_stream_and_iteration_cap(env):
+    import torch
+    thth, to, p = env
+    etas = np.geomspace(0.5, 2.0, 6) * p["eta"]
+    ref = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        cs = thth.conjugate_spectrum(p["dyn"], 0, pad_value=0.0)
+        got = thth.eval_sweep(cs, p["tau"], p["fd"], etas, p["edges"])
+        red = thth.thth_redmap(cs, p["tau"], p["fd"], etas[2], p["edges"])[0]
+    s.synchronize()
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
+    assert np.array_equal(red, to.thth_redmap(cs.cpu().numpy(), p["tau"], p["fd"], etas[2], p["edges"])[0])
+    # an iteration cap that cannot converge -> status NOCONV -> NaN (the reference's nan on failure)
+    capped, info = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], max_iter=6, return_info=True)
+    assert np.all(np.isnan(capped)) and np.all(info["status"] == 4) and np.all(info["iters"] == 6)
+
+
+def test_threads_with_their_own_streams(env):
+    """Two Python threads, each on its own stream and workspace, give the single-thread answer."""
+    import threading
+    import torch
+    thth, to, p = env
+    etas = np.geomspace(0.5, 2.0, 9) * p["eta"]
+    ref = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+    out = {}
+
+    def work(k):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(3):
+                out[k] = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=2 + k)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
