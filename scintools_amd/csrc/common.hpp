@@ -42,6 +42,11 @@ __device__ inline cplx gload(const cplx* p) {
     const v2d v = *(const SCINT_GLOBAL v2d*)p;
     return mk(v.x, v.y);
 }
+// streamed-once data (the packed matrix): non-temporal hint keeps it from evicting the vectors
+__device__ inline cplx gload_nt(const cplx* p) {
+    const v2d v = __builtin_nontemporal_load((const SCINT_GLOBAL v2d*)p);
+    return mk(v.x, v.y);
+}
 __device__ inline double gload(const double* p) { return *(const SCINT_GLOBAL double*)p; }
 __device__ inline int32_t gload(const int32_t* p) { return *(const SCINT_GLOBAL int32_t*)p; }
 __device__ inline void gstore(cplx* p, cplx v) {
@@ -49,6 +54,10 @@ __device__ inline void gstore(cplx* p, cplx v) {
     *(SCINT_GLOBAL v2d*)p = t;
 }
 __device__ inline void gstore(double* p, double v) { *(SCINT_GLOBAL double*)p = v; }
+__device__ inline void gstore_nt(cplx* p, cplx v) {
+    v2d t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, (SCINT_GLOBAL v2d*)p);
+}
 
 // ---- wavefront (64 lanes) reductions ------------------------------------------
 __device__ inline double wave_sum(double v) {

@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(256) lanczos_matvec_kernel(const LanczosJob* j
             cplx a0[kRowsPerWave], a1[kRowsPerWave];
 #pragma unroll
             for (int r = 0; r < kRowsPerWave; ++r) {
-                a0[r] = rowp[r][c0 + c];
-                a1[r] = rowp[r][c0 + c + 64];
+                a0[r] = gload_nt(rowp[r] + c0 + c);
+                a1[r] = gload_nt(rowp[r] + c0 + c + 64);
             }
 #pragma unroll
             for (int r = 0; r < kRowsPerWave; ++r) acc[r] = acc[r] + a0[r] * x0 + a1[r] * x1;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) lanczos_matvec_kernel(const LanczosJob* j
         for (; c < cn; c += 64) {
             const cplx x0 = xs[c];
 #pragma unroll
-            for (int r = 0; r < kRowsPerWave; ++r) acc[r] = acc[r] + rowp[r][c0 + c] * x0;
+            for (int r = 0; r < kRowsPerWave; ++r) acc[r] = acc[r] + gload_nt(rowp[r] + c0 + c) * x0;
         }
     }
     // the normalised q_j rows owned by this block (needed by the update and by step j+1)

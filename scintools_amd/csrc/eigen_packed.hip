@@ -122,7 +122,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
     const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
     cplx a0[8], a1[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = gload(tp + r * kTB);
+    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
     const StepScalars sc = step_scalars_wave(par ? jp->apart[1] : jp->apart[0],
                                              par ? jp->upart[1] : jp->upart[0], nb, lane);
     // lane l of every wave holds x_I[l]; rows read it back with v_readlane (scalar broadcast)
@@ -140,7 +140,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
         const int J = st.J0 + t;
         const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a1[r] = gload(tc + (8 + r) * kTB);   // second half of this tile
+        for (int r = 0; r < 8; ++r) a1[r] = gload_nt(tc + (8 + r) * kTB);   // second half of this tile
         const cplx uj = gload(Up + J * kTB + lane), qj = gload(Qp + J * kTB + lane);
         const cplx xJ = mk((uj.x - sc.alpha * qj.x) * sc.inv, (uj.y - sc.alpha * qj.y) * sc.inv);
         cplx c = mk(0.0, 0.0);
@@ -152,7 +152,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
         }
         if (t + 1 < ntile) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a0[r] = gload(tc + kTileElems + r * kTB);   // first half of the next tile
+            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + kTileElems + r * kTB);   // first half of the next tile
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {

@@ -146,7 +146,7 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
             if (wgt[r] < 0.0) v = conj(v);
             v = mk(nan_to_num(v.x), nan_to_num(v.y));
         }
-        gstore(tile + (qi * 32 + ty + 8 * r) * kTB + cj, v);
+        gstore_nt(tile + (qi * 32 + ty + 8 * r) * kTB + cj, v);   // written once, read much later
     }
 }
 
