@@ -15,7 +15,9 @@
  *     0 = ok, >0 = SCINT_E_*; the message is available from scint_last_error();
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
  *     work is enqueued on it; only entry points documented as synchronous
- *     wait for it;
+ *     wait for it.  The sweep entry points additionally drive one internal
+ *     stream per host thread (half of the resident curvatures run there so that
+ *     read-backs never idle the GPU); they return with both streams drained;
  *   - no function throws, allocates caller-visible memory, or keeps pointers
  *     after it returns.  The only persistent state is a mutex-guarded cache of
  *     FFT twiddle tables.
@@ -63,8 +65,9 @@ int32_t scint_device_count(void);
 
 /* Optional per-kernel timing for the benchmark: between begin and end every launch of
  * the theta-theta gather kernel ([0]) and of the eigen mat-vec kernel ([1]) is bracketed
- * by hipEvents on its stream.  end() synchronises the device and returns the summed
- * milliseconds and launch counts (HOST arrays of 2).  Not thread-safe; off by default. */
+ * by hipEvents on its stream.  end() synchronises the device and returns, per kernel, the length
+ * in milliseconds of the UNION of its launch intervals (the sweep drives two streams, so
+ * launches may overlap) and the launch counts (HOST arrays of 2).  Not thread-safe; off by default. */
 int32_t scint_profile_begin(void);
 int32_t scint_profile_end(double* ms_out /*HOST[2]*/, int64_t* launches_out /*HOST[2]*/);
 

@@ -27,7 +27,7 @@ Profiler& profiler() {
 
 extern "C" int32_t scint_profile_begin(void) {
     scint::Profiler& p = scint::profiler();
-    p.reset();
+    p.reset(nullptr);
     p.enabled = true;
     return SCINT_OK;
 }
@@ -36,6 +36,7 @@ extern "C" int32_t scint_profile_end(double* ms_out, int64_t* launches_out) {
     scint::Profiler& p = scint::profiler();
     if (hipDeviceSynchronize() != hipSuccess) return SCINT_E_HIP;
     p.collect();
+    p.finish();
     p.enabled = false;
     for (int k = 0; k < scint::kProfCount; ++k) {
         if (ms_out) ms_out[k] = p.ms[k];

@@ -22,7 +22,9 @@
 //                     the Sturm count, Ritz residual by the backward recurrence, and the
 //                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
-// Scheduling: `batch` slots are kept full -- as soon as a curvature converges (flags are read
+// Scheduling: the `batch` slots are split into two groups driven on two streams: while the host
+// waits for / reads back / refills one group, the other group's kernels keep the GPU busy.
+// Within a group the slots are kept full -- as soon as a curvature converges (flags are read
 // back every 4 launches) its slot is re-filled with the next eta of the sweep: gather + init
 // for the new slots only, then the common step launches continue.  Every job carries the launch
 // index it started at, so jobs at different Lanczos steps share one launch (continuous
@@ -519,6 +521,191 @@ static int32_t* pinned_flags(size_t count) {
     return buf;
 }
 
+// A second stream per host thread: the sweep alternates two groups of slots so that while the
+// host reads one group's convergence flags and refills its slots, the other group's kernels
+// keep the GPU busy (no sync bubbles, and the latency-bound reduce/check kernels of one group
+// overlap the bandwidth-bound mat-vec of the other).
+static hipStream_t second_stream() {
+    thread_local hipStream_t s = nullptr;
+    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    return s;
+}
+static hipEvent_t make_event() {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    return e;
+}
+
+struct SweepShared {
+    // problem
+    const cplx* cs; int64_t cs_stride; const int32_t* cs_index; const double* th_cents; int64_t M;
+    const int32_t* keep_idx; const int32_t* keep_n; const double* etas; int64_t neta;
+    double* eigs_out; int32_t* status_out; int32_t* iters_out;
+    bool want_vec; cplx* vec_out; int64_t vstride;
+    int nbmax, steps_cap;
+    // device tables
+    char* base; const SlabLayout* L; PackedJob* jobs_dev; const GeomDev* geoms_dev;
+    // the queue of curvatures still to be started
+    int64_t next_eta;
+};
+
+// One group of slots [s0, s1) driven on its own stream.
+struct SweepGroup {
+    SweepShared* sh;
+    int s0, s1;
+    hipStream_t stream;
+    hipEvent_t done;
+    Strip* strips_dev; int32_t* states_dev; int32_t* slots_dev; int32_t* fin_slots_dev; int64_t* fin_eta_dev;
+    int32_t* flags;                              // pinned, 4 words per slot of the group
+    std::vector<PackedJob>* jobs;                // host copy of the whole job table
+    std::vector<int64_t> slot_eta;               // per slot of the group: running eta or -1
+    std::vector<Strip> strips;
+    std::vector<int32_t> rs_all, fresh, fin_slots;
+    std::vector<int64_t> fin_eta;
+    int launch = 0, active = 0;
+    bool in_flight = false;
+
+    int nslots() const { return s1 - s0; }
+
+    // refill idle slots, then enqueue kCheckEvery steps + the check + the flag read-back
+    int32_t enqueue() {
+        SweepShared& S = *sh;
+        const SlabLayout& L = *S.L;
+        hipError_t he = hipSuccess;
+        fresh.clear();
+        for (int s = s0; s < s1 && S.next_eta < S.neta; ++s) {
+            if (slot_eta[(size_t)(s - s0)] >= 0) continue;
+            const int64_t e = S.next_eta++;
+            slot_eta[(size_t)(s - s0)] = e;
+            ++active;
+            PackedJob& J = (*jobs)[(size_t)s];
+            const int n = S.keep_n[e];
+            J.eta = S.etas[e]; J.two_eta = 2 * S.etas[e];
+            const int64_t c = S.cs_index ? S.cs_index[e] : 0;
+            J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
+            J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
+            J.max_steps = std::min(S.steps_cap, std::max(n, 1));
+            J.strip_len = strip_len_for(J.nb);
+            J.start = launch;
+            J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
+            J.iters_out = S.iters_out ? S.iters_out + e : nullptr;
+            fresh.push_back(s);
+        }
+        if (active == 0) { in_flight = false; return SCINT_OK; }
+        if (!fresh.empty()) {
+            // strips of every running job of the group, block row by block row
+            strips.clear();
+            int nb_fresh = 0;
+            for (int s = s0; s < s1; ++s) {
+                if (slot_eta[(size_t)(s - s0)] < 0) continue;
+                const PackedJob& J = (*jobs)[(size_t)s];
+                int32_t* rs0 = rs_all.data() + (size_t)(s - s0) * (size_t)(S.nbmax + 1);
+                int idx = 0;
+                for (int I = 0; I < J.nb; ++I) {
+                    rs0[I] = idx;
+                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
+                        Strip st;
+                        st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
+                        strips.push_back(st);
+                    }
+                }
+                rs0[J.nb] = idx;
+            }
+            // longest strips first: the short ones of the last block rows then fill the tail
+            // of the launch (dispatch order only; the arithmetic does not depend on it)
+            std::stable_sort(strips.begin(), strips.end(), [](const Strip& a, const Strip& b) {
+                return (a.J1 - a.J0) > (b.J1 - b.J0);
+            });
+            for (int s : fresh) {
+                const PackedJob& J = (*jobs)[(size_t)s];
+                nb_fresh = std::max(nb_fresh, J.nb);
+                he = hipMemcpyAsync(S.base + L.total * (size_t)s + L.row_strip0,
+                                    rs_all.data() + (size_t)(s - s0) * (size_t)(S.nbmax + 1),
+                                    sizeof(int32_t) * (size_t)(J.nb + 1), hipMemcpyHostToDevice, stream);
+                if (he != hipSuccess) break;
+            }
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(S.jobs_dev + s0, jobs->data() + s0, sizeof(PackedJob) * (size_t)nslots(),
+                                    hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(strips_dev, strips.data(), sizeof(Strip) * strips.size(), hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(slots_dev, fresh.data(), sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(stream);   // host vectors are reused; the stream is idle here
+            if (he != hipSuccess) return hip_fail(he, "sweep job upload", __FILE__, __LINE__);
+            int32_t rc = launch_gather_packed(S.geoms_dev, S.M, S.jobs_dev, slots_dev, (int)fresh.size(), nb_fresh, stream);
+            if (rc != SCINT_OK) return rc;
+            hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                               S.jobs_dev, slots_dev);
+        }
+        int nb_run = 1;
+        for (int s = s0; s < s1; ++s)
+            if (slot_eta[(size_t)(s - s0)] >= 0) nb_run = std::max(nb_run, (*jobs)[(size_t)s].nb);
+        const unsigned nstrips = (unsigned)strips.size();
+        for (int i = 0; i < kCheckEvery; ++i, ++launch) {
+            const int slot = profiler().begin(kProfMatvec, stream);
+            hipLaunchKernelGGL(pk_matvec_kernel, dim3(nstrips), dim3(256), 0, stream, S.jobs_dev, strips_dev, launch);
+            profiler().end(kProfMatvec, slot, stream);
+            hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots()), dim3(64 * kRedGroups), 0,
+                               stream, S.jobs_dev + s0, launch);
+        }
+        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots()), dim3(64), 0, stream, S.jobs_dev + s0, launch);
+        he = hipGetLastError();
+        if (he == hipSuccess)
+            he = hipMemcpyAsync(flags, states_dev, sizeof(int32_t) * 4 * (size_t)nslots(), hipMemcpyDeviceToHost, stream);
+        if (he == hipSuccess) he = hipEventRecord(done, stream);
+        if (he != hipSuccess) return hip_fail(he, "sweep step", __FILE__, __LINE__);
+        in_flight = true;
+        return SCINT_OK;
+    }
+
+    // wait for the group's last chunk, retire converged curvatures (and export their vectors)
+    int32_t harvest() {
+        if (!in_flight) return SCINT_OK;
+        SweepShared& S = *sh;
+        hipError_t he = hipEventSynchronize(done);
+        if (he != hipSuccess) return hip_fail(he, "sweep wait", __FILE__, __LINE__);
+        in_flight = false;
+        if (profiler().enabled) profiler().collect();
+        fin_slots.clear();
+        fin_eta.clear();
+        int nb_fin = 1;
+        for (int s = s0; s < s1; ++s) {
+            const size_t k = (size_t)(s - s0);
+            if (slot_eta[k] >= 0 && flags[4 * k] != 0) {
+                if (S.want_vec && (*jobs)[(size_t)s].n >= 2) {
+                    fin_slots.push_back(s);
+                    fin_eta.push_back(slot_eta[k]);
+                    nb_fin = std::max(nb_fin, (*jobs)[(size_t)s].nb);
+                }
+                slot_eta[k] = -1;             // finished: results were written by the check kernel
+                (*jobs)[(size_t)s].n = 0;     // an idle slot's kernels exit at once (host copy only)
+                --active;
+            }
+        }
+        if (!fin_slots.empty()) {
+            // export the Ritz vectors before the slots are re-used (the device job table still
+            // describes the finished jobs: it is only rewritten at the next refill)
+            he = hipMemcpyAsync(fin_slots_dev, fin_slots.data(), sizeof(int32_t) * fin_slots.size(),
+                                hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(fin_eta_dev, fin_eta.data(), sizeof(int64_t) * fin_eta.size(),
+                                    hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess) {
+                const dim3 grid((unsigned)nb_fin, (unsigned)fin_slots.size());
+                hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, S.jobs_dev, fin_slots_dev, fin_eta_dev,
+                                   S.vec_out, S.vstride);
+                hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, S.jobs_dev, fin_slots_dev,
+                                   fin_eta_dev, S.vec_out, S.vstride);
+                he = hipGetLastError();
+            }
+            if (he == hipSuccess) he = hipStreamSynchronize(stream);
+            if (he != hipSuccess) return hip_fail(he, "sweep ritz vectors", __FILE__, __LINE__);
+        }
+        return SCINT_OK;
+    }
+};
+
 // Shared driver of scint_eval_sweep (eigenvalues), scint_eigvec_sweep (eigenpairs) and
 // scint_eval_sweep_multi.  `ncs` conjugate spectra of one shape live `cs_stride` elements apart
 // from `cs`, each with its own geometry geom[c] and theta grid th_cents + c*M; curvature e reads
@@ -555,20 +742,14 @@ static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, c
     int32_t* slots_dev = (int32_t*)(base + BL.slots);
     int32_t* fin_slots_dev = (int32_t*)(base + BL.fin_slots);
     int64_t* fin_eta_dev = (int64_t*)(base + BL.fin_eta);
-    std::vector<int32_t> fin_slots;
-    std::vector<int64_t> fin_eta;
     GeomDev* geoms_dev = (GeomDev*)(base + BL.geoms);
     std::vector<GeomDev> geoms_host((size_t)ncs);
     for (int64_t c = 0; c < ncs; ++c) geoms_host[(size_t)c] = to_dev(geom[c]);
     SCINT_HIP(hipMemcpyAsync(geoms_dev, geoms_host.data(), sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice,
                              stream));
-    SCINT_HIP(hipStreamSynchronize(stream));
+    SCINT_HIP(hipStreamSynchronize(stream));   // also: everything queued before us (the CS) is complete
 
     std::vector<PackedJob> jobs((size_t)nslots);
-    std::vector<int64_t> slot_eta((size_t)nslots, -1);   // eta index running in each slot, -1 = idle
-    std::vector<Strip> strips;
-    std::vector<int32_t> rs_all((size_t)nslots * (size_t)(nbmax + 1));
-    std::vector<int32_t> fresh;                           // slots (re)filled in this round
     int32_t* flags = pinned_flags((size_t)nslots * 4);
     if (!flags) return SCINT_E_HIP;
     for (int s = 0; s < nslots; ++s) {                    // static part of every slot
@@ -590,132 +771,61 @@ static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, c
         J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
         J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
     }
+    // idle slots must look idle on the device before any group launches over them
+    SCINT_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream));
+    SCINT_HIP(hipMemsetAsync(states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream));
+    SCINT_HIP(hipStreamSynchronize(stream));
 
+    SweepShared S;
+    S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
+    S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
+    S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
+    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride;
+    S.nbmax = nbmax; S.steps_cap = steps_cap;
+    S.base = base; S.L = &L; S.jobs_dev = jobs_dev; S.geoms_dev = geoms_dev;
+    S.next_eta = 0;
+
+    // two groups on two streams when there are enough slots to split
+    static const int forced_groups = [] { const char* e = getenv("SCINT_SWEEP_GROUPS"); return e ? atoi(e) : 0; }();
+    hipStream_t s2 = second_stream();
+    int ngroups = (nslots >= 4 && s2) ? 2 : 1;
+    if (forced_groups == 1) ngroups = 1;
+    SweepGroup G[2];
     int32_t rc = SCINT_OK;
-    int64_t next_eta = 0;
-    int launch = 0;          // global launch counter: a job's Lanczos step = launch - job.start
-    int active = 0;
-    hipError_t he = hipSuccess;
+    for (int g = 0; g < ngroups; ++g) {
+        SweepGroup& q = G[g];
+        q.sh = &S;
+        q.s0 = g == 0 ? 0 : nslots / 2;
+        q.s1 = (g == ngroups - 1) ? nslots : nslots / 2;
+        q.stream = g == 0 ? stream : s2;
+        q.done = make_event();
+        if (!q.done) { set_error("scint: hipEventCreate failed"); rc = SCINT_E_HIP; }
+        q.strips_dev = strips_dev + (size_t)q.s0 * (size_t)BL.smax;
+        q.states_dev = states_dev + 4 * q.s0;
+        q.slots_dev = slots_dev + q.s0;
+        q.fin_slots_dev = fin_slots_dev + q.s0;
+        q.fin_eta_dev = fin_eta_dev + q.s0;
+        q.flags = flags + 4 * q.s0;
+        q.jobs = &jobs;
+        q.slot_eta.assign((size_t)q.nslots(), -1);
+        q.rs_all.assign((size_t)q.nslots() * (size_t)(nbmax + 1), 0);
+    }
+    // pipeline: enqueue A, enqueue B, then repeatedly {harvest g, enqueue g} alternating groups
+    for (int g = 0; g < ngroups && rc == SCINT_OK; ++g) rc = G[g].enqueue();
     while (rc == SCINT_OK) {
-        // ---- (re)fill idle slots with the next curvatures ---------------------------------
-        fresh.clear();
-        for (int s = 0; s < nslots && next_eta < neta; ++s) {
-            if (slot_eta[(size_t)s] >= 0) continue;
-            const int64_t e = next_eta++;
-            slot_eta[(size_t)s] = e;
-            ++active;
-            PackedJob& J = jobs[(size_t)s];
-            const int n = keep_n[e];
-            J.eta = etas[e]; J.two_eta = 2 * etas[e];
-            const int64_t c = cs_index ? cs_index[e] : 0;
-            J.cs = (const cplx*)cs + c * cs_stride; J.th = th_cents + c * M; J.geom = (int32_t)c;
-            J.keep = keep_idx + e * M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            J.max_steps = std::min(steps_cap, std::max(n, 1));
-            J.strip_len = strip_len_for(J.nb);
-            J.start = launch;
-            J.eig_out = eigs_out + e; J.status_out = status_out + e;
-            J.iters_out = iters_out ? iters_out + e : nullptr;
-            fresh.push_back(s);
+        bool any = false;
+        for (int g = 0; g < ngroups && rc == SCINT_OK; ++g) {
+            if (!G[g].in_flight) continue;
+            any = true;
+            rc = G[g].harvest();
+            if (rc == SCINT_OK) rc = G[g].enqueue();
         }
-        if (active == 0) break;
-        if (!fresh.empty()) {
-            // strips of every running job, block row by block row (rebuilt: slots changed size)
-            strips.clear();
-            int nb_fresh = 0;
-            for (int s = 0; s < nslots; ++s) {
-                if (slot_eta[(size_t)s] < 0) continue;
-                const PackedJob& J = jobs[(size_t)s];
-                int32_t* rs0 = rs_all.data() + (size_t)s * (size_t)(nbmax + 1);
-                int idx = 0;
-                for (int I = 0; I < J.nb; ++I) {
-                    rs0[I] = idx;
-                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
-                        Strip st;
-                        st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
-                        strips.push_back(st);
-                    }
-                }
-                rs0[J.nb] = idx;
-            }
-            // longest strips first: the short ones of the last block rows then fill the tail
-            // of the launch (dispatch order only; the arithmetic does not depend on it)
-            std::stable_sort(strips.begin(), strips.end(), [](const Strip& a, const Strip& b) {
-                return (a.J1 - a.J0) > (b.J1 - b.J0);
-            });
-            for (int s : fresh) {
-                const PackedJob& J = jobs[(size_t)s];
-                nb_fresh = std::max(nb_fresh, J.nb);
-                he = hipMemcpyAsync(base + L.total * (size_t)s + L.row_strip0,
-                                    rs_all.data() + (size_t)s * (size_t)(nbmax + 1),
-                                    sizeof(int32_t) * (size_t)(J.nb + 1), hipMemcpyHostToDevice, stream);
-                if (he != hipSuccess) break;
-            }
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(strips_dev, strips.data(), sizeof(Strip) * strips.size(), hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(slots_dev, fresh.data(), sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(stream);   // host vectors are reused
-            if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep job upload", __FILE__, __LINE__); break; }
-            rc = launch_gather_packed(geoms_dev, M, jobs_dev, slots_dev, (int)fresh.size(), nb_fresh, stream);
-            if (rc != SCINT_OK) break;
-            hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0,
-                               stream, jobs_dev, slots_dev);
-        }
-        // ---- kCheckEvery common Lanczos steps, then look at the Ritz pairs -------------------
-        int nb_run = 1;
-        for (int s = 0; s < nslots; ++s)
-            if (slot_eta[(size_t)s] >= 0) nb_run = std::max(nb_run, jobs[(size_t)s].nb);
-        const unsigned nstrips = (unsigned)strips.size();
-        for (int i = 0; i < kCheckEvery; ++i, ++launch) {
-            const int slot = profiler().begin(kProfMatvec, stream);
-            hipLaunchKernelGGL(pk_matvec_kernel, dim3(nstrips), dim3(256), 0, stream, jobs_dev, strips_dev, launch);
-            profiler().end(kProfMatvec, slot, stream);
-            hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0, stream,
-                               jobs_dev, launch);
-        }
-        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, jobs_dev, launch);
-        he = hipGetLastError();
-        if (he == hipSuccess)
-            he = hipMemcpyAsync(flags, states_dev, sizeof(int32_t) * 4 * (size_t)nslots, hipMemcpyDeviceToHost, stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(stream);
-        if (he != hipSuccess) { rc = hip_fail(he, "eval_sweep step", __FILE__, __LINE__); break; }
-        if (profiler().enabled) profiler().collect();
-        fin_slots.clear();
-        fin_eta.clear();
-        int nb_fin = 1;
-        for (int s = 0; s < nslots; ++s) {
-            if (slot_eta[(size_t)s] >= 0 && flags[4 * s] != 0) {
-                if (want_vec && jobs[(size_t)s].n >= 2) {
-                    fin_slots.push_back(s);
-                    fin_eta.push_back(slot_eta[(size_t)s]);
-                    nb_fin = std::max(nb_fin, jobs[(size_t)s].nb);
-                }
-                slot_eta[(size_t)s] = -1;     // finished: results were written by the check kernel
-                jobs[(size_t)s].n = 0;        // an idle slot's kernels exit at once (host copy only)
-                --active;
-            }
-        }
-        if (!fin_slots.empty()) {
-            // export the Ritz vectors before the slots are re-used (the device job table still
-            // describes the finished jobs: it is only rewritten at the next refill)
-            he = hipMemcpyAsync(fin_slots_dev, fin_slots.data(), sizeof(int32_t) * fin_slots.size(),
-                                hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(fin_eta_dev, fin_eta.data(), sizeof(int64_t) * fin_eta.size(),
-                                    hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess) {
-                const dim3 grid((unsigned)nb_fin, (unsigned)fin_slots.size());
-                hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, jobs_dev, fin_slots_dev, fin_eta_dev,
-                                   vec_out, vstride);
-                hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, jobs_dev, fin_slots_dev,
-                                   fin_eta_dev, vec_out, vstride);
-                he = hipGetLastError();
-            }
-            if (he == hipSuccess) he = hipStreamSynchronize(stream);
-            if (he != hipSuccess) { rc = hip_fail(he, "sweep ritz vectors", __FILE__, __LINE__); break; }
-        }
+        if (!any) break;
+    }
+    // leave nothing running on the internal stream, and order the caller's stream after it
+    for (int g = 0; g < ngroups; ++g) {
+        if (G[g].stream) (void)hipStreamSynchronize(G[g].stream);
+        if (G[g].done) (void)hipEventDestroy(G[g].done);
     }
     return rc;
 }
