@@ -67,9 +67,12 @@ int32_t scint_device_count(void);
  * the theta-theta gather kernel ([0]) and of the eigen mat-vec kernel ([1]) is bracketed
  * by hipEvents on its stream.  end() synchronises the device and returns, per kernel, the length
  * in milliseconds of the UNION of its launch intervals (the sweep drives two streams, so
- * launches may overlap) and the launch counts (HOST arrays of 2).  Not thread-safe; off by default. */
+ * launches may overlap), the plain SUM of the individual launch spans (sum / launches is the
+ * average a kernel trace reports) and the launch counts (HOST arrays of 2).  Not thread-safe;
+ * off by default. */
 int32_t scint_profile_begin(void);
-int32_t scint_profile_end(double* ms_out /*HOST[2]*/, int64_t* launches_out /*HOST[2]*/);
+int32_t scint_profile_end(double* ms_out /*HOST[2]*/, double* ms_sum_out /*HOST[2]*/,
+                          int64_t* launches_out /*HOST[2]*/);
 
 /* ---- secondary spectrum: Dynspec.calc_sspec core (dynspec.py:3665-3721) -- */
 /* dyn[nf,nt] -> sec[(halve? nrfft/2 : nrfft), ncfft] in dB, where

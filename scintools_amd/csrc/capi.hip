@@ -32,7 +32,7 @@ extern "C" int32_t scint_profile_begin(void) {
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_profile_end(double* ms_out, int64_t* launches_out) {
+extern "C" int32_t scint_profile_end(double* ms_out, double* ms_sum_out, int64_t* launches_out) {
     scint::Profiler& p = scint::profiler();
     if (hipDeviceSynchronize() != hipSuccess) return SCINT_E_HIP;
     p.collect();
@@ -40,6 +40,7 @@ extern "C" int32_t scint_profile_end(double* ms_out, int64_t* launches_out) {
     p.enabled = false;
     for (int k = 0; k < scint::kProfCount; ++k) {
         if (ms_out) ms_out[k] = p.ms[k];
+        if (ms_sum_out) ms_sum_out[k] = p.ms_sum[k];
         if (launches_out) launches_out[k] = p.launches[k];
     }
     return SCINT_OK;

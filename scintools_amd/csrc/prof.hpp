@@ -17,6 +17,7 @@ struct Profiler {
     // ms[k] is the length of the UNION of kernel k's launch intervals: the sweep drives two
     // streams, so launches of one kernel may overlap in time and must not be counted twice.
     double ms[kProfCount] = {0, 0};
+    double ms_sum[kProfCount] = {0, 0};    // plain sum of the individual launch spans (what rocprofv3 averages)
     int64_t launches[kProfCount] = {0, 0};
     hipEvent_t base = nullptr;             // time origin of the current begin/end window
     std::vector<std::pair<float, float>> spans[kProfCount];
@@ -50,6 +51,7 @@ struct Profiler {
                 if (hipEventElapsedTime(&t0, base, pr.first) == hipSuccess &&
                     hipEventElapsedTime(&t1, base, pr.second) == hipSuccess) {
                     spans[k].push_back({t0, t1});
+                    ms_sum[k] += (double)(t1 - t0);
                     launches[k] += 1;
                 }
                 pool.push_back(pr.first);
@@ -80,7 +82,7 @@ struct Profiler {
     void reset(hipStream_t s) {
         (void)hipDeviceSynchronize();
         collect();
-        for (int k = 0; k < kProfCount; ++k) { ms[k] = 0; launches[k] = 0; spans[k].clear(); }
+        for (int k = 0; k < kProfCount; ++k) { ms[k] = 0; ms_sum[k] = 0; launches[k] = 0; spans[k].clear(); }
         if (!base) (void)hipEventCreate(&base);
         if (base) (void)hipEventRecord(base, s);
     }
