@@ -175,12 +175,13 @@ int32_t scint_eigh_top(const scint_c128* a, int64_t n, const scint_c128* v0,
 /* thth[N,N] on centres th_cents[N] (already re-centred) -> recov[ntau,nfd].
  * If `rank1` != 0, thth is not read: thth = |w| V V^H with V = vec[N], w = *w
  * (device), which is modeler's thth2_red (ththmod.py:312-313).
- * norm_ws: 3*ntau*nfd doubles of scratch (weight sums and counts).  The sums use
- * float64 atomics, so the result is reproducible to rounding, not bit for bit. */
+ * Every pixel of recov_out is written (no scratch, no zero-fill needed).  The per-pixel
+ * sums are accumulated with float64 LDS atomics, so the result is reproducible to
+ * rounding, not bit for bit. */
 int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
                       int32_t rank1, const double* th_cents, int64_t N,
                       const scint_cs_geom* geom /*HOST*/, double eta, int32_t hermitian,
-                      scint_c128* recov_out, double* norm_ws, void* stream);
+                      scint_c128* recov_out, void* stream);
 
 /* ---- model dynamic spectrum: ifft2(ifftshift(recov)).real (ththmod.py:322-324) */
 int32_t scint_model_workspace_bytes(int64_t ntau, int64_t nfd, size_t* bytes /*HOST*/);

@@ -191,64 +191,118 @@ struct RevParams {
     const double* th; int N;
     double eta, two_eta;
     int hermitian;
-    double* acc_re; double* acc_im; double* norm;  // [ntau*nfd] each
+    int slab;         // tau rows per workgroup
+    int64_t centre;   // flat index of the pixel the i == j terms poison, or -1
+    cplx* recov;      // [ntau, nfd]
 };
 
-__global__ void __launch_bounds__(256) rev_scatter_kernel(RevParams p, GeomDev g) {
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= p.N || j >= p.N || i == j) return;  // i == j lands in the poisoned centre bin
-    // rank-1 Hermitian model (modeler): element (j, i) is the exact conjugate of (i, j) and maps
-    // to the exactly negated (fd, tau), i.e. it repeats what the mirrored pass adds for (i, j).
-    // Scattering only i < j halves the atomics; sums and counts are both halved, so every
-    // recov = sum / count is unchanged (a power-of-two scaling is exact).
-    if (p.rank1 && p.hermitian && i > j) return;
-    const double th_i = p.th[i], th_j = p.th[j];
-    const double x = th_j - th_i;                          // fd_map[i, j]   (ththmod.py:207)
-    const double y = p.eta * (th_j * th_j - th_i * th_i);  // tau_map[i, j]  (ththmod.py:208-210)
-    cplx v;
-    if (p.rank1) {
-        // thth2_red = outer(V, conj(V)) * |w|   (ththmod.py:312-313)
-        const cplx o = mulc(p.vec[i], p.vec[j]);
-        const double aw = fabs(p.w[0]);
-        v = mk(o.x * aw, o.y * aw);
+constexpr int kRevSlab = 2048;  // tau rows accumulated per workgroup: 2048 * 20 B = 40 KB of LDS
+
+// smallest j in [0, N] with th[j] - thi >= lo (N if none), galloping out from the guess g.
+// fl(th[j] - thi) is non-decreasing in j, so the predicate is monotone.
+__device__ inline int rev_first_ge(const double* th, int N, double thi, double lo, int g) {
+    g = min(max(g, 0), N - 1);
+    int a, b;  // answer in [a, b]; pred(a - 1) false or a == 0; pred(b) true or b == N
+    if (gload(th + g) - thi >= lo) {
+        b = g; a = 0;
+        for (int step = 1; b - step >= 0; step <<= 1) {
+            if (gload(th + (b - step)) - thi >= lo) { b -= step; }
+            else { a = b - step + 1; break; }
+        }
+        if (a == 0 && b > 0 && !(gload(th) - thi >= lo)) a = 1;
     } else {
-        v = p.thth[(int64_t)i * p.ld + j];
-    }
-    // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
-    const double c = sqrt(fabs(p.two_eta * (th_i - th_j)));
-    const double scl = 1.0 / c;
-    const double wr = v.x * scl, wi = v.y * scl;
-    int64_t bx = hist_bin(x, g.fd0, g.fd1_step, g.nfd);
-    int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau);
-    if (bx >= 0 && by >= 0) {
-        const int64_t o = by * g.nfd + bx;
-        atomicAdd(&p.acc_re[o], wr);
-        atomicAdd(&p.acc_im[o], wi);
-        atomicAdd(&p.norm[o], 1.0);
-    }
-    if (p.hermitian) {
-        bx = hist_bin(-x, g.fd0, g.fd1_step, g.nfd);
-        by = hist_bin(-y, g.tau0, g.tau1_step, g.ntau);
-        if (bx >= 0 && by >= 0) {
-            const int64_t o = by * g.nfd + bx;
-            atomicAdd(&p.acc_re[o], wr);
-            atomicAdd(&p.acc_im[o], -wi);
-            atomicAdd(&p.norm[o], 1.0);
+        a = g + 1; b = N;
+        for (int step = 1; a - 1 + step < N; step <<= 1) {
+            if (gload(th + (a - 1 + step)) - thi >= lo) { b = a - 1 + step; break; }
+            a += step;
         }
     }
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (gload(th + m) - thi >= lo) b = m; else a = m + 1;
+    }
+    return a;
 }
 
-// recov = nan_to_num((re + i im) / norm); the bin that receives the i == j terms is
-// NaN in the reference (x/0 weights) and therefore 0 after nan_to_num.
-__global__ void __launch_bounds__(256)
-rev_normalise_kernel(const double* acc_re, const double* acc_im, const double* norm, cplx* recov,
-                     int64_t total, int64_t centre) {
-    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    if (o == centre) { recov[o] = mk(0.0, 0.0); return; }
-    const double scl = 1.0 / norm[o];
-    recov[o] = mk(nan_to_num(acc_re[o] * scl), nan_to_num(acc_im[o] * scl));
+// One workgroup owns the `slab` tau rows [blockIdx.y*slab, ...) of ONE fd column of recov
+// and gathers every theta-theta pixel that np.histogram2d would drop there
+// (ththmod.py:207-262): for each i the j with fd_map[i, j] in the column form one short
+// interval (th is increasing); their tau bin picks the row.  Weighted sums and counts
+// accumulate in LDS (ds_add_f64), are divided and written once -- no global atomics, no
+// zero-fill and no separate normalise pass over the [ntau, nfd] image.
+//
+// The Hermitian second pass of the reference (-fd, -tau, conj) puts the mirror of pixel
+// (j, i) exactly where the direct image of (i, j) falls (negation is exact in floating
+// point), so pixel (i, j) contributes  w_ij + conj(w_ji)  with count 2.  For the rank-1
+// Hermitian model w_ji == conj(w_ij) exactly, and sum and count are both halved.
+__global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g) {
+    extern __shared__ double rev_lds[];
+    const int slab = p.slab;
+    double* acc_re = rev_lds;
+    double* acc_im = rev_lds + slab;
+    uint32_t* cnt = (uint32_t*)(rev_lds + 2 * slab);
+    // columns of 4 neighbouring workgroups of one XCD are adjacent, so their 16 B stores
+    // complete 64 B lines in that XCD's L2
+    int64_t col = blockIdx.x;
+    if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);
+    const int64_t row0 = (int64_t)blockIdx.y * slab;
+    const int rows = (int)min((int64_t)slab, g.ntau - row0);
+    for (int r = threadIdx.x; r < rows; r += 256) { acc_re[r] = 0.0; acc_im[r] = 0.0; cnt[r] = 0u; }
+    __syncthreads();
+
+    const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;        // histogram edges of the column
+    const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
+    const bool last = (col == g.nfd - 1);                              // last bin is closed on the right
+    const double aw = p.rank1 ? fabs(gload(p.w)) : 0.0;
+    // start of the neighbour search: offset of the column centre in mean theta spacings
+    const double th_step = p.N > 1 ? (gload(p.th + p.N - 1) - gload(p.th)) / (double)(p.N - 1) : 0.0;
+    const double est = th_step > 0.0 ? 0.5 * (lo + hi) / th_step : 0.0;
+    const int shift = (int)fmin(fmax(rint(est), -(double)p.N), (double)p.N);
+    const bool usable = g.fd1_step > 0.0 && g.tau1_step > 0.0;
+    for (int i = threadIdx.x; usable && i < p.N; i += 256) {
+        const double th_i = gload(p.th + i);
+        int j = rev_first_ge(p.th, p.N, th_i, lo, i + shift);
+        for (; j < p.N; ++j) {
+            const double th_j = gload(p.th + j);
+            const double x = th_j - th_i;                              // fd_map[i, j]  (ththmod.py:207)
+            if (last ? (x > hi) : (x >= hi)) break;
+            if (i == j) continue;                                      // lands in the poisoned centre bin
+            const double y = p.eta * (th_j * th_j - th_i * th_i);      // tau_map[i, j] (ththmod.py:208-210)
+            const int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau) - row0;
+            if (by < 0 || by >= rows) continue;
+            // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
+            const double scl = 1.0 / sqrt(fabs(p.two_eta * (th_i - th_j)));
+            double wr, wi;
+            uint32_t c = 1u;
+            if (p.rank1) {
+                const cplx o = mulc(gload(p.vec + i), gload(p.vec + j));  // outer(V, conj(V)) * |w|  (:312-313)
+                wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
+            } else {
+                const cplx v = gload(p.thth + (int64_t)i * p.ld + j);
+                wr = v.x * scl; wi = v.y * scl;
+                if (p.hermitian) {
+                    const cplx u = gload(p.thth + (int64_t)j * p.ld + i);
+                    wr += u.x * scl; wi += -(u.y * scl);
+                    c = 2u;
+                }
+            }
+            atomicAdd(&acc_re[by], wr);
+            atomicAdd(&acc_im[by], wi);
+            atomicAdd(&cnt[by], c);
+        }
+    }
+    __syncthreads();
+    // recov = nan_to_num(sum / count); the bin that receives the i == j terms is NaN in the
+    // reference (x/0 weights) and therefore 0 after nan_to_num.
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const int64_t o = (row0 + r) * g.nfd + col;
+        cplx out = mk(0.0, 0.0);
+        if (o != p.centre) {
+            const double scl = 1.0 / (double)cnt[r];
+            out = mk(nan_to_num(acc_re[r] * scl), nan_to_num(acc_im[r] * scl));
+        }
+        gstore(p.recov + o, out);
+    }
 }
 
 }  // namespace scint
@@ -278,35 +332,27 @@ extern "C" int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geo
 extern "C" int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
                                  int32_t rank1, const double* th_cents, int64_t N,
                                  const scint_cs_geom* geom, double eta, int32_t hermitian,
-                                 scint_c128* recov_out, double* norm_ws, void* stream_) {
-    SCINT_REQUIRE(geom && th_cents && recov_out && norm_ws, "rev_map: null pointer");
+                                 scint_c128* recov_out, void* stream_) {
+    SCINT_REQUIRE(geom && th_cents && recov_out, "rev_map: null pointer");
     SCINT_REQUIRE(rank1 ? (vec && w) : (thth != nullptr), "rev_map: missing input");
     SCINT_REQUIRE(N >= 1, "rev_map: bad N");
     hipStream_t stream = (hipStream_t)stream_;
     const GeomDev g = to_dev(*geom);
-    const int64_t total = g.ntau * g.nfd;
-    // workspace planes: [0] = sum of real weights, [1] = imaginary, [2] = counts
-    double* acc_re = norm_ws;
-    double* acc_im = norm_ws + total;
-    double* norm = norm_ws + 2 * total;
-    SCINT_HIP(hipMemsetAsync(norm_ws, 0, sizeof(double) * 3 * (size_t)total, stream));
     RevParams p;
     p.thth = (const cplx*)thth; p.ld = N;
     p.vec = (const cplx*)vec; p.w = w; p.rank1 = rank1;
     p.th = th_cents; p.N = (int)N;
     p.eta = eta; p.two_eta = 2 * eta;
     p.hermitian = hermitian;
-    p.acc_re = acc_re; p.acc_im = acc_im; p.norm = norm;
-    dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(N, 4));
-    SCINT_REQUIRE(grid.y <= 65535, "rev_map: N too large");
-    hipLaunchKernelGGL(rev_scatter_kernel, grid, dim3(256), 0, stream, p, g);
-    SCINT_LAUNCH_CHECK();
+    p.slab = (int)std::min<int64_t>(g.ntau, kRevSlab);
     // the bin the i == j terms fall in (fd_map = 0, tau_map = eta*0)
     const int64_t cbx = hist_bin(0.0, g.fd0, g.fd1_step, g.nfd);
     const int64_t cby = hist_bin(eta * 0.0, g.tau0, g.tau1_step, g.ntau);
-    const int64_t centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
-    hipLaunchKernelGGL(rev_normalise_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
-                       acc_re, acc_im, norm, (cplx*)recov_out, total, centre);
+    p.centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
+    p.recov = (cplx*)recov_out;
+    dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
+    SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
+    hipLaunchKernelGGL(rev_gather_kernel, grid, dim3(256), (size_t)p.slab * 20, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

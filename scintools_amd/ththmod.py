@@ -211,13 +211,11 @@ def _eigh_top_dev(a_t, v0_t=None, want_vec=True, tol=DEFAULT_TOL, max_iter=DEFAU
 
 def _rev_map_dev(grid_geom, th_t, n, eta, hermetian, thth_t=None, vec_t=None, w_t=None):
     lib = _lib.load()
-    total = grid_geom.ntau * grid_geom.nfd
     recov = empty((grid_geom.ntau, grid_geom.nfd), torch.complex128)
-    scratch = workspace.get(3 * total * 8)
     rank1 = thth_t is None
     rc = lib.scint_rev_map(ptr(thth_t), ptr(vec_t), ptr(w_t), 1 if rank1 else 0, ptr(th_t), n,
                            ctypes.byref(grid_geom), eta, 1 if hermetian else 0, ptr(recov),
-                           ptr(scratch), stream_ptr())
+                           stream_ptr())
     _lib.check(rc, "scint_rev_map")
     return recov
 

@@ -7,7 +7,7 @@ Tolerances:
   sspec             1e-8 dB absolute where the power is above the rounding floor
   eigenvalue |w|    rtol 1e-9 against ARPACK eigsh
   V                 1 - |<V_gpu, V_ref>| <= 1e-9
-  rev_map / model   rtol 1e-9 of the array maximum (float64 atomics ordering)
+  rev_map / model   rtol 1e-9 of the array maximum (float64 LDS-atomic summation order)
 """
 import numpy as np
 import pytest
