@@ -278,8 +278,63 @@ def gen_psrflux():
     save("psrflux.npz", **out)
 
 
+# ---------------------------------------------------------------------------
+# 8. arc normalisation: scale_dyn('lambda') -> calc_sspec(lamsteps) -> fit_arc / norm_sspec
+#    (dynspec.py:3928-3959, 970-1346, 1920-2183)
+# ---------------------------------------------------------------------------
+def gen_arcfit():
+    sim = Simulation(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.25,
+                     freq=1400, dt=30, nx=256, ny=64, nf=192, seed=77, lamsteps=False)
+    dyn = Dynspec(dyn=sim, process=False, verbose=False)
+    dyn.dyn = np.array(dyn.dyn, dtype=np.float64)       # float64 input (see gen_sim)
+    out = dict(dyn=dyn.dyn, dt=dyn.dt, df=dyn.df, freqs=dyn.freqs, times=dyn.times, freq=dyn.freq,
+               sim_eta=sim.eta)
+    dyn.calc_sspec(lamsteps=True)
+    out.update(lamdyn=dyn.lamdyn, lam=dyn.lam, dlam=dyn.dlam, beta=dyn.beta, lamsspec=dyn.lamsspec,
+               fdop=dyn.fdop, tdel=dyn.tdel)
+
+    def grab(tag, d, keys2d=True):
+        out[f"{tag}_avg"] = np.ma.filled(np.ma.array(d.normsspecavg, dtype=float), np.nan)
+        out[f"{tag}_fdop"] = np.array(d.normsspec_fdop)
+        out[f"{tag}_tdel"] = np.array(d.normsspec_tdel)
+        out[f"{tag}_pow"] = np.ma.filled(np.ma.array(d.powerspectrum, dtype=float), np.nan)
+        out[f"{tag}_weights"] = np.array(d.weights)
+        if keys2d:
+            out[f"{tag}_norm"] = np.array(d.normsspec.data)
+            out[f"{tag}_mask"] = np.array(np.ma.getmaskarray(d.normsspec))
+
+    # (a) the default Hough-style curvature search in wavelength steps
+    dyn.fit_arc(lamsteps=True, numsteps=2000)
+    grab("fa", dyn, keys2d=False)
+    out.update(fa_betaeta=dyn.betaeta, fa_betaetaerr=dyn.betaetaerr, fa_betaetaerr2=dyn.betaetaerr2,
+               fa_noise=dyn.noise, fa_eta_array=dyn.eta_array, fa_spec=dyn.norm_sspec_avg,
+               fa_prob=dyn.prob_eta_peak)
+    # (b) asymmetric, log-parabola, log-spaced, weighted, with bounds and a constraint
+    dyn.fit_arc(lamsteps=True, numsteps=1500, asymm=True, log_parabola=True, logsteps=True,
+                weighted=True, etamin=40.0, etamax=4000.0, constraint=[100, 2000], nsmooth=7,
+                startbin=4, cutmid=5, delmax=0.8 * np.max(dyn.tdel))
+    out.update(fb_left=dyn.betaeta_left, fb_right=dyn.betaeta_right,
+               fb_lefterr=dyn.betaetaerr_left, fb_righterr=dyn.betaetaerr_right,
+               fb_spec1=dyn.norm_sspec_avg1, fb_spec2=dyn.norm_sspec_avg2, fb_eta_array=dyn.eta_array)
+    # (c) norm_sspec variants, 2-D output included
+    dyn.norm_sspec(eta=out["fa_betaeta"], lamsteps=True, plot=False)
+    grab("na", dyn)
+    dyn.norm_sspec(eta=out["fa_betaeta"], lamsteps=True, plot=False, logsteps=True, numsteps=301,
+                   weighted=False, maxnormfac=3, startbin=2, cutmid=4)
+    grab("nb", dyn)
+    dyn.norm_sspec(eta=out["fa_betaeta"], lamsteps=True, plot=False, subtract_artefacts=True,
+                   powerspec_cut=True, minnormfac=0.3, maxnormfac=2, delmax=0.5 * np.max(dyn.tdel))
+    grab("nc", dyn)
+    # (d) frequency-step spectrum (eta given in the units norm_sspec converts from, dynspec.py:2033-2038)
+    dyn.calc_sspec()
+    out["sspec"] = dyn.sspec
+    dyn.norm_sspec(eta=130.0, lamsteps=False, plot=False, startbin=3, maxnormfac=3, cutmid=4)
+    grab("nd", dyn)
+    save("arcfit.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval", "psrflux"]
+    which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval", "psrflux", "arcfit"]
     if "small" in which:
         gen_thth_small()
     if "sample" in which:
@@ -294,3 +349,5 @@ if __name__ == "__main__":
         gen_retrieval()
     if "psrflux" in which:
         gen_psrflux()
+    if "arcfit" in which:
+        gen_arcfit()

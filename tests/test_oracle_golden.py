@@ -208,3 +208,81 @@ def test_calc_asymmetry(golden):
         fm = freq[fs].mean()
         a = to.calc_asymmetry(np.nan_to_num(d2), edges * (fm / fref), time, freq[fs], ththeta * (fref / fm) ** 2, 3)
         assert a == pytest.approx(g["asymmetry"][cf, 0].real, rel=1e-7, abs=1e-9)
+
+
+# ---------------------------------------------------------------- arc normalisation (section 8f, rank 3)
+from oracle import arcfit_oracle as ao  # noqa: E402
+
+
+def _same(a, b, **kw):
+    np.testing.assert_allclose(np.ma.filled(np.ma.array(a, dtype=float), np.nan), b, equal_nan=True, **kw)
+
+
+def test_scale_dyn_lambda_and_lamsspec(golden):
+    g = golden("arcfit.npz")
+    r = ao.calc_sspec_lam(g["dyn"], g["freqs"], float(g["dt"]), float(g["df"]))
+    assert np.array_equal(r["lamdyn"], g["lamdyn"])
+    assert np.array_equal(r["lam"], g["lam"])
+    assert r["dlam"] == float(g["dlam"])
+    assert np.array_equal(r["beta"], g["beta"])
+    np.testing.assert_allclose(r["lamsspec"], g["lamsspec"], rtol=1e-12, atol=1e-9)
+
+
+_NORM_CASES = {
+    "na": dict(lamsteps=True),
+    "nb": dict(lamsteps=True, logsteps=True, numsteps=301, weighted=False, maxnormfac=3, startbin=2, cutmid=4),
+    "nc": dict(lamsteps=True, subtract_artefacts=True, powerspec_cut=True, minnormfac=0.3, maxnormfac=2,
+               delmax_frac=0.5),
+    "nd": dict(lamsteps=False, startbin=3, maxnormfac=3, cutmid=4, eta=130.0),
+}
+
+
+def norm_case(g, tag, fn):
+    kw = dict(_NORM_CASES[tag])
+    lam = kw["lamsteps"]
+    eta = kw.pop("eta", float(g["fa_betaeta"]))
+    frac = kw.pop("delmax_frac", None)
+    if frac is not None:
+        kw["delmax"] = frac * np.max(g["tdel"])
+    return fn(g["lamsspec"] if lam else g["sspec"], g["beta"] if lam else g["tdel"], g["tdel"], g["fdop"],
+              float(g["freq"]), eta, **kw)
+
+
+@pytest.mark.parametrize("tag", sorted(_NORM_CASES))
+def test_norm_sspec_oracle(golden, tag):
+    g = golden("arcfit.npz")
+    r = norm_case(g, tag, ao.norm_sspec)
+    assert np.array_equal(np.ma.getmaskarray(r["normsspec"]), g[f"{tag}_mask"])
+    assert np.array_equal(np.asarray(r["normsspec"].data), g[f"{tag}_norm"], equal_nan=True)
+    assert np.array_equal(r["normsspec_fdop"], g[f"{tag}_fdop"])
+    assert np.array_equal(r["normsspec_tdel"], g[f"{tag}_tdel"])
+    _same(r["powerspectrum"], g[f"{tag}_pow"], rtol=1e-14)
+    _same(r["weights"], g[f"{tag}_weights"], rtol=1e-14)
+    _same(r["normsspecavg"], g[f"{tag}_avg"], rtol=1e-13)
+
+
+def test_fit_arc_oracle(golden):
+    g = golden("arcfit.npz")
+    r = ao.fit_arc(g["lamsspec"], g["beta"], g["tdel"], g["beta"], g["fdop"], float(g["freq"]),
+                   lamsteps=True, numsteps=2000)
+    s = r["sides"][0]
+    assert r["noise"] == pytest.approx(float(g["fa_noise"]), rel=1e-14)
+    _same(r["norm"]["normsspecavg"], g["fa_avg"], rtol=1e-13)
+    np.testing.assert_allclose(s["eta_array"], g["fa_eta_array"], rtol=1e-14)
+    np.testing.assert_allclose(s["spec"], g["fa_spec"], rtol=1e-13)
+    np.testing.assert_allclose(s["prob"], g["fa_prob"], rtol=1e-10)
+    assert s["eta"] == pytest.approx(float(g["fa_betaeta"]), rel=1e-10)
+    assert s["etaerr"] == pytest.approx(float(g["fa_betaetaerr"]), rel=1e-10)
+    assert s["etaerr2"] == pytest.approx(float(g["fa_betaetaerr2"]), rel=1e-8)
+    r = ao.fit_arc(g["lamsspec"], g["beta"], g["tdel"], g["beta"], g["fdop"], float(g["freq"]),
+                   lamsteps=True, numsteps=1500, asymm=True, log_parabola=True, logsteps=True, weighted=True,
+                   etamin=40.0, etamax=4000.0, constraint=[100, 2000], nsmooth=7, startbin=4, cutmid=5,
+                   delmax=0.8 * np.max(g["tdel"]))
+    left, right = r["sides"]
+    assert left["eta"] == pytest.approx(float(g["fb_left"]), rel=1e-10)
+    assert right["eta"] == pytest.approx(float(g["fb_right"]), rel=1e-10)
+    assert left["etaerr"] == pytest.approx(float(g["fb_lefterr"]), rel=1e-10)
+    assert right["etaerr"] == pytest.approx(float(g["fb_righterr"]), rel=1e-10)
+    np.testing.assert_allclose(left["spec"], g["fb_spec1"], rtol=1e-13)
+    np.testing.assert_allclose(right["spec"], g["fb_spec2"], rtol=1e-13)
+    np.testing.assert_allclose(right["eta_array"], g["fb_eta_array"], rtol=1e-14)
