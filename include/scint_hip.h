@@ -219,6 +219,64 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
                     int64_t nf, int64_t nt, const uint8_t* mask, double noise_n,
                     double* out, void* stream);
 
+/* ==== arc normalisation: scale_dyn / norm_sspec / fit_arc ==== */
+
+/* ---- equal-wavelength resample: Dynspec.scale_dyn(scale='lambda') (dynspec.py:3948-3957) ----
+ * Every time column of dyn[nf, nt] is interpolated with the not-a-knot cubic spline
+ * (scipy interp1d(kind='cubic')) from the channel frequencies to nout target frequencies, and
+ * the rows are written flipped (np.flipud): out[nout-1-k, :] = S(target k).
+ * The spline is solved in second-derivative form (moments M[i]); the tridiagonal system
+ * depends on the frequency axis only, so the caller passes its Thomas factors (DEVICE arrays):
+ *   h[nf-1] knot spacings; interior rows i = 1..nf-2 with right-hand side
+ *   r_i = 6*((y[i+1]-y[i])/h[i] - (y[i]-y[i-1])/h[i-1]):  forward  d_i = (r_i - sub[i]*d_{i-1})*inv[i],
+ *   backward M[i] = d_i - sup[i]*M[i+1];  not-a-knot ends (HOST end[4]):
+ *   M[0] = end[0]*M[1] + end[1]*M[2],  M[nf-1] = end[2]*M[nf-2] + end[3]*M[nf-3];
+ *   per target k: interval idx[k] and coef[k][4]: S = c0*y[i] + c1*y[i+1] + c2*M[i] + c3*M[i+1].
+ * `reverse` != 0: the frequency axis is descending and row i of the spline is dyn row nf-1-i.
+ * workspace: nf*nt doubles. */
+int32_t scint_spline_resample(const double* dyn, int64_t nf, int64_t nt, int32_t reverse,
+                              const double* h, const double* sub, const double* inv,
+                              const double* sup, const double* end /*HOST [4]*/,
+                              const int32_t* idx, const double* coef, int64_t nout,
+                              double* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Dynspec.norm_sspec row loop (dynspec.py:2093-2127) ------------------------------------
+ * For delay rows r = 0..nr-1 (row row0+r of sspec[., ld], nc columns, dB):
+ *   scale = sqrt(yaxis[row0+r]/eta); sel = |fdop| <= maxnormfac*scale;
+ *   norm_out[r, k] = np.interp(x[k], fdop[sel]/scale, sspec[row0+r, sel])   (exact NumPy
+ *   branch structure and rounding: searchsorted bracket, slope*(x-xp[j])+fp[j], NaN retry);
+ *   mask_out[r, k] = (|x[k]| > max|fdop[sel]/scale|) or isnan(norm_out[r, k]);
+ *   pow_out[r]     = mean over unmasked finite entries of 10**(v/10), v = norm_out[r, k] or,
+ *                    when xlin is given (logsteps), np.interp(xlin[k], ...)  (NaN if none).
+ * Columns [cut_lo, cut_hi) read as NaN (cutmid); row_offset[nr] (or NULL) is subtracted from
+ * the row first (subtract_artefacts).  fdop must be ascending.  All pointers DEVICE. */
+int32_t scint_norm_sspec(const double* sspec, int64_t ld, int64_t nc, const double* fdop,
+                         const double* yaxis, int64_t row0, int64_t nr, double eta,
+                         double maxnormfac, int64_t cut_lo, int64_t cut_hi,
+                         const double* row_offset, const double* x, const double* xlin,
+                         int64_t nx, double* norm_out, uint8_t* mask_out, double* pow_out,
+                         void* stream);
+
+/* ---- np.ma.average(norm, axis=0, weights=w) (dynspec.py:2171-2181) --------------------------
+ * avg_out[k] = sum_r w[r]*norm[r,k] / sum_r w[r] over rows with rowsel[r] != 0 (NULL = all) and
+ * mask[r,k] == 0.  A column with no entry gets empty_out[k] = 1 and avg_out[k] = 0 (the value
+ * numpy.ma leaves under the mask).  Fixed summation order (deterministic). */
+int32_t scint_masked_colavg_workspace_bytes(int64_t nr, int64_t nx, size_t* bytes /*HOST*/);
+int32_t scint_masked_colavg(const double* norm, const uint8_t* mask, int64_t nr, int64_t nx,
+                            const double* weights, const uint8_t* rowsel, double* avg_out,
+                            uint8_t* empty_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- np.nanmean(sspec[rows, colsel], axis=1) (dynspec.py:2060-2061) ------------------------ */
+int32_t scint_row_nanmean(const double* sspec, int64_t ld, int64_t nc, int64_t row0, int64_t nr,
+                          const uint8_t* colsel, int64_t cut_lo, int64_t cut_hi, double* out,
+                          void* stream);
+
+/* ---- np.std over rows [r0, r1), columns [0, c_lo) + [c_hi, nc) (fit_arc noise, dynspec.py:1097-1101)
+ * out: DEVICE double[1]; workspace: 1032 doubles. */
+int32_t scint_block_std(const double* a, int64_t ld, int64_t nc, int64_t r0, int64_t r1,
+                        int64_t c_lo, int64_t c_hi, double* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* ---- plain 2-D complex FFT (forward, numpy sign convention) -------------- */
 /* Exposed for tests: out may alias in. */
 int32_t scint_fft2_workspace_bytes(int64_t rows, int64_t cols, size_t* bytes /*HOST*/);

@@ -2,9 +2,9 @@
 
     python -m scintools_amd.build [--force]
 
-hipcc cross-compiles without a GPU.  thth.hip is built with -ffp-contract=off
-(the gather/scatter bin decisions must round like NumPy); the other units keep
-the default contraction.  Objects land in scintools_amd/csrc/_obj, the shared
+hipcc cross-compiles without a GPU.  thth.hip and arcnorm.hip are built with
+-ffp-contract=off (bin decisions and np.interp arithmetic must round like NumPy);
+the other units keep the default contraction.  Objects land in scintools_amd/csrc/_obj, the shared
 library next to the package so that it travels with a repository snapshot.
 """
 import os
@@ -24,6 +24,7 @@ UNITS = {
     "thth.hip": ["-ffp-contract=off"],
     "eigen.hip": [],
     "eigen_packed.hip": [],
+    "arcnorm.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 

@@ -34,7 +34,7 @@ def to_device(x, dtype):
         t = x.to(device=dev, dtype=dtype)
     else:
         np_dtype = {torch.float64: np.float64, torch.complex128: np.complex128,
-                    torch.int32: np.int32, torch.uint8: np.uint8}[dtype]
+                    torch.int32: np.int32, torch.int64: np.int64, torch.uint8: np.uint8}[dtype]
         t = torch.from_numpy(np.ascontiguousarray(x, dtype=np_dtype)).to(dev)
     return t.contiguous()
 

@@ -10,8 +10,11 @@ reference ``Dynspec``, or plain arrays) with
   the global eta ~ nu**-2 fit stay on the host exactly as in the reference, every
   chunk's conjugate spectrum + eta sweep runs on the GPU (``ththmod.single_search``).
 
-File I/O, cleaning, arc fitting from the secondary spectrum (``fit_arc``), phase
-retrieval and plotting are out of scope.
+* ``scale_dyn(scale='lambda')``, ``norm_sspec``, ``fit_arc`` (dynspec.py:3928-3959,
+  1920-2183, 970-1313): the arc-curvature search on the secondary spectrum that supplies
+  ``prep_thetatheta`` with its default curvature bounds (``scintools_amd/arcfit.py``).
+
+Cleaning, velocity / trapezoid rescaling and plotting are out of scope.
 """
 import ctypes
 import os
@@ -20,7 +23,7 @@ import numpy as np
 import scipy.constants as sc
 import torch
 
-from . import _lib, units
+from . import _lib, arcfit, units
 from . import ththmod as thth
 from .device import empty, ptr, require_gpu, stream_ptr, to_device, workspace
 
@@ -210,18 +213,24 @@ class Dynspec:
                    return_sspec=False, velocity=False):
         """Secondary spectrum (dynspec.py:3584-3748) on the GPU.
 
-        Sets ``self.sspec / self.fdop / self.tdel`` or, with ``input_dyn`` or
-        ``return_sspec``, returns ``(fdop, tdel, sec)``.  The wavelength-,
-        velocity- and trapezoid-rescaled variants depend on ``scale_dyn``
-        (outside the hot path) and raise ``NotImplementedError``.
+        Sets ``self.sspec / self.fdop / self.tdel`` (``self.lamsspec`` and ``self.beta`` with
+        ``lamsteps``, on the wavelength-scaled spectrum of ``scale_dyn``) or, with ``input_dyn``
+        or ``return_sspec``, returns ``(fdop, yaxis, sec)``.  The velocity- and
+        trapezoid-rescaled variants are outside the hot path and raise ``NotImplementedError``.
         """
-        if lamsteps or velocity or trap:
-            raise NotImplementedError("lamsteps / velocity / trap need Dynspec.scale_dyn, "
+        if velocity or trap:
+            raise NotImplementedError("velocity / trap need Dynspec.scale_dyn('velocity'/'trapezoid'), "
                                       "which is outside the accelerated hot path")
         if plot:
             raise NotImplementedError("plotting is outside the accelerated hot path")
-        dyn = self.dyn if input_dyn is None else input_dyn
-        dyn_t = to_device(dyn, torch.float64)
+        if input_dyn is not None:
+            dyn_t = to_device(input_dyn, torch.float64)
+        elif lamsteps:
+            if not hasattr(self, "lamdyn"):
+                self.scale_dyn()
+            dyn_t = to_device(self.lamdyn, torch.float64)
+        else:
+            dyn_t = to_device(self.dyn, torch.float64)
         sec = sspec_device(dyn_t, prewhite=prewhite, halve=halve, window=window,
                            window_frac=window_frac).cpu().numpy()
         nf, nt = dyn_t.shape
@@ -231,12 +240,54 @@ class Dynspec:
         fd = np.array(list(range(int(-ncfft / 2), int(ncfft / 2))))
         fdop = np.reshape(np.multiply(fd, 1e3 / (ncfft * self.dt)), [len(fd)])   # mHz
         tdel = np.reshape(np.divide(td, (nrfft * self.df)), [len(td)])           # us
+        if lamsteps:
+            beta = np.divide(td, (nrfft * self.dlam))                            # m^-1 (dynspec.py:3703-3704)
         if input_dyn is None and not return_sspec:
-            self.sspec = sec
+            if lamsteps:
+                self.lamsspec = sec
+                self.beta = beta
+            else:
+                self.sspec = sec
             self.fdop = fdop
             self.tdel = tdel
             return None
-        return fdop, tdel, sec
+        return fdop, (beta if lamsteps else tdel), sec
+
+    # ------------------------------------------------------------------ arc normalisation
+    def scale_dyn(self, scale='lambda', window_frac=0.1, pars=None, parfile=None, window='hanning',
+                  spacing='auto', s=None, d=None, vism_ra=None, vism_dec=None, Omega=None, inc=None,
+                  vism_zeta=None, zeta=None, lamsteps=False, velocity=False, trap=False):
+        """Rescale the dynamic spectrum (dynspec.py:3872-4080): the equal-wavelength resample
+        (``'lambda'`` / ``'wavelength'`` / ``lamsteps``) runs on the GPU -- one not-a-knot cubic
+        spline per time column -- and sets ``lamdyn / lam / nlam / dlam``.  The velocity, orbit and
+        trapezoid scalings need ephemerides and are outside the accelerated hot path."""
+        if ('velocity' in scale) or ('orbit' in scale) or velocity or ('trapezoid' in scale) or trap:
+            raise NotImplementedError("velocity / orbit / trapezoid scaling is outside the accelerated hot path")
+        if ('lambda' in scale) or ('wavelength' in scale) or lamsteps:
+            arcfit.scale_dyn_lambda(self, spacing=spacing)
+
+    norm_sspec = arcfit.norm_sspec
+    fit_arc = arcfit.fit_arc
+
+    @property
+    def normsspec(self):
+        """2-D normalised secondary spectrum of the last ``norm_sspec`` (masked array); copied
+        from the device on first access."""
+        return arcfit.normsspec_host(self)
+
+    @normsspec.setter
+    def normsspec(self, value):
+        self._normsspec_host = value
+
+    @property
+    def mask(self):
+        """Mask of ``normsspec`` (dynspec.py:2118-2126)."""
+        override = getattr(self, "_mask_host", None)
+        return override if override is not None else np.ma.getmaskarray(arcfit.normsspec_host(self))
+
+    @mask.setter
+    def mask(self, value):
+        self._mask_host = value
 
     def calc_acf(self, method='direct', input_dyn=None, normalise=True, window_frac=0.1):
         """Autocovariance function (dynspec.py:3750-3814), 'direct' method on the GPU:
@@ -272,18 +323,14 @@ class Dynspec:
 
         Same keywords as the reference: cwf, cwt, fref, eta_min, eta_max, nedge, edges_lim,
         tau_lim, tau_mask (bare numbers in s**3 / mHz / us / MHz, or astropy Quantities).
-        ``eta_min`` and ``eta_max`` are required: the reference falls back to ``fit_arc``
-        (a Hough transform of the secondary spectrum) for them, which is outside the
-        accelerated hot path.  The 'thin' procedure (rectangular theta-theta + SVD) is out
-        of scope as well.
+        Without ``eta_min`` / ``eta_max`` the bounds come from ``fit_arc(lamsteps=True)`` on
+        the secondary spectrum, as in the reference (dynspec.py:1458-1473).  The 'thin'
+        procedure (rectangular theta-theta + SVD) is out of scope.
         """
         fitting_procs = ['standard', 'thin', 'incoherent']
         assert fitting_proc in fitting_procs, f'fitting_proc must be one of {fitting_procs}'
         if fitting_proc == 'thin':
             raise NotImplementedError("fitting_proc='thin' (two-curvature SVD) is outside the hot path")
-        if not ('eta_min' in kwargs and 'eta_max' in kwargs):
-            raise NotImplementedError("give eta_min and eta_max: the reference's fit_arc fallback "
-                                      "(dynspec.py:1458-1473) is outside the accelerated hot path")
         val = lambda key, unit, name: float(units.strip(kwargs[key], name, unit, warn=False))
         self.thetatheta_proc = fitting_proc
         self.npad = npad
@@ -309,8 +356,19 @@ class Dynspec:
         eta_max = tau.max() / (fd[1] - fd[0])**2
         eta_min *= (self.freqs.max() / self.fref)**2
         eta_max *= (self.freqs.min() / self.fref)**2
-        self.eta_min = max((val('eta_min', 's3', 'eta_min'), eta_min))
-        self.eta_max = min((val('eta_max', 's3', 'eta_max'), eta_max))
+        self.eta_min = max((val('eta_min', 's3', 'eta_min'), eta_min)) if 'eta_min' in kwargs else eta_min
+        self.eta_max = min((val('eta_max', 's3', 'eta_max'), eta_max)) if 'eta_max' in kwargs else eta_max
+        if not ('eta_min' in kwargs and 'eta_max' in kwargs):         # dynspec.py:1458-1473
+            # curvature from the secondary spectrum; s**3 <-> 1/(m mHz**2) through c / fref**2
+            if not hasattr(self, "betaeta"):
+                self.fit_arc(lamsteps=True, numsteps=1e4, etamin=self.eta_min * self.fref**2 * 1e6 / sc.c,
+                             etamax=self.eta_max * self.fref**2 * 1e6 / sc.c, delmax=tau_lim)
+            eta_hough = sc.c * self.betaeta / (self.fref**2 * 1e6)
+            err_hough = sc.c * 2 * max((self.betaetaerr, self.betaetaerr2)) / (self.fref**2 * 1e6)
+            if 'eta_min' not in kwargs:
+                self.eta_min = max((self.eta_min, eta_hough - err_hough))
+            if 'eta_max' not in kwargs:
+                self.eta_max = min((self.eta_max, eta_hough + err_hough))
         l0, l1 = np.log10(self.eta_min), np.log10(self.eta_max)
         self.neta = int(1 + (l1 - l0) / np.log10(1 + self.fw / 10))     # dynspec.py:1478
         fd_cut = (fd.max() / 2) * (self.fref / self.freqs.max())

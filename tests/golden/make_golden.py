@@ -330,6 +330,17 @@ def gen_arcfit():
     out["sspec"] = dyn.sspec
     dyn.norm_sspec(eta=130.0, lamsteps=False, plot=False, startbin=3, maxnormfac=3, cutmid=4)
     grab("nd", dyn)
+    # (e) prep_thetatheta without curvature bounds: they come from fit_arc (dynspec.py:1458-1473)
+    from scintools.dynspec import BasicDyn
+    d = np.load("/root/reference/scintools/examples/data/ththsims/Sample_Data.npz")
+    dspec = np.abs(d["Espec"]) ** 2
+    freq, tme = d["f_MHz"], d["t_s"]
+    b = BasicDyn(name="Sample Data", header=["Sample Data"], times=tme, freqs=freq, dyn=dspec,
+                 nsub=tme.shape[0], nchan=freq.shape[0], dt=(tme[1] - tme[0]), df=(freq[1] - freq[0]))
+    sd = Dynspec(dyn=b, process=False, verbose=False)
+    sd.prep_thetatheta(verbose=False, cwf=64, edges_lim=.3)
+    out.update(pt_eta_min=V(sd.eta_min), pt_eta_max=V(sd.eta_max), pt_neta=sd.neta, pt_betaeta=sd.betaeta,
+               pt_betaetaerr=sd.betaetaerr, pt_betaetaerr2=sd.betaetaerr2, pt_edges=V(sd.edges))
     save("arcfit.npz", **out)
 
 

@@ -180,6 +180,8 @@ class Quantity(np.ndarray):
         return out
 
     def to(self, unit):
+        if isinstance(unit, Quantity):      # astropy accepts `1 / (u.m * u.mHz**2)` as a unit
+            unit = UnitBase(unit.unit.scale * float(unit.value), unit.unit.powers)
         f = self._unit._to(unit)
         v = self.view(np.ndarray)
         v = v.copy() if f == 1.0 else v * f

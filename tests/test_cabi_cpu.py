@@ -97,8 +97,9 @@ def test_prep_thetatheta_host_logic_matches_reference(golden):
     assert d.fref == float(g["fref"])
     assert d.eta_min == float(g["eta_min"]) and d.eta_max == float(g["eta_max"])
     assert np.array_equal(d.edges, g["edges"])
-    with pytest.raises(NotImplementedError):
-        d.prep_thetatheta(cwf=64, edges_lim=.3)            # needs fit_arc in the reference
+    from scintools_amd._lib import ScintHipError
+    with pytest.raises(ScintHipError, match="no HIP device"):
+        d.prep_thetatheta(cwf=64, edges_lim=.3)            # bounds from fit_arc: device work, no CPU fallback
     with pytest.raises(AssertionError):
         d.prep_thetatheta(eta_min=30, eta_max=50, nedge=301)
 
