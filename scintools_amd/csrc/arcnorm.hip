@@ -93,24 +93,36 @@ struct NormRow {
         if (x != x) return x;
         if (x > x_hi) return fp(c1);
         if (x < x_lo) return fp(c0);
-        // j = largest column with xp(j) <= x: uniform-axis guess, short walk, bisection fallback
-        double g = floor((x - x_lo) * inv_step);
+        // j = largest column with xp(j) <= x: uniform-axis guess, short walk, bisection fallback.
+        // xp(j) and xp(j+1) are carried along so that the usual case costs two divisions.
+        const double g = floor((x - x_lo) * inv_step);
         int64_t j = c0 + (int64_t)fmin(fmax(g, 0.0), (double)(n - 1));
+        double xj = xp(j), xj1 = 0.0;
+        bool have1 = false;
         int walk = 0;
-        while (j < c1 && xp(j + 1) <= x && walk < 4) { ++j; ++walk; }
-        while (j > c0 && xp(j) > x && walk < 8) { --j; ++walk; }
-        if ((j < c1 && xp(j + 1) <= x) || xp(j) > x) {
+        while (xj > x && j > c0 && walk < 6) { xj1 = xj; have1 = true; --j; xj = xp(j); ++walk; }
+        if (!(xj > x)) {
+            while (j < c1 && walk < 6) {
+                if (!have1) { xj1 = xp(j + 1); have1 = true; }
+                if (xj1 > x) break;
+                ++j; xj = xj1; have1 = false; ++walk;
+            }
+        }
+        if (xj > x || (j < c1 && (have1 ? xj1 : xp(j + 1)) <= x)) {
             int64_t lo = c0, hi = c1 + 1;  // first column with xp > x is in (lo, hi]
             while (lo < hi) {
                 const int64_t mid = lo + ((hi - lo) >> 1);
                 if (x >= xp(mid)) lo = mid + 1; else hi = mid;
             }
             j = lo - 1;
+            xj = xp(j);
+            have1 = false;
         }
         if (j == c1) return fp(j);
-        const double xj = xp(j), fj = fp(j);
+        const double fj = fp(j);
         if (xj == x) return fj;
-        const double xj1 = xp(j + 1), fj1 = fp(j + 1);
+        if (!have1) xj1 = xp(j + 1);
+        const double fj1 = fp(j + 1);
         const double slope = (fj1 - fj) / (xj1 - xj);
         double r = slope * (x - xj) + fj;
         if (r != r) {

@@ -186,3 +186,132 @@ def test_norm_sspec_errors(ds, golden):
     for kw in (dict(plot=True), dict(velocity=True), dict(interp_nan=True), dict(fit_spectrum=True)):
         with pytest.raises(NotImplementedError):
             d.norm_sspec(eta=float(g["fa_betaeta"]), **kw)
+
+
+# ------------------------------------------------------------------ kernels, directly
+def _interp_rows(ds, sspec, fdop, yaxis, eta, maxnormfac, x, cut=(0, 0), offset=None, xlin=None, row0=0):
+    import torch
+    from scintools_amd import _lib
+    from scintools_amd.device import empty, ptr, stream_ptr, to_device
+    lib = _lib.load()
+    nrow, nc = sspec.shape
+    nr, nx = nrow - row0, len(x)
+    t = lambda a: None if a is None else to_device(np.ascontiguousarray(a, dtype=float), torch.float64)
+    s_t, f_t, y_t, x_t, o_t, l_t = t(sspec), t(fdop), t(yaxis), t(x), t(offset), t(xlin)
+    norm, mask, pw = empty((nr, nx), torch.float64), empty((nr, nx), torch.uint8), empty((nr,), torch.float64)
+    rc = lib.scint_norm_sspec(ptr(s_t), nc, nc, ptr(f_t), ptr(y_t), row0, nr, float(eta), float(maxnormfac),
+                              int(cut[0]), int(cut[1]), ptr(o_t), ptr(x_t), ptr(l_t), nx, ptr(norm), ptr(mask),
+                              ptr(pw), stream_ptr())
+    _lib.check(rc, "scint_norm_sspec")
+    return norm.cpu().numpy(), mask.cpu().numpy().astype(bool), pw.cpu().numpy()
+
+
+def _interp_rows_numpy(sspec, fdop, yaxis, eta, maxnormfac, x, cut=(0, 0), offset=None, row0=0):
+    s = np.array(sspec[row0:], dtype=float)
+    s[:, cut[0]:cut[1]] = np.nan
+    if offset is not None:
+        s = s - offset[:, None]
+    out, mask = [], []
+    for r in range(s.shape[0]):
+        scale = np.sqrt(yaxis[row0 + r] / eta)
+        sel = abs(fdop) <= maxnormfac * scale
+        xp = fdop[sel] / scale
+        out.append(np.interp(x, xp, s[r, sel]))
+        mask.append((np.abs(x) > np.max(np.abs(xp))) | np.isnan(out[-1]))
+    return np.array(out), np.array(mask)
+
+
+@pytest.mark.parametrize("axis", ["uniform", "irregular", "coarse"])
+def test_interp_kernel_bit_exact_incl_nonfinite(ds, axis):
+    """np.interp reproduced bit for bit on axes that defeat the uniform-grid guess, with NaN,
+    +-inf and repeated values in the data, x exactly on sample points and outside the range."""
+    rng = np.random.default_rng(5)
+    nc, nrow = (257, 40) if axis != "coarse" else (9, 12)
+    if axis == "irregular":
+        fdop = np.sort(np.concatenate([rng.uniform(-20, 20, nc - 60), rng.normal(0, 0.05, 60)]))
+    else:
+        fdop = np.linspace(-20, 20, nc)
+    sspec = rng.standard_normal((nrow, nc)) * 10 + 30
+    sspec[3, 100 % nc] = np.nan
+    sspec[4, 5 % nc] = -np.inf
+    sspec[5, 7 % nc] = np.inf
+    sspec[6, :] = 2.5                       # equal neighbours: the dy[j] == dy[j+1] retry branch
+    sspec[6, nc // 3] = np.nan
+    sspec[7, nc // 2:] = -np.inf
+    yaxis = np.linspace(0.1, 4.0, nrow)
+    eta = 0.01
+    x = np.concatenate([np.linspace(-3, 3, 801), fdop[::7] / np.sqrt(yaxis[nrow // 2] / eta), [np.nan, -50.0, 50.0]])
+    for cut, off in (((0, 0), None), ((nc // 2 - 2, nc // 2 + 2), rng.standard_normal(nrow - 1))):
+        got, gmask, pw = _interp_rows(ds, sspec, fdop, yaxis, eta, 3.0, x, cut=cut, offset=off, row0=1)
+        ref, rmask = _interp_rows_numpy(sspec, fdop, yaxis, eta, 3.0, x, cut=cut, offset=off, row0=1)
+        assert np.array_equal(got, ref, equal_nan=True)
+        assert np.array_equal(gmask, rmask)
+        lin = np.where(rmask | ~np.isfinite(ref), np.nan, 10**(ref / 10))
+        with np.errstate(invalid="ignore"):
+            want = np.array([np.nanmean(r) if np.any(~np.isnan(r)) else np.nan for r in lin])
+        np.testing.assert_allclose(pw, want, rtol=1e-12, equal_nan=True)
+
+
+def test_masked_colavg_rownanmean_blockstd(ds):
+    import ctypes
+    import torch
+    from scintools_amd import _lib
+    from scintools_amd.device import empty, ptr, stream_ptr, to_device
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    nr, nx = 131, 300
+    a = rng.standard_normal((nr, nx)) * 5 + 20
+    m = rng.random((nr, nx)) < 0.3
+    m[:, 17] = True                                     # a column with no entry
+    w = rng.uniform(0.5, 2.0, nr)
+    sel = (rng.random(nr) < 0.7).astype(np.uint8)
+    a_t, m_t = to_device(a, torch.float64), to_device(m.astype(np.uint8), torch.uint8)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_masked_colavg_workspace_bytes(nr, nx, ctypes.byref(need)))
+    ws = empty((need.value,), torch.uint8)
+    for rowsel in (None, sel):
+        avg, none = empty((nx,), torch.float64), empty((nx,), torch.uint8)
+        r_t = None if rowsel is None else to_device(rowsel, torch.uint8)
+        _lib.check(lib.scint_masked_colavg(ptr(a_t), ptr(m_t), nr, nx, ptr(to_device(w, torch.float64)), ptr(r_t),
+                                           ptr(avg), ptr(none), ptr(ws), ws.numel(), stream_ptr()))
+        rows = np.ones(nr, bool) if rowsel is None else rowsel.astype(bool)
+        ref = np.ma.average(np.ma.array(a, mask=m)[rows], axis=0, weights=w[rows])
+        assert np.array_equal(none.cpu().numpy().astype(bool), np.ma.getmaskarray(ref))
+        got = avg.cpu().numpy()
+        ok = ~np.ma.getmaskarray(ref)
+        np.testing.assert_allclose(got[ok], np.asarray(ref[ok]), rtol=1e-13)
+        assert np.all(got[~ok] == 0.0)
+    # nanmean over selected columns of a row block
+    b = a.copy()
+    b[rng.random(b.shape) < 0.1] = np.nan
+    colsel = (rng.random(nx) < 0.4).astype(np.uint8)
+    out = empty((nr - 3,), torch.float64)
+    _lib.check(lib.scint_row_nanmean(ptr(to_device(b, torch.float64)), nx, nx, 3, nr - 3,
+                                     ptr(to_device(colsel, torch.uint8)), 40, 44, ptr(out), stream_ptr()))
+    bb = b[3:].copy()
+    bb[:, 40:44] = np.nan
+    np.testing.assert_allclose(out.cpu().numpy(), np.nanmean(bb[:, colsel.astype(bool)], axis=1), rtol=1e-13)
+    # std of the outer block
+    std = empty((1,), torch.float64)
+    w2 = empty((8 * 1032,), torch.uint8)
+    _lib.check(lib.scint_block_std(ptr(a_t), nx, nx, nr // 2, nr, 140, 155, ptr(std), ptr(w2), w2.numel(), stream_ptr()))
+    ref = np.std(np.concatenate((a[nr // 2:, 155:].ravel(), a[nr // 2:, :140].ravel())))
+    assert float(std.cpu().numpy()[0]) == pytest.approx(ref, rel=1e-13)
+
+
+@pytest.mark.parametrize("nf", [4, 5, 33])
+def test_spline_resample_irregular_knots(ds, nf):
+    """Not-a-knot cubic spline on irregular channel spacing, down to scipy's 4-point minimum."""
+    import torch
+    from scipy.interpolate import interp1d
+    from scintools_amd.arcfit import spline_resample_device
+    from scintools_amd.device import to_device
+    rng = np.random.default_rng(nf)
+    x = np.sort(rng.uniform(1000, 1400, nf))
+    y = rng.standard_normal((nf, 70)) * 3 + 7
+    f = np.concatenate([[x[0], x[-1]], rng.uniform(x[0], x[-1], 41), x[1:-1]])
+    got = spline_resample_device(to_device(y, torch.float64), x, f).cpu().numpy()
+    ref = np.flipud(np.stack([interp1d(x, y[:, k], kind="cubic")(f) for k in range(y.shape[1])], axis=1))
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-12
+    with pytest.raises(ValueError):
+        spline_resample_device(to_device(y, torch.float64), x, np.array([x[0] - 1.0]))
