@@ -133,7 +133,7 @@ def scale_dyn_lambda(self, spacing="auto"):
         feq[np.argmin(feq)] = min(freqs)
     dyn_t = to_device(np.asarray(self.dyn, dtype=float), torch.float64)
     lam_t = spline_resample_device(dyn_t, freqs, feq)
-    self.lamdyn = lam_t.cpu().numpy()
+    type(self).lamdyn.park(self, lam_t)                 # stays in HBM until the host reads it
     self.lam = np.flipud(lam_eq)
     self.nlam = len(self.lam)
 
@@ -142,22 +142,16 @@ def scale_dyn_lambda(self, spacing="auto"):
 # norm_sspec
 # ----------------------------------------------------------------------------
 def _sspec_for(self, lamsteps):
-    """The dB spectrum / delay axis pair norm_sspec and fit_arc work on, computing it if absent."""
+    """Device tensor of the dB spectrum norm_sspec / fit_arc work on and its delay axis,
+    computing the spectrum if absent (dynspec.py:1993-2023, 1069-1090)."""
+    cls = type(self)
     if lamsteps:
-        if not hasattr(self, "lamsspec"):
+        if not cls.lamsspec.present(self):
             self.calc_sspec(lamsteps=True)
-        return self.lamsspec, self.beta
-    if not hasattr(self, "sspec"):
+        return cls.lamsspec.tensor(self), self.beta
+    if not cls.sspec.present(self):
         self.calc_sspec()
-    return self.sspec, self.tdel
-
-
-def _device_copy(self, host):
-    """Device copy of a host spectrum; reuses the tensor a running fit_arc parked on self."""
-    cached = getattr(self, "_arc_dev_cache", None)
-    if cached is not None and cached[0] is host:
-        return cached[1]
-    return to_device(np.asarray(host, dtype=float), torch.float64)
+    return cls.sspec.tensor(self), self.tdel
 
 
 def norm_sspec(self, eta=None, delmax=None, plot=False, startbin=1, maxnormfac=5, minnormfac=0, cutmid=0,
@@ -182,7 +176,11 @@ def norm_sspec(self, eta=None, delmax=None, plot=False, startbin=1, maxnormfac=5
     if not hasattr(self, "tdel"):
         self.calc_sspec(lamsteps=lamsteps)
     delmax = np.max(self.tdel) if delmax is None else delmax
-    sspec_h, yaxis = _sspec_for(self, lamsteps)
+    held = getattr(self, "_arc_dev_cache", None)          # a running fit_arc: (tensor, yaxis, lamsteps)
+    if held is not None and held[2] == bool(lamsteps):
+        sspec_t, yaxis = held[0], held[1]
+    else:
+        sspec_t, yaxis = _sspec_for(self, lamsteps)
     if eta is None:
         if not hasattr(self, "betaeta" if lamsteps else "eta"):
             self.fit_arc(lamsteps=lamsteps, delmax=delmax, plot=plot, startbin=startbin)
@@ -197,7 +195,7 @@ def norm_sspec(self, eta=None, delmax=None, plot=False, startbin=1, maxnormfac=5
     if np.any(np.diff(fdop) <= 0):
         raise ValueError("norm_sspec: the fdop axis must be ascending")
     ind = int(np.argmin(abs(self.tdel - delmax)))
-    nrow_all, nc = np.shape(sspec_h)
+    nrow_all, nc = (int(v) for v in sspec_t.shape)
     row0 = int(startbin)
     nr = len(range(nrow_all)[startbin:ind])
     tdel = np.array(yaxis[startbin:ind], dtype=float)
@@ -205,7 +203,6 @@ def norm_sspec(self, eta=None, delmax=None, plot=False, startbin=1, maxnormfac=5
         raise IndexError("index -1 is out of bounds for axis 0 with size 0")
     cut_lo = int(nc / 2 - np.floor(cutmid / 2))
     cut_hi = int(nc / 2 + np.floor(cutmid / 2))
-    sspec_t = _device_copy(self, sspec_h)
     fdop_t = to_device(fdop, torch.float64)
     yaxis_t = to_device(np.asarray(yaxis, dtype=float), torch.float64)
     offset_t = None
@@ -347,13 +344,12 @@ def fit_arc(self, asymm=False, plot=False, delmax=None, numsteps=1e4, startbin=3
     if not hasattr(self, "tdel"):
         self.calc_sspec()
     delmax = np.max(self.tdel) if delmax is None else delmax
-    sspec_h, yaxis = _sspec_for(self, lamsteps)
-    yaxis = np.array(yaxis, dtype=float)
+    sspec_t, yaxis_full = _sspec_for(self, lamsteps)
+    yaxis = np.array(yaxis_full, dtype=float)
     ind = int(np.argmin(abs(self.tdel - delmax)))
     ymax = self.beta[ind]                                # dynspec.py:1092 (needs a lamsteps spectrum)
-    nr, nc = np.shape(sspec_h)
+    nr, nc = (int(v) for v in sspec_t.shape)
     # noise of the spectrum: std of the outer half in delay, centre columns excluded (dynspec.py:1097-1101)
-    sspec_t = to_device(np.asarray(sspec_h, dtype=float), torch.float64)
     c_hi = int(nc / 2 + np.ceil(cutmid / 2))
     c_lo = int(nc / 2 - np.floor(cutmid / 2))
     std_t = empty((1,), torch.float64)
@@ -377,7 +373,7 @@ def fit_arc(self, asymm=False, plot=False, delmax=None, numsteps=1e4, startbin=3
         etamin_array = np.array([etamin])
         etamax_array = np.array([etamax])
     sqrt_eta_all = np.linspace(np.sqrt(np.min(etamin_array)), np.sqrt(np.max(etamax_array)), int(numsteps))
-    self._arc_dev_cache = (sspec_h, sspec_t)
+    self._arc_dev_cache = (sspec_t, yaxis_full, bool(lamsteps))
     try:
         for iarc in range(len(etamin_array)):
             if len(etamin_array) != 1:

@@ -80,3 +80,55 @@ class _PerThreadWorkspace:
 
 
 workspace = _PerThreadWorkspace()
+
+
+class DeviceBacked:
+    """Attribute that stays in HBM until the host first looks at it.
+
+    The reference keeps its spectra as NumPy attributes (``self.sspec`` ...).  Here a kernel's
+    output is parked as a device tensor; internal consumers take it straight from HBM
+    (``DeviceBacked.tensor``).  The first host read copies it down ONCE and hands ownership to
+    the host array -- the device copy is dropped, so in-place edits of the NumPy array are
+    always honoured by later calls (they re-upload it).  Assignment stores a host value."""
+
+    def __init__(self, name):
+        self.name = name
+        self.slot = "_devbacked_" + name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        state = obj.__dict__.get(self.slot)
+        if state is None:
+            raise AttributeError(f"'{type(obj).__name__}' object has no attribute '{self.name}'")
+        if state[0] is None:
+            state[0] = state[1].cpu().numpy()
+            state[1] = None
+        return state[0]
+
+    def __set__(self, obj, value):
+        obj.__dict__[self.slot] = [value, None]
+
+    def __delete__(self, obj):
+        obj.__dict__.pop(self.slot, None)
+
+    # -- internal side ---------------------------------------------------------------
+    def park(self, obj, tensor):
+        """Store a kernel output without copying it to the host."""
+        obj.__dict__[self.slot] = [None, tensor]
+
+    def present(self, obj):
+        return obj.__dict__.get(self.slot) is not None
+
+    def tensor(self, obj, dtype=torch.float64):
+        """Device tensor of the current value: the parked one, or an upload of the host array."""
+        state = obj.__dict__.get(self.slot)
+        if state is None:
+            raise AttributeError(f"'{type(obj).__name__}' object has no attribute '{self.name}'")
+        if state[1] is not None:
+            return state[1]
+        return to_device(np.asarray(state[0]), dtype)
+
+    def shape(self, obj):
+        state = obj.__dict__[self.slot]
+        return tuple(state[1].shape) if state[1] is not None else np.shape(state[0])

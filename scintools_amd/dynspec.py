@@ -25,7 +25,7 @@ import torch
 
 from . import _lib, arcfit, units
 from . import ththmod as thth
-from .device import empty, ptr, require_gpu, stream_ptr, to_device, workspace
+from .device import DeviceBacked, empty, ptr, require_gpu, stream_ptr, to_device, workspace
 
 _WINDOWS = {"hanning": np.hanning, "hamming": np.hamming,
             "blackman": np.blackman, "bartlett": np.bartlett}
@@ -77,7 +77,14 @@ def sspec_device(dyn_t, prewhite=False, halve=True, window="hanning", window_fra
 
 class Dynspec:
     """Dynamic-spectrum holder with the reference's attribute names
-    (dynspec.py:400-413) and a GPU ``calc_sspec``."""
+    (dynspec.py:400-413) and a GPU ``calc_sspec``.
+
+    ``sspec``, ``lamsspec`` and ``lamdyn`` are the reference's NumPy attributes, but a freshly
+    computed one stays in HBM until it is first read (``device.DeviceBacked``): the chain
+    ``scale_dyn -> calc_sspec(lamsteps=True) -> fit_arc`` then never crosses PCIe."""
+    sspec = DeviceBacked("sspec")
+    lamsspec = DeviceBacked("lamsspec")
+    lamdyn = DeviceBacked("lamdyn")
 
     def __init__(self, filename=None, dyn=None, verbose=True, process=False, lamsteps=False,
                  remove_short_subs=True, subint_thresh=2.33, mjd=None):
@@ -223,16 +230,16 @@ class Dynspec:
                                       "which is outside the accelerated hot path")
         if plot:
             raise NotImplementedError("plotting is outside the accelerated hot path")
+        cls = type(self)
         if input_dyn is not None:
             dyn_t = to_device(input_dyn, torch.float64)
         elif lamsteps:
-            if not hasattr(self, "lamdyn"):
+            if not cls.lamdyn.present(self):
                 self.scale_dyn()
-            dyn_t = to_device(self.lamdyn, torch.float64)
+            dyn_t = cls.lamdyn.tensor(self)
         else:
             dyn_t = to_device(self.dyn, torch.float64)
-        sec = sspec_device(dyn_t, prewhite=prewhite, halve=halve, window=window,
-                           window_frac=window_frac).cpu().numpy()
+        sec_t = sspec_device(dyn_t, prewhite=prewhite, halve=halve, window=window, window_frac=window_frac)
         nf, nt = dyn_t.shape
         nrfft = int(2 ** (np.ceil(np.log2(nf)) + 1))
         ncfft = int(2 ** (np.ceil(np.log2(nt)) + 1))
@@ -244,14 +251,14 @@ class Dynspec:
             beta = np.divide(td, (nrfft * self.dlam))                            # m^-1 (dynspec.py:3703-3704)
         if input_dyn is None and not return_sspec:
             if lamsteps:
-                self.lamsspec = sec
+                cls.lamsspec.park(self, sec_t)      # copied to the host when first read
                 self.beta = beta
             else:
-                self.sspec = sec
+                cls.sspec.park(self, sec_t)
             self.fdop = fdop
             self.tdel = tdel
             return None
-        return fdop, (beta if lamsteps else tdel), sec
+        return fdop, (beta if lamsteps else tdel), sec_t.cpu().numpy()
 
     # ------------------------------------------------------------------ arc normalisation
     def scale_dyn(self, scale='lambda', window_frac=0.1, pars=None, parfile=None, window='hanning',

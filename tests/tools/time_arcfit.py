@@ -53,6 +53,17 @@ out["norm_sspec_shape"] = [len(d.normsspec_tdel), len(np.ravel(d.normsspec_fdop)
 out["fit_arc_s"] = timed(lambda: d.fit_arc(lamsteps=True, numsteps=1e4))
 out["betaeta"] = float(d.betaeta)
 
+
+def chain():
+    """What prep_thetatheta's fallback runs: dynspec -> lambda resample -> sspec -> fit_arc, with
+    every intermediate parked in HBM (only the dynamic spectrum crosses PCIe)."""
+    e = Dynspec(dyn=o, verbose=False)
+    e.fit_arc(lamsteps=True, numsteps=1e4)
+    return e
+
+
+out["chain_dyn_to_betaeta_s"] = timed(chain)
+
 # kernel-only time of the norm_sspec row kernel through the library's hipEvent profiler
 lib = _lib.load()
 import ctypes  # noqa: E402
