@@ -233,10 +233,14 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
  *   M[0] = end[0]*M[1] + end[1]*M[2],  M[nf-1] = end[2]*M[nf-2] + end[3]*M[nf-3];
  *   per target k: interval idx[k] and coef[k][4]: S = c0*y[i] + c1*y[i+1] + c2*M[i] + c3*M[i+1].
  * `reverse` != 0: the frequency axis is descending and row i of the spline is dyn row nf-1-i.
- * workspace: nf*nt doubles. */
+ * Both sweeps contract, so they run in independent frequency blocks of `block_rows` rows, each
+ * started `warm` rows early from zero; the caller sizes `warm` from the factors so that the
+ * start-up error is below rounding (block_rows <= 0: one block, the plain sequential sweep).
+ * workspace: 2*nf*nt doubles. */
 int32_t scint_spline_resample(const double* dyn, int64_t nf, int64_t nt, int32_t reverse,
                               const double* h, const double* sub, const double* inv,
                               const double* sup, const double* end /*HOST [4]*/,
+                              int64_t block_rows, int64_t warm,
                               const int32_t* idx, const double* coef, int64_t nout,
                               double* out, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -68,8 +68,8 @@ _SIGNATURES = {
     "scint_acf_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_acf": ([_P, c_int64, c_int64, c_int32, c_int32, _P, _P, c_size_t, _P], c_int32),
     "scint_chisq": ([_P, c_int64, _P, c_int64, c_int64, _P, c_double, _P, _P], c_int32),
-    "scint_spline_resample": ([_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, POINTER(c_double), _P, _P, c_int64,
-                               _P, _P, c_size_t, _P], c_int32),
+    "scint_spline_resample": ([_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, POINTER(c_double), c_int64, c_int64,
+                               _P, _P, c_int64, _P, _P, c_size_t, _P], c_int32),
     "scint_norm_sspec": ([_P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_double, c_double, c_int64, c_int64,
                           _P, _P, _P, c_int64, _P, _P, _P, _P], c_int32),
     "scint_masked_colavg_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),

@@ -62,6 +62,35 @@ def _spline_system(x):
     return h, a, inv, sup, end
 
 
+_SPLINE_BLOCK_ROWS = 128
+
+
+def _spline_blocks(sub, inv, sup, n):
+    """Frequency blocking of the two Thomas sweeps.  An error e in the forward value d_{i-1}
+    reaches d_i as -sub[i]*inv[i]*e, one in M[i+1] reaches M[i] as -sup[i]*e: both factors are
+    ~0.27 on a uniform axis, so a block may start `warm` rows early from zero.  `warm` is the
+    shortest run over which EVERY window of factors multiplies to < 1e-22 (far below the 1e-16
+    rounding of the values themselves); if the axis is so irregular that this needs more than a
+    few blocks' worth of rows, fall back to one block (the plain sequential sweep)."""
+    rows = n - 2
+    if rows < 4 * _SPLINE_BLOCK_ROWS:
+        return 0, 0
+    tiny = 1e-300                                              # an exact zero factor (uniform ends) decouples
+    lf = np.log(np.maximum(np.abs(sub[2:n - 1] * inv[2:n - 1]), tiny))   # forward factors, rows 2..n-2
+    lb = np.log(np.maximum(np.abs(sup[1:n - 2]), tiny))                   # backward factors, rows 1..n-3
+    target = np.log(1e-22)
+    warm = 0
+    for lg in (lf, lb):
+        c = np.concatenate([[0.0], np.cumsum(lg)])
+        w = 8
+        while w < len(lg) and np.max(c[w:] - c[:-w]) > target:
+            w += 8
+        warm = max(warm, w)
+    if warm > 2 * _SPLINE_BLOCK_ROWS:
+        return 0, 0
+    return _SPLINE_BLOCK_ROWS, int(warm)
+
+
 def spline_resample_device(dyn_t, freqs, feq):
     """Cubic-spline (scipy ``interp1d(kind='cubic')``) resample of every time column of the
     device array dyn_t[nf, nt] from `freqs` to `feq`, rows flipped (dynspec.py:3948-3957)."""
@@ -94,14 +123,15 @@ def spline_resample_device(dyn_t, freqs, feq):
     A = (x[idx + 1] - feq) / hk
     B = (feq - x[idx]) / hk
     coef = np.stack([A, B, (A**3 - A) * hk**2 / 6.0, (B**3 - B) * hk**2 / 6.0], axis=1)
-    ws = workspace.get(8 * nf * nt)
+    block_rows, warm = _spline_blocks(sub, inv, sup, nf)
+    ws = workspace.get(2 * 8 * nf * nt)
     out = empty((len(feq), nt), torch.float64)
     dev = lambda v: to_device(np.ascontiguousarray(v, dtype=float), torch.float64)
     h_t, sub_t, inv_t, sup_t, coef_t = dev(h), dev(sub), dev(inv), dev(sup), dev(coef)
     idx_t = to_device(idx.astype(np.int32), torch.int32)
     rc = lib.scint_spline_resample(ptr(dyn_t), nf, nt, reverse, ptr(h_t), ptr(sub_t), ptr(inv_t), ptr(sup_t),
-                                   end.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ptr(idx_t), ptr(coef_t),
-                                   len(feq), ptr(out), ptr(ws), ws.numel(), stream_ptr())
+                                   end.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), block_rows, warm,
+                                   ptr(idx_t), ptr(coef_t), len(feq), ptr(out), ptr(ws), ws.numel(), stream_ptr())
     _lib.check(rc, "scint_spline_resample")
     return out
 

@@ -28,32 +28,52 @@ struct SplineSys {
     double e0, e1, e2, e3;
 };
 
-// One thread per time column (loads coalesce across the wavefront); the recurrence along
-// frequency is sequential.  M (second derivatives) overwrite the forward-sweep values in ws.
+// Thomas sweeps of the moment system, one thread per (time column, frequency block); loads
+// coalesce across the wavefront along time.  Both recurrences contract (|sub*inv|, |sup| are
+// about 0.27 on a uniform axis), so a block does not wait for its neighbour: it starts `warm`
+// rows early from zero and the start-up error has decayed below rounding (the host sizes `warm`
+// from the actual factors) by the first row it stores.  blockIdx.y = frequency block.
 __global__ void __launch_bounds__(64)
-spline_moments_kernel(const double* dyn, int64_t nf, int64_t nt, int reverse, SplineSys s, double* ws) {
+spline_forward_kernel(const double* dyn, int64_t nf, int64_t nt, int reverse, SplineSys s,
+                      int64_t block_rows, int64_t warm, double* D) {
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= nt) return;
+    const int64_t first = 1 + (int64_t)blockIdx.y * block_rows;       // rows [first, last) are stored
+    const int64_t last = min(first + block_rows, nf - 1);
+    const int64_t i0 = max((int64_t)1, first - warm);
     auto row = [&](int64_t i) { return (reverse ? nf - 1 - i : i) * nt + t; };
-    double y_prev = gload(dyn + row(0)), y_cur = gload(dyn + row(1));
+    double y_prev = gload(dyn + row(i0 - 1)), y_cur = gload(dyn + row(i0));
     double dp = 0.0;
-    for (int64_t i = 1; i <= nf - 2; ++i) {
+    for (int64_t i = i0; i < last; ++i) {
         const double y_next = gload(dyn + row(i + 1));
         const double r = 6.0 * ((y_next - y_cur) / gload(s.h + i) - (y_cur - y_prev) / gload(s.h + i - 1));
         dp = (r - gload(s.sub + i) * dp) * gload(s.inv + i);
-        gstore(ws + i * nt + t, dp);
+        if (i >= first) gstore(D + i * nt + t, dp);
         y_prev = y_cur; y_cur = y_next;
     }
-    double m_next = dp;  // M[nf-2] is the last forward value
-    for (int64_t i = nf - 3; i >= 1; --i) {
-        m_next = gload(ws + i * nt + t) - gload(s.sup + i) * m_next;
-        gstore(ws + i * nt + t, m_next);
+}
+
+__global__ void __launch_bounds__(64)
+spline_backward_kernel(const double* D, int64_t nf, int64_t nt, SplineSys s, int64_t block_rows,
+                       int64_t warm, double* M) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= nt) return;
+    const int64_t first = 1 + (int64_t)blockIdx.y * block_rows;
+    const int64_t last = min(first + block_rows, nf - 1);
+    const int64_t i1 = min(nf - 2, last - 1 + warm);
+    double m_next = 0.0;   // exact at i1 == nf-2 (sup[nf-2] == 0), decayed away otherwise
+    for (int64_t i = i1; i >= first; --i) {
+        m_next = gload(D + i * nt + t) - gload(s.sup + i) * m_next;
+        if (i < last) gstore(M + i * nt + t, m_next);
     }
-    // not-a-knot ends: M[0] and M[nf-1] follow from their two neighbours (own writes, same thread)
-    const double m1 = gload(ws + nt + t), m2 = gload(ws + 2 * nt + t);
-    const double mn2 = gload(ws + (nf - 2) * nt + t), mn3 = gload(ws + (nf - 3) * nt + t);
-    gstore(ws + t, s.e0 * m1 + s.e1 * m2);
-    gstore(ws + (nf - 1) * nt + t, s.e2 * mn2 + s.e3 * mn3);
+}
+
+// not-a-knot ends: M[0] and M[nf-1] follow from their two neighbours
+__global__ void __launch_bounds__(256) spline_ends_kernel(int64_t nf, int64_t nt, SplineSys s, double* M) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    gstore(M + t, s.e0 * gload(M + nt + t) + s.e1 * gload(M + 2 * nt + t));
+    gstore(M + (nf - 1) * nt + t, s.e2 * gload(M + (nf - 2) * nt + t) + s.e3 * gload(M + (nf - 3) * nt + t));
 }
 
 __global__ void __launch_bounds__(256)
@@ -285,22 +305,34 @@ using namespace scint;
 
 extern "C" int32_t scint_spline_resample(const double* dyn, int64_t nf, int64_t nt, int32_t reverse,
                                          const double* h, const double* sub, const double* inv,
-                                         const double* sup, const double* end, const int32_t* idx,
-                                         const double* coef, int64_t nout, double* out,
-                                         void* workspace, size_t workspace_bytes, void* stream_) {
+                                         const double* sup, const double* end, int64_t block_rows,
+                                         int64_t warm, const int32_t* idx, const double* coef,
+                                         int64_t nout, double* out, void* workspace,
+                                         size_t workspace_bytes, void* stream_) {
     SCINT_REQUIRE(dyn && h && sub && inv && sup && end && idx && coef && out && workspace,
                   "spline_resample: null pointer");
     SCINT_REQUIRE(nf >= 4 && nt >= 1 && nout >= 1, "spline_resample: need at least 4 channels");
     SCINT_REQUIRE(nout <= 65535, "spline_resample: too many output rows");
-    if (workspace_bytes < sizeof(double) * (size_t)nf * (size_t)nt) {
+    SCINT_REQUIRE(warm >= 0, "spline_resample: bad warm-up length");
+    if (workspace_bytes < 2 * sizeof(double) * (size_t)nf * (size_t)nt) {
         set_error("scint: spline_resample workspace too small");
         return SCINT_E_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_;
     SplineSys s{h, sub, inv, sup, end[0], end[1], end[2], end[3]};
-    double* M = (double*)workspace;
-    hipLaunchKernelGGL(spline_moments_kernel, dim3((unsigned)ceil_div(nt, 64)), dim3(64), 0, stream,
-                       dyn, nf, nt, (int)reverse, s, M);
+    double* D = (double*)workspace;
+    double* M = D + nf * nt;
+    const int64_t rows = nf - 2;                       // interior rows 1..nf-2
+    if (block_rows <= 0 || block_rows > rows) block_rows = rows;   // one block = the plain sweep
+    const int64_t nblk = ceil_div(rows, block_rows);
+    SCINT_REQUIRE(nblk <= 65535, "spline_resample: too many frequency blocks");
+    const dim3 grid((unsigned)ceil_div(nt, 64), (unsigned)nblk);
+    hipLaunchKernelGGL(spline_forward_kernel, grid, dim3(64), 0, stream, dyn, nf, nt, (int)reverse, s,
+                       block_rows, warm, D);
+    SCINT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(spline_backward_kernel, grid, dim3(64), 0, stream, D, nf, nt, s, block_rows, warm, M);
+    SCINT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(spline_ends_kernel, dim3((unsigned)ceil_div(nt, 256)), dim3(256), 0, stream, nf, nt, s, M);
     SCINT_LAUNCH_CHECK();
     hipLaunchKernelGGL(spline_eval_kernel, dim3((unsigned)ceil_div(nt, 256), (unsigned)nout), dim3(256), 0,
                        stream, dyn, nf, nt, (int)reverse, M, idx, coef, nout, out);

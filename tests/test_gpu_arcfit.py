@@ -299,7 +299,7 @@ def test_masked_colavg_rownanmean_blockstd(ds):
     assert float(std.cpu().numpy()[0]) == pytest.approx(ref, rel=1e-13)
 
 
-@pytest.mark.parametrize("nf", [4, 5, 33])
+@pytest.mark.parametrize("nf", [4, 5, 33, 700, 1500])
 def test_spline_resample_irregular_knots(ds, nf):
     """Not-a-knot cubic spline on irregular channel spacing, down to scipy's 4-point minimum."""
     import torch
