@@ -1,0 +1,140 @@
+"""Host-side logic of the arc-normalisation row, checked on the CPU (no kernels run):
+the spline system the host factors for scint_spline_resample, its frequency blocking, the
+DeviceBacked attribute protocol, and the parabola fits against the reference's goldens."""
+import numpy as np
+import pytest
+import torch
+from scipy.interpolate import interp1d
+
+from scintools_amd import arcfit
+from scintools_amd.device import DeviceBacked
+
+
+def _moments(x, y, block_rows=0, warm=0):
+    """What spline_forward/backward/ends_kernel compute, in NumPy (same recurrences, same order)."""
+    n = len(x)
+    h, a, inv, sup, end = arcfit._spline_system(x)
+    rows = n - 2
+    R = rows if block_rows <= 0 else block_rows
+    D = np.zeros_like(y)
+    M = np.zeros_like(y)
+    nblk = (rows + R - 1) // R
+    for b in range(nblk):
+        first, last = 1 + b * R, min(1 + b * R + R, n - 1)
+        dp = np.zeros(y.shape[1])
+        for i in range(max(1, first - warm), last):
+            r = 6.0 * ((y[i + 1] - y[i]) / h[i] - (y[i] - y[i - 1]) / h[i - 1])
+            dp = (r - a[i] * dp) * inv[i]
+            if i >= first:
+                D[i] = dp
+    for b in range(nblk):
+        first, last = 1 + b * R, min(1 + b * R + R, n - 1)
+        m = np.zeros(y.shape[1])
+        for i in range(min(n - 2, last - 1 + warm), first - 1, -1):
+            m = D[i] - sup[i] * m
+            if i < last:
+                M[i] = m
+    M[0] = end[0] * M[1] + end[1] * M[2]
+    M[n - 1] = end[2] * M[n - 2] + end[3] * M[n - 3]
+    return h, M
+
+
+def _evaluate(x, y, h, M, f):
+    idx = np.clip(np.searchsorted(x, f, side="right") - 1, 0, len(x) - 2)
+    hk = h[idx]
+    A, B = (x[idx + 1] - f) / hk, (f - x[idx]) / hk
+    return (A[:, None] * y[idx] + B[:, None] * y[idx + 1] + ((A**3 - A) * hk**2 / 6)[:, None] * M[idx] +
+            ((B**3 - B) * hk**2 / 6)[:, None] * M[idx + 1])
+
+
+@pytest.mark.parametrize("n,kind", [(4, "irregular"), (5, "irregular"), (33, "irregular"), (192, "uniform"),
+                                    (700, "irregular")])
+def test_spline_system_matches_scipy_cubic(n, kind):
+    rng = np.random.default_rng(n)
+    x = np.linspace(1200, 1500, n) if kind == "uniform" else np.sort(rng.uniform(1200, 1500, n))
+    y = rng.standard_normal((n, 3)) * 5 + 10
+    f = np.concatenate([[x[0], x[-1]], rng.uniform(x[0], x[-1], 60), x[1:-1]])
+    h, M = _moments(x, y)
+    ref = np.stack([interp1d(x, y[:, k], kind="cubic")(f) for k in range(3)], axis=1)
+    assert np.abs(_evaluate(x, y, h, M, f) - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["uniform", "irregular"])
+def test_spline_frequency_blocks_reproduce_the_sequential_sweep(kind):
+    n = 1400
+    rng = np.random.default_rng(3)
+    x = np.linspace(1200, 1500, n) if kind == "uniform" else np.sort(rng.uniform(1200, 1500, n))
+    h, a, inv, sup, end = arcfit._spline_system(x)
+    block_rows, warm = arcfit._spline_blocks(a, inv, sup, n)
+    assert block_rows == 128 and 8 <= warm <= 256
+    y = rng.standard_normal((n, 2)) * 7
+    _, seq = _moments(x, y)
+    _, blk = _moments(x, y, block_rows, warm)
+    assert np.abs(blk - seq).max() <= 1e-15 * np.abs(seq).max()
+    # few channels: one block (the plain sweep)
+    assert arcfit._spline_blocks(*arcfit._spline_system(x[:200])[1:4], 200) == (0, 0)
+
+
+def test_spline_blocks_fall_back_on_a_hostile_axis():
+    """Spacing that shrinks geometrically makes the forward recurrence contract too slowly for a
+    short warm-up: the host must then ask for the single sequential block."""
+    n = 1200
+    x = 1000.0 + np.cumsum(0.5 * 0.985**np.arange(n))[::-1].cumsum() * 1e-3
+    x = np.sort(x)
+    h, a, inv, sup, end = arcfit._spline_system(x)
+    block_rows, warm = arcfit._spline_blocks(a, inv, sup, n)
+    lf = np.abs(a[2:n - 1] * inv[2:n - 1])
+    if block_rows:     # accepted: then every window of `warm` factors really is below 1e-22
+        c = np.concatenate([[0.0], np.cumsum(np.log(np.maximum(lf, 1e-300)))])
+        assert np.max(c[warm:] - c[:-warm]) <= np.log(1e-22)
+    else:
+        assert warm == 0
+
+
+def test_device_backed_attribute_protocol():
+    class Holder:
+        spec = DeviceBacked("spec")
+
+    h = Holder()
+    assert not Holder.spec.present(h) and not hasattr(h, "spec")
+    t = torch.arange(6, dtype=torch.float64).reshape(2, 3)     # stands in for a device tensor
+    Holder.spec.park(h, t)
+    assert Holder.spec.present(h) and Holder.spec.shape(h) == (2, 3)
+    assert Holder.spec.tensor(h) is t                           # internal consumers: no copy
+    host = h.spec                                               # first host read: copied down once ...
+    assert isinstance(host, np.ndarray) and np.array_equal(host, t.numpy())
+    assert h.spec is host                                       # ... and from now on the host array owns the value
+    assert h.__dict__[Holder.spec.slot][1] is None              # the parked tensor is dropped
+    host[0, 0] = 99.0
+    assert h.spec[0, 0] == 99.0
+    h.spec = np.ones((4, 4))                                    # plain assignment stores a host value
+    assert Holder.spec.shape(h) == (4, 4) and h.spec.sum() == 16
+    del h.spec
+    assert not Holder.spec.present(h)
+    with pytest.raises(AttributeError):
+        h.spec
+
+
+def test_parabola_fits_match_reference_goldens(golden):
+    """fit_arc's last step on the reference's own profile (tests/golden/arcfit.npz)."""
+    g = golden("arcfit.npz")
+    eta_array, spec = g["fa_eta_array"], g["fa_spec"]
+    from scipy.signal import savgol_filter
+    smooth = savgol_filter(spec, 5, 1)
+    pk = int(np.argmin(np.abs(smooth - np.max(smooth))))
+    i1 = i2 = 1
+    power = smooth[pk]
+    while power > smooth[pk] - 1 and pk + i1 < len(smooth) - 1:
+        i1 += 1
+        power = smooth[pk - i1]
+    power = smooth[pk]
+    while power > smooth[pk] - 0.5 and pk + i2 < len(smooth) - 1:
+        i2 += 1
+        power = smooth[pk + i2]
+    yfit, eta, err = arcfit.fit_parabola(eta_array[pk - i1:pk + i2], spec[pk - i1:pk + i2])
+    assert eta == pytest.approx(float(g["fa_betaeta"]), rel=1e-10)
+    assert err / np.sqrt(2) == pytest.approx(float(g["fa_betaetaerr2"]), rel=1e-8)
+    from oracle import arcfit_oracle as ao
+    got = arcfit.fit_log_parabola(eta_array[pk - i1:pk + i2], spec[pk - i1:pk + i2])
+    ref = ao.fit_log_parabola(eta_array[pk - i1:pk + i2], spec[pk - i1:pk + i2])
+    assert got[1] == ref[1] and got[2] == ref[2] and np.array_equal(got[0], ref[0])
