@@ -44,6 +44,17 @@ def test_workspace_queries_and_argument_errors(lib):
     assert "null" in _lib.last_error()
     with pytest.raises(_lib.ScintHipError):
         _lib.check(lib.scint_fft2(None, None, 8, 16, None, 0, None), "scint_fft2")
+    # arc-normalisation entry points: sizes are host arithmetic, pointers are checked before any launch
+    assert lib.scint_masked_colavg_workspace_bytes(100, 300, ctypes.byref(n)) == 0
+    assert n.value == 8 * 3 * 4 * 300            # 4 partials of 32 rows, (sum, weight, count) per column
+    assert lib.scint_norm_sspec(None, 8, 8, None, None, 0, 4, 1.0, 5.0, 4, 4, None, None, None, 16,
+                                None, None, None, None) == 1
+    assert "norm_sspec: null pointer" in _lib.last_error()
+    assert lib.scint_spline_resample(None, 8, 8, 0, None, None, None, None, None, 0, 0, None, None, 4,
+                                     None, None, 0, None) == 1
+    assert "spline_resample: null pointer" in _lib.last_error()
+    assert lib.scint_block_std(None, 8, 8, 0, 4, 2, 6, None, None, 0, None) == 1
+    assert lib.scint_row_nanmean(None, 8, 8, 0, 4, None, 0, 0, None, None) == 1
 
 
 def test_no_cpu_fallback():
