@@ -1,6 +1,9 @@
-import sys, os, time
+"""Time the secondary-spectrum and conjugate-spectrum FFT paths on the GPU (hipEvents)."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from scintools_amd import ththmod as thth
 from scintools_amd.dynspec import sspec_device
 def t(fn, n=10):
