@@ -133,3 +133,34 @@ def test_psrflux_io_matches_reference(golden, tmp_path):
     d2 = Dynspec(filename=out, verbose=False)
     assert np.array_equal(d2.dyn, g["rt_dyn"]) and np.array_equal(d2.times, g["rt_times"])
     assert np.array_equal(d2.freqs, g["rt_freqs"]) and d2.mjd == float(g["rt_mjd"])
+
+
+def test_host_grid_randomised_against_oracle():
+    """Property test of the host grid logic (centres, crop, reduced edges, fft axes) over random
+    axis lengths, paddings, edge limits and curvatures: always identical to the oracle."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import thth_oracle as to
+    from scintools_amd.ththmod import _Grid, fft_axis
+
+    @settings(max_examples=60, deadline=None)
+    @given(nf=st.integers(8, 96), nt=st.integers(8, 96), npad=st.integers(0, 3), nedge=st.integers(4, 80),
+           lim=st.floats(0.05, 1.4), eta_scale=st.floats(0.02, 50.0), df=st.floats(0.01, 2.0),
+           dt=st.floats(1.0, 60.0))
+    def check(nf, nt, npad, nedge, lim, eta_scale, df, dt):
+        freqs = 1300.0 + df * np.arange(nf)
+        times = dt * np.arange(nt)
+        fd = fft_axis(times, 1000.0, npad)
+        tau = fft_axis(freqs, 1.0, npad)
+        assert np.array_equal(fd, to.fft_axis(times, 1000.0, npad))
+        assert np.array_equal(tau, to.fft_axis(freqs, 1.0, npad))
+        edges = np.linspace(-lim * fd.max(), lim * fd.max(), 2 * (nedge // 2))
+        eta = eta_scale * tau.max() / fd.max()**2
+        grid = _Grid(tau, fd, edges)
+        assert np.array_equal(grid.th_cents, to.theta_centres(edges))
+        keep, th = to.reduced_keep(tau, fd, eta, edges)
+        k = grid.keep(eta)
+        assert np.array_equal(k, np.nonzero(keep)[0])
+        if len(k) >= 3:
+            assert np.array_equal(grid.edges_red(k), to.reduced_edges(th[keep]))
+
+    check()
