@@ -1,0 +1,137 @@
+"""modeler / rev_map / chisq_calc at the BASELINE sizes (2048^2: config 2, 4096^2: config 3)
+against the CPU oracle (ththmod.py:176-368).
+
+At 4096^2 the conjugate spectrum has more delay rows than one workgroup of the rev_map kernel
+accumulates, so every back-map takes the multi-slab path (several tau slabs per Doppler column)
+that the small goldens never reach; 2048^2 is the largest single-slab case.  One oracle `modeler` per size is computed once (about 8 s at 2048^2 and
+about 40 s at 4096^2 of host time) and shared by the tests of that size.
+
+Tolerances: recov / model <= 1e-9 of the array maximum with IDENTICAL empty-bin masks;
+w rtol 1e-9; 1 - |<V, V_ref>| <= 1e-9; chi^2 rtol 1e-9.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(2048, 2), (4096, 3)]
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import thth_oracle as to
+    from scintools_amd import ththmod as thth
+    from scintools_amd.device import require_gpu
+    require_gpu()
+    return thth, to
+
+
+@pytest.fixture(scope="module", params=SIZES, ids=lambda p: f"{p[0]}sq")
+def case(env, request):
+    """Workload + oracle modeler + GPU modeler of one size.  Module-scoped and parametrised:
+    pytest groups the tests by size, so each oracle model is computed once."""
+    size, seed = request.param
+    thth, to = env
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=seed, nimg=64)
+    dyn -= dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    eta = 0.93 * eta_true
+    CS = to.conjugate_spectrum(dyn, 0)
+    ref = to.modeler(CS, tau, fd, eta, edges)
+    got = thth.modeler(CS, tau, fd, eta, edges)
+    return dict(size=size, dyn=dyn, fd=fd, tau=tau, edges=edges, eta=eta, CS=CS, ref=ref, got=got)
+
+
+def _assert_image_close(got, ref, rel, tag):
+    assert got.shape == ref.shape, tag
+    assert np.array_equal(got == 0, ref == 0), f"{tag}: empty-bin masks differ"
+    assert np.abs(got - ref).max() <= rel * np.abs(ref).max(), tag
+
+
+def test_modeler_vs_oracle(env, case):
+    """thth_red bit-equal; eigenpair, rank-1 model, back-mapped CS (multi-slab rev_map, rank-1
+    path) and model dynamic spectrum within 1e-9 of the oracle's (ththmod.py:274-327)."""
+    c = case
+    size = c["size"]
+    ref, got = c["ref"], c["got"]
+    assert got[0].shape == (size - 1, size - 1)
+    assert np.array_equal(got[0], ref[0])                                # thth_red
+    assert np.array_equal(got[4], ref[4])                                # edges_red
+    assert got[5] == pytest.approx(ref[5], rel=1e-9)                     # w
+    assert 1 - abs(np.vdot(ref[6], got[6])) <= 1e-9                      # V up to a phase
+    assert np.abs(got[1] - ref[1]).max() <= 1e-9 * np.abs(ref[1]).max()  # thth2_red (phase-free)
+    _assert_image_close(got[2], ref[2], 1e-9, "recov")
+    assert np.abs(got[3] - ref[3]).max() <= 1e-9 * np.abs(ref[3]).max()  # model
+
+
+def test_rev_map_explicit_hermitian_vs_oracle(env, case):
+    """rev_map on an explicit N x N matrix (the reference's own call, ththmod.py:321), Hermitian
+    mirror pass included, against the oracle's histogram on the same matrix."""
+    thth, to = env
+    c = case
+    thth2_ref, edges_red = c["ref"][1], c["ref"][4]
+    got = thth.rev_map(thth2_ref, c["tau"], c["fd"], c["eta"], edges_red, hermetian=True)
+    _assert_image_close(got, c["ref"][2], 1e-9, "rev_map hermitian")
+
+
+def test_rev_map_not_hermitian_vs_oracle(env, case):
+    """The phase-retrieval form (ththmod.py:1459-1463): only the theta_2 = 0 row filled, no mirror
+    pass, plus a dense random block so that every slab of every column receives points."""
+    thth, to = env
+    c = case
+    size = c["size"]
+    V, w, edges_red = c["ref"][6], c["ref"][5], c["ref"][4]
+    n = V.shape[0]
+    E = np.zeros((n, n), dtype=complex)
+    E[n // 2, :] = np.conjugate(V) * np.sqrt(w)
+    rng = np.random.default_rng(size)
+    blk = slice(n // 4, n // 4 + 257)
+    E[blk, :] += rng.standard_normal((257, n)) + 1j * rng.standard_normal((257, n))
+    ref = to.rev_map(E, c["tau"], c["fd"], c["eta"], edges_red, hermetian=False)
+    got = thth.rev_map(E, c["tau"], c["fd"], c["eta"], edges_red, hermetian=False)
+    _assert_image_close(got, ref, 1e-9, "rev_map non-hermitian")
+
+
+def test_chisq_calc_vs_oracle(env, case):
+    """chisq_calc (ththmod.py:330-368) with the default mask and with an explicit one; the
+    oracle value is formed from the oracle model already computed for this size."""
+    thth, to = env
+    c = case
+    dyn, model_ref = c["dyn"], c["ref"][3]
+    N = float(dyn.size)
+    ref = np.sum((model_ref[: dyn.shape[0], : dyn.shape[1]] - dyn) ** 2) / N
+    got = thth.chisq_calc(dyn, c["CS"], c["tau"], c["fd"], c["eta"], c["edges"], N)
+    assert got == pytest.approx(ref, rel=1e-9)
+    mask = np.ones(dyn.shape, dtype=bool)
+    mask[::7, :] = False
+    mask[:, 5::11] = False
+    ref_m = np.sum((model_ref[: dyn.shape[0], : dyn.shape[1]] - dyn)[mask] ** 2) / N
+    got_m = thth.chisq_calc(dyn, c["CS"], c["tau"], c["fd"], c["eta"], c["edges"], N, mask=mask)
+    assert got_m == pytest.approx(ref_m, rel=1e-9)
+
+
+def test_chisq_sweep_vs_chisq_calc(env, case):
+    """The batched modeler sweep against per-eta chisq_calc on four curvatures spread over the
+    BASELINE range (different reduced sizes N), and against the oracle at the one curvature the
+    oracle model exists for."""
+    thth, to = env
+    c = case
+    dyn = c["dyn"]
+    N = float(dyn.size)
+    eta_true = c["eta"] / 0.93
+    etas = np.array([0.3, 0.93, 1.7, 3.6]) * eta_true
+    cs_t = thth.to_device(c["CS"])
+    chis, info = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], etas, c["edges"], N, return_info=True)
+    assert np.all(info["status"] == 0)
+    assert len(set(int(v) for v in info["N"])) >= 3            # the crop really changes N
+    for e, chi in zip(etas, chis):
+        one = thth.chisq_calc(dyn, cs_t, c["tau"], c["fd"], e, c["edges"], N)
+        assert chi == pytest.approx(one, rel=1e-9)
+    ref = np.sum((c["ref"][3] - dyn) ** 2) / N
+    assert chis[1] == pytest.approx(ref, rel=1e-9)
+    # the minimum of chi^2 sits at the injected curvature
+    fine = np.linspace(0.9, 1.1, 9) * eta_true
+    chi_f = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], fine, c["edges"], N)
+    assert abs(fine[np.argmin(chi_f)] / eta_true - 1) <= 0.06
