@@ -9,24 +9,33 @@ curvatures: theta-theta gather (nedge=4096) + dominant 'LA' eigenvalue -> eigs[2
 host -> parabola fit (the body of ththmod.single_search, ththmod.py:773-859).  This is
 BASELINE.json configs[2], the configuration the metric is quoted on.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU, RCCL): the path shards by
-observation -- every rank sweeps its own observation (different seed) and the eigenvalue
-curves are all-gathered at the end of each step.  Per-GPU work is fixed: weak scaling;
-`value` is the whole-job eta-points/s.
+Multi-GPU: one rank per GPU over RCCL.  The driver launches the ranks with
+torch.distributed.run; `python bench.py --gpus N` with no WORLD_SIZE in the environment
+launches them itself (same command line).  The path shards by observation -- every rank
+sweeps its own observation(s) and the eigenvalue curves are all-gathered at the end of each
+step (the only collective).  Default: per-GPU work fixed (weak scaling); `--obs-total T`
+(BASELINE config 4: `--size 2048 --obs-total 64`) deals T observations round-robin to the
+ranks instead (strong scaling).  `value` is the whole-job eta-points/s.
 
 Besides the contract fields the JSON line carries
   roofline      the dominant kernel (eigen mat-vec on the Hermitian tile-packed matrix):
                 algorithmic bytes 8 N (N+1) per mat-vec per eta -- every upper-triangle
                 element once; SURVEY.md 8d's 16 N^2 assumed the full matrix -- summed over
-                every Lanczos step of the timed region, divided by the summed hipEvent time
-                of that kernel's launches;
-  cpu_baseline  the NumPy/SciPy oracle (a restatement of the reference) timed on this host
-                on a 3-eta sample of the same workload (rank 0, N=1 only).
+                every Lanczos step of the timed region, divided by the time that kernel was
+                running (hipEvents on the launch streams, union of the launch intervals);
+  gather        the same for the theta-theta gather kernel (16 N^2 bytes per eta);
+  modeler       (N=1) the OTHER objective of BASELINE configs[2]: the ththmod.modeler /
+                chisq_calc sweep over the same 256 curvatures, timed after the headline region,
+                with one curvature checked against the oracle's chisq_calc;
+  cpu_baseline  (N=1) the NumPy/SciPy oracle (a restatement of the reference) timed on this
+                host: a 3-eta sample as shipped, and eta-parallel over a process pool.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,9 +49,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 
 
 def pmc_traffic_ratio():
-    """HBM bytes / algorithmic bytes of the dominant kernel, from the committed PMC summary
-    (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same script, gfx950
-    FETCH x2 correction -- tools/pmc_summary.py).  None if no summary is committed."""
+    """HBM bytes / algorithmic bytes of the dominant kernel, from the newest committed PMC
+    summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same script,
+    gfx950 FETCH x2 correction -- tools/pmc_summary.py).  None if no summary is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")))
     if not files:
@@ -62,16 +71,39 @@ def parse():
     ap.add_argument("--nedge", type=int, default=None, help="default: size")
     ap.add_argument("--batch", type=int, default=None, help="etas resident per launch")
     ap.add_argument("--npad", type=int, default=0, help="zero-padding multiple of the CS (reference default 3)")
-    ap.add_argument("--obs", type=int, default=1,
-                    help="observations swept per GPU per step (BASELINE config 4: --size 2048 --obs 8 on 8 GPUs)")
+    ap.add_argument("--obs", type=int, default=1, help="observations swept per GPU per step (weak scaling)")
+    ap.add_argument("--obs-total", type=int, default=0,
+                    help="total observations per step, dealt round-robin to the ranks (strong scaling; "
+                         "BASELINE config 4: --size 2048 --obs-total 64)")
     ap.add_argument("--objective", choices=["eig", "chisq"], default="eig",
-                    help="eig: Eval_calc sweep of single_search (headline); chisq: modeler/chisq_calc sweep")
+                    help="objective of the headline timed region: eig = Eval_calc sweep of single_search; "
+                         "chisq = modeler/chisq_calc sweep")
+    ap.add_argument("--modeler-steps", type=int, default=None,
+                    help="steps of the modeler/chisq objective timed after the headline region at N=1 "
+                         "(default min(steps, 3); 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="etas timed on the CPU oracle")
-    ap.add_argument("--cpu-pool", type=int, default=8,
-                    help="also time the oracle eta-parallel with multiprocessing.Pool(P), one BLAS thread "
-                         "per worker (how a user parallelises the reference, dynspec.py:1715-1719); 0 = skip")
+    ap.add_argument("--cpu-pool", type=int, default=-1,
+                    help="workers of the eta-parallel oracle baseline (multiprocessing.Pool, one BLAS thread "
+                         "each: how a user parallelises the reference, dynspec.py:1715-1719); -1 = every "
+                         "core the host memory allows, 0 = skip")
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """Re-run this command line under torch.distributed.run with n ranks; relay its output."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def make_workload(size, neta, nedge, seed, npad=0):
@@ -86,24 +118,27 @@ def make_workload(size, neta, nedge, seed, npad=0):
     return dyn, freqs, times, fd, tau, edges, etas, eta_true
 
 
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(dyn, tau, fd, edges, etas, nsample, npad=0):
     """Oracle (port of the reference) on a bounded sample: `nsample` curvatures spread over
     the sweep; the FFT is done once and not counted (it is amortised over 256 etas)."""
     from oracle import thth_oracle
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
     CS = thth_oracle.conjugate_spectrum(dyn, npad)
     idx = np.unique(np.linspace(0, len(etas) - 1, nsample + 2).astype(int)[1:-1])
     t0 = time.perf_counter()
     vals = [thth_oracle.Eval_calc(CS, tau, fd, etas[i], edges) for i in idx]
     dt = time.perf_counter() - t0
-    return {"value": len(idx) / dt, "unit": "eta-points/s", "cores": int(cores), "kind": "port",
+    return {"value": len(idx) / dt, "unit": "eta-points/s", "cores": int(blas_threads()), "kind": "port",
             "sample": f"oracle Eval_calc (NumPy gather + ARPACK eigsh) on {len(idx)} of {len(etas)} etas "
                       f"(indices {idx.tolist()}) of the same {dyn.shape[0]}x{dyn.shape[1]} workload, "
-                      f"{dt:.1f} s; BLAS threads as shipped; CS FFT excluded"}, dict(zip(idx.tolist(), vals))
+                      f"{dt:.1f} s; one process, BLAS threads as shipped; CS FFT excluded"}, dict(zip(idx.tolist(), vals))
 
 
 def _pool_worker(job):
@@ -123,9 +158,37 @@ def _pool_worker(job):
     return i, val
 
 
+def pool_size(requested, nedge):
+    """Workers for the eta-parallel baseline: every core, capped by host memory (one oracle
+    gather holds about 80 M^2 bytes of temporaries) and by 64."""
+    if requested >= 0:
+        return requested
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = None
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            with open(path) as fh:
+                v = fh.read().strip()
+            if v.isdigit():
+                avail = min(avail, int(v)) if avail else int(v)
+        except OSError:
+            pass
+    per_worker = 80 * nedge * nedge + (1 << 30)
+    by_mem = int((avail or (64 << 30)) * 0.5 // per_worker)
+    return int(max(1, min(cores, by_mem, 64)))
+
+
 def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
     """eta-parallel oracle: Pool(nproc).map over 2*nproc curvatures spread over the sweep."""
     import multiprocessing as mp
+    import shutil
     import tempfile
     from oracle import thth_oracle
     CS = thth_oracle.conjugate_spectrum(dyn, npad)
@@ -139,18 +202,21 @@ def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
         with ctx.Pool(nproc) as pool:
             pool.map(_pool_worker, [(path, idx[0])] * nproc)          # warm the workers (imports, page cache)
             t0 = time.perf_counter()
-            res = pool.map_async(_pool_worker, [(path, i) for i in idx]).get(timeout=600)
+            pool.map_async(_pool_worker, [(path, i) for i in idx]).get(timeout=900)
             dt = time.perf_counter() - t0
     finally:
-        import shutil
         shutil.rmtree(tmp, ignore_errors=True)
     return {"value": len(idx) / dt, "unit": "eta-points/s", "cores": int(nproc), "kind": "port",
+            "host_cores": os.cpu_count(),
             "sample": f"oracle Eval_calc over multiprocessing.Pool({nproc}) (spawn, 1 BLAS thread per worker) on "
                       f"{len(idx)} of {len(etas)} etas, {dt:.1f} s"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from scintools_amd import _lib, ththmod
@@ -159,16 +225,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("SCINT_BENCH_BACKEND", "nccl")   # "gloo": 2 ranks on one GPU (tests only)
+    ndev = max(1, torch.cuda.device_count())
+    # one rank per GPU over RCCL; with fewer GPUs than ranks (the 1-GPU test box) the ranks share
+    # devices and the curves travel over gloo -- the JSON line says so (ranks_per_gpu)
+    backend = os.environ.get("SCINT_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+    ranks_per_gpu = -(-world // ndev)
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dev_index = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
-    else:
-        torch.cuda.set_device(0)
     comm_dev = "cuda" if backend == "nccl" else "cpu"
     require_gpu()
     lib = _lib.load()
@@ -177,83 +245,114 @@ def main():
 
     size, neta = args.size, args.neta
     nedge = args.nedge or size
-    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3 + rank, npad=args.npad)
-    dyn_t = ththmod.to_device(dyn, torch.float64)      # resident in HBM before the clock starts
-    extra_obs = [ththmod.to_device(make_workload(size, neta, nedge, seed=1000 + 97 * rank + k, npad=args.npad)[0], torch.float64)
-                 for k in range(1, args.obs)]
-    gathered = [torch.empty(neta, dtype=torch.float64, device=comm_dev) for _ in range(world)]
+    if args.obs_total > 0:
+        obs_ids = list(range(rank, args.obs_total, world))       # round-robin (dynspec.py:1706-1723 is the pattern)
+        n_obs_job, scaling = args.obs_total, "strong"
+    else:
+        obs_ids = [rank * args.obs + k for k in range(args.obs)]
+        n_obs_job, scaling = world * args.obs, "weak"
+    per_rank_max = -(-n_obs_job // world)
+    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3, npad=args.npad)
+    dyns = []
+    for i in obs_ids:                      # every observation resident in HBM before the clock starts
+        d_i = dyn if i == 0 else make_workload(size, neta, nedge, seed=3 + 97 * i, npad=args.npad)[0]
+        dyns.append(ththmod.to_device(d_i, torch.float64))
+    R, C = (args.npad + 1) * size, (args.npad + 1) * size
+    stack = torch.empty((max(1, len(dyns)), R, C), dtype=torch.complex128, device="cuda") if len(dyns) > 1 else None
+    gathered = [torch.empty((per_rank_max, neta), dtype=torch.float64, device=comm_dev) for _ in range(world)]
 
-    def step():
-        for other in extra_obs:                      # further observations of this rank's share
-            cs_o = ththmod.conjugate_spectrum(other, args.npad, tau, 0.0, True)
-            e_o = ththmod.eval_sweep(cs_o, tau, fd, etas, edges, batch=args.batch)
-            ththmod.fit_eig_peak(etas, e_o, 0.1)
-        # body of single_search (ththmod.py:773-859): CS once, the eta loop, the peak fit
-        cs_t = ththmod.conjugate_spectrum(dyn_t, args.npad, tau, 0.0, True)
-        if args.objective == "chisq":
-            # the other objective of BASELINE config 3: chisq_calc(modeler(...)) for every eta
-            chis, info = ththmod.chisq_sweep(dyn_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
-            if world > 1:
-                dist.all_gather(gathered, torch.from_numpy(chis).to(comm_dev))
-            return chis, info, (etas[np.nanargmin(chis)], np.nan, None)
-        eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
+    def step(objective):
+        """One pass of the hot path over this rank's observations: the body of single_search
+        (ththmod.py:773-859) -- CS once per observation, the eta loop, the peak fit."""
+        curves = np.full((per_rank_max, neta), np.nan)
+        fit, info = (np.nan, np.nan, None), None
+        if objective == "chisq":
+            for k, d_t in enumerate(dyns):
+                cs_t = ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True)
+                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
+                fit = (etas[np.nanargmin(curves[k])], np.nan, None)
+        elif len(dyns) == 1:
+            cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
+            curves[0], info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
+            fit = ththmod.fit_eig_peak(etas, curves[0], 0.1)
+        elif dyns:
+            # several observations on this GPU: all conjugate spectra in one stack, all
+            # (observation, eta) pairs in ONE continuously batched sweep
+            for k, d_t in enumerate(dyns):
+                ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True, out=stack[k])
+            eig_list, info = ththmod.eval_sweep_multi(stack, [(tau, fd, edges)] * len(dyns), [etas] * len(dyns),
+                                                      batch=args.batch, return_info=True)
+            for k, e in enumerate(eig_list):
+                curves[k] = e
+                fit = ththmod.fit_eig_peak(etas, e, 0.1)
         if world > 1:
-            dist.all_gather(gathered, torch.from_numpy(eigs).to(comm_dev))
-        fit = ththmod.fit_eig_peak(etas, eigs, 0.1)
-        return eigs, info, fit
+            dist.all_gather(gathered, torch.from_numpy(curves).to(comm_dev))
+        return curves, info, fit
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lib.scint_profile_begin()
-    t0 = time.perf_counter()
-    alg_bytes = 0.0
-    for _ in range(args.steps):
-        eigs, info, fit = step()
-        n_ = info["N"].astype(float)
-        alg_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"])) * args.obs   # Hermitian: upper triangle once
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ms = (ctypes.c_double * 2)()        # union of each kernel's launch intervals (two streams overlap)
-    ms_sum = (ctypes.c_double * 2)()    # plain sum of the individual launch spans
-    launches = (ctypes.c_int64 * 2)()
-    lib.scint_profile_end(ms, ms_sum, launches)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(objective, steps, warmup):
+        for _ in range(warmup):
+            step(objective)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lib.scint_profile_begin()
+        t0 = time.perf_counter()
+        mv_bytes = 0.0
+        for _ in range(steps):
+            curves, info, fit = step(objective)
+            if info is not None:
+                n_ = info["N"].astype(float)
+                mv_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"]))   # Hermitian: upper triangle once
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ms = (ctypes.c_double * 2)()        # union of each kernel's launch intervals
+        ms_sum = (ctypes.c_double * 2)()    # plain sum of the individual launch spans
+        launches = (ctypes.c_int64 * 2)()
+        lib.scint_profile_end(ms, ms_sum, launches)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return dict(elapsed=elapsed, curves=curves, info=info, fit=fit, mv_bytes=mv_bytes,
+                    busy_ms=list(ms), sum_ms=list(ms_sum), launches=list(launches))
+
+    head = timed(args.objective, args.steps, args.warmup)
 
     if rank == 0:
+        elapsed, info, fit = head["elapsed"], head["info"], head["fit"]
+        eigs = head["curves"][0]
         n_ = info["N"].astype(float)
         # packed gather: one CS read per strict-upper element + the upper-triangle tiles written
         gather_bytes = float(np.sum(8.0 * n_ * (n_ - 1.0) + 8.0 * n_ * (n_ + 1.0))) * args.steps
-        mv_s = ms[1] / 1e3
+        mv_s, ga_s = head["busy_ms"][1] / 1e3, head["busy_ms"][0] / 1e3
+        alg_bytes = head["mv_bytes"]
         achieved = alg_bytes / mv_s / 1e9 if mv_s > 0 else 0.0
         ratio, ratio_src = pmc_traffic_ratio()
+        launches = head["launches"]
         alg_per_launch = alg_bytes / max(1, launches[1])
+        what = ("theta-theta eigenvalue sweep (Eval_calc loop of single_search)" if args.objective == "eig"
+                else "modeler/chisq_calc sweep")
         out = {
             "metric": "eta_curvature_sweep_points_per_sec",
-            "value": world * args.obs * neta * args.steps / elapsed,
+            "value": n_obs_job * neta * args.steps / elapsed,
             "unit": "eta-points/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": (f"{size}x{size} dynspec, {neta}-eta theta-theta eigenvalue sweep "
-                                    f"(Eval_calc loop of single_search), nedge={nedge}, npad={args.npad}, "
-                                    f"one observation per GPU") if args.objective == "eig" else
-                                   (f"{size}x{size} dynspec, {neta}-eta modeler/chisq_calc sweep, nedge={nedge}, "
-                                    f"npad={args.npad}, one observation per GPU"),
-                       "observations_per_gpu_per_step": args.obs,
+            "config": {"workload": f"{size}x{size} dynspec, {neta}-eta {what}, nedge={nedge}, npad={args.npad}, "
+                                   + (f"{args.obs_total} observations dealt round-robin to the GPUs"
+                                      if args.obs_total > 0 else f"{args.obs} observation(s) per GPU"),
+                       "observations_per_step": n_obs_job, "ranks_per_gpu": ranks_per_gpu,
+                       "collective": f"all_gather of float64 [{per_rank_max}, {neta}] per rank per step ({backend})"
+                       if world > 1 else None,
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
@@ -266,31 +365,60 @@ def main():
                          "traffic_note": (f"HBM bytes per launch = {ratio:.3f} x algorithmic bytes; ratio measured "
                                           f"with rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
                                           f"separate passes), {ratio_src}") if ratio else None,
-                         "avg_launch_ms": ms_sum[1] / max(1, launches[1]), "launches": int(launches[1]),
-                         "busy_ms": ms[1],
-                         "timing_note": "achieved = algorithmic bytes / busy_ms, busy_ms = union of this kernel's "
-                                        "hipEvent launch intervals (the sweep runs two streams whose launches "
-                                        "overlap); avg_launch_ms = mean individual launch span, the figure a "
-                                        "rocprofv3 kernel trace averages",
+                         "avg_launch_ms": head["sum_ms"][1] / max(1, launches[1]), "launches": int(launches[1]),
+                         "busy_ms": head["busy_ms"][1],
+                         "timing_note": "achieved = algorithmic bytes / busy_ms; busy_ms = union of this kernel's "
+                                        "hipEvent launch intervals on its launch streams (equal to launches x "
+                                        "avg_launch_ms when the sweep runs on one stream); tools/rocpd_summary.py "
+                                        "computes the same union from a rocprofv3 kernel trace",
                          "algorithmic_bytes_per_step": alg_bytes / args.steps,
                          "share_of_step_time": mv_s / elapsed},
-            "gather": {"kernel": "thth_gather_packed_kernel", "achieved_GBs": gather_bytes / (ms[0] / 1e3) / 1e9
-                       if ms[0] > 0 else 0.0, "avg_launch_ms": ms_sum[0] / max(1, launches[0]),
-                       "launches": int(launches[0]),
-                       "frac": (gather_bytes / (ms[0] / 1e3) / 1e9 / HBM_PEAK_GBS) if ms[0] > 0 else 0.0},
+            "gather": {"kernel": "thth_gather_packed_kernel", "bound": "hbm",
+                       "achieved_GBs": gather_bytes / ga_s / 1e9 if ga_s > 0 else 0.0,
+                       "avg_launch_ms": head["sum_ms"][0] / max(1, launches[0]), "launches": int(launches[0]),
+                       "busy_ms": head["busy_ms"][0],
+                       "algorithmic_bytes_per_eta": "16 N^2 (one 16-B CS read per strict-upper element + the "
+                                                    "upper-triangle tiles written)",
+                       "frac": (gather_bytes / ga_s / 1e9 / HBM_PEAK_GBS) if ga_s > 0 else 0.0},
         }
+        msteps = args.modeler_steps if args.modeler_steps is not None else min(args.steps, 3)
+        if world == 1 and args.objective == "eig" and msteps > 0 and len(dyns) == 1:
+            mod = timed("chisq", msteps, 1)
+            chis, minfo = mod["curves"][0], mod["info"]
+            out["modeler"] = {
+                "workload": f"ththmod.modeler / chisq_calc over the same {neta} curvatures (ththmod.py:274-368): "
+                            "eigenPAIR (Ritz-residual stop), rank-1 rev_map, inverse FFT, chi^2",
+                "value": neta * msteps / mod["elapsed"], "unit": "eta-points/s", "steps": msteps,
+                "ms_per_step": 1e3 * mod["elapsed"] / msteps,
+                "lanczos_steps_mean": float(minfo["iters"].mean()),
+                "failed_etas": int(np.sum(minfo["status"] != 0)),
+                "matvec_share_of_step_time": mod["busy_ms"][1] / 1e3 / mod["elapsed"],
+                "matvec_GBs": mod["mv_bytes"] / (mod["busy_ms"][1] / 1e3) / 1e9 if mod["busy_ms"][1] > 0 else 0.0,
+                "eta_at_min_chisq_over_true": float(etas[np.nanargmin(chis)] / eta_true)}
         if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
             cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad)
             out["cpu_baseline"] = cb
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(
                 max(abs(eigs[i] - v) / abs(v) for i, v in ref_vals.items()))
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
-            if args.cpu_pool > 0:
+            nproc = pool_size(args.cpu_pool, nedge)
+            if nproc > 0:
                 try:
-                    out["cpu_baseline_pool"] = cpu_baseline_pool(dyn, tau, fd, edges, etas, args.cpu_pool, args.npad)
+                    out["cpu_baseline_pool"] = cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, args.npad)
                     out["speedup_vs_cpu_baseline_pool"] = out["value"] / out["cpu_baseline_pool"]["value"]
                 except Exception as exc:          # a baseline must never take the benchmark down
                     out["cpu_baseline_pool"] = {"error": repr(exc)}
+            if "modeler" in out:
+                # one curvature of the modeler objective against the oracle's chisq_calc
+                from oracle import thth_oracle
+                i = int(np.argmin(np.abs(etas - eta_true)))
+                t0 = time.perf_counter()
+                ref = thth_oracle.chisq_calc(dyn, thth_oracle.conjugate_spectrum(dyn, args.npad), tau, fd,
+                                             etas[i], edges, 1.0)
+                dt = time.perf_counter() - t0
+                out["modeler"]["parity_sample"] = {"eta_index": i, "rel_diff_vs_oracle_chisq_calc":
+                                                   float(abs(chis[i] - ref) / abs(ref)), "oracle_seconds": dt}
+                out["modeler"]["cpu_baseline_value"] = 1.0 / dt
             # practical read ceiling of this GPU for the roofline context (a 2 GiB torch.sum; not
             # part of the timed region, not part of the product path)
             try:
@@ -310,6 +438,7 @@ def main():
                 pass
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -18,9 +18,12 @@
  *     wait for it.  The sweep entry points additionally drive one internal
  *     stream per host thread (half of the resident curvatures run there so that
  *     read-backs never idle the GPU); they return with both streams drained;
- *   - no function throws, allocates caller-visible memory, or keeps pointers
- *     after it returns.  The only persistent state is a mutex-guarded cache of
- *     FFT twiddle tables.
+ *   - no function throws, allocates caller-visible memory, or keeps pointers to
+ *     caller buffers after it returns.  Persistent library-owned state, all small
+ *     and created on first use: a mutex-guarded cache of FFT twiddle tables per
+ *     device; an 8 KiB reduction scratch per (device, stream) used by scint_mean /
+ *     scint_chisq; per host thread a pinned flag buffer (4 int32 per resident
+ *     curvature) and, per device, the internal sweep stream mentioned above.
  */
 #ifndef SCINT_HIP_H
 #define SCINT_HIP_H

@@ -124,6 +124,14 @@ def spline_resample_device(dyn_t, freqs, feq):
     B = (feq - x[idx]) / hk
     coef = np.stack([A, B, (A**3 - A) * hk**2 / 6.0, (B**3 - B) * hk**2 / 6.0], axis=1)
     block_rows, warm = _spline_blocks(sub, inv, sup, nf)
+    if block_rows:
+        # A NaN/inf pixel must poison its whole time column, as scipy's sequential solve (and
+        # the unblocked sweep) does; warm-started blocks would confine it to one block.  One
+        # device reduction tells: the mean is non-finite iff some pixel is.
+        m = ctypes.c_double()
+        _lib.check(lib.scint_mean(ptr(dyn_t), nf * nt, ctypes.byref(m), stream_ptr()), "scint_mean")
+        if not np.isfinite(m.value):
+            block_rows, warm = 0, 0
     ws = workspace.get(2 * 8 * nf * nt)
     out = empty((len(feq), nt), torch.float64)
     dev = lambda v: to_device(np.ascontiguousarray(v, dtype=float), torch.float64)

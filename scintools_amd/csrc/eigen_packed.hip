@@ -37,6 +37,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "packed.hpp"
@@ -526,8 +527,14 @@ static int32_t* pinned_flags(size_t count) {
 // keep the GPU busy (no sync bubbles, and the latency-bound reduce/check kernels of one group
 // overlap the bandwidth-bound mat-vec of the other).
 static hipStream_t second_stream() {
-    thread_local hipStream_t s = nullptr;
-    if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    thread_local std::map<int, hipStream_t> streams;      // one per (host thread, device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    auto it = streams.find(dev);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    streams[dev] = s;
     return s;
 }
 static hipEvent_t make_event() {

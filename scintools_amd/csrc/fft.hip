@@ -182,21 +182,22 @@ static int32_t launch_reduce(F f, int64_t n, double scale, double* partial /*kRe
     return SCINT_OK;
 }
 
-// Per-device scratch for the two-stage reductions (cached like the FFT tables; calls on one
-// device are expected to be stream-ordered, as everywhere in this library).
-static std::map<int, double*> g_red_scratch;
-static double* reduce_scratch() {
+// Scratch for the two-stage reductions, one small buffer per (device, stream): calls on one
+// stream are ordered, calls on different streams (one per host thread) never share partials.
+static std::map<std::pair<int, hipStream_t>, double*> g_red_scratch;
+static double* reduce_scratch(hipStream_t stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { set_error("scint: hipGetDevice failed"); return nullptr; }
     std::lock_guard<std::mutex> lock(g_tab_mutex);
-    auto it = g_red_scratch.find(dev);
+    const auto key = std::make_pair(dev, stream);
+    auto it = g_red_scratch.find(key);
     if (it != g_red_scratch.end()) return it->second;
     double* d = nullptr;
     if (hipMalloc(&d, sizeof(double) * (kRedBlocks + 8)) != hipSuccess) {
         set_error("scint: hipMalloc of reduction scratch failed");
         return nullptr;
     }
-    g_red_scratch[dev] = d;
+    g_red_scratch[key] = d;
     return d;
 }
 
@@ -624,7 +625,7 @@ extern "C" int32_t scint_fft2(const scint_c128* in, scint_c128* out, int64_t row
 extern "C" int32_t scint_mean(const double* x, int64_t n, double* mean_out, void* stream_) {
     SCINT_REQUIRE(x && mean_out && n > 0, "mean: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
-    double* scratch = reduce_scratch();
+    double* scratch = reduce_scratch(stream);
     if (!scratch) return SCINT_E_HIP;
     int32_t rc = launch_reduce(PlainValue{x}, n, 1.0 / (double)n, scratch, scratch + kRedBlocks, stream);
     if (rc == SCINT_OK) {
@@ -754,7 +755,7 @@ extern "C" int32_t scint_chisq(const double* model, int64_t ld_model, const doub
                                double* out, void* stream_) {
     SCINT_REQUIRE(model && dspec && out && nf > 0 && nt > 0, "chisq: bad arguments");
     hipStream_t stream = (hipStream_t)stream_;
-    double* partial = reduce_scratch();
+    double* partial = reduce_scratch(stream);
     if (!partial) return SCINT_E_HIP;
     return launch_reduce(ChisqValue{model, ld_model, dspec, nt, mask}, nf * nt, 1.0 / noise_n, partial, out,
                          stream);

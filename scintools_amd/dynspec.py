@@ -18,12 +18,13 @@ Cleaning, velocity / trapezoid rescaling and plotting are out of scope (SURVEY.m
 """
 import ctypes
 import os
+import warnings
 
 import numpy as np
 import scipy.constants as sc
 import torch
 
-from . import _lib, arcfit, units
+from . import _lib, arcfit, psrflux, units
 from . import ththmod as thth
 from .device import DeviceBacked, empty, ptr, require_gpu, stream_ptr, to_device, workspace
 
@@ -102,97 +103,45 @@ class Dynspec:
     # ------------------------------------------------------------------ psrflux text I/O (host)
     def load_file(self, filename, verbose=True, process=False, lamsteps=False, remove_short_subs=True,
                   subint_thresh=2.33, mjd=None):
-        """Load a psrflux-format dynamic spectrum (dynspec.py:144-230): header lines start with
-        '#', data columns are ``isub ichan time(min) freq(MHz) flux flux_err``.  Host-side text
-        parsing; same attribute conventions as the reference (times from 0, ascending freqs)."""
+        """Load a psrflux-format dynamic spectrum (reference: dynspec.py:144-230).  The parsing
+        lives in :mod:`scintools_amd.psrflux` (single-pass tokeniser, optional binary side-car);
+        the attributes set here are the reference's."""
         if process:
             raise NotImplementedError("process=True: cleaning is outside the accelerated hot path")
         if verbose:
             print("LOADING {0}...".format(filename))
-        head = []
-        with open(filename, "r") as fh:
-            for line in fh:
-                if line.startswith("#"):
-                    headline = str.strip(line[1:])
-                    head.append(headline)
-                    if str.split(headline) != [] and str.split(headline)[0] == 'MJD0:' \
-                            and not hasattr(self, 'mjd'):
-                        self.mjd = float(str.split(headline)[1])
+        parsed = psrflux.load_sidecar(filename) or psrflux.read_table(filename)
+        obs = psrflux.observation(*parsed, mjd=mjd, mjd_known=getattr(self, "mjd", None))
         self.name = os.path.basename(filename)
         self.filename = filename
-        self.header = head
-        rawdata = np.loadtxt(filename).transpose()
-        self.times = np.unique(rawdata[2] * 60)
-        if mjd is not None:
-            self.mjd = mjd
-        else:
-            self.mjd = self.mjd + self.times[0] / 86400
-        self.times = self.times - self.times[0]
-        self.freqs = rawdata[3]
-        fluxes = rawdata[4]
-        self.nchan = int(np.max(rawdata[1])) + 1
-        self.bw = self.freqs[-1] - self.freqs[0]
-        self.df = round(self.bw / self.nchan, 5)
-        self.bw = round(self.bw + self.df, 2)
-        self.nsub = int(np.max(rawdata[0])) + 1
-        self.dt = np.mean(np.diff(self.times))
-        self.tobs = np.max(self.times) + self.dt
-        self.freqs = np.unique(self.freqs)
-        self.freq = round(np.mean(self.freqs), 2)
-        fluxes = fluxes.reshape([self.nsub, self.nchan]).transpose()
-        if self.df < 0:   # descending channels in the file: flip to match the ascending freqs
-            self.df = -self.df
-            self.bw = -self.bw
-            fluxes = np.flip(fluxes, 0)
-        self.dyn = fluxes
+        self.__dict__.update(obs)
         if remove_short_subs and np.std(np.diff(self.times)) != 0:
             self.remove_short_subs(threshold=subint_thresh)
         self.lamsteps = lamsteps
 
     def remove_short_subs(self, threshold=2.33):
-        """Drop short sub-integrations at the start of the observation (dynspec.py:232-258)."""
-        dt0 = np.abs(np.diff(self.times))[0]
-        dt = np.mean(np.abs(np.diff(self.times))[1:])
-        sdt = np.std(np.abs(np.diff(self.times))[1:])
-        while dt0 - dt <= -threshold * sdt and sdt >= 0:
-            self.dyn = np.delete(self.dyn, (0), axis=1)
-            self.times = np.delete(self.times, (0))
-            dt0 = np.abs(np.diff(self.times))[0]
-            dt = np.mean(np.abs(np.diff(self.times))[1:])
-            sdt = np.std(np.abs(np.diff(self.times))[1:])
-        self.mjd += np.min(self.times) / 86400
-        self.times -= np.min(self.times)
+        """Drop short sub-integrations at the start of the observation (reference:
+        dynspec.py:232-258) and re-derive the time attributes."""
+        k = psrflux.leading_short_subs(self.times, threshold)
+        self.dyn = self.dyn[:, k:]
+        self.times = self.times[k:]
+        self.mjd += self.times[0] / 86400
+        self.times = self.times - self.times[0]
         self.nsub = len(self.times)
         self.dt = round(np.mean(np.diff(self.times)), 3)
         self.tobs = round(max(self.times) + self.dt, 3)
 
-    def write_file(self, filename=None, verbose=True, note=None):
-        """Write the dynamic spectrum in psrflux format (dynspec.py:330-376)."""
+    def write_file(self, filename=None, verbose=True, note=None, sidecar=False):
+        """Write the dynamic spectrum in psrflux format (reference: dynspec.py:330-376); with
+        ``sidecar=True`` also the binary image that ``load_file`` prefers while it is current."""
         if filename is None:
-            ext = self.filename.split('.')[-1]
-            fname = '.'.join(self.filename.split('.')[0:-1]) + '.processed.' + ext
-        else:
-            fname = filename
-        with open(fname, 'w') as fn:
-            fn.write("# Scintools-modified dynamic spectrum in psrflux format\n")
-            fn.write("# Created using write_file method in Dynspec class\n")
-            if note is not None:
-                fn.write("# Note: {0}\n".format(note))
-            fn.write("# MJD0: {0}\n".format(self.mjd))
-            fn.write("# Original header begins below:\n")
-            isub = False
-            for line in self.header:
-                fn.write("# {} \n".format(line))
-                if 'isub' in line:
-                    isub = True
-            if not isub:
-                fn.write('# isub ichan time(min) freq(MHz) flux flux_err\n')
-            for i in range(len(self.times)):
-                ti = self.times[i] / 60
-                for j in range(len(self.freqs)):
-                    fn.write("{0} {1} {2} {3} {4} {5}\n".format(i, j, ti, self.freqs[j], self.dyn[j, i], 0))
+            stem, ext = self.filename.rsplit('.', 1)
+            filename = f"{stem}.processed.{ext}"
+        psrflux.write(filename, self.header, self.mjd, self.times, self.freqs, self.dyn, note=note)
+        if sidecar:
+            psrflux.save_sidecar(filename, *psrflux.read_table(filename))
         if verbose:
-            print("Wrote dynamic spectrum file as {}".format(fname))
+            print("Wrote dynamic spectrum file as {}".format(filename))
 
     def load_dyn_obj(self, dyn, verbose=True, process=False, lamsteps=False):
         """Copy the reference's attribute set from any object that has it (dynspec.py:378-419)."""
@@ -414,11 +363,15 @@ class Dynspec:
         return np.logspace(np.log10(self.eta_min), np.log10(self.eta_max), self.neta) \
             * (self.fref / freq2.mean())**2
 
-    def thetatheta_single(self, cf=0, ct=0, fname=None, verbose=False, plot=False, arrays=True):
-        """theta-theta curvature search on one chunk (dynspec.py:1539-1655); returns
-        (etas, eigs, popt).  No diagnostic plot (plotting is out of scope)."""
+    def thetatheta_single(self, cf=0, ct=0, fname=None, verbose=False, plot=True, arrays=False):
+        """theta-theta curvature search on one chunk (dynspec.py:1539-1655).  Same defaults as
+        the reference: with ``arrays=True`` returns (etas, eigs, popt); the diagnostic plot is
+        outside the accelerated path, so ``plot=True`` only warns."""
         if not hasattr(self, 'cwf'):
-            raise RuntimeError("call prep_thetatheta(eta_min=..., eta_max=..., ...) first")
+            self.prep_thetatheta(verbose=verbose)            # dynspec.py:1555-1556
+        if plot:
+            warnings.warn("scintools_amd: thetatheta_single does not draw the diagnostic plot; "
+                          "pass arrays=True for the curve and the fit")
         cf, ct = min(cf, self.ncf_fit - 1), min(ct, self.nct_fit - 1)
         fs, ts = self._chunk(cf, ct)
         time2, freq2 = self.times[ts], self.freqs[fs]
@@ -435,48 +388,85 @@ class Dynspec:
         if arrays:
             return etas, eigs, popt
 
+    def _fit_chunks(self, group_all):
+        """Curvature fits of the listed chunks on this GPU: rows [eta_fit, eta_sig, eigs...].
+        Chunks are grouped so that a stack of conjugate spectra stays below ~8 GiB; each group is
+        one ``eval_sweep_multi`` call (all (chunk, eta) pairs batched together)."""
+        coher = (self.thetatheta_proc != 'incoherent')
+        R, C = (self.npad + 1) * self.cwf, (self.npad + 1) * self.cwt
+        per_group = max(1, int((8 << 30) // (16 * R * C)))
+        rows = np.full((len(group_all), 2 + self.neta), np.nan)
+        for g0 in range(0, len(group_all), per_group):
+            group = group_all[g0:g0 + per_group]
+            stack = empty((len(group), R, C), torch.complex128)
+            grids, etas_list = [], []
+            for k, (cf, ct) in enumerate(group):
+                dspec2, freq2, time2, etas, edges = self._search_params(cf, ct)[:5]
+                fd = thth.fft_axis(time2, 1000.0, self.npad)          # ththmod.py:773
+                tau = thth.fft_axis(freq2, 1.0, self.npad)            # ththmod.py:774
+                thth.conjugate_spectrum(dspec2, self.npad, tau, self.thth_tau_mask, coher, out=stack[k])
+                grids.append((tau, fd, edges))
+                etas_list.append(etas)
+            eig_list = thth.eval_sweep_multi(stack, grids, etas_list)
+            for k, (etas, eigs) in enumerate(zip(etas_list, eig_list)):
+                eta_fit, eta_sig, _ = thth.fit_eig_peak(etas, eigs, self.fw)   # ththmod.py:814-859
+                rows[g0 + k, 0], rows[g0 + k, 1] = eta_fit, eta_sig
+                rows[g0 + k, 2:] = eigs
+        return rows
+
+    def _search_params(self, cf, ct, verbose=False):
+        """The 12-element parameter list the reference hands to ``single_search`` for fitting
+        chunk (cf, ct) (dynspec.py:1689-1704), plain floats."""
+        fs, ts = self._chunk(cf, ct)
+        freq2, time2 = np.copy(self.freqs[fs]), np.copy(self.times[ts])
+        dspec2 = np.copy(self.dyn[fs, ts])
+        dspec2 -= np.nanmean(dspec2)
+        dspec2 = np.nan_to_num(dspec2)
+        coher = (self.thetatheta_proc != 'incoherent')
+        return [dspec2, freq2, time2, self._chunk_etas(freq2), self.edges * (freq2.mean() / self.fref),
+                None, False, self.fw, self.npad, coher, self.thth_tau_mask, verbose]
+
     def fit_thetatheta(self, verbose=False, plot=False, pool=None, time_avg=False):
         """Curvature search over all fitting chunks and the global eta ~ nu**-2 fit
         (dynspec.py:1657-1763).  Sets eta_evo, eta_evo_err, f0s, t0s, ththeta, ththetaerr
-        (plain floats: s**3, MHz, s).  `pool` is accepted for signature compatibility; the
-        chunks run one after another on the GPU."""
+        (plain floats: s**3, MHz, s).
+
+        Where the chunks run:
+          * ``pool=None`` (default): every chunk's conjugate spectrum goes into one device stack
+            and all (chunk, eta) pairs run as ONE continuously batched sweep on this GPU; under an
+            initialised ``torch.distributed`` group the chunks are dealt round-robin to the ranks
+            (one GPU each) and the fitted curvatures are all-gathered (``sweep.sharded_chunks``);
+          * ``pool`` given: exactly the reference's ``pool.map(thth.single_search, pars)``
+            (dynspec.py:1715-1719) -- with ``sweep.gpu_pool(n)`` every worker process drives its
+            own GPU.
+        """
         if not hasattr(self, 'cwf'):
-            raise RuntimeError("call prep_thetatheta(eta_min=..., eta_max=..., ...) first")
+            self.prep_thetatheta(verbose=verbose)             # dynspec.py:1673-1674
+        if plot:
+            warnings.warn("scintools_amd: fit_thetatheta does not plot the curvature evolution")
         self.eta_evo = np.zeros((self.ncf_fit, self.nct_fit))
         self.eta_evo_err = np.zeros((self.ncf_fit, self.nct_fit))
         self.f0s = np.zeros(self.ncf_fit)
         self.t0s = np.zeros(self.nct_fit)
         self.thth_eigs = np.zeros((self.ncf_fit, self.nct_fit, self.neta))
-        coher = (self.thetatheta_proc != 'incoherent')
-        # Every chunk's conjugate spectrum goes into one device stack and ALL (chunk, eta) pairs
-        # run as one continuously-batched sweep; chunks are grouped so that a stack stays
-        # below ~8 GiB.
-        R, C = (self.npad + 1) * self.cwf, (self.npad + 1) * self.cwt
-        per_group = max(1, int((8 << 30) // (16 * R * C)))
         chunks = [(cf, ct) for cf in range(self.ncf_fit) for ct in range(self.nct_fit)]
-        for g0 in range(0, len(chunks), per_group):
-            group = chunks[g0:g0 + per_group]
-            stack = empty((len(group), R, C), torch.complex128)
-            grids, etas_list = [], []
-            for k, (cf, ct) in enumerate(group):
-                fs, ts = self._chunk(cf, ct)
-                freq2, time2 = np.copy(self.freqs[fs]), np.copy(self.times[ts])
-                self.f0s[cf] = freq2.mean()
-                self.t0s[ct] = time2.mean()
-                dspec2 = np.copy(self.dyn[fs, ts])
-                dspec2 -= np.nanmean(dspec2)
-                dspec2 = np.nan_to_num(dspec2)
-                fd = thth.fft_axis(time2, 1000.0, self.npad)          # ththmod.py:773
-                tau = thth.fft_axis(freq2, 1.0, self.npad)            # ththmod.py:774
-                thth.conjugate_spectrum(dspec2, self.npad, tau, self.thth_tau_mask, coher, out=stack[k])
-                grids.append((tau, fd, self.edges * (freq2.mean() / self.fref)))
-                etas_list.append(self._chunk_etas(freq2))
-            eig_list = thth.eval_sweep_multi(stack, grids, etas_list)
-            for (cf, ct), etas, eigs in zip(group, etas_list, eig_list):
-                eta_fit, eta_sig, _ = thth.fit_eig_peak(etas, eigs, self.fw)   # ththmod.py:814-859
-                self.eta_evo[cf, ct] = eta_fit
-                self.eta_evo_err[cf, ct] = eta_sig
-                self.thth_eigs[cf, ct] = eigs
+        for cf, ct in chunks:
+            fs, ts = self._chunk(cf, ct)
+            self.f0s[cf] = self.freqs[fs].mean()
+            self.t0s[ct] = self.times[ts].mean()
+        if pool is not None:
+            res = pool.map(thth.single_search, [self._search_params(cf, ct, verbose) for cf, ct in chunks])
+            for (cf, ct), r in zip(chunks, res):
+                self.eta_evo[cf, ct] = r[0]
+                self.eta_evo_err[cf, ct] = r[1]
+                self.thth_eigs[cf, ct] = np.nan
+        else:
+            from . import sweep
+            fits = sweep.sharded_chunks(len(chunks), lambda idx: self._fit_chunks([chunks[i] for i in idx]),
+                                        self.neta)
+            for (cf, ct), row in zip(chunks, fits):
+                self.eta_evo[cf, ct], self.eta_evo_err[cf, ct] = row[0], row[1]
+                self.thth_eigs[cf, ct] = row[2:]
         f0 = self.f0s[:, np.newaxis]
         with np.errstate(divide='ignore', invalid='ignore'):
             if time_avg:                                                   # dynspec.py:1724-1732

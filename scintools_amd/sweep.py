@@ -13,9 +13,17 @@ Two partitionings:
   * :func:`sharded_observations` -- a batch of observations dealt round-robin to the ranks,
     each rank running whole sweeps (BASELINE config 4; what ``bench.py --gpus N`` times).
 
+  * :func:`sharded_chunks` -- the fitting chunks of ``Dynspec.fit_thetatheta`` dealt
+    round-robin; what the reference does with ``pool.map`` (dynspec.py:1715-1719).
+  * :func:`gpu_pool` -- a ``multiprocessing`` pool whose workers each bind one GPU, for callers
+    that keep the reference's ``fit_thetatheta(pool=...)`` idiom instead of ``torchrun``.
+
 ``local_fn`` is the per-rank compute; it defaults to the HIP path and exists so that the CPU
-tests can exercise the sharding/gather logic with the oracle in its place.
+tests can exercise the sharding/gather logic with the oracle in its place (the HIP path under
+ranks is covered by ``tests/test_gpu_multirank.py``).
 """
+import multiprocessing as mp
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -85,3 +93,46 @@ def sharded_observations(n_obs, sweep_fn, neta, group=None):
         for slot, i in enumerate(range(r, n_obs, world)):
             full[i] = out[r][slot].cpu().numpy()
     return full
+
+
+def sharded_chunks(n_items, rows_fn, width, group=None):
+    """Deal `n_items` independent work items (fitting chunks) round-robin to the ranks.
+
+    ``rows_fn(indices) -> float64 [len(indices), 2 + width]`` computes this rank's items in one
+    call (so that it can batch them on its GPU); every rank gets the full
+    ``[n_items, 2 + width]`` table back (one all-gather).  Without an initialised process group
+    it is a plain call."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return np.asarray(rows_fn(list(range(n_items))), dtype=np.float64)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = list(range(rank, n_items, world))
+    per_rank = -(-n_items // world)
+    dev = _device_for_backend(group)
+    buf = torch.full((per_rank, 2 + width), float("nan"), dtype=torch.float64, device=dev)
+    if mine:
+        rows = np.ascontiguousarray(rows_fn(mine), dtype=np.float64)
+        buf[: len(mine)] = torch.from_numpy(rows).to(dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    full = np.empty((n_items, 2 + width), dtype=np.float64)
+    for r in range(world):
+        for slot, i in enumerate(range(r, n_items, world)):
+            full[i] = out[r][slot].cpu().numpy()
+    return full
+
+
+def _bind_worker(counter):
+    """Pool initializer: worker k drives GPU k (mod the number of visible GPUs)."""
+    with counter.get_lock():
+        k = counter.value
+        counter.value += 1
+    torch.cuda.set_device(k % max(1, torch.cuda.device_count()))
+
+
+def gpu_pool(n_workers=None):
+    """``multiprocessing.Pool`` (spawn) with one worker per GPU, for the reference's
+    ``Dynspec.fit_thetatheta(pool=pool)`` / ``pool.map(thth.single_search, pars)`` idiom: every
+    worker runs the HIP path on its own device.  Close it like any pool."""
+    ctx = mp.get_context("spawn")
+    n = int(n_workers or max(1, torch.cuda.device_count()))
+    return ctx.Pool(n, initializer=_bind_worker, initargs=(ctx.Value("i", 0),))

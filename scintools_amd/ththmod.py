@@ -182,10 +182,19 @@ def _thth_dev(cs_t, grid, eta, keep_idx, hermetian):
     rc = lib.scint_thth_map(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), grid.M,
                             ptr(keep_t), n, eta, 1 if hermetian else 0, ptr(out), stream_ptr())
     _lib.check(rc, "scint_thth_map")
-    if not hermetian and bool(torch.isnan(out.real).any()):
-        # NumPy raises here: a negative fd index below -len(fd) (ththmod.py:104)
-        raise IndexError("theta-theta gather index out of bounds for the conjugate spectrum")
     return out
+
+
+def _host_checked(arr, grid, hermetian):
+    """NumPy raises IndexError when the non-Hermitian gather wraps an fd index below -len(fd)
+    (ththmod.py:104); the kernel marks such pixels NaN.  Checked on the host copy, and only
+    when the grid can produce such an index at all (a NaN in CS itself must pass through)."""
+    if not hermetian and arr.size:
+        g, th = grid.geom, grid.th_cents
+        lowest = np.floor(((th.min() - th.max()) - g.fd0 + g.dfd / 2) / g.dfd)
+        if lowest < -g.nfd and np.isnan(arr.real).any():
+            raise IndexError("theta-theta gather index out of bounds for the conjugate spectrum")
+    return arr
 
 
 def _eigh_top_dev(a_t, v0_t=None, want_vec=True, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER):
@@ -240,7 +249,7 @@ def thth_map(CS, tau, fd, eta, edges, hermetian=True):
     grid = _Grid(tau, fd, edges)
     cs_t = _cs_dev(CS, grid)
     keep = np.arange(grid.M, dtype=np.int32)
-    return _thth_dev(cs_t, grid, _eta_float(eta), keep, hermetian).cpu().numpy()
+    return _host_checked(_thth_dev(cs_t, grid, _eta_float(eta), keep, hermetian).cpu().numpy(), grid, hermetian)
 
 
 def thth_redmap(CS, tau, fd, eta, edges, hermetian=True):
@@ -250,7 +259,7 @@ def thth_redmap(CS, tau, fd, eta, edges, hermetian=True):
     cs_t = _cs_dev(CS, grid)
     e = _eta_float(eta)
     keep = grid.keep(e)
-    red = _thth_dev(cs_t, grid, e, keep, hermetian).cpu().numpy()
+    red = _host_checked(_thth_dev(cs_t, grid, e, keep, hermetian).cpu().numpy(), grid, hermetian)
     return red, units.attach(grid.edges_red(keep), "mHz")
 
 
@@ -596,7 +605,9 @@ def single_search(params):
         print(f"Chunk completed (eta = {eta_fit} +- {eta_sig} at {freq_v.mean()})", flush=True)
     if np.isfinite(eta_fit):
         eta_fit, eta_sig = units.attach(eta_fit, "s3"), units.attach(eta_sig, "s3")
-    return (eta_fit, eta_sig, units.attach(freq_v.mean(), "MHz"), units.attach(time_v.mean(), "s"), eigs)
+    # the reference returns the curve with failed curvatures removed (ththmod.py:817)
+    return (eta_fit, eta_sig, units.attach(freq_v.mean(), "MHz"), units.attach(time_v.mean(), "s"),
+            eigs[np.isfinite(eigs)])
 
 
 # ----------------------------------------------------------------------------
@@ -637,8 +648,9 @@ def single_chunk_retrieval(params):
         red_t, V_t, w, _, _, keep = _modeler_dev(cs_t, grid, e)
         n = int(keep.shape[0])
         # ththE_red: only the theta_2 = 0 row is filled, with conj(V) sqrt(w)   (ththmod.py:1459-1461)
-        E_t = torch.zeros((n, n), dtype=torch.complex128, device=cs_t.device)
-        E_t[n // 2, :] = torch.conj(V_t) * float(np.sqrt(w))
+        E_t = torch.zeros((n, n), dtype=torch.complex128, device=cs_t.device)      # allocation + memset
+        row = np.conjugate(V_t.cpu().numpy()) * np.sqrt(w)                          # n numbers: host
+        E_t[n // 2].copy_(torch.from_numpy(row))                                    # memcpy
         th_red = _theta_centres(grid.edges_red(keep))
         recov_E = _rev_map_dev(grid.geom, _dv.to_device(th_red, torch.float64), n, e, False, thth_t=E_t)
         nf, nt = dspec2.shape
@@ -734,7 +746,7 @@ def calc_asymmetry(params):
         if info["status"][0] != 0:
             raise ArithmeticError(f"eigenpair iteration failed (status {int(info['status'][0])})")
         n = int(info["N"][0])
-        p = (torch.abs(V_t[0, :n]) ** 2).cpu().numpy()
+        p = np.abs(V_t[0, :n].cpu().numpy()) ** 2
         half = (n - 1) // 2                     # cents.shape[0] == n  (ththmod.py:2447-2449)
         left, right = p[:half].sum(), p[1 + half:].sum()
         asymm = (left - right) / (left + right)

@@ -315,3 +315,30 @@ def test_spline_resample_irregular_knots(ds, nf):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-12
     with pytest.raises(ValueError):
         spline_resample_device(to_device(y, torch.float64), x, np.array([x[0] - 1.0]))
+
+
+def test_spline_resample_nonfinite_pixel_poisons_its_whole_column(ds):
+    """nf large enough for the frequency-blocked Thomas sweeps: a NaN / inf pixel must turn its
+    WHOLE time column NaN, exactly as scipy's interp1d(kind='cubic') (the reference,
+    dynspec.py:3948-3957) does, and every other column must be untouched."""
+    import torch
+    from scipy.interpolate import interp1d
+    from scintools_amd.arcfit import spline_resample_device
+    from scintools_amd.device import to_device
+    nf, nt = 1536, 48
+    rng = np.random.default_rng(7)
+    x = 1200.0 + 0.25 * np.arange(nf)
+    y = rng.standard_normal((nf, nt)) + 3
+    f = np.linspace(x[0], x[-1], 900)
+    clean = spline_resample_device(to_device(y, torch.float64), x, f).cpu().numpy()
+    y[700, 5] = np.nan
+    y[20, 17] = np.inf
+    got = spline_resample_device(to_device(y, torch.float64), x, f).cpu().numpy()
+    ref = np.flipud(np.stack([interp1d(x, y[:, k], kind="cubic")(f) for k in range(nt)], axis=1))
+    bad = np.zeros(nt, dtype=bool)
+    bad[[5, 17]] = True
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    assert not np.isfinite(got[:, bad]).any()
+    assert np.abs(got[:, ~bad] - ref[:, ~bad]).max() / np.abs(ref[:, ~bad]).max() < 1e-12
+    # the sequential fallback and the blocked sweep agree to rounding on the clean columns
+    assert np.abs(got[:, ~bad] - clean[:, ~bad]).max() <= 1e-12 * np.abs(clean).max()

@@ -1,0 +1,143 @@
+"""The PRODUCT under ranks: two `gloo` ranks sharing the one GPU of the test box, each running the
+HIP eta sweep on its share (sweep.sharded_eval_sweep / sharded_observations / Dynspec.fit_thetatheta's
+chunk sharding / gpu_pool), and the gathered result compared BIT FOR BIT with the single-process
+HIP result.  (On an 8-GPU node the same code runs with backend nccl = RCCL, one GPU per rank; the
+partitioning and the gather are identical, only the transport differs.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem(size=512, neta=11, seed=31):
+    from scintools_amd.synth import arc_dynspec
+    from scintools_amd.ththmod import fft_axis
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=seed, nimg=24)
+    dyn = dyn - dyn.mean()
+    fd, tau = fft_axis(times, 1000.0, 0), fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    etas = np.geomspace(0.4, 2.5, neta) * eta_true          # 11: uneven split over 2 ranks
+    return dyn, freqs, times, tau, fd, etas, edges
+
+
+def _chunked_dynspec():
+    from scintools_amd.dynspec import Dynspec
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(256, 128, seed=5, nimg=16)
+
+    class B:
+        pass
+    b = B()
+    b.dyn, b.freqs, b.times, b.dt, b.df = dyn, freqs, times, times[1] - times[0], freqs[1] - freqs[0]
+    d = Dynspec(dyn=b, verbose=False)
+    d.prep_thetatheta(cwf=64, cwt=64, npad=1, eta_min=0.5 * eta_true, eta_max=2.0 * eta_true, nedge=64)
+    return d
+
+
+def _single_process():
+    from scintools_amd import ththmod as thth
+    dyn, freqs, times, tau, fd, etas, edges = _problem()
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
+    full = thth.eval_sweep(cs, tau, fd, etas, edges)
+    obs = []
+    for i in range(5):
+        d_i = _problem(seed=100 + i)[0]
+        obs.append(thth.eval_sweep(thth.conjugate_spectrum(d_i, 0, pad_value=0.0), tau, fd, etas[:4], edges))
+    d = _chunked_dynspec()
+    d.fit_thetatheta()
+    return full, np.stack(obs), d.eta_evo.copy(), d.thth_eigs.copy(), d.ththeta
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)                                  # both ranks share the one GPU
+    from scintools_amd import sweep
+    from scintools_amd import ththmod as thth
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dyn, freqs, times, tau, fd, etas, edges = _problem()
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
+    full = sweep.sharded_eval_sweep(cs, tau, fd, etas, edges)       # HIP eval_sweep on this rank's eta block
+
+    def one_obs(i):
+        d_i = _problem(seed=100 + i)[0]
+        return thth.eval_sweep(thth.conjugate_spectrum(d_i, 0, pad_value=0.0), tau, fd, etas[:4], edges)
+    obs = sweep.sharded_observations(5, one_obs, 4)
+    d = _chunked_dynspec()
+    d.fit_thetatheta()                                               # chunks dealt to the ranks
+    with open("/proc/self/maps") as fh:
+        native = "libscint_hip.so" in fh.read()
+    q.put((rank, full, obs, d.eta_evo.copy(), d.thth_eigs.copy(), d.ththeta, native))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_hip_sweep_under_two_ranks_is_bit_identical():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=480) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_full, ref_obs, ref_evo, ref_eigs, ref_ththeta = _single_process()
+    assert np.all(np.isfinite(ref_full)) and np.all(np.isfinite(ref_evo))
+    for rank, full, obs, evo, eigs, ththeta, native in results:
+        assert native, "rank did not load libscint_hip.so"
+        assert np.array_equal(full, ref_full), rank
+        assert np.array_equal(obs, ref_obs), rank
+        assert np.array_equal(evo, ref_evo) and np.array_equal(eigs, ref_eigs), rank
+        assert ththeta == ref_ththeta, rank
+
+
+@pytest.mark.timeout(600)
+def test_fit_thetatheta_with_gpu_pool_matches_batched_path():
+    """The reference's own idiom, fit_thetatheta(pool=...): pool.map(single_search, pars) with
+    workers that each drive a GPU (here: two workers on the one GPU)."""
+    from scintools_amd import sweep
+    d = _chunked_dynspec()
+    d.fit_thetatheta()
+    evo, err, a = d.eta_evo.copy(), d.eta_evo_err.copy(), d.ththeta
+    with sweep.gpu_pool(2) as pool:
+        d.fit_thetatheta(pool=pool)
+    # per-chunk single_search pads with the chunk mean (ththmod.py:779-784) exactly like the
+    # batched path; the eigenvalue curves are the same kernels on the same inputs
+    assert np.array_equal(d.eta_evo, evo) and np.array_equal(d.eta_evo_err, err) and d.ththeta == a
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_spawns_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment launches its own two
+    ranks (torch.distributed.run) and prints ONE line with n_gpus == 2."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--size", "512",
+                          "--neta", "16", "--steps", "2", "--warmup", "1", "--modeler-steps", "0"],
+                         capture_output=True, text=True, timeout=800, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 16 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
+    assert d["config"]["ranks_per_gpu"] == 2          # oversubscribed on the 1-GPU test box, and says so

@@ -279,7 +279,9 @@ def test_fit_thetatheta_vs_reference_golden(golden):
         dyn, freqs, times, dt, df = g["dspec"], g["freq"], g["time"], float(g["dt"]), float(g["df"])
     d = Dynspec(dyn=B(), verbose=False)
     d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50)
-    etas, eigs, popt = d.thetatheta_single(cf=0, ct=0)
+    with pytest.warns(UserWarning, match="does not draw"):
+        assert d.thetatheta_single(cf=0, ct=0) is None          # reference defaults: plot=True, arrays=False
+    etas, eigs, popt = d.thetatheta_single(cf=0, ct=0, plot=False, arrays=True)
     assert np.array_equal(etas, g["single_etas"])
     np.testing.assert_allclose(eigs, g["single_eigs"], rtol=1e-9)
     np.testing.assert_allclose(popt, g["single_popt"], rtol=1e-6)

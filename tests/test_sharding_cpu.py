@@ -48,7 +48,12 @@ def _worker(rank, world, port, q):
     def one_obs(i):
         return _oracle_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges)
     obs = sweep.sharded_observations(5, one_obs, 3)
-    q.put((rank, full, obs))
+
+    def rows(idx):        # [eta_fit, eta_sig, curve...] per chunk index, as Dynspec._fit_chunks returns
+        return np.array([[10.0 + i, 0.5 * i] + list(_oracle_sweep(CS * (2.0 + i), tau, fd, etas[:2], edges))
+                         for i in idx])
+    chunks = sweep.sharded_chunks(5, rows, 2)
+    q.put((rank, full, obs, chunks))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,9 +83,12 @@ def test_world2_gloo_matches_single_process():
     to, CS, tau, fd, etas, edges = _problem()
     ref = _oracle_sweep(CS, tau, fd, etas, edges)
     ref_obs = np.stack([_oracle_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges) for i in range(5)])
-    for rank, full, obs in results:
+    ref_chunks = np.array([[10.0 + i, 0.5 * i] + list(_oracle_sweep(CS * (2.0 + i), tau, fd, etas[:2], edges))
+                           for i in range(5)])
+    for rank, full, obs, chunks in results:
         assert np.array_equal(full, ref), rank          # same bits on every rank
         assert np.array_equal(obs, ref_obs), rank
+        assert np.array_equal(chunks, ref_chunks), rank
 
 
 def test_single_process_path_needs_no_process_group():
