@@ -178,13 +178,15 @@ int32_t scint_eigh_top(const scint_c128* a, int64_t n, const scint_c128* v0,
 /* thth[N,N] on centres th_cents[N] (already re-centred) -> recov[ntau,nfd].
  * If `rank1` != 0, thth is not read: thth = |w| V V^H with V = vec[N], w = *w
  * (device), which is modeler's thth2_red (ththmod.py:312-313).
- * Every pixel of recov_out is written (no scratch, no zero-fill needed).  The per-pixel
- * sums are accumulated with float64 LDS atomics, so the result is reproducible to
- * rounding, not bit for bit. */
+ * Every pixel of recov_out is written (no zero-fill needed).  The per-pixel sums are
+ * order-independent: each addend is split on a fixed binary grid so that the float64 LDS
+ * accumulations are exact (thth.hip, RevSplit), hence the image is bit-reproducible from run
+ * to run like np.histogram2d's.  Workspace: scint_rev_map_workspace_bytes() (a few words). */
+int32_t scint_rev_map_workspace_bytes(size_t* bytes /*HOST*/);
 int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
                       int32_t rank1, const double* th_cents, int64_t N,
                       const scint_cs_geom* geom /*HOST*/, double eta, int32_t hermitian,
-                      scint_c128* recov_out, void* stream);
+                      scint_c128* recov_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- model dynamic spectrum: ifft2(ifftshift(recov)).real (ththmod.py:322-324) */
 int32_t scint_model_workspace_bytes(int64_t ntau, int64_t nfd, size_t* bytes /*HOST*/);

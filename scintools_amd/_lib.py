@@ -59,7 +59,9 @@ _SIGNATURES = {
                             c_double, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P, c_size_t, _P], c_int32),
     "scint_eigh_top_workspace_bytes": ([c_int64, c_int32, POINTER(c_size_t)], c_int32),
     "scint_eigh_top": ([_P, c_int64, _P, c_double, c_int32, _P, _P, _P, _P, _P, c_size_t, _P], c_int32),
-    "scint_rev_map": ([_P, _P, _P, c_int32, _P, c_int64, POINTER(CsGeom), c_double, c_int32, _P, _P], c_int32),
+    "scint_rev_map_workspace_bytes": ([POINTER(c_size_t)], c_int32),
+    "scint_rev_map": ([_P, _P, _P, c_int32, _P, c_int64, POINTER(CsGeom), c_double, c_int32, _P, _P, c_size_t, _P],
+                      c_int32),
     "scint_model_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_model_from_recov": ([_P, c_int64, c_int64, _P, _P, c_size_t, _P], c_int32),
     "scint_ifft2_shifted": ([_P, c_int64, c_int64, c_double, c_int64, c_int64, _P, _P, c_size_t, _P], c_int32),

@@ -22,6 +22,7 @@
 // All transforms are forward (numpy sign convention, exp(-2 pi i jk/n)); inverse
 // transforms are expressed as conj-forward-conj by the functors.
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.hpp"
@@ -393,14 +394,99 @@ int32_t launch_cols_pass(const ColPass& p, int64_t batches, Loader ld, Storer st
     return SCINT_OK;
 }
 
-// Runs all passes of a strided-axis FFT.  `first` loads the first pass, `mid_ld/mid_st`
-// are the plain in-place accessors, `last` stores the final (natural-order) result.
+// ------------------------------------------------------------------------------
+// cols, two-pass form: the strided-axis FFT of length L = L1 * L2 (16 <= L1, L2 <= 128) as the
+// four-step algorithm on tiles of 16 adjacent columns, each step one trip through HBM:
+//
+//   pass A  for every n2 < L2:   Y[k1][n2] = W_L^{n2 k1} * sum_n1 x[n1 L2 + n2] W_L1^{n1 k1}
+//           (rows n1 L2 + n2 of the source, L1-point FFTs, twiddle, stored at row k1 L2 + n2)
+//   pass B  for every k1 < L1:   X[k1 + L1 k2] = sum_n2 Y[k1][n2] W_L2^{n2 k2}
+//           (L2 CONSECUTIVE rows of the intermediate, L2-point FFTs, natural-order sink)
+//
+// Both passes are the row kernel above (one "slot" = one column of one sub-transform, living in
+// LDS) behind transposing loaders: consecutive slots are consecutive columns and the threads of a
+// slot are consecutive sub-transform indices, so one wave instruction touches 16 adjacent
+// columns (256 contiguous bytes) of 4-8 rows -- whole cache lines in both directions.  The radix
+// passes of fft_cols_kernel need log16(L) trips instead of two.
+template <class First>
+struct ColsALoad {
+    First first; int64_t ncols, ntiles; int l2;        // L2 = 1 << l2
+    __device__ inline cplx operator()(int64_t slot, int n1) const {
+        const int c = (int)(slot & 15);
+        int64_t rest = slot >> 4;
+        const int64_t n2 = rest & ((1 << l2) - 1);
+        rest >>= l2;
+        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
+        if (col >= ncols) return mk(0.0, 0.0);
+        return first(batch, ((int64_t)n1 << l2) + n2, col);
+    }
+};
+template <class MidStorer>
+struct ColsAStore {
+    static constexpr bool kPair = false;
+    MidStorer mid; int64_t ncols, ntiles; int l2; const cplx* tw;   // tw = W_L table
+    __device__ inline void operator()(int64_t slot, int k1, cplx v) const {
+        const int c = (int)(slot & 15);
+        int64_t rest = slot >> 4;
+        const int64_t n2 = rest & ((1 << l2) - 1);
+        rest >>= l2;
+        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
+        if (col >= ncols) return;
+        mid(batch, ((int64_t)k1 << l2) + n2, col, v * tw[n2 * k1]);
+    }
+};
+template <class MidLoader>
+struct ColsBLoad {
+    MidLoader mid; int64_t ncols, ntiles; int l1, l2;
+    __device__ inline cplx operator()(int64_t slot, int n2) const {
+        const int c = (int)(slot & 15);
+        int64_t rest = slot >> 4;
+        const int64_t k1 = rest & ((1 << l1) - 1);
+        rest >>= l1;
+        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
+        if (col >= ncols) return mk(0.0, 0.0);
+        return mid(batch, (k1 << l2) + n2, col);
+    }
+};
+template <class LastStorer>
+struct ColsBStore {
+    static constexpr bool kPair = false;
+    LastStorer last; int64_t ncols, ntiles; int l1;
+    __device__ inline void operator()(int64_t slot, int k2, cplx v) const {
+        const int c = (int)(slot & 15);
+        int64_t rest = slot >> 4;
+        const int64_t k1 = rest & ((1 << l1) - 1);
+        rest >>= l1;
+        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
+        if (col >= ncols) return;
+        last(batch, k1 + ((int64_t)k2 << l1), col, v);
+    }
+};
+
+template <class Loader, class Storer>
+int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStream_t stream);
+
+// Runs a strided-axis FFT.  `first` loads the source, `mid_ld/mid_st` are the plain in-place
+// accessors of the working array, `last` stores the final (natural-order) result.
+// Lengths >= 256: two tiled passes (above); shorter ones: radix passes of fft_cols_kernel.
 template <class FirstLoader, class MidLoader, class MidStorer, class LastStorer>
 int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader first,
                      MidLoader mid_ld, MidStorer mid_st, LastStorer last, hipStream_t stream) {
     SCINT_REQUIRE(is_pow2(len) && len >= 2, "fft cols: length must be a power of two >= 2");
     const cplx* tw = twiddle_table(len);
     if (!tw) return SCINT_E_HIP;
+    static const int two_pass = [] { const char* e = getenv("SCINT_FFT_TWO_PASS"); return e ? atoi(e) : 1; }();
+    if (two_pass && len >= 256 && len <= 16384) {
+        const int l = ilog2(len), l2 = l / 2, l1 = l - l2;          // L1 >= L2, both in [16, 128]
+        const int64_t ntiles = ceil_div(ncols, 16);
+        int32_t rc = launch_fft_rows((int64_t)1 << l1, batches * ntiles * ((int64_t)1 << l2) * 16,
+                                     ColsALoad<FirstLoader>{first, ncols, ntiles, l2},
+                                     ColsAStore<MidStorer>{mid_st, ncols, ntiles, l2, tw}, stream);
+        if (rc != SCINT_OK) return rc;
+        return launch_fft_rows((int64_t)1 << l2, batches * ntiles * ((int64_t)1 << l1) * 16,
+                               ColsBLoad<MidLoader>{mid_ld, ncols, ntiles, l1, l2},
+                               ColsBStore<LastStorer>{last, ncols, ntiles, l1}, stream);
+    }
     ColPlan pl = make_col_plan(len);
     int64_t Lp = len;
     ColPass p;

@@ -89,64 +89,122 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 // ------------------------------------------------------------------------------
 // packed gather (eta sweep): only tiles on/above the block diagonal, 64 KiB contiguous each
 // ------------------------------------------------------------------------------
-// One 32 x 32 quadrant of a 64 x 64 packed tile per 256-thread block (32 lanes x 8 rows, four
-// rows per thread): the quadrant's footprint in the CS is a compact patch (~16 f_D bins wide),
-// which keeps the scattered 16-B reads inside few cache lines per wave.
+// One 64 x 64 packed tile per 256-thread workgroup.  Lanes run along the 64 columns (every row a
+// wave stores is one contiguous 1 KiB segment of the tile), wave w owns rows 16w .. 16w+15, i.e.
+// 16 elements per lane, handled as two batches of 8 whose scattered 16-B CS reads are all issued
+// before the first result is needed (16 independent loads in flight per lane).  Everything that
+// depends on the row only (keep index, theta_i, theta_i^2) is wave-uniform and is read through
+// the scalar unit; the column's theta_j costs each lane ONE dependent load pair for the whole
+// tile.  The bin index is the exact floor of thth.hpp, computed without a division.
+//
+// Non-finite geometry (a_tau or a_fd NaN/inf) gives q = NaN -> the range test fails -> 0, which
+// is what the reference's  pnts  mask does with the int-converted NaN as well.
+struct GatherElem { int64_t off; double wgt; };
+
+// Branch-free: `live` false (outside the matrix, the diagonal, the anti-diagonal) gives off = -1.
+__device__ inline GatherElem gather_elem(const GeomDev& g, double eta, double two_eta, double t2, double t1,
+                                         double sq2, double sq1, bool live) {
+    // (theta2 = t2, theta1 = t1): ththmod.py:94-97 in the reference's operation order
+    const double a_tau = ((eta * (sq1 - sq2)) - g.tau0) + g.half_dtau;
+    const double a_fd = ((t1 - t2) - g.fd0) + g.half_dfd;
+    const double qt = floor_div_exact_rcp(a_tau, g.dtau, g.inv_dtau);
+    const double qf = floor_div_exact_rcp(a_fd, g.dfd, g.inv_dfd);
+    // pnts = (tau_inv > 0) * (tau_inv < ntau) * (fd_inv < nfd)   (ththmod.py:103); comparisons
+    // with NaN are false.  Inside that range both quotients fit an int32 except a very negative
+    // fd index, which NumPy would reject (IndexError): -2.
+    const bool in = live && qt > 0.0 && qt < g.ntau_d && qf < g.nfd_d;
+    const bool wrap_ok = qf >= -g.nfd_d;
+    const int it = __double2int_rz(qt);                 // saturating conversions: harmless when !in
+    int jf = __double2int_rz(qf);
+    jf += jf < 0 ? (int)g.nfd : 0;                      // NumPy's negative-index wrap
+    GatherElem e;
+    e.off = in ? (wrap_ok ? (int64_t)it * g.nfd + jf : -2) : -1;
+    e.wgt = sqrt(fabs(two_eta * (t2 - t1)));
+    return e;
+}
+
+// packed tile index -> (I, J): largest I with tile_offset(nb, I) <= t
+__device__ inline void tile_coords(int nb, int t, int& I, int& J) {
+    const float s = 2.0f * (float)nb + 1.0f;
+    int i = (int)((s - sqrtf(fmaxf(s * s - 8.0f * (float)t, 0.0f))) * 0.5f);
+    i = min(max(i, 0), nb - 1);
+    while (i > 0 && tile_offset(nb, i) > t) --i;
+    while (i + 1 < nb && tile_offset(nb, i + 1) <= t) ++i;
+    I = i;
+    J = i + (t - (int)tile_offset(nb, i));
+}
+
+// DEEP: both batches' reads in flight before the first is consumed (16 loads per lane, ~168
+// VGPRs); otherwise batch by batch (8 loads per lane, ~100 VGPRs, one more wave per SIMD).
+template <bool DEEP>
 __global__ void __launch_bounds__(256)
 thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
                           const PackedJob* __restrict__ jobs, const int32_t* __restrict__ slots) {
-    const PackedJob* __restrict__ jp = jobs + slots[blockIdx.z];
+    const PackedJob* __restrict__ jp = jobs + slots[blockIdx.y];
+    const int nb = jp->nb, n = jp->n;
+    const int t = blockIdx.x;
+    if (t >= tile_count(nb)) return;
+    int I, J;
+    tile_coords(nb, t, I, J);
     const cplx* __restrict__ cs = jp->cs;
     const double* __restrict__ th = jp->th;
-    const GeomDev g = geoms[jp->geom];
-    const int I = blockIdx.y >> 1, J = blockIdx.x >> 1;       // 64-tile coordinates
-    const int qi = blockIdx.y & 1, qj = blockIdx.x & 1;       // quadrant inside the tile
-    const int nb = jp->nb, n = jp->n;
-    if (I >= nb || J >= nb || J < I) return;
     const int32_t* __restrict__ keep = jp->keep;
+    const GeomDev g = geoms[jp->geom];
     const double eta = jp->eta, two_eta = jp->two_eta;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int cj = qj * 32 + tx;                              // column inside the 64-tile
-    const int j = J * kTB + cj;
-    const int kj = j < n ? gload(keep + j) : 0;
-    const double th_j = j < n ? gload(th + kj) : 0.0;
-    cplx* __restrict__ tile = jp->tiles + (tile_offset(nb, I) + (J - I)) * kTileElems;
-    // Three phases so that a lane's scattered CS reads are all in flight together:
-    // (1) index math, (2) the loads, (3) weights and stores.
-    int64_t off[4];
-    double wgt[4];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform row group
+    const int j = J * kTB + lane;
+    const bool jin = j < n;
+    const int kj = jin ? gload(keep + j) : 0;
+    const double th_j = jin ? gload(th + kj) : 0.0;
+    const double sq_j = th_j * th_j;
+    cplx* __restrict__ tile = jp->tiles + (int64_t)t * kTileElems + lane;
+    const bool diag = (I == J);
+    // the wave's 16 rows: lanes 0..15 fetch keep / theta_i once (one dependent load pair), every
+    // row then reads them back through the scalar unit
+    const int i_l = I * kTB + 16 * w + (lane & 15);
+    const int ki_l = i_l < n ? gload(keep + i_l) : 0;
+    const double thi_l = i_l < n ? gload(th + ki_l) : 0.0;
+    GatherElem el[2][8];
+    cplx val[2][8];
+    auto index_and_load = [&](int b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int ri = qi * 32 + ty + 8 * r;
-        const int i = I * kTB + ri;
-        off[r] = -1;
-        wgt[r] = 0.0;
-        if (i < n && j < n && i != j) {
-            const int ki = gload(keep + i);
-            const double th_i = gload(th + ki);
+        for (int k = 0; k < 8; ++k) {
+            const int i = I * kTB + 16 * w + 8 * b + k;    // wave-uniform
+            const int ki = __builtin_amdgcn_readlane(ki_l, 8 * b + k);
+            const double th_i = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(thi_l), 8 * b + k),
+                                                 __builtin_amdgcn_readlane(__double2loint(thi_l), 8 * b + k));
+            const double sq_i = th_i * th_i;
             // upper element (i < j) reads (theta2 = th_i, theta1 = th_j); the lower half of a
             // diagonal tile is the conjugate of the mirrored upper element
-            const double t2 = i < j ? th_i : th_j, t1 = i < j ? th_j : th_i;
-            int64_t o = thth_offset(g, eta, t2, t1);
-            if ((int64_t)ki + kj == M - 1) o = -1;          // anti-diagonal (ththmod.py:113)
-            off[r] = o;
-            wgt[r] = sqrt(fabs(two_eta * (t2 - t1)));
-            if (i > j) wgt[r] = -wgt[r];                    // sign carries "conjugate"
+            const bool up = !diag || i < j;
+            const bool live = i < n && jin && i != j && ((int64_t)ki + kj != M - 1);   // anti-diagonal: ththmod.py:113
+            el[b][k] = gather_elem(g, eta, two_eta, up ? th_i : th_j, up ? th_j : th_i, up ? sq_i : sq_j,
+                                   up ? sq_j : sq_i, live);
+            if (!up) el[b][k].wgt = -el[b][k].wgt;         // sign carries "conjugate"
         }
-    }
-    cplx val[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) val[r] = gload(cs + (off[r] >= 0 ? off[r] : 0));
+        for (int k = 0; k < 8; ++k) val[b][k] = gload(cs + (el[b][k].off >= 0 ? el[b][k].off : 0));
+    };
+    auto weight_and_store = [&](int b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        cplx v = mk(0.0, 0.0);
-        if (off[r] >= 0) {
-            const double aw = fabs(wgt[r]);
-            v = mk(val[r].x * aw, val[r].y * aw);
-            if (wgt[r] < 0.0) v = conj(v);
-            v = mk(nan_to_num(v.x), nan_to_num(v.y));
+        for (int k = 0; k < 8; ++k) {
+            const GatherElem e = el[b][k];
+            const double aw = fabs(e.wgt);
+            const bool cj = e.wgt < 0.0;
+            double vx = nan_to_num(val[b][k].x * aw), vy = nan_to_num(val[b][k].y * aw);
+            vy = cj ? -vy : vy;
+            // off == -1: outside the CS / diagonal / anti-diagonal -> 0;  off == -2: NumPy would
+            // raise IndexError (cannot happen in a Hermitian job) -> NaN marker
+            const double none = e.off == -2 ? nan("") : 0.0;
+            const cplx v = mk(e.off >= 0 ? vx : none, e.off >= 0 ? vy : none);
+            gstore_nt(tile + (16 * w + 8 * b + k) * kTB, v);   // written once, read much later
         }
-        gstore_nt(tile + (qi * 32 + ty + 8 * r) * kTB + cj, v);   // written once, read much later
+    };
+    if (DEEP) {
+        index_and_load(0); index_and_load(1); weight_and_store(0); weight_and_store(1);
+    } else {
+        index_and_load(0); weight_and_store(0); index_and_load(1); weight_and_store(1);
     }
 }
 
@@ -155,8 +213,12 @@ int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJo
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
     SCINT_REQUIRE(nbmax <= 32767 && njobs <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
-    hipLaunchKernelGGL(thth_gather_packed_kernel, dim3(2u * (unsigned)nbmax, 2u * (unsigned)nbmax, (unsigned)njobs),
-                       dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
+    static const int variant = [] { const char* e = getenv("SCINT_GATHER_DEEP"); return e ? atoi(e) : 1; }();
+    const dim3 grid((unsigned)tile_count(nbmax), (unsigned)njobs);
+    if (variant)
+        hipLaunchKernelGGL(thth_gather_packed_kernel<true>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
+    else
+        hipLaunchKernelGGL(thth_gather_packed_kernel<false>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
@@ -194,11 +256,82 @@ struct RevParams {
     int slab;         // tau rows per workgroup
     int64_t centre;   // flat index of the pixel the i == j terms poison, or -1
     cplx* recov;      // [ntau, nfd]
+    const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
 };
 
-constexpr int kRevSlab = 2048;  // tau rows accumulated per workgroup: 2048 * 20 B = 40 KB of LDS
+constexpr int kRevSlab = 1792;  // tau rows accumulated per workgroup: 1792 * 36 B = 63 KiB of LDS (2 WGs per CU)
 
-// smallest j in [0, N] with th[j] - thi >= lo (N if none), galloping out from the guess g.
+// ---- order-independent (bit-reproducible) accumulation ---------------------------------------
+// Many (i, j) pairs fall in one CS pixel and arrive in scheduling order.  Plain float64 adds
+// would make the sum depend on that order, so every addend x is first split on a fixed binary
+// grid derived from an a-priori bound 2^E > |x|:
+//     hi = x rounded to a multiple of 2^(E-36),   lo = (x - hi) rounded to a multiple of 2^(E-73)
+// Up to 2^17 addends then sum EXACTLY in float64 in both accumulators (multiples of the grid,
+// below 2^53 grid steps), so the two sums do not depend on the order, and hi_sum + lo_sum is one
+// deterministic rounding.  What is dropped is < 2^(E-74) per addend: far below the float64
+// rounding of any pixel that matters (E is within a few tens of binades of the largest pixel).
+struct RevSplit {
+    double s1, s2;     // 1.5 * 2^(E-36+52), 1.5 * 2^(E-73+52): (x + s) - s rounds x to the grid
+    bool exact;        // false: degenerate bound (0, inf, NaN, extreme exponent) -> plain adds
+};
+__device__ inline RevSplit rev_split_for(double vmax, double min_dth, double two_eta, bool doubled) {
+    RevSplit r;
+    // |value / sqrt(|2 eta (th_i - th_j)|)| <= vmax / sqrt(|2 eta| min_dth); a Hermitian explicit
+    // pixel adds w_ij + conj(w_ji): twice that
+    const double bound = (doubled ? 2.0 : 1.0) * vmax / sqrt(fabs(two_eta) * min_dth);
+    r.exact = isfinite(bound) && bound > 0.0;
+    int e = 0;
+    if (r.exact) { (void)frexp(bound, &e); r.exact = e > -900 && e < 900; }   // bound < 2^e
+    r.s1 = ldexp(1.5, e + 16);
+    r.s2 = ldexp(1.5, e - 21);
+    return r;
+}
+
+// max |value| and the smallest theta spacing, as bit patterns of non-negative doubles (their
+// integer order is their numeric order, so atomicMax / atomicMin are exact and deterministic).
+// value: rank-1 -> |w| * max|v|^2 is formed by the consumer from max|v|; explicit -> max|thth_ij|.
+__global__ void __launch_bounds__(256) rev_bound_kernel(RevParams p, unsigned long long* out) {
+    __shared__ double red[4];
+    const int64_t nvals = p.rank1 ? (int64_t)p.N : (int64_t)p.N * p.N;
+    const cplx* __restrict__ src = p.rank1 ? p.vec : p.thth;
+    double vmax = 0.0, dmin = INFINITY;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nvals; k += (int64_t)gridDim.x * 256) {
+        const cplx v = gload(src + (p.rank1 ? k : (k / p.N) * p.ld + (k % p.N)));
+        const double a = fmax(fabs(v.x), fabs(v.y));
+        bad |= !(a == a);
+        vmax = fmax(vmax, a);
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i + 1 < p.N; i += 256) {
+            const double d = gload(p.th + i + 1) - gload(p.th + i);
+            bad |= !(d > 0.0);
+            dmin = fmin(dmin, d);
+        }
+    if (bad) { vmax = INFINITY; dmin = 0.0; }          // poisons the bound -> plain adds
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax = fmax(vmax, __shfl_xor(vmax, o, 64));
+        dmin = fmin(dmin, __shfl_xor(dmin, o, 64));
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        vmax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(out, (unsigned long long)__double_as_longlong(vmax * 1.4142135623730951));   // |v| <= sqrt2 max(|re|,|im|)
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (lane == 0) red[w] = dmin;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            dmin = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+            atomicMin(out + 1, (unsigned long long)__double_as_longlong(dmin));
+        }
+    }
+}
+
+// first j in [0, N] with th[j] - thi >= lo (N if none): gallop out from the guess g, then bisect.
 // fl(th[j] - thi) is non-decreasing in j, so the predicate is monotone.
 __device__ inline int rev_first_ge(const double* th, int N, double thi, double lo, int g) {
     g = min(max(g, 0), N - 1);
@@ -228,45 +361,60 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // and gathers every theta-theta pixel that np.histogram2d would drop there
 // (ththmod.py:207-262): for each i the j with fd_map[i, j] in the column form one short
 // interval (th is increasing); their tau bin picks the row.  Weighted sums and counts
-// accumulate in LDS (ds_add_f64), are divided and written once -- no global atomics, no
-// zero-fill and no separate normalise pass over the [ntau, nfd] image.
+// accumulate in LDS, are divided and written once -- no global atomics, no zero-fill and no
+// separate normalise pass over the [ntau, nfd] image.  The sums are order-independent (RevSplit
+// above), so the image is bit-reproducible.
+//
+// Every thread walks a run of CONSECUTIVE i: the start of the j interval moves monotonically with
+// i, so after one search for the run's first i the interval is carried along (two pointers).
 //
 // The Hermitian second pass of the reference (-fd, -tau, conj) puts the mirror of pixel
 // (j, i) exactly where the direct image of (i, j) falls (negation is exact in floating
 // point), so pixel (i, j) contributes  w_ij + conj(w_ji)  with count 2.  For the rank-1
 // Hermitian model w_ji == conj(w_ij) exactly, and sum and count are both halved.
 __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g) {
-    extern __shared__ double rev_lds[];
+    extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
-    double* acc_re = rev_lds;
-    double* acc_im = rev_lds + slab;
-    uint32_t* cnt = (uint32_t*)(rev_lds + 2 * slab);
+    double* acc_rh = rev_lds;                 // real: hi / lo grids
+    double* acc_rl = rev_lds + slab;
+    double* acc_ih = rev_lds + 2 * slab;      // imag
+    double* acc_il = rev_lds + 3 * slab;
+    uint32_t* cnt = (uint32_t*)(rev_lds + 4 * slab);
     // columns of 4 neighbouring workgroups of one XCD are adjacent, so their 16 B stores
     // complete 64 B lines in that XCD's L2
     int64_t col = blockIdx.x;
     if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);
     const int64_t row0 = (int64_t)blockIdx.y * slab;
     const int rows = (int)min((int64_t)slab, g.ntau - row0);
-    for (int r = threadIdx.x; r < rows; r += 256) { acc_re[r] = 0.0; acc_im[r] = 0.0; cnt[r] = 0u; }
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        acc_rh[r] = 0.0; acc_rl[r] = 0.0; acc_ih[r] = 0.0; acc_il[r] = 0.0; cnt[r] = 0u;
+    }
     __syncthreads();
 
     const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;        // histogram edges of the column
     const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
     const bool last = (col == g.nfd - 1);                              // last bin is closed on the right
     const double aw = p.rank1 ? fabs(gload(p.w)) : 0.0;
+    const double vmax = __longlong_as_double((long long)p.bound[0]);
+    const RevSplit sp = rev_split_for(p.rank1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)p.bound[1]),
+                                      p.two_eta, !p.rank1 && p.hermitian);
     // start of the neighbour search: offset of the column centre in mean theta spacings
     const double th_step = p.N > 1 ? (gload(p.th + p.N - 1) - gload(p.th)) / (double)(p.N - 1) : 0.0;
     const double est = th_step > 0.0 ? 0.5 * (lo + hi) / th_step : 0.0;
     const int shift = (int)fmin(fmax(rint(est), -(double)p.N), (double)p.N);
     const bool usable = g.fd1_step > 0.0 && g.tau1_step > 0.0;
-    for (int i = threadIdx.x; usable && i < p.N; i += 256) {
+    const int run = (p.N + 255) / 256;                                 // consecutive i per thread
+    const int i0 = threadIdx.x * run, i1 = min(p.N, i0 + run);
+    int j = 0;
+    for (int i = i0; usable && i < i1; ++i) {
         const double th_i = gload(p.th + i);
-        int j = rev_first_ge(p.th, p.N, th_i, lo, i + shift);
-        for (; j < p.N; ++j) {
-            const double th_j = gload(p.th + j);
+        if (i == i0) j = rev_first_ge(p.th, p.N, th_i, lo, i + shift);
+        else while (j < p.N && !(gload(p.th + j) - th_i >= lo)) ++j;   // interval start only moves up
+        for (int jj = j; jj < p.N; ++jj) {
+            const double th_j = gload(p.th + jj);
             const double x = th_j - th_i;                              // fd_map[i, j]  (ththmod.py:207)
             if (last ? (x > hi) : (x >= hi)) break;
-            if (i == j) continue;                                      // lands in the poisoned centre bin
+            if (i == jj) continue;                                     // lands in the poisoned centre bin
             const double y = p.eta * (th_j * th_j - th_i * th_i);      // tau_map[i, j] (ththmod.py:208-210)
             const int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau) - row0;
             if (by < 0 || by >= rows) continue;
@@ -275,19 +423,25 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
             double wr, wi;
             uint32_t c = 1u;
             if (p.rank1) {
-                const cplx o = mulc(gload(p.vec + i), gload(p.vec + j));  // outer(V, conj(V)) * |w|  (:312-313)
+                const cplx o = mulc(gload(p.vec + i), gload(p.vec + jj));  // outer(V, conj(V)) * |w|  (:312-313)
                 wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
             } else {
-                const cplx v = gload(p.thth + (int64_t)i * p.ld + j);
+                const cplx v = gload(p.thth + (int64_t)i * p.ld + jj);
                 wr = v.x * scl; wi = v.y * scl;
                 if (p.hermitian) {
-                    const cplx u = gload(p.thth + (int64_t)j * p.ld + i);
+                    const cplx u = gload(p.thth + (int64_t)jj * p.ld + i);
                     wr += u.x * scl; wi += -(u.y * scl);
                     c = 2u;
                 }
             }
-            atomicAdd(&acc_re[by], wr);
-            atomicAdd(&acc_im[by], wi);
+            if (sp.exact) {
+                const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
+                const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
+                atomicAdd(&acc_rh[by], rh); atomicAdd(&acc_rl[by], rl);
+                atomicAdd(&acc_ih[by], ih); atomicAdd(&acc_il[by], il);
+            } else {
+                atomicAdd(&acc_rh[by], wr); atomicAdd(&acc_ih[by], wi);
+            }
             atomicAdd(&cnt[by], c);
         }
     }
@@ -299,10 +453,45 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
         cplx out = mk(0.0, 0.0);
         if (o != p.centre) {
             const double scl = 1.0 / (double)cnt[r];
-            out = mk(nan_to_num(acc_re[r] * scl), nan_to_num(acc_im[r] * scl));
+            out = mk(nan_to_num((acc_rh[r] + acc_rl[r]) * scl), nan_to_num((acc_ih[r] + acc_il[r]) * scl));
         }
         gstore(p.recov + o, out);
     }
+}
+
+RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, int rank1, const double* th, int N,
+                          const GeomDev& g, double eta, int hermitian, cplx* recov) {
+    RevParams p;
+    p.thth = thth; p.ld = N;
+    p.vec = vec; p.w = w; p.rank1 = rank1;
+    p.th = th; p.N = N;
+    p.eta = eta; p.two_eta = 2 * eta;
+    p.hermitian = hermitian;
+    p.slab = 0;
+    // the bin the i == j terms fall in (fd_map = 0, tau_map = eta*0)
+    const int64_t cbx = hist_bin(0.0, g.fd0, g.fd1_step, g.nfd);
+    const int64_t cby = hist_bin(eta * 0.0, g.tau0, g.tau1_step, g.ntau);
+    p.centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
+    p.recov = recov;
+    p.bound = nullptr;
+    return p;
+}
+
+// Enqueue the back-map: bound pre-pass (max |value|, min theta spacing) + the column gather.
+int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound /*[2] device scratch*/,
+                       hipStream_t stream) {
+    static const unsigned long long init[2] = {0ull, 0x7ff0000000000000ull};   // 0.0, +inf
+    SCINT_HIP(hipMemcpyAsync(bound, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    const int64_t nvals = p.rank1 ? (int64_t)p.N : (int64_t)p.N * p.N;
+    const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
+    hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
+    p.bound = bound;
+    p.slab = (int)std::min<int64_t>(g.ntau, kRevSlab);
+    dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
+    SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
+    hipLaunchKernelGGL(rev_gather_kernel, grid, dim3(256), (size_t)p.slab * 36, stream, p, g);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
 }
 
 }  // namespace scint
@@ -329,30 +518,24 @@ extern "C" int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geo
     return launch_gather((const cplx*)cs, to_dev(*geom), th_cents, M, job, stream);
 }
 
+extern "C" int32_t scint_rev_map_workspace_bytes(size_t* bytes) {
+    SCINT_REQUIRE(bytes != nullptr, "rev_map_workspace_bytes: null output");
+    *bytes = 256;
+    return SCINT_OK;
+}
+
 extern "C" int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
                                  int32_t rank1, const double* th_cents, int64_t N,
                                  const scint_cs_geom* geom, double eta, int32_t hermitian,
-                                 scint_c128* recov_out, void* stream_) {
-    SCINT_REQUIRE(geom && th_cents && recov_out, "rev_map: null pointer");
+                                 scint_c128* recov_out, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
+    SCINT_REQUIRE(geom && th_cents && recov_out && workspace, "rev_map: null pointer");
+    SCINT_REQUIRE(workspace_bytes >= 256, "rev_map: workspace too small");
     SCINT_REQUIRE(rank1 ? (vec && w) : (thth != nullptr), "rev_map: missing input");
     SCINT_REQUIRE(N >= 1, "rev_map: bad N");
     hipStream_t stream = (hipStream_t)stream_;
     const GeomDev g = to_dev(*geom);
-    RevParams p;
-    p.thth = (const cplx*)thth; p.ld = N;
-    p.vec = (const cplx*)vec; p.w = w; p.rank1 = rank1;
-    p.th = th_cents; p.N = (int)N;
-    p.eta = eta; p.two_eta = 2 * eta;
-    p.hermitian = hermitian;
-    p.slab = (int)std::min<int64_t>(g.ntau, kRevSlab);
-    // the bin the i == j terms fall in (fd_map = 0, tau_map = eta*0)
-    const int64_t cbx = hist_bin(0.0, g.fd0, g.fd1_step, g.nfd);
-    const int64_t cby = hist_bin(eta * 0.0, g.tau0, g.tau1_step, g.ntau);
-    p.centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
-    p.recov = (cplx*)recov_out;
-    dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
-    SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    hipLaunchKernelGGL(rev_gather_kernel, grid, dim3(256), (size_t)p.slab * 20, stream, p, g);
-    SCINT_LAUNCH_CHECK();
-    return SCINT_OK;
+    return launch_rev_map(make_rev_params((const cplx*)thth, (const cplx*)vec, w, rank1, th_cents, (int)N, g, eta,
+                                          hermitian, (cplx*)recov_out),
+                          g, (unsigned long long*)workspace, stream);
 }

@@ -15,6 +15,8 @@ struct GeomDev {
     double tau0, dtau, half_dtau;  // tau[0], diff(tau).mean(), dtau/2
     double fd0, dfd, half_dfd;     // fd[0],  diff(fd).mean(),  dfd/2
     double tau1_step, fd1_step;    // tau[1]-tau[0], fd[1]-fd[0]   (rev_map)
+    double inv_dtau, inv_dfd;      // 1/dtau, 1/dfd: first guess of the floor (floor_div_exact_rcp)
+    double ntau_d, nfd_d;          // the sizes as doubles (range tests on the un-converted quotients)
 };
 inline GeomDev to_dev(const scint_cs_geom& g) {
     GeomDev d;
@@ -22,6 +24,8 @@ inline GeomDev to_dev(const scint_cs_geom& g) {
     d.tau0 = g.tau0; d.dtau = g.dtau; d.half_dtau = g.dtau / 2;
     d.fd0 = g.fd0; d.dfd = g.dfd; d.half_dfd = g.dfd / 2;
     d.tau1_step = g.tau1_step; d.fd1_step = g.fd1_step;
+    d.inv_dtau = 1.0 / g.dtau; d.inv_dfd = 1.0 / g.dfd;
+    d.ntau_d = (double)g.ntau; d.nfd_d = (double)g.nfd;
     return d;
 }
 
@@ -36,6 +40,19 @@ __device__ inline double floor_div_exact(double a, double b) {
     double q = floor(a / b);
     if (__builtin_fma(-q, b, a) < 0.0) q -= 1.0;
     return q;
+}
+
+// The same exact floor(a/b), b > 0, without the division: the first guess floor(a * (1/b)) is
+// within one of the answer (|a/b| < 2^31 here, the product is good to ~2 ulp), and the sign of a
+// single-rounded fma remainder is the sign of the exact remainder, so two sign tests settle it:
+//   a - q b < 0        -> q was one too high
+//   a - (q+1) b >= 0   -> q was one too low
+// (testing "a - q b >= b" instead would be wrong: that remainder may round up onto b.)
+__device__ inline double floor_div_exact_rcp(double a, double b, double inv_b) {
+    const double q = floor(a * inv_b);
+    const double r0 = __builtin_fma(-q, b, a);             // both remainders unconditionally, then pure
+    const double r1 = __builtin_fma(-(q + 1.0), b, a);     // arithmetic (the two cases exclude each other)
+    return (q - (r0 < 0.0 ? 1.0 : 0.0)) + (r1 >= 0.0 ? 1.0 : 0.0);
 }
 
 // np.nan_to_num on one float64

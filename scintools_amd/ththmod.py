@@ -222,9 +222,10 @@ def _rev_map_dev(grid_geom, th_t, n, eta, hermetian, thth_t=None, vec_t=None, w_
     lib = _lib.load()
     recov = empty((grid_geom.ntau, grid_geom.nfd), torch.complex128)
     rank1 = thth_t is None
+    scratch = empty((256,), torch.uint8)       # its own buffer: `workspace` may be live in a caller
     rc = lib.scint_rev_map(ptr(thth_t), ptr(vec_t), ptr(w_t), 1 if rank1 else 0, ptr(th_t), n,
                            ctypes.byref(grid_geom), eta, 1 if hermetian else 0, ptr(recov),
-                           stream_ptr())
+                           ptr(scratch), scratch.numel(), stream_ptr())
     _lib.check(rc, "scint_rev_map")
     return recov
 

@@ -135,3 +135,23 @@ def test_chisq_sweep_vs_chisq_calc(env, case):
     fine = np.linspace(0.9, 1.1, 9) * eta_true
     chi_f = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], fine, c["edges"], N)
     assert abs(fine[np.argmin(chi_f)] / eta_true - 1) <= 0.06
+
+
+def test_rev_map_and_modeler_are_bit_reproducible(env, case):
+    """np.histogram2d is deterministic, so the back-map must be too: the per-pixel sums are
+    accumulated on a fixed binary grid (order-independent), and repeated calls -- explicit and
+    rank-1, Hermitian and not -- return identical bits."""
+    thth, to = env
+    c = case
+    thth2_ref, edges_red = c["ref"][1], c["ref"][4]
+    a = thth.rev_map(thth2_ref, c["tau"], c["fd"], c["eta"], edges_red, hermetian=True)
+    for _ in range(2):
+        assert np.array_equal(a, thth.rev_map(thth2_ref, c["tau"], c["fd"], c["eta"], edges_red, hermetian=True))
+    b = thth.rev_map(thth2_ref, c["tau"], c["fd"], c["eta"], edges_red, hermetian=False)
+    assert np.array_equal(b, thth.rev_map(thth2_ref, c["tau"], c["fd"], c["eta"], edges_red, hermetian=False))
+    m1 = thth.modeler(c["CS"], c["tau"], c["fd"], c["eta"], c["edges"])
+    m2 = thth.modeler(c["CS"], c["tau"], c["fd"], c["eta"], c["edges"])
+    assert np.array_equal(m1[2], m2[2]) and np.array_equal(m1[3], m2[3]) and m1[5] == m2[5]
+    dyn = c["dyn"]
+    x1 = thth.chisq_calc(dyn, c["CS"], c["tau"], c["fd"], c["eta"], c["edges"], 1.0)
+    assert x1 == thth.chisq_calc(dyn, c["CS"], c["tau"], c["fd"], c["eta"], c["edges"], 1.0)
