@@ -212,6 +212,34 @@ def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
                       f"{len(idx)} of {len(etas)} etas, {dt:.1f} s"}
 
 
+def sspec_timing(torch, size):
+    """Dynspec.calc_sspec (window, zero-padded real-to-complex 2-D FFT, |.|^2, shift, dB;
+    dynspec.py:3665-3721) on a size^2 and a (2 size)^2 dynamic spectrum resident in HBM.
+    Algorithmic bytes: 8 nf nt read + 8 (nrfft/2) ncfft written."""
+    from scintools_amd.dynspec import sspec_device
+    res = {}
+    for n in (size, 2 * size):
+        try:
+            x = torch.randn(n, n, dtype=torch.float64, device="cuda")      # input creation, not the product path
+            sspec_device(x)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10 if n <= 4096 else 4
+            a.record()
+            for _ in range(reps):
+                sspec_device(x)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / reps
+            alg = 8.0 * n * n + 8.0 * n * (2 * n)          # nrfft/2 = n rows kept, ncfft = 2n columns
+            res[f"{n}x{n}"] = {"ms": ms, "algorithmic_bytes": alg, "GBs": alg / ms / 1e6,
+                               "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS}
+            del x
+        except Exception as exc:
+            res[f"{n}x{n}"] = {"error": repr(exc)}
+    return res
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -395,6 +423,8 @@ def main():
                 "matvec_share_of_step_time": mod["busy_ms"][1] / 1e3 / mod["elapsed"],
                 "matvec_GBs": mod["mv_bytes"] / (mod["busy_ms"][1] / 1e3) / 1e9 if mod["busy_ms"][1] > 0 else 0.0,
                 "eta_at_min_chisq_over_true": float(etas[np.nanargmin(chis)] / eta_true)}
+        if world == 1 and args.objective == "eig" and msteps > 0:
+            out["sspec"] = sspec_timing(torch, size)
         if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
             cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad)
             out["cpu_baseline"] = cb

@@ -15,15 +15,18 @@
  *     0 = ok, >0 = SCINT_E_*; the message is available from scint_last_error();
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
  *     work is enqueued on it; only entry points documented as synchronous
- *     wait for it.  The sweep entry points additionally drive one internal
- *     stream per host thread (half of the resident curvatures run there so that
- *     read-backs never idle the GPU); they return with both streams drained;
+ *     wait for it.  The sweep entry points queue their Lanczos steps two chunks
+ *     ahead of the convergence flags they have read (so the stream never waits
+ *     for the host); scint_chisq_sweep additionally drives one internal stream
+ *     per host thread and device for the model step of retired curvatures.
+ *     They return with every stream drained;
  *   - no function throws, allocates caller-visible memory, or keeps pointers to
  *     caller buffers after it returns.  Persistent library-owned state, all small
  *     and created on first use: a mutex-guarded cache of FFT twiddle tables per
  *     device; an 8 KiB reduction scratch per (device, stream) used by scint_mean /
  *     scint_chisq; per host thread a pinned flag buffer (4 int32 per resident
- *     curvature) and, per device, the internal sweep stream mentioned above.
+ *     curvature) and staging for the sweep's job tables, and, per device, the internal
+ *     stream mentioned above.
  */
 #ifndef SCINT_HIP_H
 #define SCINT_HIP_H
@@ -223,6 +226,29 @@ int32_t scint_acf(const double* dyn, int64_t nf, int64_t nt, int32_t subtract_me
 int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
                     int64_t nf, int64_t nt, const uint8_t* mask, double noise_n,
                     double* out, void* stream);
+
+/* ---- modeler / chisq_calc sweep: [chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask) for eta in etas]
+ * (ththmod.py:330-368 over :274-327) in ONE call.  The dominant eigenPAIR of every curvature is found
+ * by the batched Lanczos sweep (as scint_eigvec_sweep); as each curvature retires, its model step --
+ * rank-1 rev_map of |w| V V^H, inverse FFT, chi^2 against dspec[nf, nt] -- is chained on an internal
+ * stream beside the Lanczos steps of the curvatures still resident, without returning to the host.
+ *   th_red   DEVICE [neta, M]: row e = the N_e centres of the reduced edges (ththmod.py:157-172 then
+ *            :204-205), host-computed like the other grid quantities;
+ *   mask     DEVICE uint8[nf*nt] or NULL (= isfinite(dspec));
+ *   chisq_out DEVICE [neta]: sum((model[:nf,:nt]-dspec)[mask]**2)/noise_n; entries of curvatures whose
+ *            reduced matrix has < 2 points are left untouched (pre-fill with NaN);
+ *   w_out / vec_out / status_out / iters_out as in scint_eigvec_sweep.
+ * Synchronous like the other sweep entry points (returns with all internal streams drained). */
+int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,
+                                          int64_t ntau, int64_t nfd, int64_t nf, int64_t nt,
+                                          size_t* bytes /*HOST*/);
+int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/, const double* th_cents,
+                          int64_t M, const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
+                          const double* etas /*HOST*/, int64_t neta, double tol, int32_t max_iter,
+                          int64_t batch, const double* th_red, const double* dspec, int64_t nf, int64_t nt,
+                          const uint8_t* mask, double noise_n, double* chisq_out, double* w_out,
+                          scint_c128* vec_out, int64_t vec_stride, int32_t* status_out, int32_t* iters_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ==== arc normalisation: scale_dyn / norm_sspec / fit_arc ==== */
 

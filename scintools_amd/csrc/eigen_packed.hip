@@ -22,13 +22,13 @@
 //                     the Sturm count, Ritz residual by the backward recurrence, and the
 //                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
-// Scheduling: the `batch` slots are split into two groups driven on two streams: while the host
-// waits for / reads back / refills one group, the other group's kernels keep the GPU busy.
-// Within a group the slots are kept full -- as soon as a curvature converges (flags are read
-// back every 4 launches) its slot is re-filled with the next eta of the sweep: gather + init
-// for the new slots only, then the common step launches continue.  Every job carries the launch
-// index it started at, so jobs at different Lanczos steps share one launch (continuous
-// batching); per-job arithmetic does not depend on the schedule.
+// Scheduling (struct Sweep below): the `batch` slots are kept full -- when a curvature converges
+// its slot is re-filled with the next eta of the sweep (continuous batching; every job carries
+// the launch index it started at, so jobs at different Lanczos steps share one launch).  The
+// steps are queued in chunks of 4 + a convergence check, two chunks ahead of the state the host
+// has seen, so the stream never waits for the host; the gather and start vector of an entering
+// curvature run on a second stream beside the mat-vecs of the resident ones.  Per-job arithmetic
+// does not depend on the schedule.
 //
 // Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
 // 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| over the
@@ -62,7 +62,7 @@ __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
 __global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs, const int32_t* slots) {
     const PackedJob jb = jobs[slots[blockIdx.y]];
     const int K = blockIdx.x, e = threadIdx.x;
-    if (K == 0 && e == 0) { jb.state[0] = 0; jb.state[1] = 0; jb.result[3] = -INFINITY; }
+    if (K == 0 && e == 0) { jb.state[1] = 0; jb.result[1] = -INFINITY; jb.result[3] = -INFINITY; }   // state[0] keeps the finished generation
     if (K >= jb.nb) return;
     const int r = K * kTB + e;
     cplx v = mk(0.0, 0.0);
@@ -108,7 +108,7 @@ pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ s
     const Strip st = strips[blockIdx.x];
     const PackedJob* __restrict__ jp = jobs + st.job;
     const int step = launch - jp->start;
-    if (jp->n < 2 || step < 0 || step >= jp->max_steps || jp->state[0]) return;
+    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
     const int par = step & 1;
     const int nb = jp->nb;
     const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
@@ -195,7 +195,7 @@ pk_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     const PackedJob jb = jobs[blockIdx.y];
     const int K = blockIdx.x;
     const int step = launch - jb.start;
-    if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || jb.state[0]) return;
+    if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
     // fixed summation order: group g adds entries g, g+16, g+32, ... of the list
@@ -286,12 +286,12 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
     __shared__ double a[kMaxK + 1];
     __shared__ double b[kMaxK + 2];
     const PackedJob jb = jobs[blockIdx.x];
-    if (jb.state[0]) return;
+    if (jb.gen <= 0 || jb.state[0] >= jb.gen) return;      // idle slot / finished job
     const int lane = threadIdx.x;
     const int k_done = launches_done - jb.start;   // Lanczos steps this job has completed
     if (jb.n < 2) {
         if (lane == 0) {
-            jb.state[0] = 1;
+            jb.state[0] = jb.gen;
             jb.status_out[0] = SCINT_E_EMPTY;
             jb.eig_out[0] = nan("");
             if (jb.iters_out) jb.iters_out[0] = 0;
@@ -366,19 +366,25 @@ __global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int
         err = (gap > resid) ? resid * resid / gap : resid;
     }
     if (lane == 0) {
-        const double prev = jb.result[3];
+        const double prev = jb.result[3], prev2 = jb.result[1];
         const double at = fmax(fabs(theta), 1e-300);
         const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
         const bool exact = finite && (k >= jb.n || beta_k == 0.0);
-        // eigenvalue only: a-posteriori bound on theta; eigenvector wanted: the Ritz residual
-        // itself (vector error ~ resid / gap)
-        const bool ok = jb.want_vec ? (resid <= jb.tol * at) : (err <= jb.tol * at && settled);
+        // eigenvalue only: a-posteriori bound on theta.  Eigenvector wanted: the error of the Ritz
+        // vector is ~ resid / gap; ask for 30 tol (3e-11 at the default) of it, with the gap taken
+        // from the two top Ritz values once the second one has stopped moving (theta_2 <= lambda_2
+        // approaches from below, so an unsettled theta_2 would flatter the gap); resid <= tol
+        // |theta| always suffices.
+        const double gap2 = theta - theta2;
+        const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
+        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= 30.0 * jb.tol * gap2);
+        const bool ok = jb.want_vec ? vec_ok : (err <= jb.tol * at && settled);
         const bool conv = finite && (ok || exact);
         const bool stop = conv || !finite || k >= jb.max_steps;
-        jb.result[0] = theta; jb.result[1] = err; jb.result[2] = resid; jb.result[3] = theta;
+        jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
         if (stop) {
-            jb.state[0] = 1;
             jb.state[1] = k;
+            jb.state[0] = jb.gen;
             jb.eig_out[0] = jb.want_vec ? theta : fabs(theta);   // modeler keeps the sign of w
             if (jb.iters_out) jb.iters_out[0] = k;
             jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
@@ -466,10 +472,13 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     return L;
 }
 
+constexpr int kTabs = 3;   // rotating copies of the per-chunk tables (job table, strips, slot lists, flags)
+
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, states, slots, fin_slots, fin_eta, geoms, total;
+    size_t jobs, strips, states, slots, fin_slots, fin_eta, geoms, total;   // table offsets: copy 0; copies are *_stride apart
+    size_t jobs_stride, strips_stride, list_stride, fin_eta_stride;
 };
 
 static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs) {
@@ -479,20 +488,24 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_
     for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb));
     size_t off = B.slab.total * (size_t)nbatch;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
-    B.jobs = take(sizeof(PackedJob) * (size_t)nbatch);
-    B.strips = take(sizeof(Strip) * (size_t)nbatch * (size_t)B.smax);
+    B.jobs_stride = align_up(sizeof(PackedJob) * (size_t)nbatch, 256);
+    B.strips_stride = align_up(sizeof(Strip) * (size_t)nbatch * (size_t)B.smax, 256);
+    B.list_stride = align_up(sizeof(int32_t) * (size_t)nbatch, 256);
+    B.fin_eta_stride = align_up(sizeof(int64_t) * (size_t)nbatch, 256);
+    B.jobs = take(B.jobs_stride * kTabs);
+    B.strips = take(B.strips_stride * kTabs);
     B.states = take(sizeof(int32_t) * 4 * (size_t)nbatch);
-    B.slots = take(sizeof(int32_t) * (size_t)nbatch);
-    B.fin_slots = take(sizeof(int32_t) * (size_t)nbatch);
-    B.fin_eta = take(sizeof(int64_t) * (size_t)nbatch);
+    B.slots = take(B.list_stride * kTabs);
+    B.fin_slots = take(B.list_stride * kTabs);
+    B.fin_eta = take(B.fin_eta_stride * kTabs);
     B.geoms = take(sizeof(GeomDev) * (size_t)ncs);
     B.total = align_up(off, 256);
     return B;
 }
 
 
-static int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,
-                                     bool want_vec, int64_t ncs, size_t* bytes) {
+int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
+                              int64_t ncs, size_t* bytes) {
     SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && ncs >= 1,
                   "sweep_workspace_bytes: bad arguments");
     const int nbmax = (int)ceil_div(M, kTB);
@@ -502,18 +515,19 @@ static int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int
     return SCINT_OK;
 }
 
-// Pinned read-back buffer for the per-slot state words, kept per host thread and grown on
-// demand (a hipHostMalloc per sweep call costs more than a small sweep).
-static int32_t* pinned_flags(size_t count) {
-    thread_local int32_t* buf = nullptr;
+// Pinned host staging, kept per host thread and grown on demand (a hipHostMalloc per sweep call
+// costs more than a small sweep).  Every table that travels to or from the device while kernels
+// are in flight lives here, in kTabs rotating copies.
+static char* pinned_staging(size_t bytes) {
+    thread_local char* buf = nullptr;
     thread_local size_t cap = 0;
-    if (count > cap) {
+    if (bytes > cap) {
         if (buf) (void)hipHostFree(buf);
         buf = nullptr;
         cap = 0;
-        const size_t want = std::max<size_t>(count, 1024);
-        if (hipHostMalloc(&buf, sizeof(int32_t) * want) != hipSuccess) {
-            set_error("scint: hipHostMalloc of the flag buffer failed");
+        const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+        if (hipHostMalloc(&buf, want) != hipSuccess) {
+            set_error("scint: hipHostMalloc of the sweep staging buffer failed");
             buf = nullptr;
             return nullptr;
         }
@@ -522,207 +536,261 @@ static int32_t* pinned_flags(size_t count) {
     return buf;
 }
 
-// A second stream per host thread: the sweep alternates two groups of slots so that while the
-// host reads one group's convergence flags and refills its slots, the other group's kernels
-// keep the GPU busy (no sync bubbles, and the latency-bound reduce/check kernels of one group
-// overlap the bandwidth-bound mat-vec of the other).
-static hipStream_t second_stream() {
-    thread_local std::map<int, hipStream_t> streams;      // one per (host thread, device)
+// Internal stream, one per (host thread, device): `tail` (chi^2 sweep only) runs the per-curvature
+// model step of the retired curvatures beside the mat-vecs of the resident ones.
+struct SideStreams { hipStream_t tail = nullptr; };
+static SideStreams* side_streams() {
+    thread_local std::map<int, SideStreams> streams;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     auto it = streams.find(dev);
-    if (it != streams.end()) return it->second;
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
-    streams[dev] = s;
-    return s;
-}
-static hipEvent_t make_event() {
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-    return e;
+    if (it != streams.end()) return &it->second;
+    SideStreams s;
+    if (hipStreamCreateWithFlags(&s.tail, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return &(streams[dev] = s);
 }
 
-struct SweepShared {
+// ----------------------------------------------------------------------------------------------
+// The scheduler.  Lanczos steps are launched in CHUNKS of kCheckEvery steps + one convergence
+// check + the read-back of the per-slot state words.  The host runs `depth` chunks ahead of the
+// state it has seen (depth 2 by default): while chunk c executes, chunk c+1 is already queued, so
+// the caller's stream never waits for the host.  Retiring and refilling therefore lag: a
+// curvature that converges in chunk k is seen when chunk k+2 is prepared, its slot idles for one
+// chunk -- the kernels of chunk k+1 skip it, because every job carries the GENERATION of its slot
+// and the state word holds the last finished generation -- and the next curvature starts in chunk
+// k+2: table upload, gather and start vector are queued on the same stream in front of that
+// chunk's steps (the gather alone streams faster than the mat-vec, so overlapping the two on
+// different streams only makes them share HBM).  Host staging never changes under a queued
+// copy: job table, strip list, slot lists and flags exist in kTabs rotating copies, on the host
+// and on the device.  Per-job arithmetic does not depend on any of this (fixed-order sums inside
+// a job), so results are bit-identical for every depth, batch size and arrival order.
+struct Sweep {
     // problem
     const cplx* cs; int64_t cs_stride; const int32_t* cs_index; const double* th_cents; int64_t M;
     const int32_t* keep_idx; const int32_t* keep_n; const double* etas; int64_t neta;
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
-    int nbmax, steps_cap;
-    // device tables
-    char* base; const SlabLayout* L; PackedJob* jobs_dev; const GeomDev* geoms_dev;
-    // the queue of curvatures still to be started
-    int64_t next_eta;
-};
+    SweepTail* tail_hook;
+    int nbmax, steps_cap, nslots, depth;
+    // device
+    char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
+    hipStream_t main, tail;
+    hipEvent_t chunk_done[kTabs], export_done[kTabs];
+    // host staging (pinned), one set per table copy
+    PackedJob* h_jobs[kTabs]; Strip* h_strips[kTabs]; int32_t* h_fresh[kTabs]; int32_t* h_fin[kTabs];
+    int64_t* h_fin_eta[kTabs]; int32_t* h_rs[kTabs]; int32_t* h_flags[kTabs];
+    // schedule state
+    std::vector<PackedJob> jobs;          // current description of every slot
+    std::vector<int64_t> slot_eta;        // running eta or -1
+    std::vector<int32_t> slot_gen;
+    int64_t next_eta = 0;
+    int active = 0, chunk = 0;
+    int tab_of_chunk[kTabs];              // table copy used by chunk c, indexed c % kTabs
+    int nstrips = 0, nb_run = 1;
 
-// One group of slots [s0, s1) driven on its own stream.
-struct SweepGroup {
-    SweepShared* sh;
-    int s0, s1;
-    hipStream_t stream;
-    hipEvent_t done;
-    Strip* strips_dev; int32_t* states_dev; int32_t* slots_dev; int32_t* fin_slots_dev; int64_t* fin_eta_dev;
-    int32_t* flags;                              // pinned, 4 words per slot of the group
-    std::vector<PackedJob>* jobs;                // host copy of the whole job table
-    std::vector<int64_t> slot_eta;               // per slot of the group: running eta or -1
-    std::vector<Strip> strips;
-    std::vector<int32_t> rs_all, fresh, fin_slots;
-    std::vector<int64_t> fin_eta;
-    int launch = 0, active = 0;
-    bool in_flight = false;
+    PackedJob* d_jobs(int t) const { return (PackedJob*)(base + BL.jobs + BL.jobs_stride * (size_t)t); }
+    Strip* d_strips(int t) const { return (Strip*)(base + BL.strips + BL.strips_stride * (size_t)t); }
+    int32_t* d_fresh(int t) const { return (int32_t*)(base + BL.slots + BL.list_stride * (size_t)t); }
+    int32_t* d_fin(int t) const { return (int32_t*)(base + BL.fin_slots + BL.list_stride * (size_t)t); }
+    int64_t* d_fin_eta(int t) const { return (int64_t*)(base + BL.fin_eta + BL.fin_eta_stride * (size_t)t); }
 
-    int nslots() const { return s1 - s0; }
+    // retire what chunk `c` finished (its flags are on the host), export eigenvectors
+    int32_t harvest(int c, std::vector<int32_t>& fin_slots, std::vector<int64_t>& fin_eta) {
+        const int32_t* flags = h_flags[c % kTabs];
+        fin_slots.clear();
+        fin_eta.clear();
+        for (int s = 0; s < nslots; ++s) {
+            if (slot_eta[(size_t)s] < 0 || flags[4 * s] < slot_gen[(size_t)s]) continue;
+            fin_slots.push_back(s);
+            fin_eta.push_back(slot_eta[(size_t)s]);
+            slot_eta[(size_t)s] = -1;            // results were written by the check kernel
+            --active;
+        }
+        return SCINT_OK;
+    }
 
-    // refill idle slots, then enqueue kCheckEvery steps + the check + the flag read-back
-    int32_t enqueue() {
-        SweepShared& S = *sh;
-        const SlabLayout& L = *S.L;
-        hipError_t he = hipSuccess;
-        fresh.clear();
-        for (int s = s0; s < s1 && S.next_eta < S.neta; ++s) {
-            if (slot_eta[(size_t)(s - s0)] >= 0) continue;
-            const int64_t e = S.next_eta++;
-            slot_eta[(size_t)(s - s0)] = e;
+    // prepare and enqueue chunk `chunk`: refill idle slots, then kCheckEvery steps + check + read-back
+    int32_t enqueue(const std::vector<int32_t>& fin_slots, const std::vector<int64_t>& fin_eta, int fin_chunk) {
+        const SlabLayout& L = BL.slab;
+        std::vector<int32_t> fresh;
+        const int launch0 = chunk * kCheckEvery;
+        for (int s = 0; s < nslots && next_eta < neta; ++s) {
+            if (slot_eta[(size_t)s] >= 0) continue;
+            const int64_t e = next_eta++;
+            slot_eta[(size_t)s] = e;
             ++active;
-            PackedJob& J = (*jobs)[(size_t)s];
-            const int n = S.keep_n[e];
-            J.eta = S.etas[e]; J.two_eta = 2 * S.etas[e];
-            const int64_t c = S.cs_index ? S.cs_index[e] : 0;
-            J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
-            J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            J.max_steps = std::min(S.steps_cap, std::max(n, 1));
+            PackedJob& J = jobs[(size_t)s];
+            const int n = keep_n[e];
+            J.eta = etas[e]; J.two_eta = 2 * etas[e];
+            const int64_t c = cs_index ? cs_index[e] : 0;
+            J.cs = cs + c * cs_stride; J.th = th_cents + c * M; J.geom = (int32_t)c;
+            J.keep = keep_idx + e * M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
+            J.max_steps = std::min(steps_cap, std::max(n, 1));
             J.strip_len = strip_len_for(J.nb);
-            J.start = launch;
-            J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
-            J.iters_out = S.iters_out ? S.iters_out + e : nullptr;
+            J.start = launch0;
+            J.gen = ++slot_gen[(size_t)s];
+            J.eig_out = eigs_out + e; J.status_out = status_out + e;
+            J.iters_out = iters_out ? iters_out + e : nullptr;
             fresh.push_back(s);
         }
-        if (active == 0) { in_flight = false; return SCINT_OK; }
-        if (!fresh.empty()) {
-            // strips of every running job of the group, block row by block row
-            strips.clear();
-            int nb_fresh = 0;
-            for (int s = s0; s < s1; ++s) {
-                if (slot_eta[(size_t)(s - s0)] < 0) continue;
-                const PackedJob& J = (*jobs)[(size_t)s];
-                int32_t* rs0 = rs_all.data() + (size_t)(s - s0) * (size_t)(S.nbmax + 1);
+        const bool changed = chunk == 0 || !fresh.empty() || !fin_slots.empty();
+        int tab = chunk == 0 ? 0 : tab_of_chunk[(chunk - 1) % kTabs];
+        hipError_t he = hipSuccess;
+        if (changed) {
+            // a table copy no queued kernel can still read: not the previous chunk's, and not the one
+            // the eigenvector export of the retired jobs reads
+            if (chunk > 0) {
+                const int busy1 = tab_of_chunk[(chunk - 1) % kTabs];
+                const int busy2 = fin_chunk >= 0 ? tab_of_chunk[fin_chunk % kTabs] : busy1;
+                for (tab = 0; tab == busy1 || tab == busy2; ++tab) {}
+            }
+            // strips of every running job, block row by block row; longest strips first: the short
+            // ones of the last block rows then fill the tail of the launch (dispatch order only)
+            Strip* hs = h_strips[tab];
+            int32_t* hrs = h_rs[tab];
+            nstrips = 0;
+            nb_run = 1;
+            for (int s = 0; s < nslots; ++s) {
+                PackedJob& J = jobs[(size_t)s];
+                if (slot_eta[(size_t)s] < 0) { J.n = 0; continue; }      // idle: nothing to launch over
+                nb_run = std::max(nb_run, J.nb);
+                int32_t* rs0 = hrs + (size_t)s * (size_t)(nbmax + 1);
                 int idx = 0;
                 for (int I = 0; I < J.nb; ++I) {
                     rs0[I] = idx;
                     for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
-                        Strip st;
+                        Strip& st = hs[nstrips++];
                         st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
-                        strips.push_back(st);
                     }
                 }
                 rs0[J.nb] = idx;
             }
-            // longest strips first: the short ones of the last block rows then fill the tail
-            // of the launch (dispatch order only; the arithmetic does not depend on it)
-            std::stable_sort(strips.begin(), strips.end(), [](const Strip& a, const Strip& b) {
+            std::stable_sort(hs, hs + nstrips, [](const Strip& a, const Strip& b) {
                 return (a.J1 - a.J0) > (b.J1 - b.J0);
             });
+            std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
+            std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
+            int nb_fresh = 0;
             for (int s : fresh) {
-                const PackedJob& J = (*jobs)[(size_t)s];
+                const PackedJob& J = jobs[(size_t)s];
                 nb_fresh = std::max(nb_fresh, J.nb);
-                he = hipMemcpyAsync(S.base + L.total * (size_t)s + L.row_strip0,
-                                    rs_all.data() + (size_t)(s - s0) * (size_t)(S.nbmax + 1),
-                                    sizeof(int32_t) * (size_t)(J.nb + 1), hipMemcpyHostToDevice, stream);
+                he = hipMemcpyAsync(base + L.total * (size_t)s + L.row_strip0, hrs + (size_t)s * (size_t)(nbmax + 1),
+                                    sizeof(int32_t) * (size_t)(J.nb + 1), hipMemcpyHostToDevice, main);
                 if (he != hipSuccess) break;
             }
             if (he == hipSuccess)
-                he = hipMemcpyAsync(S.jobs_dev + s0, jobs->data() + s0, sizeof(PackedJob) * (size_t)nslots(),
-                                    hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(strips_dev, strips.data(), sizeof(Strip) * strips.size(), hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(slots_dev, fresh.data(), sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(stream);   // host vectors are reused; the stream is idle here
-            if (he != hipSuccess) return hip_fail(he, "sweep job upload", __FILE__, __LINE__);
-            int32_t rc = launch_gather_packed(S.geoms_dev, S.M, S.jobs_dev, slots_dev, (int)fresh.size(), nb_fresh, stream);
-            if (rc != SCINT_OK) return rc;
-            hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                               S.jobs_dev, slots_dev);
+                he = hipMemcpyAsync(d_jobs(tab), h_jobs[tab], sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, main);
+            if (he == hipSuccess && nstrips > 0)
+                he = hipMemcpyAsync(d_strips(tab), hs, sizeof(Strip) * (size_t)nstrips, hipMemcpyHostToDevice, main);
+            if (he == hipSuccess && !fresh.empty())
+                he = hipMemcpyAsync(d_fresh(tab), h_fresh[tab], sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, main);
+            if (he != hipSuccess) return hip_fail(he, "sweep table upload", __FILE__, __LINE__);
+            // eigenvectors of the retired jobs leave their slots BEFORE the new jobs' start vectors
+            // overwrite them (same stream); the table copy of the chunk that finished them still
+            // describes them
+            if (want_vec && !fin_slots.empty()) {
+                const int ft = tab_of_chunk[fin_chunk % kTabs];
+                int nfin = 0, nb_fin = 1;
+                for (size_t k = 0; k < fin_slots.size(); ++k) {
+                    const PackedJob& F = h_jobs[ft][fin_slots[k]];
+                    if (F.n < 2) continue;
+                    h_fin[tab][nfin] = fin_slots[k];
+                    h_fin_eta[tab][nfin] = fin_eta[k];
+                    nb_fin = std::max(nb_fin, F.nb);
+                    ++nfin;
+                }
+                if (nfin > 0) {
+                    he = hipMemcpyAsync(d_fin(tab), h_fin[tab], sizeof(int32_t) * (size_t)nfin, hipMemcpyHostToDevice, main);
+                    if (he == hipSuccess)
+                        he = hipMemcpyAsync(d_fin_eta(tab), h_fin_eta[tab], sizeof(int64_t) * (size_t)nfin,
+                                            hipMemcpyHostToDevice, main);
+                    if (he != hipSuccess) return hip_fail(he, "sweep eigenvector export", __FILE__, __LINE__);
+                    const dim3 grid((unsigned)nb_fin, (unsigned)nfin);
+                    hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, main, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                       vec_out, vstride);
+                    hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, main, d_jobs(ft), d_fin(tab),
+                                       d_fin_eta(tab), vec_out, vstride);
+                }
+            }
+            if (tail_hook && !fin_eta.empty()) {
+                he = hipEventRecord(export_done[tab], main);
+                if (he == hipSuccess) he = hipStreamWaitEvent(tail, export_done[tab], 0);
+                if (he != hipSuccess) return hip_fail(he, "sweep tail hand-off", __FILE__, __LINE__);
+                for (int64_t e : fin_eta) {
+                    const int32_t rc = tail_hook->retire(e, tail);
+                    if (rc != SCINT_OK) return rc;
+                }
+            }
+            if (!fresh.empty()) {
+                int32_t rc = launch_gather_packed(geoms_dev, M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, main);
+                if (rc != SCINT_OK) return rc;
+                hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, main,
+                                   d_jobs(tab), d_fresh(tab));
+            }
+            he = hipGetLastError();
+            if (he != hipSuccess) return hip_fail(he, "sweep refill", __FILE__, __LINE__);
         }
-        int nb_run = 1;
-        for (int s = s0; s < s1; ++s)
-            if (slot_eta[(size_t)(s - s0)] >= 0) nb_run = std::max(nb_run, (*jobs)[(size_t)s].nb);
-        const unsigned nstrips = (unsigned)strips.size();
-        for (int i = 0; i < kCheckEvery; ++i, ++launch) {
-            const int slot = profiler().begin(kProfMatvec, stream);
-            hipLaunchKernelGGL(pk_matvec_kernel, dim3(nstrips), dim3(256), 0, stream, S.jobs_dev, strips_dev, launch);
-            profiler().end(kProfMatvec, slot, stream);
-            hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots()), dim3(64 * kRedGroups), 0,
-                               stream, S.jobs_dev + s0, launch);
+        tab_of_chunk[chunk % kTabs] = tab;
+        if (nstrips > 0) {
+            for (int i = 0; i < kCheckEvery; ++i) {
+                const int launch = launch0 + i;
+                const int slot = profiler().begin(kProfMatvec, main);
+                hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, main, d_jobs(tab), d_strips(tab), launch);
+                profiler().end(kProfMatvec, slot, main);
+                hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
+                                   main, d_jobs(tab), launch);
+            }
         }
-        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots()), dim3(64), 0, stream, S.jobs_dev + s0, launch);
+        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, main, d_jobs(tab), launch0 + kCheckEvery);
         he = hipGetLastError();
         if (he == hipSuccess)
-            he = hipMemcpyAsync(flags, states_dev, sizeof(int32_t) * 4 * (size_t)nslots(), hipMemcpyDeviceToHost, stream);
-        if (he == hipSuccess) he = hipEventRecord(done, stream);
-        if (he != hipSuccess) return hip_fail(he, "sweep step", __FILE__, __LINE__);
-        in_flight = true;
+            he = hipMemcpyAsync(h_flags[chunk % kTabs], states_dev, sizeof(int32_t) * 4 * (size_t)nslots,
+                                hipMemcpyDeviceToHost, main);
+        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], main);
+        if (he != hipSuccess) return hip_fail(he, "sweep chunk", __FILE__, __LINE__);
+        ++chunk;
         return SCINT_OK;
     }
 
-    // wait for the group's last chunk, retire converged curvatures (and export their vectors)
-    int32_t harvest() {
-        if (!in_flight) return SCINT_OK;
-        SweepShared& S = *sh;
-        hipError_t he = hipEventSynchronize(done);
-        if (he != hipSuccess) return hip_fail(he, "sweep wait", __FILE__, __LINE__);
-        in_flight = false;
-        if (profiler().enabled) profiler().collect();
-        fin_slots.clear();
-        fin_eta.clear();
-        int nb_fin = 1;
-        for (int s = s0; s < s1; ++s) {
-            const size_t k = (size_t)(s - s0);
-            if (slot_eta[k] >= 0 && flags[4 * k] != 0) {
-                if (S.want_vec && (*jobs)[(size_t)s].n >= 2) {
-                    fin_slots.push_back(s);
-                    fin_eta.push_back(slot_eta[k]);
-                    nb_fin = std::max(nb_fin, (*jobs)[(size_t)s].nb);
-                }
-                slot_eta[k] = -1;             // finished: results were written by the check kernel
-                (*jobs)[(size_t)s].n = 0;     // an idle slot's kernels exit at once (host copy only)
-                --active;
+    int32_t run() {
+        std::vector<int32_t> fin_slots;
+        std::vector<int64_t> fin_eta;
+        int32_t rc = SCINT_OK;
+        int seen = 0;                       // chunks whose flags have been harvested
+        while (rc == SCINT_OK) {
+            int fin_chunk = -1;
+            fin_slots.clear();
+            fin_eta.clear();
+            const bool more = active > 0 || next_eta < neta;
+            if (chunk - seen >= depth || (!more && seen < chunk)) {
+                // wait for the oldest chunk in flight, retire what it finished
+                hipError_t he = hipEventSynchronize(chunk_done[seen % kTabs]);
+                if (he != hipSuccess) return hip_fail(he, "sweep wait", __FILE__, __LINE__);
+                if (profiler().enabled) profiler().collect();
+                rc = harvest(seen, fin_slots, fin_eta);
+                fin_chunk = seen++;
             }
-        }
-        if (!fin_slots.empty()) {
-            // export the Ritz vectors before the slots are re-used (the device job table still
-            // describes the finished jobs: it is only rewritten at the next refill)
-            he = hipMemcpyAsync(fin_slots_dev, fin_slots.data(), sizeof(int32_t) * fin_slots.size(),
-                                hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess)
-                he = hipMemcpyAsync(fin_eta_dev, fin_eta.data(), sizeof(int64_t) * fin_eta.size(),
-                                    hipMemcpyHostToDevice, stream);
-            if (he == hipSuccess) {
-                const dim3 grid((unsigned)nb_fin, (unsigned)fin_slots.size());
-                hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, S.jobs_dev, fin_slots_dev, fin_eta_dev,
-                                   S.vec_out, S.vstride);
-                hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, S.jobs_dev, fin_slots_dev,
-                                   fin_eta_dev, S.vec_out, S.vstride);
-                he = hipGetLastError();
+            if (rc != SCINT_OK) break;
+            if (active == 0 && next_eta >= neta && fin_slots.empty()) {
+                if (seen == chunk) break;   // nothing running, nothing queued
+                continue;                   // drain the chunks still in flight
             }
-            if (he == hipSuccess) he = hipStreamSynchronize(stream);
-            if (he != hipSuccess) return hip_fail(he, "sweep ritz vectors", __FILE__, __LINE__);
+            rc = enqueue(fin_slots, fin_eta, fin_chunk);
         }
-        return SCINT_OK;
+        return rc;
     }
 };
 
-// Shared driver of scint_eval_sweep (eigenvalues), scint_eigvec_sweep (eigenpairs) and
-// scint_eval_sweep_multi.  `ncs` conjugate spectra of one shape live `cs_stride` elements apart
-// from `cs`, each with its own geometry geom[c] and theta grid th_cents + c*M; curvature e reads
-// spectrum cs_index[e] (nullptr: all read spectrum 0).
-static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const int32_t* cs_index,
-                         const scint_cs_geom* geom, const double* th_cents,
-                         int64_t M, const int32_t* keep_idx, const int32_t* keep_n, const double* etas,
-                         int64_t neta, double tol, int32_t max_iter, int64_t batch, double* eigs_out,
-                         int32_t* status_out, int32_t* iters_out, bool want_vec, cplx* vec_out,
-                         int64_t vstride, void* workspace, size_t workspace_bytes, void* stream_) {
+// Shared driver of scint_eval_sweep (eigenvalues), scint_eigvec_sweep (eigenpairs),
+// scint_eval_sweep_multi and the chi^2 sweep.  `ncs` conjugate spectra of one shape live
+// `cs_stride` elements apart from `cs`, each with its own geometry geom[c] and theta grid
+// th_cents + c*M; curvature e reads spectrum cs_index[e] (nullptr: all read spectrum 0).
+int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const int32_t* cs_index,
+                  const scint_cs_geom* geom, const double* th_cents,
+                  int64_t M, const int32_t* keep_idx, const int32_t* keep_n, const double* etas,
+                  int64_t neta, double tol, int32_t max_iter, int64_t batch, double* eigs_out,
+                  int32_t* status_out, int32_t* iters_out, bool want_vec, cplx* vec_out,
+                  int64_t vstride, SweepTail* tail_hook, void* workspace, size_t workspace_bytes, void* stream_) {
     SCINT_REQUIRE(cs && geom && th_cents && keep_idx && keep_n && etas && eigs_out && status_out && workspace,
                   "sweep: null pointer");
     SCINT_REQUIRE(M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && tol > 0, "sweep: bad arguments");
@@ -737,103 +805,95 @@ static int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, c
     size_t need = 0;
     sweep_workspace_bytes(M, neta, batch, max_iter, want_vec, ncs, &need);
     if (workspace_bytes < need) { set_error("scint: sweep workspace too small"); return SCINT_E_WORKSPACE; }
-    const int nbmax = (int)ceil_div(M, kTB);
-    const int steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
-    const int nslots = (int)std::min(batch, neta);
-    const BatchLayout BL = batch_layout(nbmax, steps_cap, nslots, want_vec, ncs);
-    const SlabLayout& L = BL.slab;
-    char* base = (char*)workspace;
-    PackedJob* jobs_dev = (PackedJob*)(base + BL.jobs);
-    Strip* strips_dev = (Strip*)(base + BL.strips);
-    int32_t* states_dev = (int32_t*)(base + BL.states);
-    int32_t* slots_dev = (int32_t*)(base + BL.slots);
-    int32_t* fin_slots_dev = (int32_t*)(base + BL.fin_slots);
-    int64_t* fin_eta_dev = (int64_t*)(base + BL.fin_eta);
-    GeomDev* geoms_dev = (GeomDev*)(base + BL.geoms);
-    std::vector<GeomDev> geoms_host((size_t)ncs);
-    for (int64_t c = 0; c < ncs; ++c) geoms_host[(size_t)c] = to_dev(geom[c]);
-    SCINT_HIP(hipMemcpyAsync(geoms_dev, geoms_host.data(), sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice,
-                             stream));
-    SCINT_HIP(hipStreamSynchronize(stream));   // also: everything queued before us (the CS) is complete
+    SideStreams* side = side_streams();
+    if (!side) { set_error("scint: could not create the internal sweep streams"); return SCINT_E_HIP; }
 
-    std::vector<PackedJob> jobs((size_t)nslots);
-    int32_t* flags = pinned_flags((size_t)nslots * 4);
-    if (!flags) return SCINT_E_HIP;
-    for (int s = 0; s < nslots; ++s) {                    // static part of every slot
-        char* sl = base + L.total * (size_t)s;
-        PackedJob& J = jobs[(size_t)s];
+    Sweep S;
+    S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
+    S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
+    S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
+    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook;
+    S.nbmax = (int)ceil_div(M, kTB);
+    S.steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
+    S.nslots = (int)std::min(batch, neta);
+    const char* depth_env = getenv("SCINT_SWEEP_DEPTH");    // read per call: tests compare depths in one process
+    const int forced_depth = depth_env ? atoi(depth_env) : 0;
+    S.depth = forced_depth >= 1 && forced_depth <= 2 ? forced_depth : 2;
+    S.BL = batch_layout(S.nbmax, S.steps_cap, S.nslots, want_vec, ncs);
+    const SlabLayout& L = S.BL.slab;
+    S.base = (char*)workspace;
+    S.states_dev = (int32_t*)(S.base + S.BL.states);
+    S.geoms_dev = (const GeomDev*)(S.base + S.BL.geoms);
+    S.main = stream; S.tail = side->tail;
+
+    // pinned staging: geometry table + kTabs x {jobs, strips, fresh, fin, fin_eta, row_strip0, flags}
+    const size_t nsl = (size_t)S.nslots;
+    const size_t per_tab = align_up(sizeof(PackedJob) * nsl, 64) + align_up(sizeof(Strip) * nsl * (size_t)S.BL.smax, 64) +
+                           2 * align_up(sizeof(int32_t) * nsl, 64) + align_up(sizeof(int64_t) * nsl, 64) +
+                           align_up(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1), 64) + align_up(sizeof(int32_t) * 4 * nsl, 64);
+    const size_t geom_bytes = align_up(sizeof(GeomDev) * (size_t)ncs, 64);
+    char* pin = pinned_staging(geom_bytes + per_tab * kTabs);
+    if (!pin) return SCINT_E_HIP;
+    GeomDev* h_geoms = (GeomDev*)pin;
+    for (int64_t c = 0; c < ncs; ++c) h_geoms[c] = to_dev(geom[c]);
+    {
+        char* q = pin + geom_bytes;
+        auto take = [&](size_t bytes) { char* r = q; q += align_up(bytes, 64); return r; };
+        for (int t = 0; t < kTabs; ++t) {
+            S.h_jobs[t] = (PackedJob*)take(sizeof(PackedJob) * nsl);
+            S.h_strips[t] = (Strip*)take(sizeof(Strip) * nsl * (size_t)S.BL.smax);
+            S.h_fresh[t] = (int32_t*)take(sizeof(int32_t) * nsl);
+            S.h_fin[t] = (int32_t*)take(sizeof(int32_t) * nsl);
+            S.h_fin_eta[t] = (int64_t*)take(sizeof(int64_t) * nsl);
+            S.h_rs[t] = (int32_t*)take(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1));
+            S.h_flags[t] = (int32_t*)take(sizeof(int32_t) * 4 * nsl);
+        }
+    }
+    S.jobs.assign(nsl, PackedJob());
+    S.slot_eta.assign(nsl, -1);
+    S.slot_gen.assign(nsl, 0);
+    for (int s = 0; s < S.nslots; ++s) {                    // static part of every slot
+        char* sl = S.base + L.total * (size_t)s;
+        PackedJob& J = S.jobs[(size_t)s];
         J.tiles = (cplx*)(sl + L.tiles);
         J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
-        J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)nbmax * kTB; J.qslots = L.qslots;
+        J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
         J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
         J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
         J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
         J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
         J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
         J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
-        J.result = (double*)(sl + L.result); J.state = states_dev + 4 * s;
-        J.tol = tol; J.pad0 = 0;
+        J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * s;
+        J.tol = tol; J.gen = 0;
         J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
         J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
         J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
         J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
     }
-    // idle slots must look idle on the device before any group launches over them
-    SCINT_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream));
-    SCINT_HIP(hipMemsetAsync(states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream));
-    SCINT_HIP(hipStreamSynchronize(stream));
-
-    SweepShared S;
-    S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
-    S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
-    S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
-    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride;
-    S.nbmax = nbmax; S.steps_cap = steps_cap;
-    S.base = base; S.L = &L; S.jobs_dev = jobs_dev; S.geoms_dev = geoms_dev;
-    S.next_eta = 0;
-
-    // two groups on two streams when there are enough slots to split
-    static const int forced_groups = [] { const char* e = getenv("SCINT_SWEEP_GROUPS"); return e ? atoi(e) : 0; }();
-    hipStream_t s2 = second_stream();
-    int ngroups = (nslots >= 4 && s2) ? 2 : 1;
-    if (forced_groups == 1) ngroups = 1;
-    SweepGroup G[2];
+    // Order the tail stream after whatever the caller queued before us, then set up the state words
+    // and the geometry table.
+    hipEvent_t ev[2 * kTabs + 1] = {};
+    hipError_t he = hipSuccess;
+    for (auto& e : ev)
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
     int32_t rc = SCINT_OK;
-    for (int g = 0; g < ngroups; ++g) {
-        SweepGroup& q = G[g];
-        q.sh = &S;
-        q.s0 = g == 0 ? 0 : nslots / 2;
-        q.s1 = (g == ngroups - 1) ? nslots : nslots / 2;
-        q.stream = g == 0 ? stream : s2;
-        q.done = make_event();
-        if (!q.done) { set_error("scint: hipEventCreate failed"); rc = SCINT_E_HIP; }
-        q.strips_dev = strips_dev + (size_t)q.s0 * (size_t)BL.smax;
-        q.states_dev = states_dev + 4 * q.s0;
-        q.slots_dev = slots_dev + q.s0;
-        q.fin_slots_dev = fin_slots_dev + q.s0;
-        q.fin_eta_dev = fin_eta_dev + q.s0;
-        q.flags = flags + 4 * q.s0;
-        q.jobs = &jobs;
-        q.slot_eta.assign((size_t)q.nslots(), -1);
-        q.rs_all.assign((size_t)q.nslots() * (size_t)(nbmax + 1), 0);
+    if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
+    for (int t = 0; t < kTabs; ++t) { S.chunk_done[t] = ev[t]; S.export_done[t] = ev[kTabs + t]; }
+    if (rc == SCINT_OK) {
+        he = hipEventRecord(ev[2 * kTabs], stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(S.tail, ev[2 * kTabs], 0);
+        if (he == hipSuccess)
+            he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
+        if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * nsl, stream);
+        if (he != hipSuccess) rc = hip_fail(he, "sweep setup", __FILE__, __LINE__);
     }
-    // pipeline: enqueue A, enqueue B, then repeatedly {harvest g, enqueue g} alternating groups
-    for (int g = 0; g < ngroups && rc == SCINT_OK; ++g) rc = G[g].enqueue();
-    while (rc == SCINT_OK) {
-        bool any = false;
-        for (int g = 0; g < ngroups && rc == SCINT_OK; ++g) {
-            if (!G[g].in_flight) continue;
-            any = true;
-            rc = G[g].harvest();
-            if (rc == SCINT_OK) rc = G[g].enqueue();
-        }
-        if (!any) break;
-    }
-    // leave nothing running on the internal stream, and order the caller's stream after it
-    for (int g = 0; g < ngroups; ++g) {
-        if (G[g].stream) (void)hipStreamSynchronize(G[g].stream);
-        if (G[g].done) (void)hipEventDestroy(G[g].done);
-    }
+    if (rc == SCINT_OK) rc = S.run();
+    // leave nothing running on the internal streams, and nothing pending on the caller's
+    (void)hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(S.tail);
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -853,7 +913,7 @@ extern "C" int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* g
                                     int32_t* status_out, int32_t* iters_out, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch,
-                     eigs_out, status_out, iters_out, false, nullptr, 0, workspace, workspace_bytes, stream);
+                     eigs_out, status_out, iters_out, false, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int32_t scint_eval_sweep_multi_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
@@ -870,7 +930,7 @@ extern "C" int32_t scint_eval_sweep_multi(const scint_c128* cs_stack, int64_t nc
                                           size_t workspace_bytes, void* stream) {
     SCINT_REQUIRE(cs_index != nullptr || ncs == 1, "eval_sweep_multi: cs_index required");
     return run_sweep(cs_stack, ncs, cs_stride, cs_index, geoms, th_stack, M, keep_idx, keep_n, etas, neta, tol,
-                     max_iter, batch, eigs_out, status_out, iters_out, false, nullptr, 0, workspace,
+                     max_iter, batch, eigs_out, status_out, iters_out, false, nullptr, 0, nullptr, workspace,
                      workspace_bytes, stream);
 }
 
@@ -887,6 +947,6 @@ extern "C" int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom*
                                       int32_t* iters_out, void* workspace, size_t workspace_bytes,
                                       void* stream) {
     return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch,
-                     w_out, status_out, iters_out, true, (cplx*)vec_out, vec_stride, workspace, workspace_bytes,
+                     w_out, status_out, iters_out, true, (cplx*)vec_out, vec_stride, nullptr, workspace, workspace_bytes,
                      stream);
 }

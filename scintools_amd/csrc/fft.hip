@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "fft.hpp"
+#include "packed.hpp"
 
 namespace scint {
 
@@ -359,7 +360,13 @@ struct ColSink {
                 out_c[orow * C + ocol] = v;
                 break;
             }
-            case SINK_MODEL: out_d[k1 * C + c] = v.x * scale; break;
+            case SINK_MODEL:
+                if (crop_r > 0) {   // only the [crop_r, crop_c] corner, rows ld apart (chi^2 sweep)
+                    if (k1 < crop_r && c < crop_c) out_d[k1 * ld + c] = v.x * scale;
+                } else {
+                    out_d[k1 * C + c] = v.x * scale;
+                }
+                break;
             case SINK_CONJ:   // complex inverse transform: ifft2(x) = conj(fft2(conj x)) / (R C), cropped
                 if (k1 < crop_r && c < crop_c) out_c[k1 * ld + c] = mk(v.x * scale, -v.y * scale);
                 break;
@@ -891,4 +898,92 @@ extern "C" int32_t scint_acf(const double* dyn, int64_t nf, int64_t nt, int32_t 
     hipLaunchKernelGGL(scale_by_max_kernel, dim3(blocks), dim3(256), 0, stream, acf_out, R * C, partial, blocks);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
+}
+
+// ------------------------------------------------------------------------------
+// scint_chisq_sweep: chisq_calc(modeler(...)) for every curvature in ONE call
+// (the loop [chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask) for eta in etas], ththmod.py:330-368)
+// ------------------------------------------------------------------------------
+namespace scint {
+
+// The model step of one retired curvature, chained on the sweep's tail stream while the Lanczos
+// steps of the resident curvatures continue: rank-1 back-map of |w| V V^H -> inverse FFT (model
+// dynamic spectrum, [nf, nt] corner only) -> chi^2 reduction into chisq_out[e].
+struct ChisqTail : SweepTail {
+    GeomDev g; const int32_t* keep_n; const double* etas;
+    const cplx* vec; int64_t vstride; const double* w; const double* th_red; int64_t M;
+    const double* dspec; int64_t nf, nt; const uint8_t* mask; double noise_n; double* chisq_out;
+    cplx* recov; double* model; void* fft_ws; size_t fft_ws_bytes; double* partial; void* rev_scratch;
+
+    int32_t retire(int64_t e, hipStream_t tail) override {
+        const int64_t n = keep_n[e];
+        if (n < 2) return SCINT_OK;                       // crop-to-nothing: chi^2 stays NaN
+        int32_t rc = launch_rev_map_rank1(vec + e * vstride, w + e, th_red + e * M, n, g, etas[e], recov, rev_scratch, tail);
+        if (rc != SCINT_OK) return rc;
+        RowSource src{};
+        src.mode = SRC_MODEL; src.a = recov; src.R = g.ntau; src.C = g.nfd;
+        ColSink sink{};
+        sink.mode = SINK_MODEL; sink.out_d = model; sink.scale = 1.0 / ((double)g.ntau * (double)g.nfd);
+        sink.crop_r = nf; sink.crop_c = nt; sink.ld = nt;
+        rc = fft2_general(src, g.ntau, 0.0, g.ntau, g.nfd, sink, fft_ws, fft_ws_bytes, tail);
+        if (rc != SCINT_OK) return rc;
+        return launch_reduce(ChisqValue{model, nt, dspec, nt, mask}, nf * nt, 1.0 / noise_n, partial, chisq_out + e, tail);
+    }
+};
+
+struct ChisqSweepLayout { size_t recov, model, fft, partial, rev, sweep, total, fft_bytes, sweep_bytes; };
+static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, int64_t ntau, int64_t nfd,
+                                  int64_t nf, int64_t nt, ChisqSweepLayout* L) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
+    L->recov = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
+    L->model = take(sizeof(double) * (size_t)nf * (size_t)nt);
+    L->fft_bytes = fft2_general_ws(ntau, nfd, ntau);
+    L->fft = take(L->fft_bytes);
+    L->partial = take(sizeof(double) * (kRedBlocks + 8));
+    L->rev = take(256);
+    int32_t rc = sweep_workspace_bytes(M, neta, batch, max_iter, true, 1, &L->sweep_bytes);
+    if (rc != SCINT_OK) return rc;
+    L->sweep = take(L->sweep_bytes);
+    L->total = align_up(off, 256);
+    return SCINT_OK;
+}
+
+}  // namespace scint
+
+extern "C" int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,
+                                                     int64_t ntau, int64_t nfd, int64_t nf, int64_t nt, size_t* bytes) {
+    SCINT_REQUIRE(bytes && ntau >= 2 && nfd >= 1 && nf >= 1 && nt >= 1 && nf <= ntau && nt <= nfd,
+                  "chisq_sweep_workspace_bytes: bad arguments");
+    ChisqSweepLayout L;
+    const int32_t rc = chisq_sweep_layout(M, neta, batch, max_iter, ntau, nfd, nf, nt, &L);
+    if (rc == SCINT_OK) *bytes = L.total + 256;
+    return rc;
+}
+
+extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* geom, const double* th_cents,
+                                     int64_t M, const int32_t* keep_idx, const int32_t* keep_n,
+                                     const double* etas, int64_t neta, double tol, int32_t max_iter,
+                                     int64_t batch, const double* th_red, const double* dspec, int64_t nf,
+                                     int64_t nt, const uint8_t* mask, double noise_n, double* chisq_out,
+                                     double* w_out, scint_c128* vec_out, int64_t vec_stride,
+                                     int32_t* status_out, int32_t* iters_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    SCINT_REQUIRE(cs && geom && th_red && dspec && chisq_out && w_out && vec_out && workspace && keep_n && etas,
+                  "chisq_sweep: null pointer");
+    SCINT_REQUIRE(nf >= 1 && nt >= 1 && nf <= geom->ntau && nt <= geom->nfd && noise_n != 0.0, "chisq_sweep: bad shape");
+    ChisqSweepLayout L;
+    int32_t rc = chisq_sweep_layout(M, neta, batch, max_iter, geom->ntau, geom->nfd, nf, nt, &L);
+    if (rc != SCINT_OK) return rc;
+    if (workspace_bytes < L.total) { set_error("scint: chisq_sweep workspace too small"); return SCINT_E_WORKSPACE; }
+    char* base = (char*)workspace;
+    ChisqTail t;
+    t.g = to_dev(*geom); t.keep_n = keep_n; t.etas = etas;
+    t.vec = (const cplx*)vec_out; t.vstride = vec_stride; t.w = w_out; t.th_red = th_red; t.M = M;
+    t.dspec = dspec; t.nf = nf; t.nt = nt; t.mask = mask; t.noise_n = noise_n; t.chisq_out = chisq_out;
+    t.recov = (cplx*)(base + L.recov); t.model = (double*)(base + L.model);
+    t.fft_ws = base + L.fft; t.fft_ws_bytes = L.fft_bytes;
+    t.partial = (double*)(base + L.partial); t.rev_scratch = base + L.rev;
+    return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,
+                     status_out, iters_out, true, (cplx*)vec_out, vec_stride, &t, base + L.sweep, L.sweep_bytes, stream);
 }

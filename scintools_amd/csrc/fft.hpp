@@ -407,7 +407,7 @@ int32_t launch_cols_pass(const ColPass& p, int64_t batches, Loader ld, Storer st
 // LDS) behind transposing loaders: consecutive slots are consecutive columns and the threads of a
 // slot are consecutive sub-transform indices, so one wave instruction touches 16 adjacent
 // columns (256 contiguous bytes) of 4-8 rows -- whole cache lines in both directions.  The radix
-// passes of fft_cols_kernel need log16(L) trips instead of two.
+// passes of fft_cols_kernel need log16(L) trips instead of two; run_cols_fft picks per size.
 template <class First>
 struct ColsALoad {
     First first; int64_t ncols, ntiles; int l2;        // L2 = 1 << l2
@@ -475,8 +475,13 @@ int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader fi
     SCINT_REQUIRE(is_pow2(len) && len >= 2, "fft cols: length must be a power of two >= 2");
     const cplx* tw = twiddle_table(len);
     if (!tw) return SCINT_E_HIP;
+    // Measured on MI355X: while the working array fits the 256 MiB Infinity Cache the in-place radix
+    // passes re-read what they just wrote from the cache and win (4096^2 complex: 0.23 vs 0.28 ms);
+    // beyond it every radix pass is an HBM round trip and the two tiled passes win (16384^2: 5.6
+    // vs 7.3 ms).  SCINT_FFT_TWO_PASS = 0 / 2 forces never / always (experiments).
     static const int two_pass = [] { const char* e = getenv("SCINT_FFT_TWO_PASS"); return e ? atoi(e) : 1; }();
-    if (two_pass && len >= 256 && len <= 16384) {
+    const bool beyond_cache = (double)len * (double)ncols * (double)batches * 16.0 > 200.0 * 1048576.0;
+    if ((two_pass == 2 || (two_pass == 1 && beyond_cache)) && len >= 256 && len <= 16384) {
         const int l = ilog2(len), l2 = l / 2, l1 = l - l2;          // L1 >= L2, both in [16, 128]
         const int64_t ntiles = ceil_div(ncols, 16);
         int32_t rc = launch_fft_rows((int64_t)1 << l1, batches * ntiles * ((int64_t)1 << l2) * 16,

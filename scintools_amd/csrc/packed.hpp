@@ -49,7 +49,7 @@ struct PackedJob {
     cplx* tiles;            // [tile_count(nb)][64][64]
     // ---- Lanczos state -----------------------------------------------------------
     int32_t max_steps, strip_len;
-    int32_t start, pad0;    // launch index of this job's Lanczos step 0
+    int32_t start, gen;     // launch index of this job's Lanczos step 0; generation of the slot (>= 1)
     cplx* U[2];             // u_{j-1} / u_j                     [nb*64] each
     cplx* Q;                // q vectors: slot (j % qslots) holds q_j, slots are qstride apart
     int64_t qstride;        // elements between slots (>= nb*64)
@@ -64,7 +64,7 @@ struct PackedJob {
     double* alpha;          // [max_steps + 1]
     double* beta;           // [max_steps + 2]   beta[i] couples i-1 and i
     double* result;         // [4] theta, err estimate, resid, theta2
-    int32_t* state;         // [4] done, steps, -, -
+    int32_t* state;         // [4] last FINISHED generation of the slot (job done <=> state[0] >= gen), steps, -, -
     double* eig_out; int32_t* status_out; int32_t* iters_out;
     double tol;             // target relative accuracy of the eigenvalue
 };
@@ -78,5 +78,24 @@ struct Strip {
 // names its own CS, theta grid and geometry (geoms_dev[job.geom]).
 int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
                              const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream);
+
+// What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
+// on the host while the sweep runs; enqueues on `tail`, which already waits for the export.
+struct SweepTail {
+    virtual int32_t retire(int64_t eta_index, hipStream_t tail) = 0;
+    virtual ~SweepTail() {}
+};
+
+// The batched Lanczos sweep (eigen_packed.hip).  `ncs` conjugate spectra of one shape live
+// `cs_stride` elements apart from `cs`, each with its own geometry geom[c] and theta grid
+// th_cents + c*M; curvature e reads spectrum cs_index[e] (nullptr: all read spectrum 0).
+int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const int32_t* cs_index,
+                  const scint_cs_geom* geom, const double* th_cents, int64_t M, const int32_t* keep_idx,
+                  const int32_t* keep_n, const double* etas, int64_t neta, double tol, int32_t max_iter,
+                  int64_t batch, double* eigs_out, int32_t* status_out, int32_t* iters_out, bool want_vec,
+                  cplx* vec_out, int64_t vstride, SweepTail* tail_hook, void* workspace, size_t workspace_bytes,
+                  void* stream);
+int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
+                              int64_t ncs, size_t* bytes);
 
 }  // namespace scint

@@ -92,7 +92,7 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 // One 64 x 64 packed tile per 256-thread workgroup.  Lanes run along the 64 columns (every row a
 // wave stores is one contiguous 1 KiB segment of the tile), wave w owns rows 16w .. 16w+15, i.e.
 // 16 elements per lane, handled as two batches of 8 whose scattered 16-B CS reads are all issued
-// before the first result is needed (16 independent loads in flight per lane).  Everything that
+// before the first result of the batch is needed.  Everything that
 // depends on the row only (keep index, theta_i, theta_i^2) is wave-uniform and is read through
 // the scalar unit; the column's theta_j costs each lane ONE dependent load pair for the whole
 // tile.  The bin index is the exact floor of thth.hpp, computed without a division.
@@ -134,9 +134,6 @@ __device__ inline void tile_coords(int nb, int t, int& I, int& J) {
     J = i + (t - (int)tile_offset(nb, i));
 }
 
-// DEEP: both batches' reads in flight before the first is consumed (16 loads per lane, ~168
-// VGPRs); otherwise batch by batch (8 loads per lane, ~100 VGPRs, one more wave per SIMD).
-template <bool DEEP>
 __global__ void __launch_bounds__(256)
 thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
                           const PackedJob* __restrict__ jobs, const int32_t* __restrict__ slots) {
@@ -201,11 +198,9 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
             gstore_nt(tile + (16 * w + 8 * b + k) * kTB, v);   // written once, read much later
         }
     };
-    if (DEEP) {
-        index_and_load(0); index_and_load(1); weight_and_store(0); weight_and_store(1);
-    } else {
-        index_and_load(0); weight_and_store(0); index_and_load(1); weight_and_store(1);
-    }
+    // batch by batch (8 reads in flight per lane, ~100 VGPRs, 4 waves per SIMD); issuing both
+    // batches' reads first (168 VGPRs, 3 waves) measured the same
+    index_and_load(0); weight_and_store(0); index_and_load(1); weight_and_store(1);
 }
 
 int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
@@ -213,12 +208,8 @@ int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJo
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
     SCINT_REQUIRE(nbmax <= 32767 && njobs <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
-    static const int variant = [] { const char* e = getenv("SCINT_GATHER_DEEP"); return e ? atoi(e) : 1; }();
-    const dim3 grid((unsigned)tile_count(nbmax), (unsigned)njobs);
-    if (variant)
-        hipLaunchKernelGGL(thth_gather_packed_kernel<true>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
-    else
-        hipLaunchKernelGGL(thth_gather_packed_kernel<false>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
+    hipLaunchKernelGGL(thth_gather_packed_kernel, dim3((unsigned)tile_count(nbmax), (unsigned)njobs), dim3(256), 0,
+                       stream, geoms_dev, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
@@ -259,7 +250,7 @@ struct RevParams {
     const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
 };
 
-constexpr int kRevSlab = 1792;  // tau rows accumulated per workgroup: 1792 * 36 B = 63 KiB of LDS (2 WGs per CU)
+constexpr int kRevSlab = 1792;  // most tau rows accumulated per workgroup: 1792 * 36 B = 63 KiB of LDS
 
 // ---- order-independent (bit-reproducible) accumulation ---------------------------------------
 // Many (i, j) pairs fall in one CS pixel and arrive in scheduling order.  Plain float64 adds
@@ -365,20 +356,23 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // separate normalise pass over the [ntau, nfd] image.  The sums are order-independent (RevSplit
 // above), so the image is bit-reproducible.
 //
-// Every thread walks a run of CONSECUTIVE i: the start of the j interval moves monotonically with
-// i, so after one search for the run's first i the interval is carried along (two pointers).
+// Lanes run over i (coalesced).  On a (nearly) uniform theta grid the interval of lane i is
+// i + s0 .. i + s0 + W - 1 for a column-wide s0: the lane fetches that window and one guard on
+// either side with INDEPENDENT loads (no dependent search chain), checks that the guards bracket
+// the interval -- fl(th[j] - th[i]) is non-decreasing in j, so a guard below the column and a
+// guard beyond it prove nothing was missed -- and falls back to a galloping search otherwise.
 //
 // The Hermitian second pass of the reference (-fd, -tau, conj) puts the mirror of pixel
 // (j, i) exactly where the direct image of (i, j) falls (negation is exact in floating
 // point), so pixel (i, j) contributes  w_ij + conj(w_ji)  with count 2.  For the rank-1
 // Hermitian model w_ji == conj(w_ij) exactly, and sum and count are both halved.
+constexpr int kRevWin = 8;   // widest candidate window (theta centres per fd bin, + 2)
+
 __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g) {
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
-    double* acc_rh = rev_lds;                 // real: hi / lo grids
-    double* acc_rl = rev_lds + slab;
-    double* acc_ih = rev_lds + 2 * slab;      // imag
-    double* acc_il = rev_lds + 3 * slab;
+    // rev_lds[0 .. 4 slab): real hi, real lo, imag hi, imag lo grids; then the counts.  Always
+    // indexed off the __shared__ array itself so that every access stays an LDS instruction.
     uint32_t* cnt = (uint32_t*)(rev_lds + 4 * slab);
     // columns of 4 neighbouring workgroups of one XCD are adjacent, so their 16 B stores
     // complete 64 B lines in that XCD's L2
@@ -387,7 +381,8 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
     const int64_t row0 = (int64_t)blockIdx.y * slab;
     const int rows = (int)min((int64_t)slab, g.ntau - row0);
     for (int r = threadIdx.x; r < rows; r += 256) {
-        acc_rh[r] = 0.0; acc_rl[r] = 0.0; acc_ih[r] = 0.0; acc_il[r] = 0.0; cnt[r] = 0u;
+        rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0; rev_lds[2 * slab + r] = 0.0; rev_lds[3 * slab + r] = 0.0;
+        ((uint32_t*)(rev_lds + 4 * slab))[r] = 0u;
     }
     __syncthreads();
 
@@ -398,51 +393,79 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
     const double vmax = __longlong_as_double((long long)p.bound[0]);
     const RevSplit sp = rev_split_for(p.rank1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)p.bound[1]),
                                       p.two_eta, !p.rank1 && p.hermitian);
-    // start of the neighbour search: offset of the column centre in mean theta spacings
-    const double th_step = p.N > 1 ? (gload(p.th + p.N - 1) - gload(p.th)) / (double)(p.N - 1) : 0.0;
-    const double est = th_step > 0.0 ? 0.5 * (lo + hi) / th_step : 0.0;
-    const int shift = (int)fmin(fmax(rint(est), -(double)p.N), (double)p.N);
+    const int N = p.N;
+    // window start relative to i, and its width, from the mean theta spacing
+    const double th_step = N > 1 ? (gload(p.th + N - 1) - gload(p.th)) / (double)(N - 1) : 0.0;
+    const bool grid_ok = th_step > 0.0 && isfinite(lo / th_step) && fabs(lo / th_step) < 1e9;
+    const int s0 = grid_ok ? (int)floor(lo / th_step) - 1 : 0;
+    const int W = grid_ok ? (int)fmin(ceil(g.fd1_step / th_step) + 2.0, (double)kRevWin) : 0;
     const bool usable = g.fd1_step > 0.0 && g.tau1_step > 0.0;
-    const int run = (p.N + 255) / 256;                                 // consecutive i per thread
-    const int i0 = threadIdx.x * run, i1 = min(p.N, i0 + run);
-    int j = 0;
-    for (int i = i0; usable && i < i1; ++i) {
+
+    auto beyond = [&](double x) { return last ? (x > hi) : (x >= hi); };
+    auto contribute = [&](int i, int j, double th_i, double th_j) {
+        if (i == j) return;                                            // lands in the poisoned centre bin
+        const double y = p.eta * (th_j * th_j - th_i * th_i);          // tau_map[i, j] (ththmod.py:208-210)
+        const int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau) - row0;
+        if (by < 0 || by >= rows) return;
+        // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
+        const double scl = 1.0 / sqrt(fabs(p.two_eta * (th_i - th_j)));
+        double wr, wi;
+        uint32_t c = 1u;
+        if (p.rank1) {
+            const cplx o = mulc(gload(p.vec + i), gload(p.vec + j));   // outer(V, conj(V)) * |w|  (:312-313)
+            wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
+        } else {
+            const cplx v = gload(p.thth + (int64_t)i * p.ld + j);
+            wr = v.x * scl; wi = v.y * scl;
+            if (p.hermitian) {
+                const cplx u = gload(p.thth + (int64_t)j * p.ld + i);
+                wr += u.x * scl; wi += -(u.y * scl);
+                c = 2u;
+            }
+        }
+        if (sp.exact) {
+            const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
+            const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
+            atomicAdd(&rev_lds[by], rh); atomicAdd(&rev_lds[slab + by], rl);
+            atomicAdd(&rev_lds[2 * slab + by], ih); atomicAdd(&rev_lds[3 * slab + by], il);
+        } else {
+            atomicAdd(&rev_lds[by], wr); atomicAdd(&rev_lds[2 * slab + by], wi);
+        }
+        atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
+    };
+
+    for (int i = threadIdx.x; usable && i < N; i += 256) {
         const double th_i = gload(p.th + i);
-        if (i == i0) j = rev_first_ge(p.th, p.N, th_i, lo, i + shift);
-        else while (j < p.N && !(gload(p.th + j) - th_i >= lo)) ++j;   // interval start only moves up
-        for (int jj = j; jj < p.N; ++jj) {
-            const double th_j = gload(p.th + jj);
-            const double x = th_j - th_i;                              // fd_map[i, j]  (ththmod.py:207)
-            if (last ? (x > hi) : (x >= hi)) break;
-            if (i == jj) continue;                                     // lands in the poisoned centre bin
-            const double y = p.eta * (th_j * th_j - th_i * th_i);      // tau_map[i, j] (ththmod.py:208-210)
-            const int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau) - row0;
-            if (by < 0 || by >= rows) continue;
-            // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
-            const double scl = 1.0 / sqrt(fabs(p.two_eta * (th_i - th_j)));
-            double wr, wi;
-            uint32_t c = 1u;
-            if (p.rank1) {
-                const cplx o = mulc(gload(p.vec + i), gload(p.vec + jj));  // outer(V, conj(V)) * |w|  (:312-313)
-                wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
-            } else {
-                const cplx v = gload(p.thth + (int64_t)i * p.ld + jj);
-                wr = v.x * scl; wi = v.y * scl;
-                if (p.hermitian) {
-                    const cplx u = gload(p.thth + (int64_t)jj * p.ld + i);
-                    wr += u.x * scl; wi += -(u.y * scl);
-                    c = 2u;
-                }
+        const int g0 = i + s0;                                         // first candidate
+        double tj[kRevWin + 2];                                        // th[g0 - 1 .. g0 + W]
+#pragma unroll
+        for (int k = 0; k < kRevWin + 2; ++k) {
+            const int idx = g0 - 1 + k;
+            // the two guards are clamped into the array: a guard at the array's end that is still
+            // outside the column speaks for everything beyond it
+            const int cl = k == 0 ? min(idx, N - 1) : (k == W + 1 ? max(idx, 0) : idx);
+            tj[k] = (k <= W + 1 && cl >= 0 && cl < N) ? gload(p.th + cl) : nan("");
+        }
+        double t_hi = tj[1];                                           // tj[W + 1] without dynamic indexing
+#pragma unroll
+        for (int k = 2; k < kRevWin + 2; ++k) t_hi = (k == W + 1) ? tj[k] : t_hi;
+        const bool below_ok = (g0 - 1 < 0) || !(tj[0] - th_i >= lo);
+        const bool above_ok = (g0 + W >= N) || beyond(t_hi - th_i);
+        if (W > 0 && below_ok && above_ok) {
+#pragma unroll
+            for (int k = 1; k <= kRevWin; ++k) {
+                const int j = g0 - 1 + k;
+                if (k > W || j < 0 || j >= N) continue;
+                const double x = tj[k] - th_i;                         // fd_map[i, j]  (ththmod.py:207)
+                if (!(x >= lo) || beyond(x)) continue;
+                contribute(i, j, th_i, tj[k]);
             }
-            if (sp.exact) {
-                const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
-                const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
-                atomicAdd(&acc_rh[by], rh); atomicAdd(&acc_rl[by], rl);
-                atomicAdd(&acc_ih[by], ih); atomicAdd(&acc_il[by], il);
-            } else {
-                atomicAdd(&acc_rh[by], wr); atomicAdd(&acc_ih[by], wi);
+        } else {
+            for (int j = rev_first_ge(p.th, N, th_i, lo, g0); j < N; ++j) {
+                const double th_j = gload(p.th + j);
+                if (beyond(th_j - th_i)) break;
+                contribute(i, j, th_i, th_j);
             }
-            atomicAdd(&cnt[by], c);
         }
     }
     __syncthreads();
@@ -453,7 +476,8 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
         cplx out = mk(0.0, 0.0);
         if (o != p.centre) {
             const double scl = 1.0 / (double)cnt[r];
-            out = mk(nan_to_num((acc_rh[r] + acc_rl[r]) * scl), nan_to_num((acc_ih[r] + acc_il[r]) * scl));
+            out = mk(nan_to_num((rev_lds[r] + rev_lds[slab + r]) * scl),
+                     nan_to_num((rev_lds[2 * slab + r] + rev_lds[3 * slab + r]) * scl));
         }
         gstore(p.recov + o, out);
     }
@@ -486,12 +510,19 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
     hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
     p.bound = bound;
-    p.slab = (int)std::min<int64_t>(g.ntau, kRevSlab);
+    // equal slabs, the fewest that fit the LDS budget (4096 rows -> 3 x 1366: three workgroups per CU)
+    p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, kRevSlab));
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
     hipLaunchKernelGGL(rev_gather_kernel, grid, dim3(256), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
+}
+
+int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g,
+                             double eta, cplx* recov, void* scratch, hipStream_t stream) {
+    return launch_rev_map(make_rev_params(nullptr, vec, w, 1, th, (int)N, g, eta, 1, recov), g,
+                          (unsigned long long*)scratch, stream);
 }
 
 }  // namespace scint

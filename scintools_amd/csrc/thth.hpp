@@ -112,4 +112,9 @@ struct GatherJob {
 int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, int64_t M,
                       const GatherJob& job, hipStream_t stream);
 
+// Enqueue the rank-1 back-map  recov = rev_map(|w| v v^H)  (modeler, ththmod.py:312-321) on
+// `stream`: th[N] are the centres of the reduced edges, w a DEVICE scalar, scratch 256 bytes.
+int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g,
+                             double eta, cplx* recov, void* scratch, hipStream_t stream);
+
 }  // namespace scint

@@ -13,7 +13,7 @@ rev_map            ththmod.py:176-271     scint_rev_map
 modeler            ththmod.py:274-327     scint_thth_map + scint_eigh_top +
                                           scint_rev_map + scint_model_from_recov
 chisq_calc         ththmod.py:330-368     ... + scint_chisq
-chisq_sweep        (a loop of chisq_calc) scint_eigvec_sweep + scint_rev_map + ...
+chisq_sweep        (a loop of chisq_calc) scint_chisq_sweep
 Eval_calc          ththmod.py:371-401     scint_eval_sweep (one eta)
 single_search      ththmod.py:715-895     scint_cs + scint_eval_sweep (+ SciPy fit)
 eval_sweep         (the loop :788-799)    scint_eval_sweep
@@ -332,7 +332,7 @@ def default_batch(nmax, neta):
     nb = -(-nmax // 64)
     strip = 16 if nb >= 32 else (8 if nb >= 16 else (4 if nb >= 8 else (2 if nb >= 4 else 1)))
     strips = sum(-(-(nb - i) // strip) for i in range(nb))
-    want = -(-7500 // max(strips, 1))
+    want = -(-8500 // max(strips, 1))      # ~10 % of the slots idle one chunk between curvatures (pipelined refills)
     cap = max(1, DEFAULT_BATCH_BYTES // (8 * (nb * 64) ** 2 + 1))
     return int(max(1, min(neta, 256, want, cap)))
 
@@ -424,41 +424,54 @@ def eigvec_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX
     return w, V_t, info
 
 
-def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False):
+def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False, tol=DEFAULT_TOL,
+                max_iter=DEFAULT_MAX_ITER, batch=None):
     """chi**2 of the theta-theta model for every curvature: the loop
     ``[chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask) for eta in etas]``
-    (ththmod.py:330-368) with the eigenpairs of all curvatures found in one batched call and
-    the per-eta rank-1 back-map, inverse FFT and reduction chained on the device."""
+    (ththmod.py:330-368) as ONE device call (``scint_chisq_sweep``): the eigenpairs of all
+    curvatures come from the batched Lanczos sweep, and as each curvature retires its rank-1
+    back-map, inverse FFT and chi**2 reduction are chained on a side stream while the sweep goes
+    on -- no per-eta round trip through Python."""
     lib = _lib.load()
     grid = _Grid(tau, fd, edges)
     cs_t = _cs_dev(CS, grid)
-    etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
-    w, V_t, info = eigvec_sweep(cs_t, grid.tau, grid.fd, etas_v, grid.edges)
+    etas_v = np.ascontiguousarray(np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float))
+    neta, M = etas_v.shape[0], grid.M
+    keep_idx, keep_n = _sweep_inputs(grid, etas_v)
+    if batch is None:
+        batch = default_batch(max(int(keep_n.max()), 1), neta)
     d_t = _dv.to_device(dspec, torch.float64)
     nf, nt = (int(v) for v in d_t.shape)
     m_t = None if mask is None else _dv.to_device(np.asarray(mask, dtype=np.uint8), torch.uint8)
-    neta = etas_v.shape[0]
-    out = torch.full((neta,), float("nan"), dtype=torch.float64, device=cs_t.device)
     # centres of the reduced edges, re-derived as rev_map does (ththmod.py:204-205 on :157-172)
-    th_red = np.zeros((neta, grid.M))
+    th_red = np.zeros((neta, M))
     for i in range(neta):
-        n = int(info["N"][i])
+        n = int(keep_n[i])
         if n >= 2:
-            th_red[i, :n] = _theta_centres(grid.edges_red(info["keep_idx"][i, :n]))
+            th_red[i, :n] = _theta_centres(grid.edges_red(keep_idx[i, :n]))
     th_red_t = _dv.to_device(th_red, torch.float64)
-    for i in range(neta):
-        n = int(info["N"][i])
-        if info["status"][i] != 0 or n < 2:
-            continue
-        recov_t = _rev_map_dev(grid.geom, th_red_t[i], n, float(etas_v[i]), True, vec_t=V_t[i],
-                               w_t=info["w_dev"][i:i + 1])
-        model_t = _model_dev(recov_t)
-        rc = lib.scint_chisq(ptr(model_t), int(model_t.shape[1]), ptr(d_t), nf, nt, ptr(m_t), float(N),
-                             ptr(out[i:i + 1]), stream_ptr())
-        _lib.check(rc, "scint_chisq")
+    keep_t = _dv.to_device(keep_idx, torch.int32)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_chisq_sweep_workspace_bytes(M, neta, batch, max_iter, grid.geom.ntau, grid.geom.nfd, nf, nt,
+                                                     ctypes.byref(need)), "chisq_sweep_workspace_bytes")
+    ws = workspace.get(need.value)
+    out = torch.full((neta,), float("nan"), dtype=torch.float64, device=cs_t.device)
+    w_t = empty((neta,), torch.float64)
+    V_t = torch.zeros((neta, M), dtype=torch.complex128, device=cs_t.device)
+    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    rc = lib.scint_chisq_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
+                               keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                               etas_v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta, tol, max_iter, batch,
+                               ptr(th_red_t), ptr(d_t), nf, nt, ptr(m_t), float(N), ptr(out), ptr(w_t), ptr(V_t), M,
+                               ptr(st_t[0]), ptr(st_t[1]), ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_chisq_sweep")
+    st = st_t.cpu().numpy()
     chis = out.cpu().numpy()
+    chis[st[0] != 0] = np.nan                 # failed curvatures (the reference's loop would raise there)
     if return_info:
-        return chis, {"w": w, **{k: info[k] for k in ("N", "iters", "status", "batch")}}
+        w = w_t.cpu().numpy()
+        w[st[0] != 0] = np.nan
+        return chis, {"w": w, "N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch}
     return chis
 
 

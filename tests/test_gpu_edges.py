@@ -100,6 +100,17 @@ def test_sweep_is_schedule_invariant(env):
     assert np.array_equal(got, ref[perm])
     one = np.array([thth.Eval_calc(p["CS"], p["tau"], p["fd"], e, p["edges"]) for e in etas[:4]])
     assert np.array_equal(one, ref[:4])
+    # the host runs two chunks ahead of the convergence flags by default; synchronous scheduling
+    # (depth 1) must give the same bits, for eigenvalues and for eigenvectors
+    import os
+    w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
+    os.environ["SCINT_SWEEP_DEPTH"] = "1"
+    try:
+        assert np.array_equal(thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6), ref)
+        w1, V1, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
+    finally:
+        del os.environ["SCINT_SWEEP_DEPTH"]
+    assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
 
 
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
