@@ -81,6 +81,10 @@ def parse():
     ap.add_argument("--modeler-steps", type=int, default=None,
                     help="steps of the modeler/chisq objective timed after the headline region at N=1 "
                          "(default min(steps, 3); 0 = skip)")
+    ap.add_argument("--dyn-npz", default=None,
+                    help="observation 0 from a file (keys dyn[nf, nt], freqs [MHz], times [s], eta [s^3]) instead "
+                         "of the analytic arc -- e.g. a reference-Simulation screen written by "
+                         "tests/tools/make_sim_input.py; --size must match")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=3, help="etas timed on the CPU oracle")
     ap.add_argument("--cpu-pool", type=int, default=-1,
@@ -106,10 +110,16 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def make_workload(size, neta, nedge, seed, npad=0):
+def make_workload(size, neta, nedge, seed, npad=0, npz=None):
     from scintools_amd.synth import arc_dynspec
     from scintools_amd.ththmod import fft_axis
-    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=seed, nimg=64)
+    if npz:
+        with np.load(npz) as z:
+            dyn, freqs, times, eta_true = np.array(z["dyn"], dtype=np.float64), z["freqs"], z["times"], float(z["eta"])
+        if dyn.shape != (size, size):
+            raise SystemExit(f"--dyn-npz holds {dyn.shape}, --size says {size}")
+    else:
+        dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=seed, nimg=64)
     dyn -= dyn.mean()                # as Dynspec.fit_thetatheta hands chunks over (dynspec.py:1692)
     fd = fft_axis(times, 1000.0, npad)     # s -> mHz
     tau = fft_axis(freqs, 1.0, npad)       # MHz -> us
@@ -280,7 +290,8 @@ def main():
         obs_ids = [rank * args.obs + k for k in range(args.obs)]
         n_obs_job, scaling = world * args.obs, "weak"
     per_rank_max = -(-n_obs_job // world)
-    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3, npad=args.npad)
+    dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3, npad=args.npad,
+                                                                      npz=args.dyn_npz)
     dyns = []
     for i in obs_ids:                      # every observation resident in HBM before the clock starts
         d_i = dyn if i == 0 else make_workload(size, neta, nedge, seed=3 + 97 * i, npad=args.npad)[0]
@@ -374,7 +385,7 @@ def main():
             "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.dyn_npz else f"synthetic ({os.path.basename(args.dyn_npz)})",
             "config": {"workload": f"{size}x{size} dynspec, {neta}-eta {what}, nedge={nedge}, npad={args.npad}, "
                                    + (f"{args.obs_total} observations dealt round-robin to the GPUs"
                                       if args.obs_total > 0 else f"{args.obs} observation(s) per GPU"),

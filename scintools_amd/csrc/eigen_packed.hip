@@ -536,9 +536,10 @@ static char* pinned_staging(size_t bytes) {
     return buf;
 }
 
-// Internal stream, one per (host thread, device): `tail` (chi^2 sweep only) runs the per-curvature
-// model step of the retired curvatures beside the mat-vecs of the resident ones.
-struct SideStreams { hipStream_t tail = nullptr; };
+// Internal streams, one set per (host thread, device): `aux` runs the latency-bound reduce / check
+// kernels of one half of the slots beside the mat-vec of the other half; `tail` (chi^2 sweep only)
+// runs the per-curvature model step of the retired curvatures.
+struct SideStreams { hipStream_t aux = nullptr, tail = nullptr; };
 static SideStreams* side_streams() {
     thread_local std::map<int, SideStreams> streams;
     int dev = 0;
@@ -546,6 +547,7 @@ static SideStreams* side_streams() {
     auto it = streams.find(dev);
     if (it != streams.end()) return &it->second;
     SideStreams s;
+    if (hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipStreamCreateWithFlags(&s.tail, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return &(streams[dev] = s);
 }
@@ -560,7 +562,9 @@ static SideStreams* side_streams() {
 // and the state word holds the last finished generation -- and the next curvature starts in chunk
 // k+2: table upload, gather and start vector are queued on the same stream in front of that
 // chunk's steps (the gather alone streams faster than the mat-vec, so overlapping the two on
-// different streams only makes them share HBM).  Host staging never changes under a queued
+// different streams only makes them share HBM).  Inside a chunk the slots work as two halves:
+// mat-vec A, mat-vec B, mat-vec A ... on the caller's stream, each half's reduce / check on the
+// aux stream beside the other half's mat-vec (see enqueue()).  Host staging never changes under a queued
 // copy: job table, strip list, slot lists and flags exist in kTabs rotating copies, on the host
 // and on the device.  Per-job arithmetic does not depend on any of this (fixed-order sums inside
 // a job), so results are bit-identical for every depth, batch size and arrival order.
@@ -574,8 +578,8 @@ struct Sweep {
     int nbmax, steps_cap, nslots, depth;
     // device
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
-    hipStream_t main, tail;
-    hipEvent_t chunk_done[kTabs], export_done[kTabs];
+    hipStream_t main, aux, tail;
+    hipEvent_t chunk_done[kTabs], export_done[kTabs], mv_done[2], red_done[2];
     // host staging (pinned), one set per table copy
     PackedJob* h_jobs[kTabs]; Strip* h_strips[kTabs]; int32_t* h_fresh[kTabs]; int32_t* h_fin[kTabs];
     int64_t* h_fin_eta[kTabs]; int32_t* h_rs[kTabs]; int32_t* h_flags[kTabs];
@@ -587,6 +591,9 @@ struct Sweep {
     int active = 0, chunk = 0;
     int tab_of_chunk[kTabs];              // table copy used by chunk c, indexed c % kTabs
     int nstrips = 0, nb_run = 1;
+    int half_slot0[3] = {0, 0, 0};        // slots [half_slot0[h], half_slot0[h+1]) form half h
+    int half_strip0[3] = {0, 0, 0};       // their strips in the strip table
+    int half_nb[2] = {1, 1};
 
     PackedJob* d_jobs(int t) const { return (PackedJob*)(base + BL.jobs + BL.jobs_stride * (size_t)t); }
     Strip* d_strips(int t) const { return (Strip*)(base + BL.strips + BL.strips_stride * (size_t)t); }
@@ -650,24 +657,30 @@ struct Sweep {
             int32_t* hrs = h_rs[tab];
             nstrips = 0;
             nb_run = 1;
-            for (int s = 0; s < nslots; ++s) {
-                PackedJob& J = jobs[(size_t)s];
-                if (slot_eta[(size_t)s] < 0) { J.n = 0; continue; }      // idle: nothing to launch over
-                nb_run = std::max(nb_run, J.nb);
-                int32_t* rs0 = hrs + (size_t)s * (size_t)(nbmax + 1);
-                int idx = 0;
-                for (int I = 0; I < J.nb; ++I) {
-                    rs0[I] = idx;
-                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
-                        Strip& st = hs[nstrips++];
-                        st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
+            for (int h = 0; h < 2; ++h) {
+                half_strip0[h] = nstrips;
+                half_nb[h] = 1;
+                for (int s = half_slot0[h]; s < half_slot0[h + 1]; ++s) {
+                    PackedJob& J = jobs[(size_t)s];
+                    if (slot_eta[(size_t)s] < 0) { J.n = 0; continue; }      // idle: nothing to launch over
+                    half_nb[h] = std::max(half_nb[h], J.nb);
+                    int32_t* rs0 = hrs + (size_t)s * (size_t)(nbmax + 1);
+                    int idx = 0;
+                    for (int I = 0; I < J.nb; ++I) {
+                        rs0[I] = idx;
+                        for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
+                            Strip& st = hs[nstrips++];
+                            st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
+                        }
                     }
+                    rs0[J.nb] = idx;
                 }
-                rs0[J.nb] = idx;
+                std::stable_sort(hs + half_strip0[h], hs + nstrips, [](const Strip& a, const Strip& b) {
+                    return (a.J1 - a.J0) > (b.J1 - b.J0);
+                });
             }
-            std::stable_sort(hs, hs + nstrips, [](const Strip& a, const Strip& b) {
-                return (a.J1 - a.J0) > (b.J1 - b.J0);
-            });
+            half_strip0[2] = nstrips;
+            nb_run = std::max(half_nb[0], half_nb[1]);
             std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
             std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
             int nb_fresh = 0;
@@ -731,22 +744,41 @@ struct Sweep {
             if (he != hipSuccess) return hip_fail(he, "sweep refill", __FILE__, __LINE__);
         }
         tab_of_chunk[chunk % kTabs] = tab;
-        if (nstrips > 0) {
-            for (int i = 0; i < kCheckEvery; ++i) {
-                const int launch = launch0 + i;
-                const int slot = profiler().begin(kProfMatvec, main);
-                hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, main, d_jobs(tab), d_strips(tab), launch);
-                profiler().end(kProfMatvec, slot, main);
-                hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
-                                   main, d_jobs(tab), launch);
+        // The two halves of the slots alternate on the main stream -- their mat-vecs never share the
+        // machine -- while the reduce (and, after the last step, the check) of each half runs on the
+        // aux stream beside the OTHER half's mat-vec: the latency-bound kernels disappear behind
+        // the bandwidth-bound one.  Events: mv_done[h] main -> aux, red_done[h] aux -> main.
+        for (int i = 0; i < kCheckEvery; ++i) {
+            const int launch = launch0 + i;
+            for (int h = 0; h < 2; ++h) {
+                const int ns = half_strip0[h + 1] - half_strip0[h], nsl = half_slot0[h + 1] - half_slot0[h];
+                if (nsl <= 0) continue;
+                he = hipStreamWaitEvent(main, red_done[h], 0);
+                if (he != hipSuccess) return hip_fail(he, "sweep step order", __FILE__, __LINE__);
+                if (ns > 0) {
+                    const int slot = profiler().begin(kProfMatvec, main);
+                    hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)ns), dim3(256), 0, main, d_jobs(tab),
+                                       d_strips(tab) + half_strip0[h], launch);
+                    profiler().end(kProfMatvec, slot, main);
+                }
+                he = hipEventRecord(mv_done[h], main);
+                if (he == hipSuccess) he = hipStreamWaitEvent(aux, mv_done[h], 0);
+                if (he != hipSuccess) return hip_fail(he, "sweep step order", __FILE__, __LINE__);
+                if (ns > 0)
+                    hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)half_nb[h], (unsigned)nsl), dim3(64 * kRedGroups), 0,
+                                       aux, d_jobs(tab) + half_slot0[h], launch);
+                if (i == kCheckEvery - 1)
+                    hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nsl), dim3(64), 0, aux, d_jobs(tab) + half_slot0[h],
+                                       launch0 + kCheckEvery);
+                he = hipEventRecord(red_done[h], aux);
+                if (he != hipSuccess) return hip_fail(he, "sweep step order", __FILE__, __LINE__);
             }
         }
-        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, main, d_jobs(tab), launch0 + kCheckEvery);
         he = hipGetLastError();
         if (he == hipSuccess)
             he = hipMemcpyAsync(h_flags[chunk % kTabs], states_dev, sizeof(int32_t) * 4 * (size_t)nslots,
-                                hipMemcpyDeviceToHost, main);
-        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], main);
+                                hipMemcpyDeviceToHost, aux);
+        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], aux);
         if (he != hipSuccess) return hip_fail(he, "sweep chunk", __FILE__, __LINE__);
         ++chunk;
         return SCINT_OK;
@@ -824,7 +856,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.base = (char*)workspace;
     S.states_dev = (int32_t*)(S.base + S.BL.states);
     S.geoms_dev = (const GeomDev*)(S.base + S.BL.geoms);
-    S.main = stream; S.tail = side->tail;
+    S.main = stream; S.aux = side->aux; S.tail = side->tail;
 
     // pinned staging: geometry table + kTabs x {jobs, strips, fresh, fin, fin_eta, row_strip0, flags}
     const size_t nsl = (size_t)S.nslots;
@@ -873,16 +905,22 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     }
     // Order the tail stream after whatever the caller queued before us, then set up the state words
     // and the geometry table.
-    hipEvent_t ev[2 * kTabs + 1] = {};
+    hipEvent_t ev[2 * kTabs + 5] = {};
     hipError_t he = hipSuccess;
     for (auto& e : ev)
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
     int32_t rc = SCINT_OK;
     if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
     for (int t = 0; t < kTabs; ++t) { S.chunk_done[t] = ev[t]; S.export_done[t] = ev[kTabs + t]; }
+    for (int h = 0; h < 2; ++h) { S.mv_done[h] = ev[2 * kTabs + 1 + h]; S.red_done[h] = ev[2 * kTabs + 3 + h]; }
+    // two halves when there are enough slots to split (SCINT_SWEEP_HALVES=1: one, for experiments)
+    const char* halves_env = getenv("SCINT_SWEEP_HALVES");
+    const bool split = S.nslots >= 4 && !(halves_env && atoi(halves_env) == 1);
+    S.half_slot0[0] = 0; S.half_slot0[1] = split ? S.nslots / 2 : S.nslots; S.half_slot0[2] = S.nslots;
     if (rc == SCINT_OK) {
         he = hipEventRecord(ev[2 * kTabs], stream);
         if (he == hipSuccess) he = hipStreamWaitEvent(S.tail, ev[2 * kTabs], 0);
+        if (he == hipSuccess) he = hipStreamWaitEvent(S.aux, ev[2 * kTabs], 0);
         if (he == hipSuccess)
             he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
         if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * nsl, stream);
@@ -891,6 +929,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     if (rc == SCINT_OK) rc = S.run();
     // leave nothing running on the internal streams, and nothing pending on the caller's
     (void)hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(S.aux);
     (void)hipStreamSynchronize(S.tail);
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);

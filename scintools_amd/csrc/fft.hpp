@@ -480,7 +480,7 @@ int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader fi
     // beyond it every radix pass is an HBM round trip and the two tiled passes win (16384^2: 5.6
     // vs 7.3 ms).  SCINT_FFT_TWO_PASS = 0 / 2 forces never / always (experiments).
     static const int two_pass = [] { const char* e = getenv("SCINT_FFT_TWO_PASS"); return e ? atoi(e) : 1; }();
-    const bool beyond_cache = (double)len * (double)ncols * (double)batches * 16.0 > 200.0 * 1048576.0;
+    const bool beyond_cache = (double)len * (double)ncols * (double)batches * 16.0 > 300.0 * 1048576.0;
     if ((two_pass == 2 || (two_pass == 1 && beyond_cache)) && len >= 256 && len <= 16384) {
         const int l = ilog2(len), l2 = l / 2, l1 = l - l2;          // L1 >= L2, both in [16, 128]
         const int64_t ntiles = ceil_div(ncols, 16);

@@ -401,10 +401,16 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
     const int W = grid_ok ? (int)fmin(ceil(g.fd1_step / th_step) + 2.0, (double)kRevWin) : 0;
     const bool usable = g.fd1_step > 0.0 && g.tau1_step > 0.0;
 
+    const double inv_tstep = 1.0 / g.tau1_step;
+    const double row_lo = (double)row0 - 2.0, row_hi = (double)(row0 + rows) + 1.0;   // estimate of bin + 0.5
     auto beyond = [&](double x) { return last ? (x > hi) : (x >= hi); };
     auto contribute = [&](int i, int j, double th_i, double th_j) {
         if (i == j) return;                                            // lands in the poisoned centre bin
         const double y = p.eta * (th_j * th_j - th_i * th_i);          // tau_map[i, j] (ththmod.py:208-210)
+        // cheap slab test first (two rows of slack cover the rounding of this estimate): the exact
+        // bin, the weight and the loads are only paid for by the slab that owns the pixel
+        const double est = (y - g.tau0) * inv_tstep;
+        if (est < row_lo || est > row_hi) return;
         const int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau) - row0;
         if (by < 0 || by >= rows) return;
         // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)

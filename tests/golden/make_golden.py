@@ -344,6 +344,34 @@ def gen_arcfit():
     save("arcfit.npz", **out)
 
 
+# ---------------------------------------------------------------------------
+# 9. BASELINE-style Simulation screens at 1024^2 and 2048^2: the reference's Eval_calc over the
+#    whole geomspace(0.25, 4) * sim.eta range (flat parts of the curve included: that is where
+#    lambda_2 / lambda_1 -> 1 stresses a Lanczos stopping rule).  The dynamic spectra are not
+#    stored (4-16 MB each): oracle/sim_oracle.py regenerates them bit for bit, pinned by SHA-256.
+# ---------------------------------------------------------------------------
+def gen_sim_sweep():
+    import hashlib
+    out = {}
+    for size, seed, neta in ((1024, 1, 96), (2048, 2, 32)):
+        sim = Simulation(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.25, freq=1400, dt=30,
+                         nx=size, ny=128, nf=size, seed=seed, lamsteps=False)
+        dyn = np.array(sim.dyn, dtype=np.float64)
+        d2 = dyn - dyn.mean()
+        fd = thth.fft_axis(sim.times * u.s, u.mHz, 0)
+        tau = thth.fft_axis(sim.freqs * u.MHz, u.us, 0)
+        CS = cs_of(d2, 0)
+        edges = np.linspace(-V(fd).max() / 2, V(fd).max() / 2, size)
+        etas = np.geomspace(0.25, 4.0, neta) * sim.eta
+        eigs = np.array([thth.Eval_calc(CS, tau, fd, e * u.s**3, edges * u.mHz) for e in etas])
+        tag = f"s{size}"
+        out.update({f"{tag}_seed": seed, f"{tag}_etas": etas, f"{tag}_eigs": eigs, f"{tag}_sim_eta": sim.eta,
+                    f"{tag}_sha256": hashlib.sha256(np.ascontiguousarray(sim.dyn).tobytes()).hexdigest(),
+                    f"{tag}_freqs01": np.array(sim.freqs[:2]), f"{tag}_dt": sim.dt})
+        print(tag, "eta", sim.eta, "peak at", etas[np.argmax(eigs)] / sim.eta)
+    save("sim_sweep.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval", "psrflux", "arcfit"]
     if "small" in which:
@@ -362,3 +390,5 @@ if __name__ == "__main__":
         gen_psrflux()
     if "arcfit" in which:
         gen_arcfit()
+    if "simsweep" in which:        # ~5 min: not in the default list
+        gen_sim_sweep()

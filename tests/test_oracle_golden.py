@@ -286,3 +286,20 @@ def test_fit_arc_oracle(golden):
     np.testing.assert_allclose(left["spec"], g["fb_spec1"], rtol=1e-13)
     np.testing.assert_allclose(right["spec"], g["fb_spec2"], rtol=1e-13)
     np.testing.assert_allclose(right["eta_array"], g["fb_eta_array"], rtol=1e-14)
+
+
+def test_sim_oracle_is_bit_identical_to_the_reference_simulator(golden):
+    """oracle/sim_oracle.py against the reference's own Simulation run: the full 96 x 128 array of
+    tests/golden/sim_sspec.npz, and the SHA-256 of the 1024^2 BASELINE-style screen that
+    tests/golden/sim_sweep.npz was computed on (make_golden.py::gen_sim_sweep)."""
+    from oracle import sim_oracle as so
+    g = golden("sim_sspec.npz")
+    s = so.Simulation(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.03, freq=1400, dt=30,
+                      nx=128, ny=64, nf=96, seed=1234)
+    assert s.dyn.dtype == g["dyn"].dtype and np.array_equal(s.dyn, g["dyn"])
+    assert np.array_equal(s.freqs, g["freqs"]) and np.array_equal(s.times, g["times"])
+    assert s.eta == float(g["sim_eta"]) and s.dt == float(g["dt"]) and s.df == float(g["df"])
+    w = golden("sim_sweep.npz")
+    big = so.baseline_dynspec(1024, int(w["s1024_seed"]))
+    assert so.checksum(big.dyn) == str(w["s1024_sha256"])
+    assert big.eta == float(w["s1024_sim_eta"]) and np.array_equal(big.freqs[:2], w["s1024_freqs01"])
