@@ -22,13 +22,12 @@
 //                     the Sturm count, Ritz residual by the backward recurrence, and the
 //                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
-// Scheduling (struct Sweep below): the `batch` slots are kept full -- when a curvature converges
-// its slot is re-filled with the next eta of the sweep (continuous batching; every job carries
-// the launch index it started at, so jobs at different Lanczos steps share one launch).  The
-// steps are queued in chunks of 4 + a convergence check, two chunks ahead of the state the host
-// has seen, so the stream never waits for the host; the gather and start vector of an entering
-// curvature run on a second stream beside the mat-vecs of the resident ones.  Per-job arithmetic
-// does not depend on the schedule.
+// Scheduling (SweepGroup below): the `batch` slots are kept full -- when a curvature converges its
+// slot is re-filled with the next eta of the sweep (continuous batching; every job carries the
+// launch index it started at, so jobs at different Lanczos steps share one launch).  Two groups of
+// slots run on two streams and fill each other's gaps; in each, the steps are queued in chunks of
+// 4 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
+// waits for the host.  Per-job arithmetic does not depend on the schedule.
 //
 // Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
 // 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| over the
@@ -536,9 +535,8 @@ static char* pinned_staging(size_t bytes) {
     return buf;
 }
 
-// Internal streams, one set per (host thread, device): `aux` runs the latency-bound reduce / check
-// kernels of one half of the slots beside the mat-vec of the other half; `tail` (chi^2 sweep only)
-// runs the per-curvature model step of the retired curvatures.
+// Internal streams, one set per (host thread, device): `aux` drives the second group of slots;
+// `tail` (chi^2 sweep only) runs the per-curvature model step of the retired curvatures.
 struct SideStreams { hipStream_t aux = nullptr, tail = nullptr; };
 static SideStreams* side_streams() {
     thread_local std::map<int, SideStreams> streams;
@@ -553,56 +551,61 @@ static SideStreams* side_streams() {
 }
 
 // ----------------------------------------------------------------------------------------------
-// The scheduler.  Lanczos steps are launched in CHUNKS of kCheckEvery steps + one convergence
-// check + the read-back of the per-slot state words.  The host runs `depth` chunks ahead of the
-// state it has seen (depth 2 by default): while chunk c executes, chunk c+1 is already queued, so
-// the caller's stream never waits for the host.  Retiring and refilling therefore lag: a
-// curvature that converges in chunk k is seen when chunk k+2 is prepared, its slot idles for one
-// chunk -- the kernels of chunk k+1 skip it, because every job carries the GENERATION of its slot
-// and the state word holds the last finished generation -- and the next curvature starts in chunk
-// k+2: table upload, gather and start vector are queued on the same stream in front of that
-// chunk's steps (the gather alone streams faster than the mat-vec, so overlapping the two on
-// different streams only makes them share HBM).  Inside a chunk the slots work as two halves:
-// mat-vec A, mat-vec B, mat-vec A ... on the caller's stream, each half's reduce / check on the
-// aux stream beside the other half's mat-vec (see enqueue()).  Host staging never changes under a queued
-// copy: job table, strip list, slot lists and flags exist in kTabs rotating copies, on the host
-// and on the device.  Per-job arithmetic does not depend on any of this (fixed-order sums inside
-// a job), so results are bit-identical for every depth, batch size and arrival order.
-struct Sweep {
-    // problem
+// The scheduler.  The `batch` slots are split into two GROUPS, each driven on its own stream (the
+// caller's and `aux`): the gaps of one stream -- launch boundaries, the latency-bound reduce and
+// check kernels, refills -- are filled by the other stream's kernels.  Inside a group the Lanczos
+// steps are queued in CHUNKS of kCheckEvery steps + one convergence check + the read-back of the
+// per-slot state words, and the host runs `depth` chunks ahead of the state it has seen (depth 2
+// by default): while chunk c executes, chunk c+1 is already queued, so a stream never waits for
+// the host.  Retiring and refilling therefore lag: a curvature that converges in chunk k is seen
+// when chunk k+2 is prepared, its slot idles for one chunk -- the kernels of chunk k+1 skip it,
+// because every job carries the GENERATION of its slot and the state word holds the last finished
+// generation -- and the next curvature starts in chunk k+2: table upload, gather and start vector
+// are queued on the group's stream in front of that chunk's steps.  Host staging never changes
+// under a queued copy: job table, strip list, slot lists and flags exist in kTabs rotating
+// copies, on the host and on the device.  Per-job arithmetic does not depend on any of this
+// (fixed-order sums inside a job), so results are bit-identical for every depth, batch size,
+// grouping and arrival order.
+struct SweepProblem {
     const cplx* cs; int64_t cs_stride; const int32_t* cs_index; const double* th_cents; int64_t M;
     const int32_t* keep_idx; const int32_t* keep_n; const double* etas; int64_t neta;
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
-    SweepTail* tail_hook;
-    int nbmax, steps_cap, nslots, depth;
-    // device
+    SweepTail* tail_hook; hipStream_t tail;
+    int nbmax, steps_cap, depth;
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
-    hipStream_t main, aux, tail;
-    hipEvent_t chunk_done[kTabs], export_done[kTabs], mv_done[2], red_done[2];
-    // host staging (pinned), one set per table copy
+    int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
+};
+
+struct SweepGroup {
+    SweepProblem* P;
+    int slot0, nslots;                    // global index of the group's first slot, its slot count
+    hipStream_t stream;
+    hipEvent_t chunk_done[kTabs], export_done[kTabs];
+    // host staging (pinned), one set per table copy; slot indices in all tables are group-local
     PackedJob* h_jobs[kTabs]; Strip* h_strips[kTabs]; int32_t* h_fresh[kTabs]; int32_t* h_fin[kTabs];
     int64_t* h_fin_eta[kTabs]; int32_t* h_rs[kTabs]; int32_t* h_flags[kTabs];
     // schedule state
-    std::vector<PackedJob> jobs;          // current description of every slot
+    std::vector<PackedJob> jobs;          // current description of every slot of the group
     std::vector<int64_t> slot_eta;        // running eta or -1
     std::vector<int32_t> slot_gen;
-    int64_t next_eta = 0;
-    int active = 0, chunk = 0;
+    std::vector<int32_t> fin_slots;
+    std::vector<int64_t> fin_eta;
+    int active = 0, chunk = 0, seen = 0;  // chunks queued / chunks whose flags have been harvested
+    bool finished = false;
     int tab_of_chunk[kTabs];              // table copy used by chunk c, indexed c % kTabs
     int nstrips = 0, nb_run = 1;
-    int half_slot0[3] = {0, 0, 0};        // slots [half_slot0[h], half_slot0[h+1]) form half h
-    int half_strip0[3] = {0, 0, 0};       // their strips in the strip table
-    int half_nb[2] = {1, 1};
 
-    PackedJob* d_jobs(int t) const { return (PackedJob*)(base + BL.jobs + BL.jobs_stride * (size_t)t); }
-    Strip* d_strips(int t) const { return (Strip*)(base + BL.strips + BL.strips_stride * (size_t)t); }
-    int32_t* d_fresh(int t) const { return (int32_t*)(base + BL.slots + BL.list_stride * (size_t)t); }
-    int32_t* d_fin(int t) const { return (int32_t*)(base + BL.fin_slots + BL.list_stride * (size_t)t); }
-    int64_t* d_fin_eta(int t) const { return (int64_t*)(base + BL.fin_eta + BL.fin_eta_stride * (size_t)t); }
+    PackedJob* d_jobs(int t) const { return (PackedJob*)(P->base + P->BL.jobs + P->BL.jobs_stride * (size_t)t) + slot0; }
+    Strip* d_strips(int t) const {
+        return (Strip*)(P->base + P->BL.strips + P->BL.strips_stride * (size_t)t) + (size_t)slot0 * (size_t)P->BL.smax;
+    }
+    int32_t* d_fresh(int t) const { return (int32_t*)(P->base + P->BL.slots + P->BL.list_stride * (size_t)t) + slot0; }
+    int32_t* d_fin(int t) const { return (int32_t*)(P->base + P->BL.fin_slots + P->BL.list_stride * (size_t)t) + slot0; }
+    int64_t* d_fin_eta(int t) const { return (int64_t*)(P->base + P->BL.fin_eta + P->BL.fin_eta_stride * (size_t)t) + slot0; }
 
-    // retire what chunk `c` finished (its flags are on the host), export eigenvectors
-    int32_t harvest(int c, std::vector<int32_t>& fin_slots, std::vector<int64_t>& fin_eta) {
+    // retire what chunk `c` finished (its flags are on the host)
+    void harvest(int c) {
         const int32_t* flags = h_flags[c % kTabs];
         fin_slots.clear();
         fin_eta.clear();
@@ -613,31 +616,31 @@ struct Sweep {
             slot_eta[(size_t)s] = -1;            // results were written by the check kernel
             --active;
         }
-        return SCINT_OK;
     }
 
     // prepare and enqueue chunk `chunk`: refill idle slots, then kCheckEvery steps + check + read-back
-    int32_t enqueue(const std::vector<int32_t>& fin_slots, const std::vector<int64_t>& fin_eta, int fin_chunk) {
-        const SlabLayout& L = BL.slab;
+    int32_t enqueue(int fin_chunk) {
+        SweepProblem& S = *P;
+        const SlabLayout& L = S.BL.slab;
         std::vector<int32_t> fresh;
         const int launch0 = chunk * kCheckEvery;
-        for (int s = 0; s < nslots && next_eta < neta; ++s) {
+        for (int s = 0; s < nslots && S.next_eta < S.neta; ++s) {
             if (slot_eta[(size_t)s] >= 0) continue;
-            const int64_t e = next_eta++;
+            const int64_t e = S.next_eta++;
             slot_eta[(size_t)s] = e;
             ++active;
             PackedJob& J = jobs[(size_t)s];
-            const int n = keep_n[e];
-            J.eta = etas[e]; J.two_eta = 2 * etas[e];
-            const int64_t c = cs_index ? cs_index[e] : 0;
-            J.cs = cs + c * cs_stride; J.th = th_cents + c * M; J.geom = (int32_t)c;
-            J.keep = keep_idx + e * M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            J.max_steps = std::min(steps_cap, std::max(n, 1));
+            const int n = S.keep_n[e];
+            J.eta = S.etas[e]; J.two_eta = 2 * S.etas[e];
+            const int64_t c = S.cs_index ? S.cs_index[e] : 0;
+            J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
+            J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
+            J.max_steps = std::min(S.steps_cap, std::max(n, 1));
             J.strip_len = strip_len_for(J.nb);
             J.start = launch0;
             J.gen = ++slot_gen[(size_t)s];
-            J.eig_out = eigs_out + e; J.status_out = status_out + e;
-            J.iters_out = iters_out ? iters_out + e : nullptr;
+            J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
+            J.iters_out = S.iters_out ? S.iters_out + e : nullptr;
             fresh.push_back(s);
         }
         const bool changed = chunk == 0 || !fresh.empty() || !fin_slots.empty();
@@ -657,51 +660,46 @@ struct Sweep {
             int32_t* hrs = h_rs[tab];
             nstrips = 0;
             nb_run = 1;
-            for (int h = 0; h < 2; ++h) {
-                half_strip0[h] = nstrips;
-                half_nb[h] = 1;
-                for (int s = half_slot0[h]; s < half_slot0[h + 1]; ++s) {
-                    PackedJob& J = jobs[(size_t)s];
-                    if (slot_eta[(size_t)s] < 0) { J.n = 0; continue; }      // idle: nothing to launch over
-                    half_nb[h] = std::max(half_nb[h], J.nb);
-                    int32_t* rs0 = hrs + (size_t)s * (size_t)(nbmax + 1);
-                    int idx = 0;
-                    for (int I = 0; I < J.nb; ++I) {
-                        rs0[I] = idx;
-                        for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
-                            Strip& st = hs[nstrips++];
-                            st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
-                        }
+            for (int s = 0; s < nslots; ++s) {
+                PackedJob& J = jobs[(size_t)s];
+                if (slot_eta[(size_t)s] < 0) { J.n = 0; continue; }      // idle: nothing to launch over
+                nb_run = std::max(nb_run, J.nb);
+                int32_t* rs0 = hrs + (size_t)s * (size_t)(S.nbmax + 1);
+                int idx = 0;
+                for (int I = 0; I < J.nb; ++I) {
+                    rs0[I] = idx;
+                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
+                        Strip& st = hs[nstrips++];
+                        st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
                     }
-                    rs0[J.nb] = idx;
                 }
-                std::stable_sort(hs + half_strip0[h], hs + nstrips, [](const Strip& a, const Strip& b) {
-                    return (a.J1 - a.J0) > (b.J1 - b.J0);
-                });
+                rs0[J.nb] = idx;
             }
-            half_strip0[2] = nstrips;
-            nb_run = std::max(half_nb[0], half_nb[1]);
+            std::stable_sort(hs, hs + nstrips, [](const Strip& a, const Strip& b) {
+                return (a.J1 - a.J0) > (b.J1 - b.J0);
+            });
             std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
             std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
             int nb_fresh = 0;
             for (int s : fresh) {
                 const PackedJob& J = jobs[(size_t)s];
                 nb_fresh = std::max(nb_fresh, J.nb);
-                he = hipMemcpyAsync(base + L.total * (size_t)s + L.row_strip0, hrs + (size_t)s * (size_t)(nbmax + 1),
-                                    sizeof(int32_t) * (size_t)(J.nb + 1), hipMemcpyHostToDevice, main);
+                he = hipMemcpyAsync(S.base + L.total * (size_t)(slot0 + s) + L.row_strip0,
+                                    hrs + (size_t)s * (size_t)(S.nbmax + 1), sizeof(int32_t) * (size_t)(J.nb + 1),
+                                    hipMemcpyHostToDevice, stream);
                 if (he != hipSuccess) break;
             }
             if (he == hipSuccess)
-                he = hipMemcpyAsync(d_jobs(tab), h_jobs[tab], sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, main);
+                he = hipMemcpyAsync(d_jobs(tab), h_jobs[tab], sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream);
             if (he == hipSuccess && nstrips > 0)
-                he = hipMemcpyAsync(d_strips(tab), hs, sizeof(Strip) * (size_t)nstrips, hipMemcpyHostToDevice, main);
+                he = hipMemcpyAsync(d_strips(tab), hs, sizeof(Strip) * (size_t)nstrips, hipMemcpyHostToDevice, stream);
             if (he == hipSuccess && !fresh.empty())
-                he = hipMemcpyAsync(d_fresh(tab), h_fresh[tab], sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, main);
+                he = hipMemcpyAsync(d_fresh(tab), h_fresh[tab], sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
             if (he != hipSuccess) return hip_fail(he, "sweep table upload", __FILE__, __LINE__);
             // eigenvectors of the retired jobs leave their slots BEFORE the new jobs' start vectors
             // overwrite them (same stream); the table copy of the chunk that finished them still
             // describes them
-            if (want_vec && !fin_slots.empty()) {
+            if (S.want_vec && !fin_slots.empty()) {
                 const int ft = tab_of_chunk[fin_chunk % kTabs];
                 int nfin = 0, nb_fin = 1;
                 for (size_t k = 0; k < fin_slots.size(); ++k) {
@@ -713,103 +711,78 @@ struct Sweep {
                     ++nfin;
                 }
                 if (nfin > 0) {
-                    he = hipMemcpyAsync(d_fin(tab), h_fin[tab], sizeof(int32_t) * (size_t)nfin, hipMemcpyHostToDevice, main);
+                    he = hipMemcpyAsync(d_fin(tab), h_fin[tab], sizeof(int32_t) * (size_t)nfin, hipMemcpyHostToDevice, stream);
                     if (he == hipSuccess)
                         he = hipMemcpyAsync(d_fin_eta(tab), h_fin_eta[tab], sizeof(int64_t) * (size_t)nfin,
-                                            hipMemcpyHostToDevice, main);
+                                            hipMemcpyHostToDevice, stream);
                     if (he != hipSuccess) return hip_fail(he, "sweep eigenvector export", __FILE__, __LINE__);
                     const dim3 grid((unsigned)nb_fin, (unsigned)nfin);
-                    hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, main, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                       vec_out, vstride);
-                    hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, main, d_jobs(ft), d_fin(tab),
-                                       d_fin_eta(tab), vec_out, vstride);
+                    hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                       S.vec_out, S.vstride);
+                    hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab),
+                                       d_fin_eta(tab), S.vec_out, S.vstride);
                 }
             }
-            if (tail_hook && !fin_eta.empty()) {
-                he = hipEventRecord(export_done[tab], main);
-                if (he == hipSuccess) he = hipStreamWaitEvent(tail, export_done[tab], 0);
+            if (S.tail_hook && !fin_eta.empty()) {
+                he = hipEventRecord(export_done[tab], stream);
+                if (he == hipSuccess) he = hipStreamWaitEvent(S.tail, export_done[tab], 0);
                 if (he != hipSuccess) return hip_fail(he, "sweep tail hand-off", __FILE__, __LINE__);
                 for (int64_t e : fin_eta) {
-                    const int32_t rc = tail_hook->retire(e, tail);
+                    const int32_t rc = S.tail_hook->retire(e, S.tail);
                     if (rc != SCINT_OK) return rc;
                 }
             }
             if (!fresh.empty()) {
-                int32_t rc = launch_gather_packed(geoms_dev, M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, main);
+                int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream);
                 if (rc != SCINT_OK) return rc;
-                hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, main,
+                hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
                                    d_jobs(tab), d_fresh(tab));
             }
             he = hipGetLastError();
             if (he != hipSuccess) return hip_fail(he, "sweep refill", __FILE__, __LINE__);
         }
         tab_of_chunk[chunk % kTabs] = tab;
-        // The two halves of the slots alternate on the main stream -- their mat-vecs never share the
-        // machine -- while the reduce (and, after the last step, the check) of each half runs on the
-        // aux stream beside the OTHER half's mat-vec: the latency-bound kernels disappear behind
-        // the bandwidth-bound one.  Events: mv_done[h] main -> aux, red_done[h] aux -> main.
-        for (int i = 0; i < kCheckEvery; ++i) {
-            const int launch = launch0 + i;
-            for (int h = 0; h < 2; ++h) {
-                const int ns = half_strip0[h + 1] - half_strip0[h], nsl = half_slot0[h + 1] - half_slot0[h];
-                if (nsl <= 0) continue;
-                he = hipStreamWaitEvent(main, red_done[h], 0);
-                if (he != hipSuccess) return hip_fail(he, "sweep step order", __FILE__, __LINE__);
-                if (ns > 0) {
-                    const int slot = profiler().begin(kProfMatvec, main);
-                    hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)ns), dim3(256), 0, main, d_jobs(tab),
-                                       d_strips(tab) + half_strip0[h], launch);
-                    profiler().end(kProfMatvec, slot, main);
-                }
-                he = hipEventRecord(mv_done[h], main);
-                if (he == hipSuccess) he = hipStreamWaitEvent(aux, mv_done[h], 0);
-                if (he != hipSuccess) return hip_fail(he, "sweep step order", __FILE__, __LINE__);
-                if (ns > 0)
-                    hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)half_nb[h], (unsigned)nsl), dim3(64 * kRedGroups), 0,
-                                       aux, d_jobs(tab) + half_slot0[h], launch);
-                if (i == kCheckEvery - 1)
-                    hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nsl), dim3(64), 0, aux, d_jobs(tab) + half_slot0[h],
-                                       launch0 + kCheckEvery);
-                he = hipEventRecord(red_done[h], aux);
-                if (he != hipSuccess) return hip_fail(he, "sweep step order", __FILE__, __LINE__);
+        if (nstrips > 0) {
+            for (int i = 0; i < kCheckEvery; ++i) {
+                const int launch = launch0 + i;
+                const int slot = profiler().begin(kProfMatvec, stream);
+                hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
+                profiler().end(kProfMatvec, slot, stream);
+                hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
+                                   stream, d_jobs(tab), launch);
             }
         }
+        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + kCheckEvery);
         he = hipGetLastError();
         if (he == hipSuccess)
-            he = hipMemcpyAsync(h_flags[chunk % kTabs], states_dev, sizeof(int32_t) * 4 * (size_t)nslots,
-                                hipMemcpyDeviceToHost, aux);
-        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], aux);
+            he = hipMemcpyAsync(h_flags[chunk % kTabs], S.states_dev + 4 * slot0, sizeof(int32_t) * 4 * (size_t)nslots,
+                                hipMemcpyDeviceToHost, stream);
+        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], stream);
         if (he != hipSuccess) return hip_fail(he, "sweep chunk", __FILE__, __LINE__);
         ++chunk;
         return SCINT_OK;
     }
 
-    int32_t run() {
-        std::vector<int32_t> fin_slots;
-        std::vector<int64_t> fin_eta;
-        int32_t rc = SCINT_OK;
-        int seen = 0;                       // chunks whose flags have been harvested
-        while (rc == SCINT_OK) {
-            int fin_chunk = -1;
-            fin_slots.clear();
-            fin_eta.clear();
-            const bool more = active > 0 || next_eta < neta;
-            if (chunk - seen >= depth || (!more && seen < chunk)) {
-                // wait for the oldest chunk in flight, retire what it finished
-                hipError_t he = hipEventSynchronize(chunk_done[seen % kTabs]);
-                if (he != hipSuccess) return hip_fail(he, "sweep wait", __FILE__, __LINE__);
-                if (profiler().enabled) profiler().collect();
-                rc = harvest(seen, fin_slots, fin_eta);
-                fin_chunk = seen++;
-            }
-            if (rc != SCINT_OK) break;
-            if (active == 0 && next_eta >= neta && fin_slots.empty()) {
-                if (seen == chunk) break;   // nothing running, nothing queued
-                continue;                   // drain the chunks still in flight
-            }
-            rc = enqueue(fin_slots, fin_eta, fin_chunk);
+    // one scheduling step of the group: wait for its oldest chunk if the pipeline is full (or only
+    // draining is left), retire, and queue the next chunk.  Sets `finished` when nothing is left.
+    int32_t advance() {
+        SweepProblem& S = *P;
+        int fin_chunk = -1;
+        fin_slots.clear();
+        fin_eta.clear();
+        const bool more = active > 0 || S.next_eta < S.neta;
+        if (chunk - seen >= S.depth || (!more && seen < chunk)) {
+            hipError_t he = hipEventSynchronize(chunk_done[seen % kTabs]);
+            if (he != hipSuccess) return hip_fail(he, "sweep wait", __FILE__, __LINE__);
+            if (profiler().enabled) profiler().collect();
+            harvest(seen);
+            fin_chunk = seen++;
         }
-        return rc;
+        if (active == 0 && S.next_eta >= S.neta && fin_slots.empty()) {
+            if (seen == chunk) finished = true;     // nothing running, nothing queued
+            return SCINT_OK;                        // else: keep draining the chunks in flight
+        }
+        return enqueue(fin_chunk);
     }
 };
 
@@ -840,99 +813,117 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     SideStreams* side = side_streams();
     if (!side) { set_error("scint: could not create the internal sweep streams"); return SCINT_E_HIP; }
 
-    Sweep S;
+    SweepProblem S;
     S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
     S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
     S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
-    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook;
+    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook; S.tail = side->tail;
     S.nbmax = (int)ceil_div(M, kTB);
     S.steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
-    S.nslots = (int)std::min(batch, neta);
-    const char* depth_env = getenv("SCINT_SWEEP_DEPTH");    // read per call: tests compare depths in one process
+    const int nslots = (int)std::min(batch, neta);
+    const char* depth_env = getenv("SCINT_SWEEP_DEPTH");    // read per call: tests compare schedules in one process
     const int forced_depth = depth_env ? atoi(depth_env) : 0;
     S.depth = forced_depth >= 1 && forced_depth <= 2 ? forced_depth : 2;
-    S.BL = batch_layout(S.nbmax, S.steps_cap, S.nslots, want_vec, ncs);
+    const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
+    const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
+    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
     const SlabLayout& L = S.BL.slab;
     S.base = (char*)workspace;
     S.states_dev = (int32_t*)(S.base + S.BL.states);
     S.geoms_dev = (const GeomDev*)(S.base + S.BL.geoms);
-    S.main = stream; S.aux = side->aux; S.tail = side->tail;
 
-    // pinned staging: geometry table + kTabs x {jobs, strips, fresh, fin, fin_eta, row_strip0, flags}
-    const size_t nsl = (size_t)S.nslots;
-    const size_t per_tab = align_up(sizeof(PackedJob) * nsl, 64) + align_up(sizeof(Strip) * nsl * (size_t)S.BL.smax, 64) +
-                           2 * align_up(sizeof(int32_t) * nsl, 64) + align_up(sizeof(int64_t) * nsl, 64) +
-                           align_up(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1), 64) + align_up(sizeof(int32_t) * 4 * nsl, 64);
+    // pinned staging: geometry table + per group kTabs x {jobs, strips, fresh, fin, fin_eta, row_strip0, flags}
+    auto per_tab = [&](size_t nsl) {
+        return align_up(sizeof(PackedJob) * nsl, 64) + align_up(sizeof(Strip) * nsl * (size_t)S.BL.smax, 64) +
+               2 * align_up(sizeof(int32_t) * nsl, 64) + align_up(sizeof(int64_t) * nsl, 64) +
+               align_up(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1), 64) + align_up(sizeof(int32_t) * 4 * nsl, 64);
+    };
     const size_t geom_bytes = align_up(sizeof(GeomDev) * (size_t)ncs, 64);
-    char* pin = pinned_staging(geom_bytes + per_tab * kTabs);
+    char* pin = pinned_staging(geom_bytes + per_tab((size_t)nslots) * kTabs + 64 * 7 * kTabs * 2);
     if (!pin) return SCINT_E_HIP;
     GeomDev* h_geoms = (GeomDev*)pin;
     for (int64_t c = 0; c < ncs; ++c) h_geoms[c] = to_dev(geom[c]);
-    {
-        char* q = pin + geom_bytes;
-        auto take = [&](size_t bytes) { char* r = q; q += align_up(bytes, 64); return r; };
+    char* q = pin + geom_bytes;
+    auto take = [&](size_t bytes) { char* r = q; q += align_up(bytes, 64); return r; };
+
+    hipEvent_t start_ev = nullptr;
+    hipError_t he = hipEventCreateWithFlags(&start_ev, hipEventDisableTiming);
+    int32_t rc = he == hipSuccess ? SCINT_OK : hip_fail(he, "sweep events", __FILE__, __LINE__);
+    SweepGroup G[2];
+    for (int g = 0; g < ngroups; ++g) {
+        SweepGroup& grp = G[g];
+        grp.P = &S;
+        grp.slot0 = g == 0 ? 0 : nslots / 2;
+        grp.nslots = (ngroups == 1 ? nslots : (g == 0 ? nslots / 2 : nslots - nslots / 2));
+        grp.stream = g == 0 ? stream : side->aux;
+        const size_t nsl = (size_t)grp.nslots;
         for (int t = 0; t < kTabs; ++t) {
-            S.h_jobs[t] = (PackedJob*)take(sizeof(PackedJob) * nsl);
-            S.h_strips[t] = (Strip*)take(sizeof(Strip) * nsl * (size_t)S.BL.smax);
-            S.h_fresh[t] = (int32_t*)take(sizeof(int32_t) * nsl);
-            S.h_fin[t] = (int32_t*)take(sizeof(int32_t) * nsl);
-            S.h_fin_eta[t] = (int64_t*)take(sizeof(int64_t) * nsl);
-            S.h_rs[t] = (int32_t*)take(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1));
-            S.h_flags[t] = (int32_t*)take(sizeof(int32_t) * 4 * nsl);
+            grp.chunk_done[t] = grp.export_done[t] = nullptr;
+            grp.h_jobs[t] = (PackedJob*)take(sizeof(PackedJob) * nsl);
+            grp.h_strips[t] = (Strip*)take(sizeof(Strip) * nsl * (size_t)S.BL.smax);
+            grp.h_fresh[t] = (int32_t*)take(sizeof(int32_t) * nsl);
+            grp.h_fin[t] = (int32_t*)take(sizeof(int32_t) * nsl);
+            grp.h_fin_eta[t] = (int64_t*)take(sizeof(int64_t) * nsl);
+            grp.h_rs[t] = (int32_t*)take(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1));
+            grp.h_flags[t] = (int32_t*)take(sizeof(int32_t) * 4 * nsl);
+            if (rc == SCINT_OK) {
+                he = hipEventCreateWithFlags(&grp.chunk_done[t], hipEventDisableTiming);
+                if (he == hipSuccess) he = hipEventCreateWithFlags(&grp.export_done[t], hipEventDisableTiming);
+                if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
+            }
+        }
+        grp.jobs.assign(nsl, PackedJob());
+        grp.slot_eta.assign(nsl, -1);
+        grp.slot_gen.assign(nsl, 0);
+        for (int s = 0; s < grp.nslots; ++s) {                    // static part of every slot
+            char* sl = S.base + L.total * (size_t)(grp.slot0 + s);
+            PackedJob& J = grp.jobs[(size_t)s];
+            J.tiles = (cplx*)(sl + L.tiles);
+            J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
+            J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
+            J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
+            J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
+            J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
+            J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
+            J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
+            J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
+            J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * (grp.slot0 + s);
+            J.tol = tol; J.gen = 0;
+            J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
+            J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
+            J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
+            J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
         }
     }
-    S.jobs.assign(nsl, PackedJob());
-    S.slot_eta.assign(nsl, -1);
-    S.slot_gen.assign(nsl, 0);
-    for (int s = 0; s < S.nslots; ++s) {                    // static part of every slot
-        char* sl = S.base + L.total * (size_t)s;
-        PackedJob& J = S.jobs[(size_t)s];
-        J.tiles = (cplx*)(sl + L.tiles);
-        J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
-        J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
-        J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
-        J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
-        J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
-        J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
-        J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
-        J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
-        J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * s;
-        J.tol = tol; J.gen = 0;
-        J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
-        J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
-        J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
-        J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
-    }
-    // Order the tail stream after whatever the caller queued before us, then set up the state words
-    // and the geometry table.
-    hipEvent_t ev[2 * kTabs + 5] = {};
-    hipError_t he = hipSuccess;
-    for (auto& e : ev)
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    int32_t rc = SCINT_OK;
-    if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
-    for (int t = 0; t < kTabs; ++t) { S.chunk_done[t] = ev[t]; S.export_done[t] = ev[kTabs + t]; }
-    for (int h = 0; h < 2; ++h) { S.mv_done[h] = ev[2 * kTabs + 1 + h]; S.red_done[h] = ev[2 * kTabs + 3 + h]; }
-    // two halves when there are enough slots to split (SCINT_SWEEP_HALVES=1: one, for experiments)
-    const char* halves_env = getenv("SCINT_SWEEP_HALVES");
-    const bool split = S.nslots >= 4 && !(halves_env && atoi(halves_env) == 1);
-    S.half_slot0[0] = 0; S.half_slot0[1] = split ? S.nslots / 2 : S.nslots; S.half_slot0[2] = S.nslots;
+    // State words and geometry table on the caller's stream; the internal streams start after
+    // that (and after whatever the caller queued before us: the conjugate spectrum).
     if (rc == SCINT_OK) {
-        he = hipEventRecord(ev[2 * kTabs], stream);
-        if (he == hipSuccess) he = hipStreamWaitEvent(S.tail, ev[2 * kTabs], 0);
-        if (he == hipSuccess) he = hipStreamWaitEvent(S.aux, ev[2 * kTabs], 0);
-        if (he == hipSuccess)
-            he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
-        if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * nsl, stream);
+        he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
+        if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream);
+        if (he == hipSuccess) he = hipEventRecord(start_ev, stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(side->tail, start_ev, 0);
+        if (he == hipSuccess) he = hipStreamWaitEvent(side->aux, start_ev, 0);
         if (he != hipSuccess) rc = hip_fail(he, "sweep setup", __FILE__, __LINE__);
     }
-    if (rc == SCINT_OK) rc = S.run();
+    while (rc == SCINT_OK) {
+        bool any = false;
+        for (int g = 0; g < ngroups && rc == SCINT_OK; ++g) {
+            if (G[g].finished) continue;
+            any = true;
+            rc = G[g].advance();
+        }
+        if (!any) break;
+    }
     // leave nothing running on the internal streams, and nothing pending on the caller's
     (void)hipStreamSynchronize(stream);
-    (void)hipStreamSynchronize(S.aux);
-    (void)hipStreamSynchronize(S.tail);
-    for (auto& e : ev)
-        if (e) (void)hipEventDestroy(e);
+    (void)hipStreamSynchronize(side->aux);
+    (void)hipStreamSynchronize(side->tail);
+    for (int g = 0; g < ngroups; ++g)
+        for (int t = 0; t < kTabs; ++t) {
+            if (G[g].chunk_done[t]) (void)hipEventDestroy(G[g].chunk_done[t]);
+            if (G[g].export_done[t]) (void)hipEventDestroy(G[g].export_done[t]);
+        }
+    if (start_ev) (void)hipEventDestroy(start_ev);
     return rc;
 }
 

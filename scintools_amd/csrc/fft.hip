@@ -151,14 +151,36 @@ static const Chirp* chirp_table(int64_t n) {
 // ------------------------------------------------------------------------------
 constexpr int kRedBlocks = 1024;
 
+// Stage 1 of the deterministic reductions.  Every thread keeps four independent running sums
+// (four loads in flight, combined in a fixed order at the end).
 template <class F>
 __global__ void __launch_bounds__(256) reduce_partial_kernel(F f, int64_t n, double* partial) {
     __shared__ double red[4];
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        acc += f(i);
-    acc = block_sum(acc, red);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        a0 += f(i); a1 += f(i + stride); a2 += f(i + 2 * stride); a3 += f(i + 3 * stride);
+    }
+    for (; i < n; i += stride) a0 += f(i);
+    const double acc = block_sum((a0 + a1) + (a2 + a3), red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// The same over a [nrows, ncols] array for functors that need (row, col): block b takes rows
+// b, b + G, ...; threads stride the columns (coalesced, no index division).
+template <class F>
+__global__ void __launch_bounds__(256) reduce2d_partial_kernel(F f, int64_t nrows, int64_t ncols, double* partial) {
+    __shared__ double red[4];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        int64_t c = threadIdx.x;
+        for (; c + 768 < ncols; c += 1024) {
+            a0 += f.at(r, c); a1 += f.at(r, c + 256); a2 += f.at(r, c + 512); a3 += f.at(r, c + 768);
+        }
+        for (; c < ncols; c += 256) a0 += f.at(r, c);
+    }
+    const double acc = block_sum((a0 + a1) + (a2 + a3), red);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
@@ -177,6 +199,16 @@ static int32_t launch_reduce(F f, int64_t n, double scale, double* partial /*kRe
                              double* out, hipStream_t stream) {
     int blocks = (int)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, ceil_div(n, 256 * 4)));
     hipLaunchKernelGGL((reduce_partial_kernel<F>), dim3(blocks), dim3(256), 0, stream, f, n, partial);
+    SCINT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, out);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+template <class F>
+static int32_t launch_reduce2d(F f, int64_t nrows, int64_t ncols, double scale, double* partial /*kRedBlocks*/,
+                               double* out, hipStream_t stream) {
+    const int blocks = (int)std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, nrows));
+    hipLaunchKernelGGL((reduce2d_partial_kernel<F>), dim3(blocks), dim3(256), 0, stream, f, nrows, ncols, partial);
     SCINT_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, scale, out);
     SCINT_LAUNCH_CHECK();
@@ -678,7 +710,7 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
     int32_t rc = launch_reduce(PlainValue{dyn}, nf * nt, 1.0 / (double)(nf * nt), partial, scal, stream);
     if (rc != SCINT_OK) return rc;
     WindowedValue wv{dyn, win_t, win_f, scal, nt};
-    rc = launch_reduce(wv, nf * nt, 1.0 / (double)(nf * nt), partial, scal + 1, stream);
+    rc = launch_reduce2d(wv, nf, nt, 1.0 / (double)(nf * nt), partial, scal + 1, stream);
     if (rc != SCINT_OK) return rc;
 
     const int64_t nf_eff = prewhite ? nf - 1 : nf, nt_eff = prewhite ? nt - 1 : nt;
@@ -746,8 +778,8 @@ extern "C" int32_t scint_model_from_recov(const scint_c128* recov, int64_t ntau,
 namespace scint {
 struct ChisqValue {
     const double* model; int64_t ldm; const double* dspec; int64_t nt; const uint8_t* mask;
-    __device__ inline double operator()(int64_t i) const {
-        const int64_t r = i / nt, c = i - r * nt;
+    __device__ inline double at(int64_t r, int64_t c) const {
+        const int64_t i = r * nt + c;
         const double d = dspec[i];
         const bool use = mask ? (mask[i] != 0) : isfinite(d);
         if (!use) return 0.0;
@@ -764,8 +796,7 @@ extern "C" int32_t scint_chisq(const double* model, int64_t ld_model, const doub
     hipStream_t stream = (hipStream_t)stream_;
     double* partial = reduce_scratch(stream);
     if (!partial) return SCINT_E_HIP;
-    return launch_reduce(ChisqValue{model, ld_model, dspec, nt, mask}, nf * nt, 1.0 / noise_n, partial, out,
-                         stream);
+    return launch_reduce2d(ChisqValue{model, ld_model, dspec, nt, mask}, nf, nt, 1.0 / noise_n, partial, out, stream);
 }
 
 // ------------------------------------------------------------------------------
@@ -927,7 +958,7 @@ struct ChisqTail : SweepTail {
         sink.crop_r = nf; sink.crop_c = nt; sink.ld = nt;
         rc = fft2_general(src, g.ntau, 0.0, g.ntau, g.nfd, sink, fft_ws, fft_ws_bytes, tail);
         if (rc != SCINT_OK) return rc;
-        return launch_reduce(ChisqValue{model, nt, dspec, nt, mask}, nf * nt, 1.0 / noise_n, partial, chisq_out + e, tail);
+        return launch_reduce2d(ChisqValue{model, nt, dspec, nt, mask}, nf, nt, 1.0 / noise_n, partial, chisq_out + e, tail);
     }
 };
 

@@ -376,11 +376,16 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
 
 
 def _sweep_inputs(grid, etas_v):
+    """Crop of thth_redmap (ththmod.py:153-155) for every curvature: keep_idx[neta, M]
+    (left-packed ascending indices) and keep_n[neta]; same element-wise arithmetic as
+    ``_Grid.keep`` with the eta-independent parts hoisted."""
+    th = grid.th_cents
     neta, M = etas_v.shape[0], grid.M
+    th2, inside, tau_max = th**2, np.abs(th) < grid.geom.fd_max / 2, grid.geom.tau_max
     keep_idx = np.zeros((neta, M), dtype=np.int32)
     keep_n = np.zeros(neta, dtype=np.int32)
     for i, e in enumerate(etas_v):
-        k = grid.keep(e)
+        k = np.nonzero((th2 * e < tau_max) * inside)[0]
         keep_n[i] = k.shape[0]
         keep_idx[i, : k.shape[0]] = k
     return keep_idx, keep_n

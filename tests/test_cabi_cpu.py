@@ -133,6 +133,24 @@ def test_psrflux_io_matches_reference(golden, tmp_path):
     d2 = Dynspec(filename=out, verbose=False)
     assert np.array_equal(d2.dyn, g["rt_dyn"]) and np.array_equal(d2.times, g["rt_times"])
     assert np.array_equal(d2.freqs, g["rt_freqs"]) and d2.mjd == float(g["rt_mjd"])
+    # binary side-car: written on request, preferred while it is not older than the text file,
+    # and giving the same object as the text parse
+    import os as _os
+    from scintools_amd import psrflux
+    out2 = str(tmp_path / "sc.dynspec")
+    d.write_file(filename=out2, verbose=False, sidecar=True)
+    assert _os.path.exists(psrflux.sidecar_path(out2))
+    head, table = psrflux.load_sidecar(out2)
+    head_t, table_t = psrflux.read_table(out2)
+    assert head == head_t and np.array_equal(table, table_t)
+    d3 = Dynspec(filename=out2, verbose=False)
+    assert np.array_equal(d3.dyn, d2.dyn) and np.array_equal(d3.times, d2.times) and d3.mjd == d2.mjd
+    _os.utime(out2, (_os.path.getmtime(out2) + 10,) * 2)      # text newer than the side-car: ignored
+    assert psrflux.load_sidecar(out2) is None
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.dynspec"
+        bad.write_text("# MJD0: 1\n0 0 0.0 1400.0 1.0 0\n0 1 0.0\n")
+        psrflux.read_table(str(bad))
 
 
 def test_host_grid_randomised_against_oracle():

@@ -100,17 +100,19 @@ def test_sweep_is_schedule_invariant(env):
     assert np.array_equal(got, ref[perm])
     one = np.array([thth.Eval_calc(p["CS"], p["tau"], p["fd"], e, p["edges"]) for e in etas[:4]])
     assert np.array_equal(one, ref[:4])
-    # the host runs two chunks ahead of the convergence flags by default; synchronous scheduling
-    # (depth 1) must give the same bits, for eigenvalues and for eigenvectors
+    # by default two groups of slots run on two streams and the host queues two chunks ahead of the
+    # convergence flags; one group and/or synchronous scheduling (depth 1) must give the same
+    # bits, for eigenvalues and for eigenvectors
     import os
     w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
-    os.environ["SCINT_SWEEP_DEPTH"] = "1"
-    try:
-        assert np.array_equal(thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6), ref)
-        w1, V1, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
-    finally:
-        del os.environ["SCINT_SWEEP_DEPTH"]
-    assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
+    for depth, groups in (("1", "2"), ("2", "1"), ("1", "1")):
+        os.environ["SCINT_SWEEP_DEPTH"], os.environ["SCINT_SWEEP_GROUPS"] = depth, groups
+        try:
+            assert np.array_equal(thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6), ref)
+            w1, V1, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
+        finally:
+            del os.environ["SCINT_SWEEP_DEPTH"], os.environ["SCINT_SWEEP_GROUPS"]
+        assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
 
 
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
@@ -168,3 +170,27 @@ def test_threads_with_their_own_streams(env):
     for t in ts:
         t.join()
     assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+
+
+def test_nearly_rank_one_matrix_vs_arpack(env):
+    """A noiseless screen with one dominant image: theta-theta is close to rank one, the start
+    vector (row n/2) is already nearly the eigenvector, and beta_j << |alpha_j| from the first
+    Lanczos steps on -- the regime where beta_j^2 = |u_j|^2 - alpha_j^2 cancels.  The eigenvalue
+    must still match ARPACK to the parity bar, for eigenvalue and eigenvector sweeps."""
+    from scintools_amd.synth import arc_dynspec
+    thth, to, p = env
+    dyn, freqs, times, eta_true = arc_dynspec(256, 256, seed=9, nimg=6, noise=0.0)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 256)
+    CS = to.conjugate_spectrum(dyn, 0)
+    etas = np.array([0.9, 1.0, 1.1]) * eta_true
+    ref = np.array([to.Eval_calc(CS, tau, fd, e, edges) for e in etas])
+    eigs, info = thth.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
+    assert np.all(info["status"] == 0)
+    np.testing.assert_allclose(eigs, ref, rtol=1e-9)
+    w, V, vinfo = thth.eigvec_sweep(CS, tau, fd, etas, edges)
+    np.testing.assert_allclose(np.abs(w), ref, rtol=1e-9)
+    red, _ = to.thth_redmap(CS, tau, fd, etas[1], edges)
+    v = V[1, : red.shape[0]].cpu().numpy()
+    assert np.linalg.norm(red @ v - w[1] * v) <= 1e-8 * abs(w[1])
