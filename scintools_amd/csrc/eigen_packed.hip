@@ -18,7 +18,7 @@
 //   pk_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials,
 //                     u_j = A q_j - beta_{j-1} q_{j-1}, q_j, and the partials of
 //                     alpha_j = q_j^H u_j and |u_j|^2  (beta_j^2 = |u_j|^2 - alpha_j^2).
-//   pk_check_kernel   (every 4 steps) top two Ritz values of T_k by 64-lane multisection on
+//   pk_check_kernel   (every 2 steps) top two Ritz values of T_k by 64-lane multisection on
 //                     the Sturm count, Ritz residual by the backward recurrence, and the
 //                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
@@ -26,12 +26,12 @@
 // slot is re-filled with the next eta of the sweep (continuous batching; every job carries the
 // launch index it started at, so jobs at different Lanczos steps share one launch).  Two groups of
 // slots run on two streams and fill each other's gaps; in each, the steps are queued in chunks of
-// 4 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
+// 2 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
 // waits for the host.  Per-job arithmetic does not depend on the schedule.
 //
 // Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
-// 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| over the
-// last 4 steps.  No atomics anywhere: results are bit-reproducible and independent of how the
+// 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| since the
+// previous check.  No atomics anywhere: results are bit-reproducible and independent of how the
 // etas are batched.
 #include <math.h>
 
@@ -44,7 +44,7 @@
 
 namespace scint {
 
-constexpr int kCheckEvery = 4;
+constexpr int kCheckEvery = 2;   // Lanczos steps per chunk (between convergence checks); SCINT_CHECK_EVERY overrides
 constexpr int kFirstCheck = 8;
 constexpr int kMaxK = 512;   // upper bound on Lanczos steps held in LDS by the check kernel
 
@@ -572,7 +572,7 @@ struct SweepProblem {
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
     SweepTail* tail_hook; hipStream_t tail;
-    int nbmax, steps_cap, depth;
+    int nbmax, steps_cap, depth, check_every;
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -623,7 +623,7 @@ struct SweepGroup {
         SweepProblem& S = *P;
         const SlabLayout& L = S.BL.slab;
         std::vector<int32_t> fresh;
-        const int launch0 = chunk * kCheckEvery;
+        const int launch0 = chunk * S.check_every;
         for (int s = 0; s < nslots && S.next_eta < S.neta; ++s) {
             if (slot_eta[(size_t)s] >= 0) continue;
             const int64_t e = S.next_eta++;
@@ -743,7 +743,7 @@ struct SweepGroup {
         }
         tab_of_chunk[chunk % kTabs] = tab;
         if (nstrips > 0) {
-            for (int i = 0; i < kCheckEvery; ++i) {
+            for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
                 const int slot = profiler().begin(kProfMatvec, stream);
                 hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
@@ -752,7 +752,7 @@ struct SweepGroup {
                                    stream, d_jobs(tab), launch);
             }
         }
-        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + kCheckEvery);
+        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
         he = hipGetLastError();
         if (he == hipSuccess)
             he = hipMemcpyAsync(h_flags[chunk % kTabs], S.states_dev + 4 * slot0, sizeof(int32_t) * 4 * (size_t)nslots,
@@ -824,6 +824,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const char* depth_env = getenv("SCINT_SWEEP_DEPTH");    // read per call: tests compare schedules in one process
     const int forced_depth = depth_env ? atoi(depth_env) : 0;
     S.depth = forced_depth >= 1 && forced_depth <= 2 ? forced_depth : 2;
+    const char* every_env = getenv("SCINT_CHECK_EVERY");
+    const int forced_every = every_env ? atoi(every_env) : 0;
+    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEvery;
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);

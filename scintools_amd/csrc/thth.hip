@@ -250,7 +250,8 @@ struct RevParams {
     const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
 };
 
-constexpr int kRevSlab = 1792;  // most tau rows accumulated per workgroup: 1792 * 36 B = 63 KiB of LDS
+constexpr int kRevSlab = 4096;     // most tau rows accumulated per workgroup: 4096 * 36 B = 144 KiB of LDS
+constexpr int kRevThreads = 1024;  // one workgroup per CU then: 16 wavefronts share the column's accumulators
 
 // ---- order-independent (bit-reproducible) accumulation ---------------------------------------
 // Many (i, j) pairs fall in one CS pixel and arrive in scheduling order.  Plain float64 adds
@@ -368,7 +369,7 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // Hermitian model w_ji == conj(w_ij) exactly, and sum and count are both halved.
 constexpr int kRevWin = 8;   // widest candidate window (theta centres per fd bin, + 2)
 
-__global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g) {
+__global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
     // rev_lds[0 .. 4 slab): real hi, real lo, imag hi, imag lo grids; then the counts.  Always
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
     if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);
     const int64_t row0 = (int64_t)blockIdx.y * slab;
     const int rows = (int)min((int64_t)slab, g.ntau - row0);
-    for (int r = threadIdx.x; r < rows; r += 256) {
+    for (int r = threadIdx.x; r < rows; r += kRevThreads) {
         rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0; rev_lds[2 * slab + r] = 0.0; rev_lds[3 * slab + r] = 0.0;
         ((uint32_t*)(rev_lds + 4 * slab))[r] = 0u;
     }
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
         atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
     };
 
-    for (int i = threadIdx.x; usable && i < N; i += 256) {
+    for (int i = threadIdx.x; usable && i < N; i += kRevThreads) {
         const double th_i = gload(p.th + i);
         const int g0 = i + s0;                                         // first candidate
         double tj[kRevWin + 2];                                        // th[g0 - 1 .. g0 + W]
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(256) rev_gather_kernel(RevParams p, GeomDev g)
     __syncthreads();
     // recov = nan_to_num(sum / count); the bin that receives the i == j terms is NaN in the
     // reference (x/0 weights) and therefore 0 after nan_to_num.
-    for (int r = threadIdx.x; r < rows; r += 256) {
+    for (int r = threadIdx.x; r < rows; r += kRevThreads) {
         const int64_t o = (row0 + r) * g.nfd + col;
         cplx out = mk(0.0, 0.0);
         if (o != p.centre) {
@@ -516,11 +517,15 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
     hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
     p.bound = bound;
-    // equal slabs, the fewest that fit the LDS budget (4096 rows -> 3 x 1366: three workgroups per CU)
+    // equal slabs, the fewest that fit the LDS (a 4096-row conjugate spectrum is ONE slab: no pair is
+    // looked at twice); the accumulators of a slab take more than the default 64 KiB of dynamic LDS
     p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, kRevSlab));
+    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)rev_gather_kernel,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRevSlab * 36);
+    SCINT_HIP(lds_ok);
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    hipLaunchKernelGGL(rev_gather_kernel, grid, dim3(256), (size_t)p.slab * 36, stream, p, g);
+    hipLaunchKernelGGL(rev_gather_kernel, grid, dim3(kRevThreads), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
