@@ -18,7 +18,7 @@
 //   pk_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials,
 //                     u_j = A q_j - beta_{j-1} q_{j-1}, q_j, and the partials of
 //                     alpha_j = q_j^H u_j and |u_j|^2  (beta_j^2 = |u_j|^2 - alpha_j^2).
-//   pk_check_kernel   (every 2 steps) top two Ritz values of T_k by 64-lane multisection on
+//   pk_check_kernel   (every 4 steps) top two Ritz values of T_k by 64-lane multisection on
 //                     the Sturm count, Ritz residual by the backward recurrence, and the
 //                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
@@ -26,7 +26,7 @@
 // slot is re-filled with the next eta of the sweep (continuous batching; every job carries the
 // launch index it started at, so jobs at different Lanczos steps share one launch).  Two groups of
 // slots run on two streams and fill each other's gaps; in each, the steps are queued in chunks of
-// 2 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
+// 4 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
 // waits for the host.  Per-job arithmetic does not depend on the schedule.
 //
 // Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
@@ -44,7 +44,9 @@
 
 namespace scint {
 
-constexpr int kCheckEvery = 2;   // Lanczos steps per chunk (between convergence checks); SCINT_CHECK_EVERY overrides
+constexpr int kCheckEvery = 4;   // Lanczos steps per chunk (between convergence checks); SCINT_CHECK_EVERY overrides.
+                                 // Measured at 4096^2 / 256 eta: every 1 / 2 / 4 steps -> 39.6 / 40.1 / 41.1 steps per eta but
+                                 // 1081 / 1085 / 1093 eta/s: the saved steps do not pay for the extra checks and read-backs
 constexpr int kFirstCheck = 8;
 constexpr int kMaxK = 512;   // upper bound on Lanczos steps held in LDS by the check kernel
 
@@ -428,6 +430,447 @@ __global__ void __launch_bounds__(64) pk_ritz_scale_kernel(const PackedJob* jobs
     if (r < jb.n) out[r] = mk(out[r].x * inv, out[r].y * inv);
 }
 
+// ==============================================================================
+// Two-vector (block) Lanczos -- the eigenvalue-only sweep
+// ==============================================================================
+// Every Lanczos step streams the matrix once; its cost does not depend on how many vectors are
+// multiplied on the way (the kernel stays far below the fp64 rate: 2 flop/byte with two
+// vectors).  With a block of TWO vectors the Krylov space grows by two dimensions per pass and
+// the top Ritz value reaches a given accuracy in ~0.7x the passes of the single-vector
+// recurrence on theta-theta matrices (lambda_2 close to lambda_1 stops hurting; measured on the
+// CPU at N = 1023: 42/34/27/17/27/29/31 -> 29/27/20/13/20/23/23 passes over the eta range).
+//
+//   Q_0 R = [v0 v1]            v0 = row n/2 (Eval_calc's start vector), v1 = another row
+//   W_j   = A Q_j - Q_{j-1} B_{j-1}^H
+//   A_j   = Q_j^H W_j                       (2x2 Hermitian)
+//   W_j - Q_j A_j = Q_{j+1} B_j             (B_j 2x2 upper triangular, Cholesky of the Gram matrix)
+//
+// T_k = blocktridiag(B_{j-1}; A_j; B_j^H) is Hermitian pentadiagonal; its top two eigenvalues
+// come from a Sturm count on the banded LDL^H factorisation, the Ritz vector's last block (for
+// the residual ||B_{k-1} s_last||) from inverse iteration on the same factorisation.
+//
+// The kernels mirror the single-vector ones: Q_j is never stored ahead of its use -- every
+// consumer rebuilds  Q_j = (W_{j-1} - Q_{j-1} A_{j-1}) B_{j-1}^{-1}  from the previous step's
+// vectors and the fixed-order partial sums of A_{j-1} = Q^H W and of the Gram matrix W^H W
+// (G' = W^H W - A^H A, as beta^2 = |u|^2 - alpha^2 in the single-vector form).  Vectors are
+// stored interleaved, [row][2]; scalar partials as 4 doubles per 64-row block.
+struct Blk2 {
+    double a11, a22; cplx a12;      // A_{j-1}
+    double b11, b22; cplx b12;      // B_{j-1}
+    double i11, i22;                // 1/b11, 1/b22; 0 when that direction is exhausted
+};
+
+__device__ inline Blk2 step_block_wave(const double* __restrict__ ap, const double* __restrict__ up, int nb, int lane) {
+    double s[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = 0.0;
+    for (int i = lane; i < nb; i += 64) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s[c] += gload(ap + 4 * i + c); s[4 + c] += gload(up + 4 * i + c); }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s[c] = wave_sum(s[c]);
+    Blk2 b;
+    b.a11 = s[0]; b.a22 = s[1]; b.a12 = mk(s[2], s[3]);
+    const double n12 = s[2] * s[2] + s[3] * s[3], tr = s[0] + s[1];
+    const double h11 = s[4] - (s[0] * s[0] + n12), h22 = s[5] - (n12 + s[1] * s[1]);
+    const cplx h12 = mk(s[6] - s[2] * tr, s[7] - s[3] * tr);
+    b.b11 = h11 > 0.0 ? sqrt(h11) : 0.0;
+    b.i11 = b.b11 > 0.0 ? 1.0 / b.b11 : 0.0;
+    b.b12 = mk(h12.x * b.i11, h12.y * b.i11);
+    const double d = h22 - norm2(b.b12);
+    b.b22 = d > 0.0 ? sqrt(d) : 0.0;
+    b.i22 = b.b22 > 0.0 ? 1.0 / b.b22 : 0.0;
+    return b;
+}
+
+// the step scalars are wave-uniform (results of wave_sum): moving them to the scalar registers
+// frees two dozen vector registers in the mat-vec
+__device__ inline double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ inline Blk2 uniform_blk(Blk2 b) {
+    b.a11 = uniform_f64(b.a11); b.a22 = uniform_f64(b.a22); b.a12 = mk(uniform_f64(b.a12.x), uniform_f64(b.a12.y));
+    b.b11 = uniform_f64(b.b11); b.b22 = uniform_f64(b.b22); b.b12 = mk(uniform_f64(b.b12.x), uniform_f64(b.b12.y));
+    b.i11 = uniform_f64(b.i11); b.i22 = uniform_f64(b.i22);
+    return b;
+}
+
+// row of Q_j = (W_{j-1} - Q_{j-1} A_{j-1}) B_{j-1}^{-1} from the rows (u1, u2) of W_{j-1}, (q1, q2) of Q_{j-1}
+__device__ inline void blk_q_row(const Blk2& b, cplx u1, cplx u2, cplx q1, cplx q2, cplx& x1, cplx& x2) {
+    const cplx y1 = u1 - (q1 * b.a11 + mulc(q2, b.a12));       // q1 a11 + q2 conj(a12)
+    const cplx y2 = u2 - (q1 * b.a12 + q2 * b.a22);
+    x1 = y1 * b.i11;
+    x2 = (y2 - x1 * b.b12) * b.i22;
+}
+
+// [v0 v1]: rows n/2 and n/2+7 (or a neighbouring row in a tiny matrix) of theta-theta
+__device__ inline int second_start_row(int n) { return (n / 2 + 7 < n) ? n / 2 + 7 : (n / 2 + 1) % max(n, 1); }
+
+__global__ void __launch_bounds__(64) pk2_init_kernel(const PackedJob* jobs, const int32_t* slots) {
+    const PackedJob jb = jobs[slots[blockIdx.y]];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (K == 0 && e == 0) { jb.state[1] = 0; jb.result[1] = -INFINITY; jb.result[3] = -INFINITY; }
+    if (K >= jb.nb) return;
+    const int r = K * kTB + e;
+    cplx v0 = mk(0.0, 0.0), v1 = mk(0.0, 0.0);
+    if (r < jb.n && jb.n >= 2) { v0 = packed_at(jb, jb.n / 2, r); v1 = packed_at(jb, second_start_row(jb.n), r); }
+    jb.U[0][2 * r] = v0; jb.U[0][2 * r + 1] = v1;
+    jb.U[1][2 * r] = mk(0.0, 0.0); jb.U[1][2 * r + 1] = mk(0.0, 0.0);
+    cplx* qm1 = jb.Q + (int64_t)(jb.qslots - 1) * jb.qstride * 2;     // "Q_{-1}" = 0
+    qm1[2 * r] = mk(0.0, 0.0); qm1[2 * r + 1] = mk(0.0, 0.0);
+    jb.Q[2 * r] = mk(0.0, 0.0); jb.Q[2 * r + 1] = mk(0.0, 0.0);
+    const double g11 = wave_sum(norm2(v0)), g22 = wave_sum(norm2(v1));
+    const cplx g12 = wave_sum(mulc(v1, v0));                           // conj(v0) v1
+    if (e == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { jb.apart[0][4 * K + c] = 0.0; jb.apart[1][4 * K + c] = 0.0; jb.upart[1][4 * K + c] = 0.0; }
+        jb.upart[0][4 * K] = g11; jb.upart[0][4 * K + 1] = g22; jb.upart[0][4 * K + 2] = g12.x; jb.upart[0][4 * K + 3] = g12.y;
+    }
+}
+
+constexpr int kFlush2 = 2;     // column partials of the block kernel are reduced across the waves every 2 tiles
+
+__global__ void __launch_bounds__(256, 2)
+pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
+    __shared__ cplx cred[4][kFlush2][kTB][2];   // per-wave column partials of kFlush2 tiles, 2 vectors (16 KiB)
+    __shared__ cplx xs[kMaxStrip][kTB][2];      // the blocks X_J of the strip, rebuilt once per workgroup (32 KiB)
+    const Strip st = strips[blockIdx.x];
+    const PackedJob* __restrict__ jp = jobs + st.job;
+    const int step = launch - jp->start;
+    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
+    const int par = step & 1;
+    const int nb = jp->nb;
+    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
+    const int qs = jp->qslots;
+    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride * 2;   // Q_{j-1}
+    const cplx* __restrict__ tiles = jp->tiles;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int I = st.I;
+    const int64_t t0 = tile_offset(nb, I);
+    const int ntile = st.J1 - st.J0;
+    const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
+    cplx a0[8], a1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
+    const Blk2 sc = uniform_blk(step_block_wave(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
+    // lane l of every wave holds row l of the block X_I (both vectors); rows read it back with v_readlane
+    cplx xI1, xI2;
+    blk_q_row(sc, gload(Up + 2 * (I * kTB + lane)), gload(Up + 2 * (I * kTB + lane) + 1),
+              gload(Qp + 2 * (I * kTB + lane)), gload(Qp + 2 * (I * kTB + lane) + 1), xI1, xI2);
+    // X_J = rows J0*64 .. J1*64 of Q_j, once per workgroup (the first tile's loads stay in flight)
+    for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
+        const int r = st.J0 * kTB + idx;
+        cplx x1, x2;
+        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), x1, x2);
+        xs[idx >> 6][idx & 63][0] = x1;
+        xs[idx >> 6][idx & 63][1] = x2;
+    }
+    __syncthreads();
+    cplx acc1[16], acc2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
+    cplx* __restrict__ colpart = jp->colpart;
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a1[r] = gload_nt(tc + (8 + r) * kTB);   // second half of this tile
+        const cplx xJ1 = xs[t][lane][0], xJ2 = xs[t][lane][1];
+        cplx c1 = mk(0.0, 0.0), c2 = mk(0.0, 0.0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            acc1[r] = acc1[r] + a0[r] * xJ1;
+            acc2[r] = acc2[r] + a0[r] * xJ2;
+            const cplx x1 = mk(readlane_f64(xI1.x, 16 * w + r), readlane_f64(xI1.y, 16 * w + r));
+            const cplx x2 = mk(readlane_f64(xI2.x, 16 * w + r), readlane_f64(xI2.y, 16 * w + r));
+            c1 = mk(c1.x + a0[r].x * x1.x + a0[r].y * x1.y, c1.y + a0[r].x * x1.y - a0[r].y * x1.x);   // conj(a) x_I
+            c2 = mk(c2.x + a0[r].x * x2.x + a0[r].y * x2.y, c2.y + a0[r].x * x2.y - a0[r].y * x2.x);
+        }
+        if (t + 1 < ntile) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + kTileElems + r * kTB);   // first half of the next tile
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            acc1[8 + r] = acc1[8 + r] + a1[r] * xJ1;
+            acc2[8 + r] = acc2[8 + r] + a1[r] * xJ2;
+            const cplx x1 = mk(readlane_f64(xI1.x, 16 * w + 8 + r), readlane_f64(xI1.y, 16 * w + 8 + r));
+            const cplx x2 = mk(readlane_f64(xI2.x, 16 * w + 8 + r), readlane_f64(xI2.y, 16 * w + 8 + r));
+            c1 = mk(c1.x + a1[r].x * x1.x + a1[r].y * x1.y, c1.y + a1[r].x * x1.y - a1[r].y * x1.x);
+            c2 = mk(c2.x + a1[r].x * x2.x + a1[r].y * x2.y, c2.y + a1[r].x * x2.y - a1[r].y * x2.x);
+        }
+        cred[w][t & (kFlush2 - 1)][lane][0] = c1;   // this wave's own slot
+        cred[w][t & (kFlush2 - 1)][lane][1] = c2;
+        if ((t & (kFlush2 - 1)) == kFlush2 - 1 || t + 1 == ntile) {
+            // cross-wave reduction of the last <= kFlush2 tiles' column partials: waves 0,1 take
+            // vector 0 / 1 of the first tile, waves 2,3 of the second
+            __syncthreads();
+            const int tb = t & ~(kFlush2 - 1);
+            const int tt = tb + (w >> 1), v = w & 1;
+            if (tt <= t) {
+                const int Jt = st.J0 + tt;
+                if (Jt != I) {
+                    const int k = w >> 1;
+                    const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
+                    gstore(colpart + 2 * ((t0 + (Jt - I)) * kTB + lane) + v, sum);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    cplx* __restrict__ rowpart = jp->rowpart;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const cplx s1 = wave_sum(acc1[r]), s2 = wave_sum(acc2[r]);
+        if (lane == 0) {
+            gstore(rowpart + 2 * ((int64_t)st.index * kTB + 16 * w + r), s1);
+            gstore(rowpart + 2 * ((int64_t)st.index * kTB + 16 * w + r) + 1, s2);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64 * kRedGroups)
+pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
+    __shared__ cplx part[kRedGroups][kTB][2];
+    const PackedJob jb = jobs[blockIdx.y];
+    const int K = blockIdx.x;
+    const int step = launch - jb.start;
+    if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
+    const int par = step & 1;
+    const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
+    // fixed summation order as in pk_reduce_kernel, for both vectors
+    const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
+    cplx acc1 = mk(0.0, 0.0), acc2 = mk(0.0, 0.0);
+    for (int idx = g; idx < nrow + K; idx += kRedGroups) {
+        const cplx* src = idx < nrow ? jb.rowpart + 2 * ((int64_t)(s0 + idx) * kTB + e)
+                                     : jb.colpart + 2 * ((tile_offset(jb.nb, idx - nrow) + (K - (idx - nrow))) * kTB + e);
+        acc1 = acc1 + gload(src);
+        acc2 = acc2 + gload(src + 1);
+    }
+    part[g][e][0] = acc1;
+    part[g][e][1] = acc2;
+    __syncthreads();
+    if (g == 0) {
+        const Blk2 sc = step_block_wave(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, e);
+        cplx tot1 = part[0][e][0], tot2 = part[0][e][1];
+#pragma unroll
+        for (int k = 1; k < kRedGroups; ++k) { tot1 = tot1 + part[k][e][0]; tot2 = tot2 + part[k][e][1]; }
+        const int r = K * kTB + e;
+        const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
+        const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + jb.qslots - 1) % jb.qslots) * jb.qstride * 2;
+        cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
+        cplx* __restrict__ Qn = jb.Q + (int64_t)(step % jb.qslots) * jb.qstride * 2;
+        const cplx q1 = gload(Qp + 2 * r), q2 = gload(Qp + 2 * r + 1);
+        cplx x1, x2;
+        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), q1, q2, x1, x2);       // row of Q_j
+        // row of W_j = A Q_j - Q_{j-1} B_{j-1}^H:  (q1 b11 + q2 conj(b12), q2 b22)
+        const cplx t1 = tot1 - (q1 * sc.b11 + mulc(q2, sc.b12));
+        const cplx t2 = tot2 - q2 * sc.b22;
+        gstore(Un + 2 * r, t1); gstore(Un + 2 * r + 1, t2);
+        gstore(Qn + 2 * r, x1); gstore(Qn + 2 * r + 1, x2);
+        const double pa11 = wave_sum(x1.x * t1.x + x1.y * t1.y);      // Re(conj(x1) t1)
+        const double pa22 = wave_sum(x2.x * t2.x + x2.y * t2.y);
+        const cplx pa12 = wave_sum(mulc(t2, x1));                     // conj(x1) t2
+        const double pg11 = wave_sum(norm2(t1)), pg22 = wave_sum(norm2(t2));
+        const cplx pg12 = wave_sum(mulc(t2, t1));                     // conj(t1) t2
+        if (e == 0) {
+            double* an = par ? jb.apart[0] : jb.apart[1];
+            double* un = par ? jb.upart[0] : jb.upart[1];
+            an[4 * K] = pa11; an[4 * K + 1] = pa22; an[4 * K + 2] = pa12.x; an[4 * K + 3] = pa12.y;
+            un[4 * K] = pg11; un[4 * K + 1] = pg22; un[4 * K + 2] = pg12.x; un[4 * K + 3] = pg12.y;
+            if (K == 0) {
+                if (step > 0) {
+                    double* A = jb.alpha + 4 * (step - 1);
+                    A[0] = sc.a11; A[1] = sc.a22; A[2] = sc.a12.x; A[3] = sc.a12.y;
+                }
+                double* B = jb.beta + 4 * step;                      // B[step] couples blocks step-1 and step
+                B[0] = sc.b11; B[1] = sc.b22; B[2] = sc.b12.x; B[3] = sc.b12.y;
+            }
+        }
+    }
+}
+
+constexpr int kMaxKB = 128;    // block steps held in LDS by the block check kernel (T up to 256 x 256)
+
+// eigenvalues of the Hermitian pentadiagonal T (diagonal dg, T[i+1][i] = e1[i], T[i+2][i] = e2[i])
+// strictly below x: signs of the pivots of the banded LDL^H factorisation of T - x
+__device__ inline int band_count(const double* dg, const cplx* e1, const cplx* e2, int n, double x, double tiny) {
+    int cnt = 0;
+    double r1 = 0.0, r2 = 0.0;               // 1/d_{i-1}, 1/d_{i-2}
+    cplx p = mk(0.0, 0.0), q = mk(0.0, 0.0); // M_{i,i-1}, M_{i,i-2}  (M = L D)
+    for (int i = 0; i < n; ++i) {
+        double d = ((dg[i] - x) - norm2(p) * r1) - norm2(q) * r2;
+        if (fabs(d) < tiny) d = -tiny;
+        cnt += d < 0.0;
+        const cplx below = i >= 1 ? e2[i - 1] : mk(0.0, 0.0);     // M_{i+1,i-1}
+        const cplx pn = e1[i] - mulc(below, p) * r1;               // M_{i+1,i}
+        q = below;
+        p = pn;
+        r2 = r1;
+        r1 = 1.0 / d;
+    }
+    return cnt;
+}
+
+__device__ inline double band_multisect(const double* dg, const cplx* e1, const cplx* e2, int n, int target,
+                                        double lo, double hi, double tiny, int lane) {
+    for (int round = 0; round < 48; ++round) {
+        const double wdt = hi - lo;
+        if (!(wdt > 0.0)) break;
+        const double x = lo + wdt * ((double)(lane + 1) / 65.0);
+        const int ok = (x > lo && x < hi) ? (band_count(dg, e1, e2, n, x, tiny) >= target) : 0;
+        const unsigned long long m = __ballot(ok);
+        double nlo, nhi;
+        if (m == 0ull) { nlo = __shfl(x, 63, 64); nhi = hi; }
+        else {
+            const int first = __ffsll((long long)m) - 1;
+            nhi = __shfl(x, first, 64);
+            nlo = first > 0 ? __shfl(x, first - 1, 64) : lo;
+        }
+        if (!(nlo > lo) && !(nhi < hi)) break;
+        if (nlo > lo) lo = nlo;
+        if (nhi < hi) hi = nhi;
+        if (hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi))) break;
+    }
+    return 0.5 * (lo + hi);
+}
+
+__global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, int launches_done) {
+    __shared__ double dg[2 * kMaxKB + 2];
+    __shared__ cplx e1[2 * kMaxKB + 2], e2[2 * kMaxKB + 2];
+    __shared__ double fd[2 * kMaxKB + 2];          // pivots of the factorisation used by the inverse iteration
+    __shared__ cplx fm[2 * kMaxKB + 2];            // its M_{i+1,i}
+    __shared__ cplx sv[2 * kMaxKB + 2];
+    const PackedJob jb = jobs[blockIdx.x];
+    if (jb.gen <= 0 || jb.state[0] >= jb.gen) return;      // idle slot / finished job
+    const int lane = threadIdx.x;
+    const int k_done = launches_done - jb.start;           // block steps this job has completed
+    if (jb.n < 2) {
+        if (lane == 0) {
+            jb.state[0] = jb.gen;
+            jb.status_out[0] = SCINT_E_EMPTY;
+            jb.eig_out[0] = nan("");
+            if (jb.iters_out) jb.iters_out[0] = 0;
+        }
+        return;
+    }
+    if (k_done < kFirstCheck / 2 && k_done < jb.max_steps) return;
+    const int k = min(k_done, jb.max_steps);
+    const int n = 2 * k;
+    // A_{k-1}, B_{k-1} are still in the partials of the last reduce kernel
+    const Blk2 last = step_block_wave((k & 1) ? jb.apart[1] : jb.apart[0], (k & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane);
+    for (int j = lane; j < k; j += 64) {
+        double a11, a22; cplx a12;
+        if (j < k - 1) { const double* A = jb.alpha + 4 * j; a11 = A[0]; a22 = A[1]; a12 = mk(A[2], A[3]); }
+        else { a11 = last.a11; a22 = last.a22; a12 = last.a12; }
+        dg[2 * j] = a11; dg[2 * j + 1] = a22;
+        e1[2 * j] = conj(a12);                     // T[2j+1][2j]
+        if (j + 1 < k) {
+            const double* B = jb.beta + 4 * (j + 1);   // couples blocks j and j+1: T[2j+2.., 2j..] = B
+            e2[2 * j] = mk(B[0], 0.0);             // T[2j+2][2j]   = b11
+            e1[2 * j + 1] = mk(B[2], B[3]);        // T[2j+2][2j+1] = b12
+            e2[2 * j + 1] = mk(B[1], 0.0);         // T[2j+3][2j+1] = b22
+        } else {
+            e2[2 * j] = mk(0.0, 0.0); e1[2 * j + 1] = mk(0.0, 0.0); e2[2 * j + 1] = mk(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    double lo = INFINITY, hi = -INFINITY, scale = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        double off = 0.0;
+        if (i >= 1) off += sqrt(norm2(e1[i - 1]));
+        if (i >= 2) off += sqrt(norm2(e2[i - 2]));
+        if (i + 1 < n) off += sqrt(norm2(e1[i]));
+        if (i + 2 < n) off += sqrt(norm2(e2[i]));
+        lo = fmin(lo, dg[i] - off);
+        hi = fmax(hi, dg[i] + off);
+        scale = fmax(scale, fabs(dg[i]) + off);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o, 64));
+        hi = fmax(hi, __shfl_xor(hi, o, 64));
+        scale = fmax(scale, __shfl_xor(scale, o, 64));
+    }
+    const double bnorm = sqrt(last.b11 * last.b11 + last.b22 * last.b22 + norm2(last.b12));
+    const bool finite = isfinite(lo) && isfinite(hi) && isfinite(bnorm);
+    double theta = nan(""), theta2 = -INFINITY, resid = nan(""), err = nan("");
+    if (finite && scale == 0.0 && bnorm == 0.0) {
+        theta = 0.0; theta2 = 0.0; resid = 0.0; err = 0.0;     // all-zero theta-theta
+    } else if (finite) {
+        const double tiny = scale * 1e-300 + 1e-300;
+        lo = lo - 1e-15 * fabs(lo) - 1e-300;
+        hi = hi + 1e-15 * fabs(hi) + 1e-300;
+        theta = band_multisect(dg, e1, e2, n, n, lo, hi, tiny, lane);
+        if (n >= 2) theta2 = band_multisect(dg, e1, e2, n, n - 1, lo, theta, tiny, lane);
+        if (lane == 0) {
+            // Ritz vector by inverse iteration on T - sigma, sigma just above theta; only its last
+            // block is needed: resid = || B_{k-1} s_last || / ||s||
+            const double sigma = theta + 8e-16 * fmax(fabs(theta), scale * 1e-3);
+            double r1 = 0.0, r2 = 0.0;
+            cplx p = mk(0.0, 0.0), q = mk(0.0, 0.0);
+            for (int i = 0; i < n; ++i) {
+                double d = ((dg[i] - sigma) - norm2(p) * r1) - norm2(q) * r2;
+                if (fabs(d) < tiny) d = -tiny;
+                const cplx below = i >= 1 ? e2[i - 1] : mk(0.0, 0.0);
+                const cplx pn = e1[i] - mulc(below, p) * r1;
+                fd[i] = d; fm[i] = pn;
+                q = below; p = pn; r2 = r1; r1 = 1.0 / d;
+            }
+            for (int i = 0; i < n; ++i) sv[i] = mk(1.0, 0.0);
+            double nrm = 1.0;
+            for (int it = 0; it < 2; ++it) {
+                // L y = rhs:  L_{i,i-1} = M_{i,i-1}/d_{i-1},  L_{i,i-2} = e2[i-2]/d_{i-2}
+                for (int i = 0; i < n; ++i) {
+                    cplx y = sv[i];
+                    if (i >= 1) y = y - (fm[i - 1] * sv[i - 1]) * (1.0 / fd[i - 1]);
+                    if (i >= 2) y = y - (e2[i - 2] * sv[i - 2]) * (1.0 / fd[i - 2]);
+                    sv[i] = y;
+                }
+                for (int i = 0; i < n; ++i) sv[i] = sv[i] * (1.0 / fd[i]);
+                // L^H s = z
+                for (int i = n - 1; i >= 0; --i) {
+                    cplx z = sv[i];
+                    if (i + 1 < n) z = z - mulc(sv[i + 1], fm[i]) * (1.0 / fd[i]);        // conj(L_{i+1,i}) s_{i+1}
+                    if (i + 2 < n) z = z - mulc(sv[i + 2], e2[i]) * (1.0 / fd[i]);        // conj(L_{i+2,i}) s_{i+2}
+                    sv[i] = z;
+                }
+                double mx = 0.0;
+                for (int i = 0; i < n; ++i) mx = fmax(mx, fmax(fabs(sv[i].x), fabs(sv[i].y)));
+                const double sc = mx > 0.0 && isfinite(mx) ? 1.0 / mx : 0.0;
+                nrm = 0.0;
+                for (int i = 0; i < n; ++i) { sv[i] = sv[i] * sc; nrm += norm2(sv[i]); }
+            }
+            const cplx sl0 = sv[n - 2], sl1 = sv[n - 1];
+            const cplx rr1 = sl0 * last.b11 + last.b12 * sl1;
+            const cplx rr2 = sl1 * last.b22;
+            resid = nrm > 0.0 ? sqrt((norm2(rr1) + norm2(rr2)) / nrm) : bnorm;
+            if (!isfinite(resid)) resid = bnorm;
+        }
+        resid = __shfl(resid, 0, 64);
+        const double gap = theta - theta2;
+        err = (gap > resid) ? resid * resid / gap : resid;
+    }
+    if (lane == 0) {
+        const double prev = jb.result[3];
+        const double at = fmax(fabs(theta), 1e-300);
+        const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
+        const bool exact = finite && (n >= jb.n || bnorm == 0.0);
+        const bool ok = err <= jb.tol * at && settled;
+        const bool conv = finite && (ok || exact);
+        const bool stop = conv || !finite || k >= jb.max_steps;
+        jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
+        if (stop) {
+            jb.state[1] = k;
+            jb.state[0] = jb.gen;
+            jb.eig_out[0] = fabs(theta);
+            if (jb.iters_out) jb.iters_out[0] = k;
+            jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------
@@ -452,20 +895,24 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     int smax = 0;
     for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb));
     L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
-    L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB);
-    L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB);
+    // vectors, partial vectors and scalar histories are sized for the two-vector (block) recurrence
+    // of the eigenvalue-only sweep: 2 columns, 4 scalars per coefficient (they are small next to
+    // the tiles)
+    const size_t bw = want_vec ? 1 : 2, sc = want_vec ? 1 : 4;
+    L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
+    L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.qslots = want_vec ? max_steps + 1 : 2;
-    L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots);
+    L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
     L.svec = take(sizeof(double) * (size_t)(max_steps + 2));
-    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB);
-    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB);
+    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
+    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
-    L.apart0 = take(sizeof(double) * (size_t)nbmax);
-    L.apart1 = take(sizeof(double) * (size_t)nbmax);
-    L.upart0 = take(sizeof(double) * (size_t)nbmax);
-    L.upart1 = take(sizeof(double) * (size_t)nbmax);
-    L.alpha = take(sizeof(double) * (size_t)(max_steps + 2));
-    L.beta = take(sizeof(double) * (size_t)(max_steps + 3));
+    L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
+    L.apart1 = take(sizeof(double) * (size_t)nbmax * sc);
+    L.upart0 = take(sizeof(double) * (size_t)nbmax * sc);
+    L.upart1 = take(sizeof(double) * (size_t)nbmax * sc);
+    L.alpha = take(sizeof(double) * (size_t)(max_steps + 2) * sc);
+    L.beta = take(sizeof(double) * (size_t)(max_steps + 3) * sc);
     L.result = take(sizeof(double) * 4);
     L.total = align_up(off, 256);
     return L;
@@ -572,7 +1019,7 @@ struct SweepProblem {
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
     SweepTail* tail_hook; hipStream_t tail;
-    int nbmax, steps_cap, depth, check_every;
+    int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1 or 2)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -635,7 +1082,8 @@ struct SweepGroup {
             const int64_t c = S.cs_index ? S.cs_index[e] : 0;
             J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
             J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            J.max_steps = std::min(S.steps_cap, std::max(n, 1));
+            J.max_steps = S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
+                                       : std::min(S.steps_cap, std::max(n, 1));
             J.strip_len = strip_len_for(J.nb);
             J.start = launch0;
             J.gen = ++slot_gen[(size_t)s];
@@ -735,8 +1183,12 @@ struct SweepGroup {
             if (!fresh.empty()) {
                 int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream);
                 if (rc != SCINT_OK) return rc;
-                hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                                   d_jobs(tab), d_fresh(tab));
+                if (S.block == 2)
+                    hipLaunchKernelGGL(pk2_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                                       d_jobs(tab), d_fresh(tab));
+                else
+                    hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                                       d_jobs(tab), d_fresh(tab));
             }
             he = hipGetLastError();
             if (he != hipSuccess) return hip_fail(he, "sweep refill", __FILE__, __LINE__);
@@ -746,13 +1198,23 @@ struct SweepGroup {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
                 const int slot = profiler().begin(kProfMatvec, stream);
-                hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
+                if (S.block == 2)
+                    hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
+                else
+                    hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 profiler().end(kProfMatvec, slot, stream);
-                hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
-                                   stream, d_jobs(tab), launch);
+                if (S.block == 2)
+                    hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
+                                       stream, d_jobs(tab), launch);
+                else
+                    hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
+                                       stream, d_jobs(tab), launch);
             }
         }
-        hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+        if (S.block == 2)
+            hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+        else
+            hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
         he = hipGetLastError();
         if (he == hipSuccess)
             he = hipMemcpyAsync(h_flags[chunk % kTabs], S.states_dev + 4 * slot0, sizeof(int32_t) * 4 * (size_t)nslots,
@@ -827,6 +1289,10 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const char* every_env = getenv("SCINT_CHECK_EVERY");
     const int forced_every = every_env ? atoi(every_env) : 0;
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEvery;
+    // eigenvalue-only sweeps run the two-vector (block) recurrence; SCINT_LANCZOS_BLOCK=1 keeps the
+    // single-vector one (which the eigenvector sweeps always use)
+    const char* block_env = getenv("SCINT_LANCZOS_BLOCK");
+    S.block = (!want_vec && !(block_env && atoi(block_env) == 1)) ? 2 : 1;
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);

@@ -556,16 +556,20 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
     sink.half = 0;
     if (real_input && !p.blue_r && !p.blue_c && C <= 8192 && R >= 2) {
         const int64_t Ch = C / 2 + 1;
+        // row stride of the half-width arrays: a multiple of 8 elements (128 B), so that the 16-column
+        // tiles of the column passes cover whole cache lines (C/2 + 1 is odd); both fit their buffers
+        // (rowA holds nvalid x C, colA holds R x C elements)
+        const int64_t ChL = (Ch + 7) & ~(int64_t)7;
         src.n_in = C;
         src.chirp = nullptr;
-        rc = launch_fft_rows(C, (nvalid + 1) / 2, PairLoad{src, nvalid}, PairStore{rowA, Ch, nvalid}, stream);
+        rc = launch_fft_rows(C, (nvalid + 1) / 2, PairLoad{src, nvalid}, PairStore{rowA, ChL, nvalid}, stream);
         if (rc != SCINT_OK) return rc;
         ColSource hs;
-        hs.a = rowA; hs.ld = Ch; hs.nvalid = nvalid; hs.fill0 = fill0; hs.n_in = R;
+        hs.a = rowA; hs.ld = ChL; hs.nvalid = nvalid; hs.fill0 = fill0; hs.n_in = R;
         hs.row_post_w = nullptr; hs.row_post_scale = 1.0; hs.chirp = nullptr; hs.mulconj_b = nullptr;
         sink.R = R; sink.C = C; sink.col_post_w = nullptr; sink.col_post_scale = 1.0; sink.half = 1;
-        ArrayLoad mid_ld{colA, Ch, 0};
-        ArrayStore mid_st{colA, Ch, 0};
+        ArrayLoad mid_ld{colA, ChL, 0};
+        ArrayStore mid_st{colA, ChL, 0};
         return run_cols_fft(R, Ch, 1, hs, mid_ld, mid_st, sink, stream);
     }
 
@@ -937,39 +941,59 @@ extern "C" int32_t scint_acf(const double* dyn, int64_t nf, int64_t nt, int32_t 
 // ------------------------------------------------------------------------------
 namespace scint {
 
+// out[c][r] = in[r][c] through a 32 x 33 LDS tile (coalesced on both sides)
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in, int64_t rows, int64_t cols, T* __restrict__ out) {
+    __shared__ T tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < rows && c0 + tx < cols) tile[k][tx] = in[(r0 + k) * cols + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < cols && r0 + tx < rows) out[(c0 + k) * rows + r0 + tx] = tile[tx][k];
+}
+
 // The model step of one retired curvature, chained on the sweep's tail stream while the Lanczos
 // steps of the resident curvatures continue: rank-1 back-map of |w| V V^H -> inverse FFT (model
 // dynamic spectrum, [nf, nt] corner only) -> chi^2 reduction into chisq_out[e].
+// Everything between the back-map and the reduction is kept TRANSPOSED (recov^T, model^T against
+// dspec^T): ifft2 commutes with the transpose, and a back-map workgroup owns one Doppler column
+// of recov, which is one contiguous row of recov^T -- coalesced stores instead of 16-B stores
+// 16 nfd bytes apart.
 struct ChisqTail : SweepTail {
     GeomDev g; const int32_t* keep_n; const double* etas;
     const cplx* vec; int64_t vstride; const double* w; const double* th_red; int64_t M;
-    const double* dspec; int64_t nf, nt; const uint8_t* mask; double noise_n; double* chisq_out;
-    cplx* recov; double* model; void* fft_ws; size_t fft_ws_bytes; double* partial; void* rev_scratch;
+    const double* dspecT; int64_t nf, nt; const uint8_t* maskT; double noise_n; double* chisq_out;
+    cplx* recovT; double* modelT; void* fft_ws; size_t fft_ws_bytes; double* partial; void* rev_scratch;
 
     int32_t retire(int64_t e, hipStream_t tail) override {
         const int64_t n = keep_n[e];
         if (n < 2) return SCINT_OK;                       // crop-to-nothing: chi^2 stays NaN
-        int32_t rc = launch_rev_map_rank1(vec + e * vstride, w + e, th_red + e * M, n, g, etas[e], recov, rev_scratch, tail);
+        int32_t rc = launch_rev_map_rank1(vec + e * vstride, w + e, th_red + e * M, n, g, etas[e], recovT, true,
+                                          rev_scratch, tail);
         if (rc != SCINT_OK) return rc;
         RowSource src{};
-        src.mode = SRC_MODEL; src.a = recov; src.R = g.ntau; src.C = g.nfd;
+        src.mode = SRC_MODEL; src.a = recovT; src.R = g.nfd; src.C = g.ntau;
         ColSink sink{};
-        sink.mode = SINK_MODEL; sink.out_d = model; sink.scale = 1.0 / ((double)g.ntau * (double)g.nfd);
-        sink.crop_r = nf; sink.crop_c = nt; sink.ld = nt;
-        rc = fft2_general(src, g.ntau, 0.0, g.ntau, g.nfd, sink, fft_ws, fft_ws_bytes, tail);
+        sink.mode = SINK_MODEL; sink.out_d = modelT; sink.scale = 1.0 / ((double)g.ntau * (double)g.nfd);
+        sink.crop_r = nt; sink.crop_c = nf; sink.ld = nf;
+        rc = fft2_general(src, g.nfd, 0.0, g.nfd, g.ntau, sink, fft_ws, fft_ws_bytes, tail);
         if (rc != SCINT_OK) return rc;
-        return launch_reduce2d(ChisqValue{model, nt, dspec, nt, mask}, nf, nt, 1.0 / noise_n, partial, chisq_out + e, tail);
+        return launch_reduce2d(ChisqValue{modelT, nf, dspecT, nf, maskT}, nt, nf, 1.0 / noise_n, partial, chisq_out + e, tail);
     }
 };
 
-struct ChisqSweepLayout { size_t recov, model, fft, partial, rev, sweep, total, fft_bytes, sweep_bytes; };
+struct ChisqSweepLayout { size_t recov, model, dspecT, maskT, fft, partial, rev, sweep, total, fft_bytes, sweep_bytes; };
 static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, int64_t ntau, int64_t nfd,
                                   int64_t nf, int64_t nt, ChisqSweepLayout* L) {
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     L->recov = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
     L->model = take(sizeof(double) * (size_t)nf * (size_t)nt);
-    L->fft_bytes = fft2_general_ws(ntau, nfd, ntau);
+    L->dspecT = take(sizeof(double) * (size_t)nf * (size_t)nt);
+    L->maskT = take((size_t)nf * (size_t)nt);
+    L->fft_bytes = fft2_general_ws(nfd, ntau, nfd);
     L->fft = take(L->fft_bytes);
     L->partial = take(sizeof(double) * (kRedBlocks + 8));
     L->rev = take(256);
@@ -1008,11 +1032,23 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
     if (rc != SCINT_OK) return rc;
     if (workspace_bytes < L.total) { set_error("scint: chisq_sweep workspace too small"); return SCINT_E_WORKSPACE; }
     char* base = (char*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    // dspec^T (and mask^T) once per call, before the sweep starts (the tail stream is ordered after
+    // the caller's stream by run_sweep)
+    double* dspecT = (double*)(base + L.dspecT);
+    uint8_t* maskT = mask ? (uint8_t*)(base + L.maskT) : nullptr;
+    {
+        const dim3 grid((unsigned)ceil_div(nt, 32), (unsigned)ceil_div(nf, 32));
+        SCINT_REQUIRE(grid.y <= 65535, "chisq_sweep: nf too large");
+        hipLaunchKernelGGL((transpose_kernel<double>), grid, dim3(256), 0, st, dspec, nf, nt, dspecT);
+        if (mask) hipLaunchKernelGGL((transpose_kernel<uint8_t>), grid, dim3(256), 0, st, mask, nf, nt, maskT);
+        SCINT_LAUNCH_CHECK();
+    }
     ChisqTail t;
     t.g = to_dev(*geom); t.keep_n = keep_n; t.etas = etas;
     t.vec = (const cplx*)vec_out; t.vstride = vec_stride; t.w = w_out; t.th_red = th_red; t.M = M;
-    t.dspec = dspec; t.nf = nf; t.nt = nt; t.mask = mask; t.noise_n = noise_n; t.chisq_out = chisq_out;
-    t.recov = (cplx*)(base + L.recov); t.model = (double*)(base + L.model);
+    t.dspecT = dspecT; t.nf = nf; t.nt = nt; t.maskT = maskT; t.noise_n = noise_n; t.chisq_out = chisq_out;
+    t.recovT = (cplx*)(base + L.recov); t.modelT = (double*)(base + L.model);
     t.fft_ws = base + L.fft; t.fft_ws_bytes = L.fft_bytes;
     t.partial = (double*)(base + L.partial); t.rev_scratch = base + L.rev;
     return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,

@@ -33,7 +33,7 @@ __host__ __device__ inline int64_t tile_count(int nb) { return (int64_t)nb * (nb
 // the summation order -- and every bit of the result -- is independent of the batch)
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced > 64 ? 64 : forced;   // experiments only
+    if (forced > 0) return forced > 16 ? 16 : forced;   // experiments only (16 = kMaxStrip of the mat-vec kernels)
     return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
 }
 inline int strips_in_row(int nb, int I, int S) { return (nb - I + S - 1) / S; }

@@ -246,7 +246,8 @@ struct RevParams {
     int hermitian;
     int slab;         // tau rows per workgroup
     int64_t centre;   // flat index of the pixel the i == j terms poison, or -1
-    cplx* recov;      // [ntau, nfd]
+    cplx* recov;      // [ntau, nfd], or its transpose [nfd, ntau] when `transposed`
+    int transposed;   // column-major output: every workgroup writes one contiguous run (chi^2 sweep)
     const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
 };
 
@@ -354,7 +355,9 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // (ththmod.py:207-262): for each i the j with fd_map[i, j] in the column form one short
 // interval (th is increasing); their tau bin picks the row.  Weighted sums and counts
 // accumulate in LDS, are divided and written once -- no global atomics, no zero-fill and no
-// separate normalise pass over the [ntau, nfd] image.  The sums are order-independent (RevSplit
+// separate normalise pass over the [ntau, nfd] image.  (A workgroup's pixels are one COLUMN of the
+// row-major image: 16-B stores 16 nfd bytes apart; the chi^2 sweep asks for the transposed image
+// instead, which every workgroup writes as one contiguous run.)  The sums are order-independent (RevSplit
 // above), so the image is bit-reproducible.
 //
 // Lanes run over i (coalesced).  On a (nearly) uniform theta grid the interval of lane i is
@@ -486,7 +489,7 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
             out = mk(nan_to_num((rev_lds[r] + rev_lds[slab + r]) * scl),
                      nan_to_num((rev_lds[2 * slab + r] + rev_lds[3 * slab + r]) * scl));
         }
-        gstore(p.recov + o, out);
+        gstore(p.recov + (p.transposed ? col * g.ntau + (row0 + r) : o), out);
     }
 }
 
@@ -504,6 +507,7 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     const int64_t cby = hist_bin(eta * 0.0, g.tau0, g.tau1_step, g.ntau);
     p.centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
     p.recov = recov;
+    p.transposed = 0;
     p.bound = nullptr;
     return p;
 }
@@ -531,9 +535,10 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
 }
 
 int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g,
-                             double eta, cplx* recov, void* scratch, hipStream_t stream) {
-    return launch_rev_map(make_rev_params(nullptr, vec, w, 1, th, (int)N, g, eta, 1, recov), g,
-                          (unsigned long long*)scratch, stream);
+                             double eta, cplx* recov, bool transposed, void* scratch, hipStream_t stream) {
+    RevParams p = make_rev_params(nullptr, vec, w, 1, th, (int)N, g, eta, 1, recov);
+    p.transposed = transposed ? 1 : 0;
+    return launch_rev_map(p, g, (unsigned long long*)scratch, stream);
 }
 
 }  // namespace scint

@@ -114,7 +114,8 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 
 // Enqueue the rank-1 back-map  recov = rev_map(|w| v v^H)  (modeler, ththmod.py:312-321) on
 // `stream`: th[N] are the centres of the reduced edges, w a DEVICE scalar, scratch 256 bytes.
+// `transposed`: write recov^T [nfd, ntau] instead of recov [ntau, nfd].
 int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g,
-                             double eta, cplx* recov, void* scratch, hipStream_t stream);
+                             double eta, cplx* recov, bool transposed, void* scratch, hipStream_t stream);
 
 }  // namespace scint

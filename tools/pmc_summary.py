@@ -21,14 +21,14 @@ def per_kernel(db):
     return out
 
 
-def main(fetch_db, write_db, fetch_log, out_path):
+def main(fetch_db, write_db, fetch_log, out_path, command=None):
     line = [l for l in open(fetch_log) if l.startswith('{"metric"')][-1]
     bench = json.loads(line)
     r = bench["roofline"]
     alg_per_launch = r["algorithmic_bytes_per_step"] * bench["steps"] / r["launches"]
     f, w = per_kernel(fetch_db), per_kernel(write_db)
-    summary = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 "
-                          "--warmup 0 --no-cpu-baseline --neta 32",
+    summary = {"command": command or "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 "
+                                     "--warmup 0 --no-cpu-baseline --modeler-steps 0",
                "fetch_correction": 2.0, "write_correction": 1.0, "kernels": {}}
     for k in sorted(set(f) | set(w)):
         nf, fb = f.get(k, (0, 0.0))
@@ -40,10 +40,16 @@ def main(fetch_db, write_db, fetch_log, out_path):
     mv["algorithmic_bytes_per_launch"] = alg_per_launch
     mv["hbm_bytes_per_launch"] = mv["fetch_bytes_per_launch"] + mv["write_bytes_per_launch"]
     mv["traffic_over_algorithmic"] = mv["hbm_bytes_per_launch"] / alg_per_launch
+    ga = summary["kernels"].get("scint::thth_gather_packed_kernel")
+    if ga and "gather" in bench:
+        n_min, n_max = bench["config"]["N_min"], bench["config"]["N_max"]
+        ga["hbm_bytes_per_launch"] = ga["fetch_bytes_per_launch"] + ga["write_bytes_per_launch"]
+        ga["note"] = (f"reads come mostly from L2 / Infinity Cache (the touched CS region is a fraction of the plane); "
+                      f"algorithmic 16 N^2 per eta with N = {n_min}..{n_max}")
     with open(out_path, "w") as fh:
         json.dump(summary, fh, indent=1)
     print(json.dumps(mv, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
