@@ -847,6 +847,11 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
             const cplx rr2 = sl1 * last.b22;
             resid = nrm > 0.0 ? sqrt((norm2(rr1) + norm2(rr2)) / nrm) : bnorm;
             if (!isfinite(resid)) resid = bnorm;
+            if (jb.want_vec) {                      // unit-norm eigenvector of T_k for the Ritz vector
+                cplx* out = (cplx*)jb.svec;
+                const double inv = nrm > 0.0 ? 1.0 / sqrt(nrm) : 0.0;
+                for (int i = 0; i < n; ++i) out[i] = sv[i] * inv;
+            }
         }
         resid = __shfl(resid, 0, 64);
         const double gap = theta - theta2;
@@ -857,18 +862,43 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         const double at = fmax(fabs(theta), 1e-300);
         const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
         const bool exact = finite && (n >= jb.n || bnorm == 0.0);
-        const bool ok = err <= jb.tol * at && settled;
+        // eigenvector wanted: same gap-aware rule as the single-vector check (pk_check_kernel)
+        const double prev2 = jb.result[1], gap2 = theta - theta2;
+        const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
+        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= 30.0 * jb.tol * gap2);
+        const bool ok = jb.want_vec ? vec_ok : (err <= jb.tol * at && settled);
         const bool conv = finite && (ok || exact);
         const bool stop = conv || !finite || k >= jb.max_steps;
         jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
         if (stop) {
             jb.state[1] = k;
             jb.state[0] = jb.gen;
-            jb.eig_out[0] = fabs(theta);
+            jb.eig_out[0] = jb.want_vec ? theta : fabs(theta);   // modeler keeps the sign of w
             if (jb.iters_out) jb.iters_out[0] = k;
             jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
         }
     }
+}
+
+// Ritz vector of finished block jobs: y = sum_j (Q_j[:,0] s_{2j} + Q_j[:,1] s_{2j+1}); normalised by
+// pk_ritz_scale_kernel (the partial norms go to the first nb entries of upart[0]).
+__global__ void __launch_bounds__(64) pk2_ritz_kernel(const PackedJob* jobs, const int32_t* slots,
+                                                      const int64_t* eta_index, cplx* vec_out, int64_t vstride) {
+    const PackedJob jb = jobs[slots[blockIdx.y]];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (K >= jb.nb) return;
+    const int k = jb.state[1];
+    const int r = K * kTB + e;
+    const cplx* __restrict__ sv = (const cplx*)jb.svec;
+    cplx y = mk(0.0, 0.0);
+    for (int j = 0; j < k; ++j) {
+        const cplx* __restrict__ q = jb.Q + (int64_t)j * jb.qstride * 2 + 2 * r;
+        y = (y + q[0] * sv[2 * j]) + q[1] * sv[2 * j + 1];
+    }
+    cplx* out = vec_out + eta_index[blockIdx.y] * vstride;
+    if (r < jb.n) out[r] = y;
+    const double p = wave_sum(r < jb.n ? norm2(y) : 0.0);
+    if (e == 0) jb.upart[0][K] = p;   // the job is finished: its partial arrays are free
 }
 
 // ------------------------------------------------------------------------------
@@ -895,15 +925,15 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     int smax = 0;
     for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb));
     L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
-    // vectors, partial vectors and scalar histories are sized for the two-vector (block) recurrence
-    // of the eigenvalue-only sweep: 2 columns, 4 scalars per coefficient (they are small next to
-    // the tiles)
-    const size_t bw = want_vec ? 1 : 2, sc = want_vec ? 1 : 4;
+    // vectors, partial vectors and scalar histories are sized for the two-vector (block) recurrence:
+    // 2 columns, 4 scalars per coefficient (they are small next to the tiles); the single-vector
+    // recurrence (SCINT_LANCZOS_BLOCK=1) uses half of each
+    const size_t bw = 2, sc = 4;
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
-    L.qslots = want_vec ? max_steps + 1 : 2;
+    L.qslots = want_vec ? max_steps + 1 : 2;        // (block steps when two vectors run: <= kMaxKB + 1 are used)
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
-    L.svec = take(sizeof(double) * (size_t)(max_steps + 2));
+    L.svec = take(sizeof(cplx) * 2 * (size_t)(max_steps + 2));    // eigenvector of T_k (complex, 2 per block step)
     L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
     L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
@@ -1165,8 +1195,12 @@ struct SweepGroup {
                                             hipMemcpyHostToDevice, stream);
                     if (he != hipSuccess) return hip_fail(he, "sweep eigenvector export", __FILE__, __LINE__);
                     const dim3 grid((unsigned)nb_fin, (unsigned)nfin);
-                    hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                       S.vec_out, S.vstride);
+                    if (S.block == 2)
+                        hipLaunchKernelGGL(pk2_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                           S.vec_out, S.vstride);
+                    else
+                        hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                           S.vec_out, S.vstride);
                     hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab),
                                        d_fin_eta(tab), S.vec_out, S.vstride);
                 }
@@ -1289,10 +1323,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const char* every_env = getenv("SCINT_CHECK_EVERY");
     const int forced_every = every_env ? atoi(every_env) : 0;
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEvery;
-    // eigenvalue-only sweeps run the two-vector (block) recurrence; SCINT_LANCZOS_BLOCK=1 keeps the
-    // single-vector one (which the eigenvector sweeps always use)
+    // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     const char* block_env = getenv("SCINT_LANCZOS_BLOCK");
-    S.block = (!want_vec && !(block_env && atoi(block_env) == 1)) ? 2 : 1;
+    S.block = (block_env && atoi(block_env) == 1) ? 1 : 2;
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
