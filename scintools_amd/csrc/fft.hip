@@ -965,11 +965,14 @@ struct ChisqTail : SweepTail {
     GeomDev g; const int32_t* keep_n; const double* etas;
     const cplx* vec; int64_t vstride; const double* w; const double* th_red; int64_t M;
     const double* dspecT; int64_t nf, nt; const uint8_t* maskT; double noise_n; double* chisq_out;
-    cplx* recovT; double* modelT; void* fft_ws; size_t fft_ws_bytes; double* partial; void* rev_scratch;
+    // one set of scratch buffers per tail lane
+    cplx* recovT_[2]; double* modelT_[2]; void* fft_ws_[2]; size_t fft_ws_bytes; double* partial_[2]; void* rev_scratch_[2];
 
-    int32_t retire(int64_t e, hipStream_t tail) override {
+    int32_t retire(int64_t e, hipStream_t tail, int lane) override {
         const int64_t n = keep_n[e];
         if (n < 2) return SCINT_OK;                       // crop-to-nothing: chi^2 stays NaN
+        cplx* recovT = recovT_[lane]; double* modelT = modelT_[lane]; void* fft_ws = fft_ws_[lane];
+        double* partial = partial_[lane]; void* rev_scratch = rev_scratch_[lane];
         int32_t rc = launch_rev_map_rank1(vec + e * vstride, w + e, th_red + e * M, n, g, etas[e], recovT, true,
                                           rev_scratch, tail);
         if (rc != SCINT_OK) return rc;
@@ -984,19 +987,21 @@ struct ChisqTail : SweepTail {
     }
 };
 
-struct ChisqSweepLayout { size_t recov, model, dspecT, maskT, fft, partial, rev, sweep, total, fft_bytes, sweep_bytes; };
+struct ChisqSweepLayout { size_t recov[2], model[2], dspecT, maskT, fft[2], partial[2], rev[2], sweep, total, fft_bytes, sweep_bytes; };
 static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, int64_t ntau, int64_t nfd,
                                   int64_t nf, int64_t nt, ChisqSweepLayout* L) {
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
-    L->recov = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
-    L->model = take(sizeof(double) * (size_t)nf * (size_t)nt);
     L->dspecT = take(sizeof(double) * (size_t)nf * (size_t)nt);
     L->maskT = take((size_t)nf * (size_t)nt);
     L->fft_bytes = fft2_general_ws(nfd, ntau, nfd);
-    L->fft = take(L->fft_bytes);
-    L->partial = take(sizeof(double) * (kRedBlocks + 8));
-    L->rev = take(256);
+    for (int l = 0; l < 2; ++l) {
+        L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
+        L->model[l] = take(sizeof(double) * (size_t)nf * (size_t)nt);
+        L->fft[l] = take(L->fft_bytes);
+        L->partial[l] = take(sizeof(double) * (kRedBlocks + 8));
+        L->rev[l] = take(256);
+    }
     int32_t rc = sweep_workspace_bytes(M, neta, batch, max_iter, true, 1, &L->sweep_bytes);
     if (rc != SCINT_OK) return rc;
     L->sweep = take(L->sweep_bytes);
@@ -1048,9 +1053,12 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
     t.g = to_dev(*geom); t.keep_n = keep_n; t.etas = etas;
     t.vec = (const cplx*)vec_out; t.vstride = vec_stride; t.w = w_out; t.th_red = th_red; t.M = M;
     t.dspecT = dspecT; t.nf = nf; t.nt = nt; t.maskT = maskT; t.noise_n = noise_n; t.chisq_out = chisq_out;
-    t.recovT = (cplx*)(base + L.recov); t.modelT = (double*)(base + L.model);
-    t.fft_ws = base + L.fft; t.fft_ws_bytes = L.fft_bytes;
-    t.partial = (double*)(base + L.partial); t.rev_scratch = base + L.rev;
+    t.fft_ws_bytes = L.fft_bytes;
+    for (int l = 0; l < 2; ++l) {
+        t.recovT_[l] = (cplx*)(base + L.recov[l]); t.modelT_[l] = (double*)(base + L.model[l]);
+        t.fft_ws_[l] = base + L.fft[l];
+        t.partial_[l] = (double*)(base + L.partial[l]); t.rev_scratch_[l] = base + L.rev[l];
+    }
     return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,
                      status_out, iters_out, true, (cplx*)vec_out, vec_stride, &t, base + L.sweep, L.sweep_bytes, stream);
 }

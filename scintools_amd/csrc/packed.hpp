@@ -43,7 +43,7 @@ struct PackedJob {
     double eta, two_eta;
     const cplx* cs;         // conjugate spectrum this job reads (one per chunk/observation)
     const double* th;       // [M] theta centres of that chunk
-    int32_t geom, pad1;     // index into the launch's GeomDev table
+    int32_t geom, pad1;     // index into the launch's GeomDev table; pad1: column partials per tile (block mat-vec)
     const int32_t* keep;    // [n] indices into th
     int32_t n, nb;
     cplx* tiles;            // [tile_count(nb)][64][64]
@@ -80,9 +80,11 @@ int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJo
                              const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream);
 
 // What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
-// on the host while the sweep runs; enqueues on `tail`, which already waits for the export.
+// on the host while the sweep runs; enqueues on a tail stream that already waits for the export.
 struct SweepTail {
-    virtual int32_t retire(int64_t eta_index, hipStream_t tail) = 0;
+    // `lane` (0 or 1) names the tail stream: work of one lane is ordered, the two lanes overlap, so
+    // an implementation keeps one set of scratch buffers per lane
+    virtual int32_t retire(int64_t eta_index, hipStream_t tail, int lane) = 0;
     virtual ~SweepTail() {}
 };
 
