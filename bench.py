@@ -19,9 +19,9 @@ ranks instead (strong scaling).  `value` is the whole-job eta-points/s.
 
 Besides the contract fields the JSON line carries
   roofline      the dominant kernel (eigen mat-vec on the Hermitian tile-packed matrix):
-                algorithmic bytes 8 N (N+1) per mat-vec per eta -- every upper-triangle
+                algorithmic bytes 8 N (N+1) per matrix pass per eta -- every upper-triangle
                 element once; SURVEY.md 8d's 16 N^2 assumed the full matrix -- summed over
-                every Lanczos step of the timed region, divided by the time that kernel was
+                every (two-vector) Lanczos pass of the timed region, divided by the time that kernel was
                 running (hipEvents on the launch streams, union of the launch intervals);
   gather        the same for the theta-theta gather kernel (16 N^2 bytes per eta);
   modeler       (N=1) the OTHER objective of BASELINE configs[2]: the ththmod.modeler /
@@ -57,7 +57,8 @@ def pmc_traffic_ratio():
     if not files:
         return None, None
     with open(files[-1]) as fh:
-        k = json.load(fh)["kernels"].get("scint::pk_matvec_kernel", {})
+        summ = json.load(fh)
+    k = summ["kernels"].get(summ.get("dominant_kernel", "scint::pk_matvec_kernel"), {})
     return k.get("traffic_over_algorithmic"), os.path.relpath(files[-1], REPO)
 
 
@@ -395,9 +396,11 @@ def main():
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
+                       "lanczos_vectors_per_step": 1 if os.environ.get("SCINT_LANCZOS_BLOCK") == "1" else 2,
                        "batch": int(info["batch"]), "failed_etas": int(np.sum(info["status"] != 0)),
                        "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
-            "roofline": {"kernel": "pk_matvec_kernel", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "pk_matvec_kernel" if os.environ.get("SCINT_LANCZOS_BLOCK") == "1" else
+                         "pk2_matvec_kernel (two-vector block Lanczos mat-vec)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg_per_launch,
                          "traffic": (ratio * alg_per_launch) if ratio else None,

@@ -642,11 +642,12 @@ pk2h_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__
     }
 }
 
-// The full-strip form (16 rows per wave, 256 registers, two waves per SIMD): kept for comparison,
-// SCINT_MV2_HALF=0.
+// The full-strip form (16 rows per wave, 256 registers, two waves per SIMD, two workgroups per CU):
+// the default -- measured faster than the half-strip form above (1183 vs 1075 eta/s).
+constexpr int kFlushF = 4;     // its column partials are reduced across the waves every 4 tiles (a barrier pair each)
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx cred[4][kFlush2][kTB][2];   // per-wave column partials of kFlush2 tiles, 2 vectors (16 KiB)
+    __shared__ cplx cred[4][kFlushF][kTB][2];   // per-wave column partials of kFlushF tiles, 2 vectors (32 KiB)
     __shared__ cplx xs[kMaxStrip][kTB][2];      // the blocks X_J of the strip, rebuilt once per workgroup (32 KiB)
     const Strip st = strips[blockIdx.x];
     const PackedJob* __restrict__ jp = jobs + st.job;
@@ -713,20 +714,22 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
             c1 = mk(c1.x + a1[r].x * x1.x + a1[r].y * x1.y, c1.y + a1[r].x * x1.y - a1[r].y * x1.x);
             c2 = mk(c2.x + a1[r].x * x2.x + a1[r].y * x2.y, c2.y + a1[r].x * x2.y - a1[r].y * x2.x);
         }
-        cred[w][t & (kFlush2 - 1)][lane][0] = c1;   // this wave's own slot
-        cred[w][t & (kFlush2 - 1)][lane][1] = c2;
-        if ((t & (kFlush2 - 1)) == kFlush2 - 1 || t + 1 == ntile) {
-            // cross-wave reduction of the last <= kFlush2 tiles' column partials: waves 0,1 take
-            // vector 0 / 1 of the first tile, waves 2,3 of the second
+        cred[w][t & (kFlushF - 1)][lane][0] = c1;   // this wave's own slot
+        cred[w][t & (kFlushF - 1)][lane][1] = c2;
+        if ((t & (kFlushF - 1)) == kFlushF - 1 || t + 1 == ntile) {
+            // cross-wave reduction of the last <= kFlushF tiles' column partials: wave w takes the
+            // (tile, vector) pairs w, w + 4 of the 2 kFlushF
             __syncthreads();
-            const int tb = t & ~(kFlush2 - 1);
-            const int tt = tb + (w >> 1), v = w & 1;
-            if (tt <= t) {
-                const int Jt = st.J0 + tt;
-                if (Jt != I) {
-                    const int k = w >> 1;
-                    const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
-                    gstore(colpart + 2 * ((t0 + (Jt - I)) * kTB + lane) + v, sum);
+            const int tb = t & ~(kFlushF - 1);
+#pragma unroll
+            for (int c = w; c < 2 * kFlushF; c += 4) {
+                const int k = c >> 1, v = c & 1, tt = tb + k;
+                if (tt <= t) {
+                    const int Jt = st.J0 + tt;
+                    if (Jt != I) {
+                        const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
+                        gstore(colpart + 2 * ((t0 + (Jt - I)) * kTB + lane) + v, sum);
+                    }
                 }
             }
             __syncthreads();
@@ -1447,7 +1450,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const char* block_env = getenv("SCINT_LANCZOS_BLOCK");
     S.block = (block_env && atoi(block_env) == 1) ? 1 : 2;
     const char* half_env = getenv("SCINT_MV2_HALF");
-    S.mv_half = !(half_env && atoi(half_env) == 0);
+    S.mv_half = half_env && atoi(half_env) == 1;      // measured slower than the full-strip form (1075 vs 1183 eta/s): off
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);

@@ -256,6 +256,12 @@ struct WindowedValue {
 // ------------------------------------------------------------------------------
 // sources and sinks
 // ------------------------------------------------------------------------------
+// (i + n/2) mod n for 0 <= i < n without the 64-bit division an integer `%` costs per element
+__device__ inline int64_t shift_half(int64_t i, int64_t n) {
+    const int64_t s = i + n / 2;
+    return s >= n ? s - n : s;
+}
+
 enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULCONJ = 4, SRC_CONJ = 5,
                SRC_ACF_IN = 6, SRC_POWER = 7 };
 
@@ -298,7 +304,7 @@ struct RowSource {
                 break;
             case SRC_CS: v = mk(j < wv.nt ? wv.dyn[r * wv.nt + j] : pad, 0.0); break;
             default: {  // SRC_MODEL
-                const int64_t sr = (r + R / 2) % R, sc = (j + C / 2) % C;
+                const int64_t sr = shift_half(r, R), sc = shift_half(j, C);
                 v = conj(a[sr * C + sc]);
             }
         }
@@ -371,9 +377,9 @@ struct ColSink {
                     if (k1 >= R / 2) return;
                     orow = k1;
                 } else {
-                    orow = (k1 + R / 2) % R;
+                    orow = shift_half(k1, R);
                 }
-                const int64_t ocol = (c + C / 2) % C;
+                const int64_t ocol = shift_half(c, C);
                 double p = v.x * v.x + v.y * v.y;
                 if (prewhite) {
                     double pd = pd_fd[ocol] * pd_td[orow];
@@ -386,7 +392,7 @@ struct ColSink {
             case SINK_CS: {
                 // fftshift on both axes, zero the masked delay rows, optional abs
                 // (ththmod.py:786-787, 801)
-                const int64_t orow = (k1 + R / 2) % R, ocol = (c + C / 2) % C;
+                const int64_t orow = shift_half(k1, R), ocol = shift_half(c, C);
                 if (orow >= mask_lo && orow < mask_hi) v = mk(0.0, 0.0);
                 if (incoherent) v = mk(hypot(v.x, v.y), 0.0);
                 out_c[orow * C + ocol] = v;
@@ -403,7 +409,7 @@ struct ColSink {
                 if (k1 < crop_r && c < crop_c) out_c[k1 * ld + c] = mk(v.x * scale, -v.y * scale);
                 break;
             case SINK_ACF: {   // real(fftshift(ifft2(.)))  (dynspec.py:3793-3795)
-                const int64_t orow = (k1 + R / 2) % R, ocol = (c + C / 2) % C;
+                const int64_t orow = shift_half(k1, R), ocol = shift_half(c, C);
                 out_d[orow * C + ocol] = v.x * scale;
                 break;
             }

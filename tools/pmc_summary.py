@@ -36,7 +36,10 @@ def main(fetch_db, write_db, fetch_log, out_path, command=None):
         summary["kernels"][k] = {"launches": nf or nw,
                                  "fetch_bytes_per_launch": 2.0 * fb / max(nf, 1),
                                  "write_bytes_per_launch": wb / max(nw, 1)}
-    mv = summary["kernels"]["scint::pk_matvec_kernel"]
+    mv_name = max((k for k in summary["kernels"] if "matvec_kernel" in k and k.startswith("scint::pk")),
+                  key=lambda k: summary["kernels"][k]["fetch_bytes_per_launch"] * summary["kernels"][k]["launches"])
+    summary["dominant_kernel"] = mv_name
+    mv = summary["kernels"][mv_name]
     mv["algorithmic_bytes_per_launch"] = alg_per_launch
     mv["hbm_bytes_per_launch"] = mv["fetch_bytes_per_launch"] + mv["write_bytes_per_launch"]
     mv["traffic_over_algorithmic"] = mv["hbm_bytes_per_launch"] / alg_per_launch
