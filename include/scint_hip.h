@@ -15,18 +15,20 @@
  *     0 = ok, >0 = SCINT_E_*; the message is available from scint_last_error();
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
  *     work is enqueued on it; only entry points documented as synchronous
- *     wait for it.  The sweep entry points queue their Lanczos steps two chunks
- *     ahead of the convergence flags they have read (so the stream never waits
- *     for the host); scint_chisq_sweep additionally drives one internal stream
- *     per host thread and device for the model step of retired curvatures.
- *     They return with every stream drained;
+ *     wait for it.  The sweep entry points split the resident curvatures into two
+ *     groups, one driven on `stream`, one on an internal stream, and queue each
+ *     group's Lanczos steps two chunks ahead of the convergence flags they have
+ *     read (so no stream waits for the host); scint_chisq_sweep additionally
+ *     drives two internal streams for the model steps of retired curvatures.
+ *     Internal streams are per host thread and device.  The sweep entry points
+ *     return with every stream drained;
  *   - no function throws, allocates caller-visible memory, or keeps pointers to
  *     caller buffers after it returns.  Persistent library-owned state, all small
  *     and created on first use: a mutex-guarded cache of FFT twiddle tables per
  *     device; an 8 KiB reduction scratch per (device, stream) used by scint_mean /
  *     scint_chisq; per host thread a pinned flag buffer (4 int32 per resident
  *     curvature) and staging for the sweep's job tables, and, per device, the internal
- *     stream mentioned above.
+ *     streams mentioned above.
  */
 #ifndef SCINT_HIP_H
 #define SCINT_HIP_H
