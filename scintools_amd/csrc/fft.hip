@@ -194,6 +194,40 @@ __global__ void __launch_bounds__(256) reduce_final_kernel(const double* partial
     if (threadIdx.x == 0) out[0] = acc * scale;
 }
 
+// Both means calc_sspec needs (dynspec.py:3667-3674) in ONE pass over the dynamic spectrum:
+//   m1 = mean(dyn),   m2 = mean(w_f[r] w_t[c] (dyn - m1)) = (S_wd - m1 S_w) / n
+// with S_wd = sum w_f w_t dyn and S_w = sum w_f w_t: three fixed-order sums, then the scalars.
+__global__ void __launch_bounds__(256) sspec_sums_kernel(const double* __restrict__ dyn, const double* __restrict__ wt,
+                                                         const double* __restrict__ wf, int64_t nf, int64_t nt,
+                                                         double* partial /*3 x gridDim.x*/) {
+    __shared__ double red[4];
+    double sd = 0.0, swd = 0.0, sw = 0.0;
+    for (int64_t r = blockIdx.x; r < nf; r += gridDim.x) {
+        const double fr = wf ? wf[r] : 1.0;
+        double sd_r = 0.0, swd_r = 0.0, sw_r = 0.0;
+        for (int64_t c = threadIdx.x; c < nt; c += 256) {
+            const double d = dyn[r * nt + c], w = wt ? wt[c] : 1.0;
+            sd_r += d; swd_r += w * d; sw_r += w;
+        }
+        sd += sd_r; swd += fr * swd_r; sw += fr * sw_r;
+    }
+    sd = block_sum(sd, red); swd = block_sum(swd, red); sw = block_sum(sw, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = sd; partial[gridDim.x + blockIdx.x] = swd; partial[2 * gridDim.x + blockIdx.x] = sw;
+    }
+}
+__global__ void __launch_bounds__(256) sspec_means_kernel(const double* partial, int np, double n, double* scal) {
+    __shared__ double red[4];
+    double sd = 0.0, swd = 0.0, sw = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) { sd += partial[i]; swd += partial[np + i]; sw += partial[2 * np + i]; }
+    sd = block_sum(sd, red); swd = block_sum(swd, red); sw = block_sum(sw, red);
+    if (threadIdx.x == 0) {
+        const double m1 = sd / n;
+        scal[0] = m1;
+        scal[1] = (swd - m1 * sw) / n;
+    }
+}
+
 template <class F>
 static int32_t launch_reduce(F f, int64_t n, double scale, double* partial /*kRedBlocks*/,
                              double* out, hipStream_t stream) {
@@ -693,7 +727,7 @@ extern "C" int32_t scint_sspec_workspace_bytes(int64_t nf, int64_t nt, size_t* b
     SCINT_REQUIRE(bytes != nullptr, "sspec_workspace_bytes: null output");
     SCINT_REQUIRE(nf >= 2 && nt >= 2, "sspec_workspace_bytes: bad shape");
     const int64_t R = 2 * next_pow2(nf), C = std::max<int64_t>(16, 2 * next_pow2(nt));
-    *bytes = fft2_general_ws(R, C, nf) + sizeof(double) * (kRedBlocks + 8) + 1024;
+    *bytes = fft2_general_ws(R, C, nf) + sizeof(double) * (3 * kRedBlocks + 8) + 2048;
     return SCINT_OK;
 }
 
@@ -714,14 +748,17 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
     SCINT_REQUIRE(C >= 16, "sspec: nt must be at least 5");
     const size_t fft_bytes = fft2_general_ws(R, C, nf);
     Carver cv((char*)workspace + align_up(fft_bytes, 256), workspace_bytes - align_up(fft_bytes, 256));
-    double* partial = cv.take<double>(kRedBlocks);
+    double* partial = cv.take<double>(3 * kRedBlocks);
     double* scal = cv.take<double>(8);  // [0] = mean1, [1] = mean2
 
-    int32_t rc = launch_reduce(PlainValue{dyn}, nf * nt, 1.0 / (double)(nf * nt), partial, scal, stream);
-    if (rc != SCINT_OK) return rc;
+    {
+        const int blocks = (int)std::min<int64_t>(kRedBlocks, nf);
+        hipLaunchKernelGGL(sspec_sums_kernel, dim3(blocks), dim3(256), 0, stream, dyn, win_t, win_f, nf, nt, partial);
+        hipLaunchKernelGGL(sspec_means_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, (double)(nf * nt), scal);
+        SCINT_LAUNCH_CHECK();
+    }
     WindowedValue wv{dyn, win_t, win_f, scal, nt};
-    rc = launch_reduce2d(wv, nf, nt, 1.0 / (double)(nf * nt), partial, scal + 1, stream);
-    if (rc != SCINT_OK) return rc;
+    int32_t rc = SCINT_OK;
 
     const int64_t nf_eff = prewhite ? nf - 1 : nf, nt_eff = prewhite ? nt - 1 : nt;
     RowSource src{};

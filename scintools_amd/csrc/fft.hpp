@@ -270,7 +270,11 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
     sh.n = (int)n;
     sh.log2n = ilog2(n);
     sh.threads_per_slot = (int)(n / kEPT);
-    const int block = sh.threads_per_slot >= 256 ? sh.threads_per_slot : 256;
+    // short transforms (the 16..128-point steps of the tiled column passes, short rows): 128-thread
+    // workgroups hold 35 KiB of LDS instead of 70, so four of them fit a CU instead of two
+    static const int small_block = [] { const char* e = getenv("SCINT_FFT_SMALL_BLOCK"); return e ? atoi(e) : 1; }();
+    const int min_block = (small_block && n <= 128) ? 128 : 256;
+    const int block = sh.threads_per_slot >= min_block ? sh.threads_per_slot : min_block;
     sh.slots_per_block = block / sh.threads_per_slot;
     sh.nslots = nslots;
     sh.tw = tw;
