@@ -275,24 +275,30 @@ struct PlainValue {
 
 // (dyn - m1) * win_t[col] * win_f[row]        (dynspec.py:3667-3674)
 struct WindowedValue {
-    const double* dyn; const double* wt; const double* wf; const double* m1; int64_t nt;
-    __device__ inline double at(int64_t r, int64_t c) const {
-        double v = dyn[r * nt + c] - m1[0];
+    const double* dyn; const double* wt; const double* wf; const double* m1; int nt;
+    __device__ inline double at(int r, int c) const {
+        double v = dyn[(int64_t)r * nt + c] - m1[0];
         if (wt) { v = wt[c] * v; v = wf[r] * v; }
         return v;
     }
     __device__ inline double operator()(int64_t i) const {
         const int64_t r = i / nt;
-        return at(r, i - r * nt);
+        return at((int)r, (int)(i - r * nt));
     }
 };
 
 // ------------------------------------------------------------------------------
 // sources and sinks
 // ------------------------------------------------------------------------------
-// (i + n/2) mod n for 0 <= i < n without the 64-bit division an integer `%` costs per element
-__device__ inline int64_t shift_half(int64_t i, int64_t n) {
-    const int64_t s = i + n / 2;
+// Row / column indices, extents and strides are 32-bit in all of these (every transform here is far
+// below 2^31 along either axis); the element offset is widened once, at the access.  The `mode` of
+// a source or sink is a run-time field; the hot modes are ALSO instantiated with the mode as a
+// template argument (RowSourceM / ColSinkM, chosen by with_source / with_sink on the host), which
+// removes the switch -- sixteen unrolled copies of it per thread -- from those kernels.
+
+// (i + n/2) mod n for 0 <= i < n without the division an integer `%` costs per element
+__device__ inline int shift_half(int i, int n) {
+    const int s = i + n / 2;
     return s >= n ? s - n : s;
 }
 
@@ -302,31 +308,33 @@ enum SrcMode { SRC_ARRAY = 0, SRC_SSPEC = 1, SRC_CS = 2, SRC_MODEL = 3, SRC_MULC
 // Element (row, j) of the row-FFT input, j in [0, fft length).
 struct RowSource {
     int mode;
-    int64_t n_in;        // logical row length; j >= n_in reads as 0 (Bluestein/zero padding)
+    int n_in;            // logical row length; j >= n_in reads as 0 (Bluestein/zero padding)
     const cplx* chirp;   // optional: multiply element j < n_in by chirp[j]
     // SRC_ARRAY: a[row*ld + j];  SRC_MULCONJ: conj(a[row*ld + j] * b[j])
-    const cplx* a; int64_t ld; const cplx* b;
+    const cplx* a; int ld; const cplx* b;
     // SRC_SSPEC (dynspec.py:3667-3685)
-    WindowedValue wv; const double* m2; int64_t nt_eff; int prewhite;
+    WindowedValue wv; const double* m2; int nt_eff; int prewhite;
     // SRC_CS: np.pad(dspec, right, constant)  (ththmod.py:777-782): reuses wv.dyn / wv.nt
     double pad;
     // SRC_MODEL: conj(ifftshift(recov)) -- real(ifft2(x)) == real(fft2(conj x))/(R C)
-    int64_t R, C;
+    int R, C;
 
-    __device__ inline double sspec_d(int64_t r, int64_t c) const { return wv.at(r, c) - m2[0]; }
+    __device__ inline double sspec_d(int r, int c) const { return wv.at(r, c) - m2[0]; }
 
-    __device__ inline cplx operator()(int64_t r, int64_t j) const {
+    template <int M = -1>
+    __device__ inline cplx get(int r, int j) const {
         if (j >= n_in) return mk(0.0, 0.0);
+        const int m = M >= 0 ? M : mode;
         cplx v;
-        switch (mode) {
-            case SRC_ARRAY: v = a[r * ld + j]; break;
-            case SRC_MULCONJ: v = conj(a[r * ld + j] * b[j]); break;
-            case SRC_CONJ: v = conj(a[r * ld + j]); break;
+        switch (m) {
+            case SRC_ARRAY: v = a[(int64_t)r * ld + j]; break;
+            case SRC_MULCONJ: v = conj(a[(int64_t)r * ld + j] * b[j]); break;
+            case SRC_CONJ: v = conj(a[(int64_t)r * ld + j]); break;
             case SRC_ACF_IN:   // (dyn - mean) zero-padded on the right (dynspec.py:3783-3790)
-                v = mk(j < wv.nt ? wv.dyn[r * wv.nt + j] - wv.m1[0] : 0.0, 0.0);
+                v = mk(j < wv.nt ? wv.dyn[(int64_t)r * wv.nt + j] - wv.m1[0] : 0.0, 0.0);
                 break;
             case SRC_POWER: {  // |X|^2 (dynspec.py:3791-3792); real, so no conjugation is needed
-                const cplx x = a[r * ld + j];
+                const cplx x = a[(int64_t)r * ld + j];
                 v = mk(x.x * x.x + x.y * x.y, 0.0);
                 break;
             }
@@ -336,40 +344,65 @@ struct RowSource {
                 else  // convolve2d([[1,-1],[-1,1]], dyn, 'valid')  (dynspec.py:3681)
                     v = mk(sspec_d(r + 1, j + 1) - sspec_d(r + 1, j) - sspec_d(r, j + 1) + sspec_d(r, j), 0.0);
                 break;
-            case SRC_CS: v = mk(j < wv.nt ? wv.dyn[r * wv.nt + j] : pad, 0.0); break;
+            case SRC_CS: v = mk(j < wv.nt ? wv.dyn[(int64_t)r * wv.nt + j] : pad, 0.0); break;
             default: {  // SRC_MODEL
-                const int64_t sr = shift_half(r, R), sc = shift_half(j, C);
-                v = conj(a[sr * C + sc]);
+                const int sr = shift_half(r, R), sc = shift_half(j, C);
+                v = conj(a[(int64_t)sr * C + sc]);
             }
         }
         if (chirp) v = v * chirp[j];
         return v;
     }
+    __device__ inline cplx operator()(int r, int j) const { return get<-1>(r, j); }
 };
+template <int M>
+struct RowSourceM {
+    RowSource s;
+    __device__ inline cplx operator()(int r, int j) const { return s.template get<M>(r, j); }
+};
+// f(source functor): the hot modes get their own instantiation
+template <class F>
+static int32_t with_source(const RowSource& s, F&& f) {
+    switch (s.mode) {
+        case SRC_SSPEC: return f(RowSourceM<SRC_SSPEC>{s});
+        case SRC_CS: return f(RowSourceM<SRC_CS>{s});
+        case SRC_MODEL: return f(RowSourceM<SRC_MODEL>{s});
+        default: return f(s);
+    }
+}
 
 // First column pass: value at (row r, col c) of the row-transformed, padded array.
 struct ColSource {
-    const cplx* a; int64_t ld;  // row-FFT result
-    int64_t nvalid;             // rows computed by the row pass
+    const cplx* a; int ld;      // row-FFT result
+    int nvalid;                 // rows computed by the row pass
     double fill0;               // rows >= nvalid hold fill0 at c == 0, 0 elsewhere
-    int64_t n_in;               // logical column length; r >= n_in reads as 0 (Bluestein padding)
+    int n_in;                   // logical column length; r >= n_in reads as 0 (Bluestein padding)
     const cplx* row_post_w;     // rows went through Bluestein: value = w[c] * conj(a) * row_post_scale
     double row_post_scale;
     const cplx* chirp;          // column Bluestein pass 1: multiply by chirp[r]
     const cplx* mulconj_b;      // column Bluestein pass 2: conj(a * b[r]) (then nothing else applies)
 
-    __device__ inline cplx operator()(int64_t, int64_t r, int64_t c) const {
-        if (mulconj_b) return conj(a[r * ld + c] * mulconj_b[r]);
+    __device__ inline cplx operator()(int64_t, int r, int c) const {
+        if (mulconj_b) return conj(a[(int64_t)r * ld + c] * mulconj_b[r]);
         if (r >= n_in) return mk(0.0, 0.0);
         cplx v;
         if (r < nvalid) {
-            v = a[r * ld + c];
+            v = a[(int64_t)r * ld + c];
             if (row_post_w) { v = row_post_w[c] * conj(v); v = v * row_post_scale; }
         } else {
             v = mk(c == 0 ? fill0 : 0.0, 0.0);
         }
         if (chirp) v = v * chirp[r];
         return v;
+    }
+};
+// The common case (power-of-two lengths: no Bluestein factors): rows below nvalid from the array,
+// the constant-padded rows from fill0.
+struct ColSourcePlain {
+    const cplx* a; int ld; int nvalid; double fill0;
+    __device__ inline cplx operator()(int64_t, int r, int c) const {
+        if (r < nvalid) return a[(int64_t)r * ld + c];
+        return mk(c == 0 ? fill0 : 0.0, 0.0);
     }
 };
 
@@ -379,144 +412,221 @@ enum SinkMode { SINK_ARRAY = 0, SINK_SSPEC = 1, SINK_CS = 2, SINK_MODEL = 3, SIN
 // Final value at natural frequency (k1 along the strided axis, c along the contiguous one).
 struct ColSink {
     int mode;
-    int64_t R, C;               // logical transform shape
+    int R, C;                   // logical transform shape
     const cplx* col_post_w;     // column Bluestein: v = w[k1] * conj(v) * col_post_scale, k1 < R only
     double col_post_scale;
-    cplx* out_c; int64_t ld;    // SINK_ARRAY / SINK_CS
+    cplx* out_c; int ld;        // SINK_ARRAY / SINK_CS
     double* out_d;              // SINK_SSPEC / SINK_MODEL
     int halve, prewhite; const double* pd_fd; const double* pd_td;   // SINK_SSPEC
-    int64_t mask_lo, mask_hi; int incoherent;                        // SINK_CS
+    int mask_lo, mask_hi; int incoherent;                            // SINK_CS
     double scale;                                                    // SINK_MODEL / SINK_CONJ / SINK_GS_INV
-    int64_t crop_r, crop_c;                                          // SINK_CONJ: keep [0,crop_r) x [0,crop_c)
-    int64_t zero_lo, zero_hi;                                        // SINK_GS_FWD: natural rows to zero
+    int crop_r, crop_c;                                              // SINK_CONJ: keep [0,crop_r) x [0,crop_c)
+    int zero_lo, zero_hi;                                            // SINK_GS_FWD: natural rows to zero
     const double* amp; const uint8_t* pos;                           // SINK_GS_INV: sqrt(dyn), posdspec
 
     int half;                   // real input: only columns 0..C/2 are transformed; the rest is
                                 // X[(R-k1)%R, C-c] = conj X[k1, c]
 
-    __device__ inline void operator()(int64_t, int64_t k1, int64_t c, cplx v) const {
+    template <int M = -1>
+    __device__ inline void put(int k1, int c, cplx v) const {
         if (k1 >= R) return;
         if (col_post_w) { v = col_post_w[k1] * conj(v); v = v * col_post_scale; }
-        emit(k1, c, v);
-        if (half && c > 0 && c < C / 2) emit(k1 == 0 ? 0 : R - k1, C - c, conj(v));
+        if constexpr (M == SINK_SSPEC) {
+            // |.|^2 is the same for a value and its conjugate-symmetric partner: one log10 serves both
+            // positions (with `halve`, rows k1 and R - k1 never both survive except k1 = 0).
+            const double pw = v.x * v.x + v.y * v.y;
+            const bool mirror = half && c > 0 && c < C / 2;
+            int row[2] = {k1, k1 == 0 ? 0 : R - k1};
+            const int col[2] = {shift_half(c, C), shift_half(C - c, C)};
+            bool keep[2] = {true, mirror};
+            if (halve) {
+                keep[0] = row[0] < R / 2;
+                keep[1] = mirror && row[1] < R / 2;
+            } else {
+                row[0] = shift_half(row[0], R);
+                row[1] = shift_half(row[1], R);
+            }
+            // one copy of the (long) log10 sequence per element: the two positions share a loop that
+            // is not unrolled; with `halve` at most one of them survives (both only on row 0)
+#pragma clang loop unroll(disable)
+            for (int e = 0; e < 2; ++e) {
+                if (!keep[e]) continue;
+                double val = pw;
+                if (prewhite) {
+                    double pd = pd_fd[col[e]] * pd_td[row[e]];
+                    if (col[e] == C / 2 || row[e] == 0) pd = 1.0;
+                    val = pw / pd;
+                }
+                out_d[(int64_t)row[e] * C + col[e]] = 10.0 * log10(val);
+            }
+            return;
+        }
+        emit<M>(k1, c, v);
+        if (half && c > 0 && c < C / 2) emit<M>(k1 == 0 ? 0 : R - k1, C - c, conj(v));
     }
+    __device__ inline void operator()(int64_t, int k1, int c, cplx v) const { put<-1>(k1, c, v); }
 
-    __device__ inline void emit(int64_t k1, int64_t c, cplx v) const {
-        switch (mode) {
-            case SINK_ARRAY: out_c[k1 * ld + c] = v; break;
+    template <int M>
+    __device__ inline void emit(int k1, int c, cplx v) const {
+        const int m = M >= 0 ? M : mode;
+        switch (m) {
+            case SINK_ARRAY: out_c[(int64_t)k1 * ld + c] = v; break;
             case SINK_SSPEC: {
                 // |.|^2, fftshift, keep tdel >= 0, post-darken, dB (dynspec.py:3686-3721)
-                int64_t orow;
+                int orow;
                 if (halve) {
                     if (k1 >= R / 2) return;
                     orow = k1;
                 } else {
                     orow = shift_half(k1, R);
                 }
-                const int64_t ocol = shift_half(c, C);
+                const int ocol = shift_half(c, C);
                 double p = v.x * v.x + v.y * v.y;
                 if (prewhite) {
                     double pd = pd_fd[ocol] * pd_td[orow];
                     if (ocol == C / 2 || orow == 0) pd = 1.0;
                     p = p / pd;
                 }
-                out_d[orow * C + ocol] = 10.0 * log10(p);
+                out_d[(int64_t)orow * C + ocol] = 10.0 * log10(p);
                 break;
             }
             case SINK_CS: {
                 // fftshift on both axes, zero the masked delay rows, optional abs
                 // (ththmod.py:786-787, 801)
-                const int64_t orow = shift_half(k1, R), ocol = shift_half(c, C);
+                const int orow = shift_half(k1, R), ocol = shift_half(c, C);
                 if (orow >= mask_lo && orow < mask_hi) v = mk(0.0, 0.0);
                 if (incoherent) v = mk(hypot(v.x, v.y), 0.0);
-                out_c[orow * C + ocol] = v;
+                out_c[(int64_t)orow * C + ocol] = v;
                 break;
             }
             case SINK_MODEL:
                 if (crop_r > 0) {   // only the [crop_r, crop_c] corner, rows ld apart (chi^2 sweep)
-                    if (k1 < crop_r && c < crop_c) out_d[k1 * ld + c] = v.x * scale;
+                    if (k1 < crop_r && c < crop_c) out_d[(int64_t)k1 * ld + c] = v.x * scale;
                 } else {
-                    out_d[k1 * C + c] = v.x * scale;
+                    out_d[(int64_t)k1 * C + c] = v.x * scale;
                 }
                 break;
             case SINK_CONJ:   // complex inverse transform: ifft2(x) = conj(fft2(conj x)) / (R C), cropped
-                if (k1 < crop_r && c < crop_c) out_c[k1 * ld + c] = mk(v.x * scale, -v.y * scale);
+                if (k1 < crop_r && c < crop_c) out_c[(int64_t)k1 * ld + c] = mk(v.x * scale, -v.y * scale);
                 break;
             case SINK_ACF: {   // real(fftshift(ifft2(.)))  (dynspec.py:3793-3795)
-                const int64_t orow = shift_half(k1, R), ocol = shift_half(c, C);
-                out_d[orow * C + ocol] = v.x * scale;
+                const int orow = shift_half(k1, R), ocol = shift_half(c, C);
+                out_d[(int64_t)orow * C + ocol] = v.x * scale;
                 break;
             }
             case SINK_GS_FWD:  // CWF[tau < 0] = 0 in natural frequency order (dynspec.py:1869-1870)
                 if (k1 >= zero_lo && k1 < zero_hi) v = mk(0.0, 0.0);
-                out_c[k1 * ld + c] = v;
+                out_c[(int64_t)k1 * ld + c] = v;
                 break;
             default: {         // SINK_GS_INV: inverse transform + amplitude constraint (dynspec.py:1871-1875)
                 cplx wv = mk(v.x * scale, -v.y * scale);
-                const int64_t o = k1 * ld + c;
+                const int64_t o = (int64_t)k1 * ld + c;
                 if (pos[o]) {
                     // sqrt(dyn) * exp(1j * angle(w)); angle(0) = 0 in NumPy
-                    const double m = hypot(wv.x, wv.y);
-                    wv = (m > 0.0) ? mk(amp[o] * (wv.x / m), amp[o] * (wv.y / m)) : mk(amp[o], 0.0);
+                    const double mg = hypot(wv.x, wv.y);
+                    wv = (mg > 0.0) ? mk(amp[o] * (wv.x / mg), amp[o] * (wv.y / mg)) : mk(amp[o], 0.0);
                 }
                 out_c[o] = wv;
             }
         }
     }
 };
+template <int M>
+struct ColSinkM {
+    ColSink s;
+    __device__ inline void operator()(int64_t, int k1, int c, cplx v) const { s.template put<M>(k1, c, v); }
+};
+template <class F>
+static int32_t with_sink(const ColSink& s, F&& f) {
+    switch (s.mode) {
+        case SINK_SSPEC: return f(ColSinkM<SINK_SSPEC>{s});
+        case SINK_CS: return f(ColSinkM<SINK_CS>{s});
+        case SINK_MODEL: return f(ColSinkM<SINK_MODEL>{s});
+        default: return f(s);
+    }
+}
 
 // ------------------------------------------------------------------------------
 // row pass (contiguous axis): power-of-two lengths
 // ------------------------------------------------------------------------------
+// Loader / Storer concept of fft_rows_kernel: open(slot) -> per-slot accessor; the accessor maps an
+// element index of the slot's transform to the value (loader) or stores it (storer).
+template <class Src>
 struct SlotIsRow {
-    RowSource in;
-    __device__ inline cplx operator()(int64_t s, int j) const { return in(s, j); }
+    Src in;
+    struct Slot {
+        const SlotIsRow& p; int r;
+        __device__ inline cplx operator()(int j) const { return p.in(r, j); }
+    };
+    __device__ inline Slot open(int64_t s) const { return Slot{*this, (int)s}; }
 };
 struct RowStoreC {
     static constexpr bool kPair = false;
-    cplx* a; int64_t ld;
-    __device__ inline void operator()(int64_t slot, int k, cplx v) const { a[slot * ld + k] = v; }
+    cplx* a; int ld;
+    struct Slot {
+        cplx* row;
+        __device__ inline void operator()(int k, cplx v) const { row[k] = v; }
+    };
+    __device__ inline Slot open(int64_t s) const { return Slot{a + s * ld}; }
 };
 // Real input, two rows per slot: slot s carries rows 2s and 2s+1 as z = x_{2s} + i x_{2s+1}.
+template <class Src>
 struct PairLoad {
-    RowSource in; int64_t nrows;
-    __device__ inline cplx operator()(int64_t s, int j) const {
-        const int64_t r0 = 2 * s, r1 = 2 * s + 1;
-        return mk(in(r0, j).x, r1 < nrows ? in(r1, j).x : 0.0);
-    }
+    Src in; int nrows;
+    struct Slot {
+        const PairLoad& p; int r0;
+        __device__ inline cplx operator()(int j) const {
+            return mk(p.in(r0, j).x, r0 + 1 < p.nrows ? p.in(r0 + 1, j).x : 0.0);
+        }
+    };
+    __device__ inline Slot open(int64_t s) const { return Slot{*this, 2 * (int)s}; }
 };
 // X1[k] = (Z[k] + conj Z[n-k]) / 2,  X2[k] = (Z[k] - conj Z[n-k]) / (2i);  half-width rows
 struct PairStore {
     static constexpr bool kPair = true;
-    cplx* a; int64_t ld; int64_t nrows;
-    __device__ inline void operator()(int64_t, int, cplx) const {}
-    __device__ inline void pair(int64_t s, int k, cplx zk, cplx zm) const {
-        const cplx zc = conj(zm);
-        const cplx x1 = mk(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
-        const cplx d = mk(zk.x - zc.x, zk.y - zc.y);
-        const cplx x2 = mk(0.5 * d.y, -0.5 * d.x);   // d / (2i)
-        a[(2 * s) * ld + k] = x1;
-        if (2 * s + 1 < nrows) a[(2 * s + 1) * ld + k] = x2;
+    cplx* a; int ld; int nrows;
+    struct Slot {
+        cplx* row0; cplx* row1;   // row1 == nullptr: the last, unpaired row
+        __device__ inline void operator()(int, cplx) const {}
+        __device__ inline void pair(int k, cplx zk, cplx zm) const {
+            const cplx zc = conj(zm);
+            const cplx x1 = mk(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+            const cplx d = mk(zk.x - zc.x, zk.y - zc.y);
+            const cplx x2 = mk(0.5 * d.y, -0.5 * d.x);   // d / (2i)
+            row0[k] = x1;
+            if (row1) row1[k] = x2;
+        }
+    };
+    __device__ inline Slot open(int64_t s) const {
+        cplx* r0 = a + 2 * s * ld;
+        return Slot{r0, 2 * s + 1 < nrows ? r0 + ld : nullptr};
     }
 };
 // Decimated long rows (n = n1 * n2): slot = row*n1 + j1, element j2 -> x[row][j1 + n1*j2];
 // result y[j1][k2] * W_n^{j1 k2} -> dst[row][j1*n2 + k2].
+template <class Src>
 struct DecimLoad {
-    RowSource in; int n1;
-    __device__ inline cplx operator()(int64_t slot, int j2) const {
-        const int64_t r = slot / n1;
-        const int j1 = (int)(slot - r * n1);
-        return in(r, (int64_t)j1 + (int64_t)n1 * j2);
+    Src in; int n1;
+    struct Slot {
+        const DecimLoad& p; int r, j1;
+        __device__ inline cplx operator()(int j2) const { return p.in(r, j1 + p.n1 * j2); }
+    };
+    __device__ inline Slot open(int64_t slot) const {
+        const int r = (int)((uint32_t)slot / (uint32_t)n1);   // slots < 2^32
+        return Slot{*this, r, (int)slot - r * n1};
     }
 };
 struct DecimStore {
     static constexpr bool kPair = false;
-    cplx* dst; int64_t ld; int n1; int n2; const cplx* tw_n;  // W_n, n = n1*n2
-    __device__ inline void operator()(int64_t slot, int k2, cplx v) const {
-        const int64_t r = slot / n1;
-        const int j1 = (int)(slot - r * n1);
-        const cplx w = tw_n[(int64_t)j1 * k2];
-        dst[r * ld + (int64_t)j1 * n2 + k2] = v * w;
+    cplx* dst; int ld; int n1; int n2; const cplx* tw_n;  // W_n, n = n1*n2
+    struct Slot {
+        cplx* out; const cplx* tw; int j1;
+        __device__ inline void operator()(int k2, cplx v) const { out[k2] = v * tw[j1 * k2]; }
+    };
+    __device__ inline Slot open(int64_t slot) const {
+        const int r = (int)((uint32_t)slot / (uint32_t)n1);
+        const int j1 = (int)slot - r * n1;
+        return Slot{dst + ((int64_t)r * ld + j1 * n2), tw_n, j1};
     }
 };
 
@@ -525,20 +635,27 @@ struct DecimStore {
 static int32_t rows_fft_pow2(const RowSource& in, int64_t nrows, int64_t n, cplx* dst, int64_t ld,
                              hipStream_t stream) {
     SCINT_REQUIRE(is_pow2(n) && n >= 16, "rows_fft: n must be a power of two >= 16");
-    if (n <= 8192) return launch_fft_rows(n, nrows, SlotIsRow{in}, RowStoreC{dst, ld}, stream);
+    SCINT_REQUIRE(nrows < (1 << 30) && ld < (1 << 30), "rows_fft: extent beyond the 32-bit index range");
+    if (n <= 8192)
+        return with_source(in, [&](auto src) {
+            return launch_fft_rows(n, nrows, SlotIsRow<decltype(src)>{src}, RowStoreC{dst, (int)ld}, stream);
+        });
     const int64_t n2 = 4096, n1 = n / n2;
     SCINT_REQUIRE(n1 <= 32, "rows_fft: n too large (max 131072)");
+    SCINT_REQUIRE(nrows * n1 < ((int64_t)1 << 32), "rows_fft: too many decimated rows");
     const cplx* tw_n = twiddle_table(n);
     if (!tw_n) return SCINT_E_HIP;
-    int32_t rc = launch_fft_rows(n2, nrows * n1, DecimLoad{in, (int)n1},
-                                 DecimStore{dst, ld, (int)n1, (int)n2, tw_n}, stream);
+    int32_t rc = with_source(in, [&](auto src) {
+        return launch_fft_rows(n2, nrows * n1, DecimLoad<decltype(src)>{src, (int)n1},
+                               DecimStore{dst, (int)ld, (int)n1, (int)n2, tw_n}, stream);
+    });
     if (rc != SCINT_OK) return rc;
     // radix-n1 pass over j1 (stride n2) for every (row, k2): view dst as [nrows][n1][n2];
     // grid.z is limited to 65535, so chunk the rows
     for (int64_t b0 = 0; b0 < nrows; b0 += 32768) {
         const int64_t nb = std::min<int64_t>(32768, nrows - b0);
-        ArrayLoad al{dst + b0 * ld, n2, ld};
-        ArrayStore as{dst + b0 * ld, n2, ld};
+        ArrayLoad al{dst + b0 * ld, (int)n2, ld};
+        ArrayStore as{dst + b0 * ld, (int)n2, ld};
         rc = run_cols_fft(n1, n2, nb, al, al, as, as, stream);
         if (rc != SCINT_OK) return rc;
     }
@@ -585,6 +702,7 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
                             ColSink sink, void* workspace, size_t workspace_bytes, hipStream_t stream,
                             bool real_input = false) {
     SCINT_REQUIRE(R >= 1 && C >= 1 && nvalid >= 0 && nvalid <= R, "fft2: bad shape");
+    SCINT_REQUIRE(R < (1 << 24) && C < (1 << 24), "fft2: axis longer than 2^24");
     const Fft2Plan p = make_plan(R, C, nvalid);
     if (workspace_bytes < p.total) { set_error("scint: fft workspace too small"); return SCINT_E_WORKSPACE; }
     char* base = (char*)workspace;
@@ -599,30 +717,31 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
         // row stride of the half-width arrays: a multiple of 8 elements (128 B), so that the 16-column
         // tiles of the column passes cover whole cache lines (C/2 + 1 is odd); both fit their buffers
         // (rowA holds nvalid x C, colA holds R x C elements)
-        const int64_t ChL = (Ch + 7) & ~(int64_t)7;
-        src.n_in = C;
+        const int ChL = (int)((Ch + 7) & ~(int64_t)7);
+        src.n_in = (int)C;
         src.chirp = nullptr;
-        rc = launch_fft_rows(C, (nvalid + 1) / 2, PairLoad{src, nvalid}, PairStore{rowA, ChL, nvalid}, stream);
+        rc = with_source(src, [&](auto s) {
+            return launch_fft_rows(C, (nvalid + 1) / 2, PairLoad<decltype(s)>{s, (int)nvalid},
+                                   PairStore{rowA, ChL, (int)nvalid}, stream);
+        });
         if (rc != SCINT_OK) return rc;
-        ColSource hs;
-        hs.a = rowA; hs.ld = ChL; hs.nvalid = nvalid; hs.fill0 = fill0; hs.n_in = R;
-        hs.row_post_w = nullptr; hs.row_post_scale = 1.0; hs.chirp = nullptr; hs.mulconj_b = nullptr;
-        sink.R = R; sink.C = C; sink.col_post_w = nullptr; sink.col_post_scale = 1.0; sink.half = 1;
+        ColSourcePlain hs{rowA, ChL, (int)nvalid, fill0};
+        sink.R = (int)R; sink.C = (int)C; sink.col_post_w = nullptr; sink.col_post_scale = 1.0; sink.half = 1;
         ArrayLoad mid_ld{colA, ChL, 0};
         ArrayStore mid_st{colA, ChL, 0};
-        return run_cols_fft(R, Ch, 1, hs, mid_ld, mid_st, sink, stream);
+        return with_sink(sink, [&](auto sk) { return run_cols_fft(R, Ch, 1, hs, mid_ld, mid_st, sk, stream); });
     }
 
     // ---- rows ---------------------------------------------------------------------
     ColSource cs;
-    cs.nvalid = nvalid; cs.fill0 = fill0; cs.n_in = R;
+    cs.nvalid = (int)nvalid; cs.fill0 = fill0; cs.n_in = (int)R;
     cs.row_post_w = nullptr; cs.row_post_scale = 1.0; cs.chirp = nullptr; cs.mulconj_b = nullptr;
-    src.n_in = C;
+    src.n_in = (int)C;
     src.chirp = nullptr;
     if (!p.blue_c) {
         rc = rows_fft_pow2(src, nvalid, C, rowA, C, stream);
         if (rc != SCINT_OK) return rc;
-        cs.a = rowA; cs.ld = C;
+        cs.a = rowA; cs.ld = (int)C;
     } else {
         const Chirp* ch = chirp_table(C);
         if (!ch) return SCINT_E_HIP;
@@ -630,46 +749,47 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
         rc = rows_fft_pow2(src, nvalid, p.mC, rowA, p.mC, stream);
         if (rc != SCINT_OK) return rc;
         RowSource s2;
-        s2.mode = SRC_MULCONJ; s2.n_in = p.mC; s2.chirp = nullptr;
-        s2.a = rowA; s2.ld = p.mC; s2.b = ch->B;
+        s2.mode = SRC_MULCONJ; s2.n_in = (int)p.mC; s2.chirp = nullptr;
+        s2.a = rowA; s2.ld = (int)p.mC; s2.b = ch->B;
         rc = rows_fft_pow2(s2, nvalid, p.mC, rowB, p.mC, stream);
         if (rc != SCINT_OK) return rc;
-        cs.a = rowB; cs.ld = p.mC;
+        cs.a = rowB; cs.ld = (int)p.mC;
         cs.row_post_w = ch->w; cs.row_post_scale = 1.0 / (double)p.mC;
     }
 
     // ---- columns ------------------------------------------------------------------
-    sink.R = R; sink.C = C;
+    sink.R = (int)R; sink.C = (int)C;
     sink.col_post_w = nullptr; sink.col_post_scale = 1.0;
     if (R == 1) {  // nothing to transform along the strided axis
         // a length-1 "FFT": push the row result through the sink with a trivial pass
         SCINT_REQUIRE(false, "fft2: a single-row transform is not supported");
     }
     if (!p.blue_r) {
-        ArrayLoad mid_ld{colA, C, 0};
-        ArrayStore mid_st{colA, C, 0};
+        ArrayLoad mid_ld{colA, (int)C, 0};
+        ArrayStore mid_st{colA, (int)C, 0};
+        if (!p.blue_c) {   // no Bluestein factor anywhere: the plain first loader
+            ColSourcePlain ps{cs.a, cs.ld, cs.nvalid, cs.fill0};
+            return with_sink(sink, [&](auto sk) { return run_cols_fft(R, C, 1, ps, mid_ld, mid_st, sk, stream); });
+        }
         return run_cols_fft(R, C, 1, cs, mid_ld, mid_st, sink, stream);
     }
     const Chirp* ch = chirp_table(R);
     if (!ch) return SCINT_E_HIP;
     cs.chirp = ch->w;
     {   // pass 1: FFT_mR(x w) -> colB (mids in place in colA)
-        ArrayLoad mid_ld{colA, C, 0};
-        ArrayStore mid_st{colA, C, 0};
-        ColSink to_b;
-        to_b.mode = SINK_ARRAY; to_b.R = p.mR; to_b.C = C; to_b.col_post_w = nullptr; to_b.col_post_scale = 1.0;
-        to_b.half = 0;
-        to_b.out_c = colB; to_b.ld = C;
+        ArrayLoad mid_ld{colA, (int)C, 0};
+        ArrayStore mid_st{colA, (int)C, 0};
+        ArrayStore to_b{colB, (int)C, 0};
         rc = run_cols_fft(p.mR, C, 1, cs, mid_ld, mid_st, to_b, stream);
         if (rc != SCINT_OK) return rc;
     }
     {   // pass 2: FFT_mR(conj(A B)) -> w[k] conj(.)/mR -> sink  (mids in place in colB... the
         // first pass of run_cols_fft reads colB and writes colA, later passes stay in colA)
         ColSource c2;
-        c2.a = colB; c2.ld = C; c2.nvalid = p.mR; c2.fill0 = 0.0; c2.n_in = p.mR;
+        c2.a = colB; c2.ld = (int)C; c2.nvalid = (int)p.mR; c2.fill0 = 0.0; c2.n_in = (int)p.mR;
         c2.row_post_w = nullptr; c2.row_post_scale = 1.0; c2.chirp = nullptr; c2.mulconj_b = ch->B;
-        ArrayLoad mid_ld{colA, C, 0};
-        ArrayStore mid_st{colA, C, 0};
+        ArrayLoad mid_ld{colA, (int)C, 0};
+        ArrayStore mid_st{colA, (int)C, 0};
         sink.col_post_w = ch->w; sink.col_post_scale = 1.0 / (double)p.mR;
         return run_cols_fft(p.mR, C, 1, c2, mid_ld, mid_st, sink, stream);
     }
@@ -757,7 +877,7 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
         hipLaunchKernelGGL(sspec_means_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, (double)(nf * nt), scal);
         SCINT_LAUNCH_CHECK();
     }
-    WindowedValue wv{dyn, win_t, win_f, scal, nt};
+    WindowedValue wv{dyn, win_t, win_f, scal, (int)nt};
     int32_t rc = SCINT_OK;
 
     const int64_t nf_eff = prewhite ? nf - 1 : nf, nt_eff = prewhite ? nt - 1 : nt;

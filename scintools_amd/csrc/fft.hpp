@@ -170,7 +170,12 @@ __device__ inline int stockham_out_index(int t, int Tr, int Ns, int q, int m) {
 }
 
 // Stage sequence R0,R1,R2,R3 (1 = unused); product = n.
-template <int R0, int R1, int R2, int R3, class Loader, class Storer>
+// SPLIT: the stage exchanges move the real parts, then the imaginary parts, through an LDS buffer of
+// n doubles per slot instead of n complex values.  These kernels' occupancy is set by LDS (a slot
+// needs its whole transform there), so halving it doubles the waves per CU -- worth two more
+// barriers per exchange for the short transforms of the tiled column passes, which are pure
+// streaming.  Not available with pair storers (they read complex values back from LDS).
+template <int R0, int R1, int R2, int R3, bool SPLIT, class Loader, class Storer>
 __global__ void __launch_bounds__(512)
 fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -180,18 +185,24 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
     const int t = threadIdx.x - slot_in_block * Tr;
     const int64_t slot = (int64_t)blockIdx.x * sh.slots_per_block + slot_in_block;
     const bool active = slot < sh.nslots;
-    cplx* lds = smem + (size_t)slot_in_block * lds_pad(n);
+    cplx* lds = smem + (SPLIT ? 0 : (size_t)slot_in_block * lds_pad(n));
+    double* ldsd = reinterpret_cast<double*>(smem_raw) + (size_t)slot_in_block * lds_pad(n);
+    static_assert(!(SPLIT && Storer::kPair), "split exchange: not with pair storers");
     const cplx* __restrict__ tw = sh.tw;
 
     cplx v[kEPT];
     // ---- stage 0: inputs straight from global ---------------------------------
+    // open(slot) decodes the slot ONCE (tile, column, row base ...); the per-element call then costs
+    // an address and the access.  (Left to the compiler, the decode was repeated in each of the 16
+    // unrolled element accesses.)
+    const auto lx = ld.open(slot);
     {
         constexpr int NB = kEPT / R0;
         if (active) {
 #pragma unroll
             for (int q = 0; q < NB; ++q)
 #pragma unroll
-                for (int m = 0; m < R0; ++m) v[q * R0 + m] = ld(slot, t + q * Tr + m * (n / R0));
+                for (int m = 0; m < R0; ++m) v[q * R0 + m] = lx(t + q * Tr + m * (n / R0));
         } else {
 #pragma unroll
             for (int e = 0; e < kEPT; ++e) v[e] = mk(0.0, 0.0);
@@ -203,6 +214,33 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
     auto exchange = [&](auto rprev_tag, auto rnext_tag) {
         constexpr int RP = decltype(rprev_tag)::value;
         constexpr int RN = decltype(rnext_tag)::value;
+        if constexpr (SPLIT) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kEPT / RP; ++q)
+#pragma unroll
+                for (int m = 0; m < RP; ++m)
+                    ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].x;
+            __syncthreads();
+            double re[kEPT];
+#pragma unroll
+            for (int q = 0; q < kEPT / RN; ++q)
+#pragma unroll
+                for (int m = 0; m < RN; ++m) re[q * RN + m] = ldsd[lds_pad(t + q * Tr + m * (n / RN))];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kEPT / RP; ++q)
+#pragma unroll
+                for (int m = 0; m < RP; ++m)
+                    ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].y;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kEPT / RN; ++q)
+#pragma unroll
+                for (int m = 0; m < RN; ++m)
+                    v[q * RN + m] = mk(re[q * RN + m], ldsd[lds_pad(t + q * Tr + m * (n / RN))]);
+            return;
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < kEPT / RP; ++q)
@@ -233,6 +271,7 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
     }
     // ---- last stage: outputs straight to global ---------------------------------
     constexpr int RL = (R3 > 1) ? R3 : (R2 > 1) ? R2 : (R1 > 1) ? R1 : R0;
+    const auto sx = st.open(slot);
     if constexpr (Storer::kPair) {
         // Two real rows were transformed as one complex sequence z = x1 + i x2.  Put Z back
         // into LDS in natural order and let the storer separate X1[k], X2[k] from Z[k] and
@@ -246,7 +285,7 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
         __syncthreads();
         if (active) {
             for (int k = t; k <= n / 2; k += Tr)
-                st.pair(slot, k, lds[lds_pad(k)], lds[lds_pad((n - k) & (n - 1))]);
+                sx.pair(k, lds[lds_pad(k)], lds[lds_pad((n - k) & (n - 1))]);
         }
     } else {
         if (active) {
@@ -254,7 +293,7 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
             for (int q = 0; q < kEPT / RL; ++q)
 #pragma unroll
                 for (int m = 0; m < RL; ++m)
-                    st(slot, stockham_out_index<RL>(t, Tr, Ns, q, m), v[q * RL + m]);
+                    sx(stockham_out_index<RL>(t, Tr, Ns, q, m), v[q * RL + m]);
         }
     }
 }
@@ -279,20 +318,31 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
     sh.nslots = nslots;
     sh.tw = tw;
     const int64_t grid = ceil_div(nslots, sh.slots_per_block);
-    const size_t lds = (size_t)sh.slots_per_block * (size_t)(n + n / 16) * sizeof(cplx);
-#define SCINT_ROWS(R0, R1, R2, R3)                                                              \
+    static const int split_on = [] { const char* e = getenv("SCINT_FFT_SPLIT"); return e ? atoi(e) : 1; }();
+    constexpr bool kCanSplit = !Storer::kPair;
+    const bool split = kCanSplit && split_on && n <= 128;
+    const size_t lds = (size_t)sh.slots_per_block * (size_t)(n + n / 16) * (split ? sizeof(double) : sizeof(cplx));
+#define SCINT_ROWS_K(R0, R1, R2, R3, SP)                                                        \
     do {                                                                                        \
-        auto k = fft_rows_kernel<R0, R1, R2, R3, Loader, Storer>;                               \
+        auto k = fft_rows_kernel<R0, R1, R2, R3, SP, Loader, Storer>;                           \
         if (lds > 64 * 1024)                                                                    \
             SCINT_HIP(hipFuncSetAttribute((const void*)k,                                       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, sh, ld, st);      \
     } while (0)
+#define SCINT_ROWS(R0, R1, R2, R3) SCINT_ROWS_K(R0, R1, R2, R3, false)
+#define SCINT_ROWS_SHORT(R0, R1, R2, R3)                                                        \
+    do {                                                                                        \
+        if constexpr (kCanSplit) {                                                              \
+            if (split) { SCINT_ROWS_K(R0, R1, R2, R3, true); break; }                           \
+        }                                                                                       \
+        SCINT_ROWS_K(R0, R1, R2, R3, false);                                                    \
+    } while (0)
     switch (sh.log2n) {
         case 4: SCINT_ROWS(16, 1, 1, 1); break;
-        case 5: SCINT_ROWS(16, 2, 1, 1); break;
-        case 6: SCINT_ROWS(16, 4, 1, 1); break;
-        case 7: SCINT_ROWS(16, 8, 1, 1); break;
+        case 5: SCINT_ROWS_SHORT(16, 2, 1, 1); break;
+        case 6: SCINT_ROWS_SHORT(16, 4, 1, 1); break;
+        case 7: SCINT_ROWS_SHORT(16, 8, 1, 1); break;
         case 8: SCINT_ROWS(16, 16, 1, 1); break;
         case 9: SCINT_ROWS(16, 16, 2, 1); break;
         case 10: SCINT_ROWS(16, 16, 4, 1); break;
@@ -301,7 +351,9 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
         case 13: SCINT_ROWS(16, 16, 16, 2); break;
         default: SCINT_REQUIRE(false, "fft rows: unsupported length");
     }
+#undef SCINT_ROWS_SHORT
 #undef SCINT_ROWS
+#undef SCINT_ROWS_K
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
@@ -310,12 +362,12 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
 // cols: one DIF radix pass along the strided axis
 // ------------------------------------------------------------------------------
 struct ColPass {
-    int64_t ncols;      // contiguous extent handled by lanes
-    int64_t len;        // full FFT length R along the strided axis
-    int64_t block_len;  // Lp: current DIF block length
-    int64_t sub;        // S = Lp / radix
+    int ncols;          // contiguous extent handled by lanes
+    int len;            // full FFT length R along the strided axis
+    int block_len;      // Lp: current DIF block length
+    int sub;            // S = Lp / radix
     const cplx* tw;     // W_len table
-    int64_t tw_mult;    // len / Lp
+    int tw_mult;        // len / Lp
     // digit bookkeeping for the last pass: radices of the earlier passes (first pass
     // = least-significant digit of the output frequency index)
     int npre;
@@ -326,22 +378,23 @@ struct ColPass {
 // Loader: cplx ld(batch, row, col)   (row along the strided axis)
 // Storer: void st(batch, row, col, v)  -- row is the in-place row for inner passes
 //         and the NATURAL frequency index for the last pass.
+// Rows, columns and strides are 32-bit; the functors widen once for the element offset.
 template <int R, class Loader, class Storer>
 __global__ void __launch_bounds__(256)
 fft_cols_kernel(ColPass p, Loader ld, Storer st) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (col >= p.ncols) return;
-    const int64_t bf = blockIdx.y;         // butterfly id: b*S + s
+    const int bf = (int)blockIdx.y;        // butterfly id: b*S + s  (wave-uniform)
     const int64_t batch = blockIdx.z;
-    const int64_t b = bf / p.sub, s = bf - b * p.sub;
-    const int64_t row0 = b * p.block_len + s;
+    const int b = bf / p.sub, s = bf - b * p.sub;
+    const int row0 = b * p.block_len + s;
     cplx x[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) x[m] = ld(batch, row0 + m * p.sub, col);
     SmallFFT<R>::run(x);
     if (!p.last) {
         // twiddle W_Lp^{s k} (wave-uniform -> scalar loads), store in place
-        const int64_t step = s * p.tw_mult;
+        const int step = s * p.tw_mult;
         st(batch, row0, col, x[0]);
 #pragma unroll
         for (int k = 1; k < R; ++k) {
@@ -351,9 +404,9 @@ fft_cols_kernel(ColPass p, Loader ld, Storer st) {
     } else {
         // position digits of b (most significant first) are the earlier passes'
         // output indices k_1, k_2, ...; natural index = k_1 + R_1 k_2 + ... + (len/R) k_last
-        int64_t rem = b, scale = p.len / R, kbase = 0, weight = 1;
+        int rem = b, scale = p.len / R, kbase = 0, weight = 1;
         // decode from the least-significant position digit (the latest pass) upward
-        int64_t digits[6];
+        int digits[6];
         for (int i = p.npre - 1; i >= 0; --i) {
             digits[i] = rem % p.pre_radix[i];
             rem /= p.pre_radix[i];
@@ -412,59 +465,88 @@ int32_t launch_cols_pass(const ColPass& p, int64_t batches, Loader ld, Storer st
 // slot are consecutive sub-transform indices, so one wave instruction touches 16 adjacent
 // columns (256 contiguous bytes) of 4-8 rows -- whole cache lines in both directions.  The radix
 // passes of fft_cols_kernel need log16(L) trips instead of two; run_cols_fft picks per size.
+// Index arithmetic is 32-bit (rows, columns, strides and tile counts are far below 2^31; only the
+// final element offset is 64-bit): a 64-bit multiply is four quarter-rate instructions on CDNA, and
+// these kernels issue one address per 16-byte element.
+struct TileSlot {
+    int inner, col; int64_t batch; bool ok;
+};
+// Slot numbering of the tiled passes (c = column within the 16-column tile, fastest):
+//   tile-fast (default)  slot = (((batch << lbits | inner) * ntiles + tile) * 16 + c
+//       consecutive workgroups walk ALONG the rows of the array: the 64 slots of a workgroup are
+//       64 adjacent columns (1 KiB per row) and the workgroups in flight together cover a few
+//       contiguous multi-MiB row bands (DRAM pages and TLB entries get reused);
+//   inner-fast           slot = (((batch * ntiles + tile) << lbits | inner) * 16 + c
+//       a workgroup is one 256-byte tile of 4x as many rows (kept for comparison, SCINT_FFT_TILE_ORDER=0).
+__device__ inline TileSlot tile_slot(int64_t slot, int lbits, int ntiles, int ncols, int tile_fast) {
+    TileSlot s;
+    const uint32_t rest = (uint32_t)(slot >> 4), mask = (1u << lbits) - 1u;
+    uint32_t tile, batch;
+    if (tile_fast) {
+        const uint32_t q = rest / (uint32_t)ntiles;
+        tile = rest - q * (uint32_t)ntiles;
+        s.inner = (int)(q & mask);
+        batch = q >> lbits;
+    } else {
+        s.inner = (int)(rest & mask);
+        const uint32_t tb = rest >> lbits;
+        batch = tb / (uint32_t)ntiles;
+        tile = tb - batch * (uint32_t)ntiles;
+    }
+    s.batch = batch;
+    s.col = (int)tile * 16 + (int)(slot & 15);
+    s.ok = s.col < ncols;
+    return s;
+}
 template <class First>
 struct ColsALoad {
-    First first; int64_t ncols, ntiles; int l2;        // L2 = 1 << l2
-    __device__ inline cplx operator()(int64_t slot, int n1) const {
-        const int c = (int)(slot & 15);
-        int64_t rest = slot >> 4;
-        const int64_t n2 = rest & ((1 << l2) - 1);
-        rest >>= l2;
-        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
-        if (col >= ncols) return mk(0.0, 0.0);
-        return first(batch, ((int64_t)n1 << l2) + n2, col);
-    }
+    First first; int ncols, ntiles, tile_fast; int l2;        // L2 = 1 << l2
+    struct Slot {
+        const ColsALoad& p; TileSlot s;
+        __device__ inline cplx operator()(int n1) const {
+            if (!s.ok) return mk(0.0, 0.0);
+            return p.first(s.batch, (n1 << p.l2) + s.inner, s.col);
+        }
+    };
+    __device__ inline Slot open(int64_t slot) const { return Slot{*this, tile_slot(slot, l2, ntiles, ncols, tile_fast)}; }
 };
 template <class MidStorer>
 struct ColsAStore {
     static constexpr bool kPair = false;
-    MidStorer mid; int64_t ncols, ntiles; int l2; const cplx* tw;   // tw = W_L table
-    __device__ inline void operator()(int64_t slot, int k1, cplx v) const {
-        const int c = (int)(slot & 15);
-        int64_t rest = slot >> 4;
-        const int64_t n2 = rest & ((1 << l2) - 1);
-        rest >>= l2;
-        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
-        if (col >= ncols) return;
-        mid(batch, ((int64_t)k1 << l2) + n2, col, v * tw[n2 * k1]);
-    }
+    MidStorer mid; int ncols, ntiles, tile_fast; int l2; const cplx* tw;   // tw = W_L table
+    struct Slot {
+        const ColsAStore& p; TileSlot s;
+        __device__ inline void operator()(int k1, cplx v) const {
+            if (!s.ok) return;
+            p.mid(s.batch, (k1 << p.l2) + s.inner, s.col, v * p.tw[s.inner * k1]);
+        }
+    };
+    __device__ inline Slot open(int64_t slot) const { return Slot{*this, tile_slot(slot, l2, ntiles, ncols, tile_fast)}; }
 };
 template <class MidLoader>
 struct ColsBLoad {
-    MidLoader mid; int64_t ncols, ntiles; int l1, l2;
-    __device__ inline cplx operator()(int64_t slot, int n2) const {
-        const int c = (int)(slot & 15);
-        int64_t rest = slot >> 4;
-        const int64_t k1 = rest & ((1 << l1) - 1);
-        rest >>= l1;
-        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
-        if (col >= ncols) return mk(0.0, 0.0);
-        return mid(batch, (k1 << l2) + n2, col);
-    }
+    MidLoader mid; int ncols, ntiles, tile_fast; int l1, l2;
+    struct Slot {
+        const ColsBLoad& p; TileSlot s;
+        __device__ inline cplx operator()(int n2) const {
+            if (!s.ok) return mk(0.0, 0.0);
+            return p.mid(s.batch, (s.inner << p.l2) + n2, s.col);
+        }
+    };
+    __device__ inline Slot open(int64_t slot) const { return Slot{*this, tile_slot(slot, l1, ntiles, ncols, tile_fast)}; }
 };
 template <class LastStorer>
 struct ColsBStore {
     static constexpr bool kPair = false;
-    LastStorer last; int64_t ncols, ntiles; int l1;
-    __device__ inline void operator()(int64_t slot, int k2, cplx v) const {
-        const int c = (int)(slot & 15);
-        int64_t rest = slot >> 4;
-        const int64_t k1 = rest & ((1 << l1) - 1);
-        rest >>= l1;
-        const int64_t batch = rest / ntiles, col = (rest - batch * ntiles) * 16 + c;
-        if (col >= ncols) return;
-        last(batch, k1 + ((int64_t)k2 << l1), col, v);
-    }
+    LastStorer last; int ncols, ntiles, tile_fast; int l1;
+    struct Slot {
+        const ColsBStore& p; TileSlot s;
+        __device__ inline void operator()(int k2, cplx v) const {
+            if (!s.ok) return;
+            p.last(s.batch, s.inner + (k2 << p.l1), s.col, v);
+        }
+    };
+    __device__ inline Slot open(int64_t slot) const { return Slot{*this, tile_slot(slot, l1, ntiles, ncols, tile_fast)}; }
 };
 
 template <class Loader, class Storer>
@@ -477,6 +559,7 @@ template <class FirstLoader, class MidLoader, class MidStorer, class LastStorer>
 int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader first,
                      MidLoader mid_ld, MidStorer mid_st, LastStorer last, hipStream_t stream) {
     SCINT_REQUIRE(is_pow2(len) && len >= 2, "fft cols: length must be a power of two >= 2");
+    SCINT_REQUIRE(len <= (1 << 24) && ncols < (1 << 30), "fft cols: extent beyond the 32-bit index range");
     const cplx* tw = twiddle_table(len);
     if (!tw) return SCINT_E_HIP;
     // Measured on MI355X: while the working array fits the 256 MiB Infinity Cache the in-place radix
@@ -488,26 +571,28 @@ int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader fi
     if ((two_pass == 2 || (two_pass == 1 && beyond_cache)) && len >= 256 && len <= 16384) {
         const int l = ilog2(len), l2 = l / 2, l1 = l - l2;          // L1 >= L2, both in [16, 128]
         const int64_t ntiles = ceil_div(ncols, 16);
+        static const int tile_fast = [] { const char* e = getenv("SCINT_FFT_TILE_ORDER"); return e ? atoi(e) : 1; }();
+        SCINT_REQUIRE(batches * ntiles * 128 < ((int64_t)1 << 32), "fft cols: too many tile slots");
         int32_t rc = launch_fft_rows((int64_t)1 << l1, batches * ntiles * ((int64_t)1 << l2) * 16,
-                                     ColsALoad<FirstLoader>{first, ncols, ntiles, l2},
-                                     ColsAStore<MidStorer>{mid_st, ncols, ntiles, l2, tw}, stream);
+                                     ColsALoad<FirstLoader>{first, (int)ncols, (int)ntiles, tile_fast, l2},
+                                     ColsAStore<MidStorer>{mid_st, (int)ncols, (int)ntiles, tile_fast, l2, tw}, stream);
         if (rc != SCINT_OK) return rc;
         return launch_fft_rows((int64_t)1 << l2, batches * ntiles * ((int64_t)1 << l1) * 16,
-                               ColsBLoad<MidLoader>{mid_ld, ncols, ntiles, l1, l2},
-                               ColsBStore<LastStorer>{last, ncols, ntiles, l1}, stream);
+                               ColsBLoad<MidLoader>{mid_ld, (int)ncols, (int)ntiles, tile_fast, l1, l2},
+                               ColsBStore<LastStorer>{last, (int)ncols, (int)ntiles, tile_fast, l1}, stream);
     }
     ColPlan pl = make_col_plan(len);
-    int64_t Lp = len;
+    int Lp = (int)len;
     ColPass p;
-    p.ncols = ncols;
-    p.len = len;
+    p.ncols = (int)ncols;
+    p.len = (int)len;
     p.tw = tw;
     p.npre = 0;
     for (int i = 0; i < pl.npass; ++i) {
         const int R = pl.radix[i];
         p.block_len = Lp;
         p.sub = Lp / R;
-        p.tw_mult = len / Lp;
+        p.tw_mult = (int)len / Lp;
         p.last = (i == pl.npass - 1);
         int32_t rc = SCINT_OK;
 #define SCINT_COLS(RR)                                                                    \
@@ -533,15 +618,15 @@ int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader fi
 
 // ---- plain array accessors ------------------------------------------------------
 struct ArrayLoad {   // a[batch][row][col]
-    const cplx* a; int64_t ld; int64_t batch_stride;
-    __device__ inline cplx operator()(int64_t bt, int64_t r, int64_t c) const {
-        return a[bt * batch_stride + r * ld + c];
+    const cplx* a; int ld; int64_t batch_stride;
+    __device__ inline cplx operator()(int64_t bt, int r, int c) const {
+        return a[bt * batch_stride + ((int64_t)r * ld + c)];
     }
 };
 struct ArrayStore {
-    cplx* a; int64_t ld; int64_t batch_stride;
-    __device__ inline void operator()(int64_t bt, int64_t r, int64_t c, cplx v) const {
-        a[bt * batch_stride + r * ld + c] = v;
+    cplx* a; int ld; int64_t batch_stride;
+    __device__ inline void operator()(int64_t bt, int r, int c, cplx v) const {
+        a[bt * batch_stride + ((int64_t)r * ld + c)] = v;
     }
 };
 
