@@ -530,233 +530,9 @@ __global__ void __launch_bounds__(64) pk2_init_kernel(const PackedJob* jobs, con
     }
 }
 
-constexpr int kFlush2 = 2;     // column partials of the block kernel are reduced across the waves every 2 tiles
-
-// One workgroup per HALF strip: rows 32h .. 32h+31 of the tiles (I, J0..J1).  With two vectors the
-// row accumulators of 16 rows per wave would take 128 registers (256 in all: two waves per
-// SIMD); with 8 rows per wave the kernel fits three waves per SIMD -- three workgroups per CU
-// -- and streams faster.  Each wave keeps the 8 rows of the current tile and of the next one in
-// registers (16 independent 1-KiB wave loads in flight); column partials come per half tile and
-// the reduce kernel adds the two halves.
-__global__ void __launch_bounds__(256, 3)
-pk2h_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx cred[4][kFlush2][kTB][2];   // per-wave column partials of kFlush2 tiles, 2 vectors (16 KiB)
-    __shared__ cplx xs[kMaxStrip][kTB][2];      // the blocks X_J of the strip, rebuilt once per workgroup (32 KiB)
-    const Strip st = strips[blockIdx.x >> 1];
-    const int h = blockIdx.x & 1;
-    const PackedJob* __restrict__ jp = jobs + st.job;
-    const int step = launch - jp->start;
-    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
-    const int par = step & 1;
-    const int nb = jp->nb;
-    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
-    const int qs = jp->qslots;
-    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride * 2;   // Q_{j-1}
-    const cplx* __restrict__ tiles = jp->tiles;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int I = st.I;
-    const int64_t t0 = tile_offset(nb, I);
-    const int ntile = st.J1 - st.J0;
-    const int row0 = 32 * h + 8 * w;                       // this wave's 8 rows inside the tile
-    const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + row0 * kTB + lane;
-    cplx a0[8], a1[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
-    const Blk2 sc = uniform_blk(step_block_wave(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
-    // lanes 0..31 of every wave hold rows 32h .. 32h+31 of the block X_I (both vectors); rows read them
-    // back with v_readlane
-    cplx xI1, xI2;
-    {
-        const int r = I * kTB + 32 * h + (lane & 31);
-        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), xI1, xI2);
-    }
-    // X_J = rows J0*64 .. J1*64 of Q_j, once per workgroup (the first tile's loads stay in flight)
-    for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
-        const int r = st.J0 * kTB + idx;
-        cplx x1, x2;
-        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), x1, x2);
-        xs[idx >> 6][idx & 63][0] = x1;
-        xs[idx >> 6][idx & 63][1] = x2;
-    }
-    __syncthreads();
-    cplx acc1[8], acc2[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
-    cplx* __restrict__ colpart = jp->colpart;
-    // one tile: 8 rows x 64 columns of this wave against both vectors
-    auto tile_step = [&](const cplx (&a)[8], int t) {
-        const cplx xJ1 = xs[t][lane][0], xJ2 = xs[t][lane][1];
-        cplx c1 = mk(0.0, 0.0), c2 = mk(0.0, 0.0);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            acc1[r] = acc1[r] + a[r] * xJ1;
-            acc2[r] = acc2[r] + a[r] * xJ2;
-            const cplx x1 = mk(readlane_f64(xI1.x, 8 * w + r), readlane_f64(xI1.y, 8 * w + r));
-            const cplx x2 = mk(readlane_f64(xI2.x, 8 * w + r), readlane_f64(xI2.y, 8 * w + r));
-            c1 = mk(c1.x + a[r].x * x1.x + a[r].y * x1.y, c1.y + a[r].x * x1.y - a[r].y * x1.x);   // conj(a) x_I
-            c2 = mk(c2.x + a[r].x * x2.x + a[r].y * x2.y, c2.y + a[r].x * x2.y - a[r].y * x2.x);
-        }
-        cred[w][t & (kFlush2 - 1)][lane][0] = c1;   // this wave's own slot
-        cred[w][t & (kFlush2 - 1)][lane][1] = c2;
-        if ((t & (kFlush2 - 1)) == kFlush2 - 1 || t + 1 == ntile) {
-            // cross-wave reduction of the last <= kFlush2 tiles' column partials: waves 0,1 take
-            // vector 0 / 1 of the first tile, waves 2,3 of the second
-            __syncthreads();
-            const int tb = t & ~(kFlush2 - 1);
-            const int tt = tb + (w >> 1), v = w & 1;
-            if (tt <= t) {
-                const int Jt = st.J0 + tt;
-                if (Jt != I) {
-                    const int k = w >> 1;
-                    const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
-                    gstore(colpart + 2 * (((t0 + (Jt - I)) * 2 + h) * kTB + lane) + v, sum);
-                }
-            }
-            __syncthreads();
-        }
-    };
-#pragma unroll 1
-    for (int t = 0; t < ntile; t += 2) {
-        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
-        if (t + 1 < ntile) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a1[r] = gload_nt(tc + kTileElems + r * kTB);       // tile t + 1
-        }
-        tile_step(a0, t);
-        if (t + 1 < ntile) {
-            if (t + 2 < ntile) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + 2 * kTileElems + r * kTB);   // tile t + 2
-            }
-            tile_step(a1, t + 1);
-        }
-    }
-    cplx* __restrict__ rowpart = jp->rowpart;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const cplx s1 = wave_sum(acc1[r]), s2 = wave_sum(acc2[r]);
-        if (lane == 0) {
-            gstore(rowpart + 2 * ((int64_t)st.index * kTB + row0 + r), s1);
-            gstore(rowpart + 2 * ((int64_t)st.index * kTB + row0 + r) + 1, s2);
-        }
-    }
-}
-
-// One workgroup per strip, TWO sweeps over its tiles: wave w owns rows 16w .. 16w+15 of the tiles
-// but accumulates only 8 of them per sweep (rows 16w + 8h + r in sweep h), so the row accumulators
-// take 64 registers instead of 128 and three workgroups fit a CU; every half tile is still loaded
-// exactly once, the X_J blocks are staged once per workgroup, column partials come per half
-// (the reduce kernel adds them).  SCINT_MV2_HALF=2.
-__global__ void __launch_bounds__(256, 3)
-pk2s_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx cred[4][kFlush2][kTB][2];   // per-wave column partials of kFlush2 tiles, 2 vectors (16 KiB)
-    __shared__ cplx xs[kMaxStrip][kTB][2];      // the blocks X_J of the strip, rebuilt once per workgroup (32 KiB)
-    const Strip st = strips[blockIdx.x];
-    const PackedJob* __restrict__ jp = jobs + st.job;
-    const int step = launch - jp->start;
-    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
-    const int par = step & 1;
-    const int nb = jp->nb;
-    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
-    const int qs = jp->qslots;
-    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride * 2;   // Q_{j-1}
-    const cplx* __restrict__ tiles = jp->tiles;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int I = st.I;
-    const int64_t t0 = tile_offset(nb, I);
-    const int ntile = st.J1 - st.J0;
-    const cplx* __restrict__ tp0 = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
-    cplx a0[8], a1[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp0 + r * kTB);
-    const Blk2 sc = uniform_blk(step_block_wave(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
-    // lane l of every wave holds row l of the block X_I (both vectors); rows read it back with v_readlane
-    cplx xI1, xI2;
-    {
-        const int r = I * kTB + lane;
-        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), xI1, xI2);
-    }
-    // X_J = rows J0*64 .. J1*64 of Q_j, once per workgroup (the first tile's loads stay in flight)
-    for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
-        const int r = st.J0 * kTB + idx;
-        cplx x1, x2;
-        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), x1, x2);
-        xs[idx >> 6][idx & 63][0] = x1;
-        xs[idx >> 6][idx & 63][1] = x2;
-    }
-    __syncthreads();
-    cplx* __restrict__ colpart = jp->colpart;
-    cplx* __restrict__ rowpart = jp->rowpart;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-        const int row0 = 16 * w + 8 * h;                   // this sweep's 8 rows inside the tile
-        const cplx* __restrict__ tp = tp0 + (8 * h) * kTB;
-        if (h == 1) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
-        }
-        cplx acc1[8], acc2[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
-        // one tile: 8 rows x 64 columns of this wave against both vectors
-        auto tile_step = [&](const cplx (&a)[8], int t) {
-            const cplx xJ1 = xs[t][lane][0], xJ2 = xs[t][lane][1];
-            cplx c1 = mk(0.0, 0.0), c2 = mk(0.0, 0.0);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                acc1[r] = acc1[r] + a[r] * xJ1;
-                acc2[r] = acc2[r] + a[r] * xJ2;
-                const cplx x1 = mk(readlane_f64(xI1.x, row0 + r), readlane_f64(xI1.y, row0 + r));
-                const cplx x2 = mk(readlane_f64(xI2.x, row0 + r), readlane_f64(xI2.y, row0 + r));
-                c1 = mk(c1.x + a[r].x * x1.x + a[r].y * x1.y, c1.y + a[r].x * x1.y - a[r].y * x1.x);   // conj(a) x_I
-                c2 = mk(c2.x + a[r].x * x2.x + a[r].y * x2.y, c2.y + a[r].x * x2.y - a[r].y * x2.x);
-            }
-            cred[w][t & (kFlush2 - 1)][lane][0] = c1;   // this wave's own slot
-            cred[w][t & (kFlush2 - 1)][lane][1] = c2;
-            if ((t & (kFlush2 - 1)) == kFlush2 - 1 || t + 1 == ntile) {
-                __syncthreads();
-                const int tb = t & ~(kFlush2 - 1);
-                const int tt = tb + (w >> 1), v = w & 1;
-                if (tt <= t) {
-                    const int Jt = st.J0 + tt;
-                    if (Jt != I) {
-                        const int k = w >> 1;
-                        const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
-                        gstore(colpart + 2 * (((t0 + (Jt - I)) * 2 + h) * kTB + lane) + v, sum);
-                    }
-                }
-                __syncthreads();
-            }
-        };
-#pragma unroll 1
-        for (int t = 0; t < ntile; t += 2) {
-            const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
-            if (t + 1 < ntile) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) a1[r] = gload_nt(tc + kTileElems + r * kTB);       // tile t + 1
-            }
-            tile_step(a0, t);
-            if (t + 1 < ntile) {
-                if (t + 2 < ntile) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + 2 * kTileElems + r * kTB);   // tile t + 2
-                }
-                tile_step(a1, t + 1);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const cplx s1 = wave_sum(acc1[r]), s2 = wave_sum(acc2[r]);
-            if (lane == 0) {
-                gstore(rowpart + 2 * ((int64_t)st.index * kTB + row0 + r), s1);
-                gstore(rowpart + 2 * ((int64_t)st.index * kTB + row0 + r) + 1, s2);
-            }
-        }
-    }
-}
-
-// The full-strip form (16 rows per wave, 256 registers, two waves per SIMD, two workgroups per CU):
-// the default -- measured faster than the half-strip form above (1183 vs 1075 eta/s).
+// 16 rows per wave, 256 registers, two waves per SIMD, two workgroups per CU.  Two other shapes
+// were measured and removed: half strips (8 rows per wave, 168 registers, three waves per SIMD:
+// 1075 eta/s against 1183) and two sweeps per strip (1147 eta/s); DESIGN.md section 6.
 constexpr int kFlushF = 4;     // its column partials are reduced across the waves every 4 tiles (a barrier pair each)
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
@@ -871,12 +647,10 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     // fixed summation order as in pk_reduce_kernel, for both vectors
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc1 = mk(0.0, 0.0), acc2 = mk(0.0, 0.0);
-    const int halves = jb.pad1;                                     // column partials per tile: 2 (half-strip mat-vec) or 1
-    for (int idx = g; idx < nrow + halves * K; idx += kRedGroups) {
-        const int ci = idx - nrow;                                  // column partial ci: tile (ci / halves, K), half ci % halves
-        const int cI = ci / halves, ch = ci - cI * halves;
+    for (int idx = g; idx < nrow + K; idx += kRedGroups) {
+        const int cI = idx - nrow;                                  // column partial of tile (cI, K)
         const cplx* src = idx < nrow ? jb.rowpart + 2 * ((int64_t)(s0 + idx) * kTB + e)
-                                     : jb.colpart + 2 * (((tile_offset(jb.nb, cI) + (K - cI)) * halves + ch) * kTB + e);
+                                     : jb.colpart + 2 * ((tile_offset(jb.nb, cI) + (K - cI)) * kTB + e);
         acc1 = acc1 + gload(src);
         acc2 = acc2 + gload(src + 1);
     }
@@ -1166,7 +940,7 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
     L.svec = take(sizeof(cplx) * 2 * (size_t)(max_steps + 2));    // eigenvector of T_k (complex, 2 per block step)
     L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
-    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw * 2);   // two half-tile partials per tile (block kernel)
+    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
     L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
     L.apart1 = take(sizeof(double) * (size_t)nbmax * sc);
@@ -1282,7 +1056,6 @@ struct SweepProblem {
     bool want_vec; cplx* vec_out; int64_t vstride;
     SweepTail* tail_hook; hipStream_t tail[2]; int tail_rr = 0;   // retired curvatures alternate between two tail streams
     int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1 or 2)
-    int mv_half;                                       // block mat-vec: 0 full strips, 1 half strips, 2 two sweeps per strip
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1466,11 +1239,7 @@ struct SweepGroup {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
                 const int slot = profiler().begin(kProfMatvec, stream);
-                if (S.block == 2 && S.mv_half == 2)
-                    hipLaunchKernelGGL(pk2s_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
-                else if (S.block == 2 && S.mv_half == 1)
-                    hipLaunchKernelGGL(pk2h_matvec_kernel, dim3(2u * (unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
-                else if (S.block == 2)
+                if (S.block == 2)
                     hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 else
                     hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
@@ -1564,8 +1333,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     const char* block_env = getenv("SCINT_LANCZOS_BLOCK");
     S.block = (block_env && atoi(block_env) == 1) ? 1 : 2;
-    const char* half_env = getenv("SCINT_MV2_HALF");
-    S.mv_half = half_env ? atoi(half_env) : 0;        // half strips measured slower than full strips (1075 vs 1183 eta/s)
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
@@ -1633,7 +1400,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.tol = tol; J.gen = 0;
             J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
             J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
-            J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = S.mv_half ? 2 : 1;   // column partials per tile
+            J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
             J.eig_out = eigs_out; J.status_out = status_out; J.iters_out = iters_out;
         }
     }

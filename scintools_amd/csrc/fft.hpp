@@ -174,7 +174,8 @@ __device__ inline int stockham_out_index(int t, int Tr, int Ns, int q, int m) {
 // n doubles per slot instead of n complex values.  These kernels' occupancy is set by LDS (a slot
 // needs its whole transform there), so halving it doubles the waves per CU -- worth two more
 // barriers per exchange for the short transforms of the tiled column passes, which are pure
-// streaming.  Not available with pair storers (they read complex values back from LDS).
+// streaming (sspec 4096^2: 0.81 -> 0.76 ms).  Measured with every length split (incl. the pair
+// storers): no gain for the long row transforms, so only lengths 32..128 are instantiated split.
 template <int R0, int R1, int R2, int R3, bool SPLIT, class Loader, class Storer>
 __global__ void __launch_bounds__(512)
 fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
@@ -309,18 +310,17 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
     sh.n = (int)n;
     sh.log2n = ilog2(n);
     sh.threads_per_slot = (int)(n / kEPT);
-    // short transforms (the 16..128-point steps of the tiled column passes, short rows): 128-thread
-    // workgroups hold 35 KiB of LDS instead of 70, so four of them fit a CU instead of two
-    static const int small_block = [] { const char* e = getenv("SCINT_FFT_SMALL_BLOCK"); return e ? atoi(e) : 1; }();
-    const int min_block = (small_block && n <= 128) ? 128 : 256;
+    // short transforms (the 16..128-point steps of the tiled column passes, short rows) run in
+    // 128-thread workgroups (17 KiB of LDS with the split exchange), longer ones in >= 256 threads
+    const int min_block = n <= 128 ? 128 : 256;
     const int block = sh.threads_per_slot >= min_block ? sh.threads_per_slot : min_block;
     sh.slots_per_block = block / sh.threads_per_slot;
     sh.nslots = nslots;
     sh.tw = tw;
     const int64_t grid = ceil_div(nslots, sh.slots_per_block);
+    // SCINT_FFT_SPLIT=0 turns the split exchange of the short transforms off (experiments)
     static const int split_on = [] { const char* e = getenv("SCINT_FFT_SPLIT"); return e ? atoi(e) : 1; }();
-    constexpr bool kCanSplit = !Storer::kPair;
-    const bool split = kCanSplit && split_on && n <= 128;
+    const bool split = split_on && n >= 32 && n <= 128 && !Storer::kPair;
     const size_t lds = (size_t)sh.slots_per_block * (size_t)(n + n / 16) * (split ? sizeof(double) : sizeof(cplx));
 #define SCINT_ROWS_K(R0, R1, R2, R3, SP)                                                        \
     do {                                                                                        \
@@ -333,7 +333,7 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
 #define SCINT_ROWS(R0, R1, R2, R3) SCINT_ROWS_K(R0, R1, R2, R3, false)
 #define SCINT_ROWS_SHORT(R0, R1, R2, R3)                                                        \
     do {                                                                                        \
-        if constexpr (kCanSplit) {                                                              \
+        if constexpr (!Storer::kPair) {                                                         \
             if (split) { SCINT_ROWS_K(R0, R1, R2, R3, true); break; }                           \
         }                                                                                       \
         SCINT_ROWS_K(R0, R1, R2, R3, false);                                                    \

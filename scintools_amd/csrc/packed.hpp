@@ -43,7 +43,7 @@ struct PackedJob {
     double eta, two_eta;
     const cplx* cs;         // conjugate spectrum this job reads (one per chunk/observation)
     const double* th;       // [M] theta centres of that chunk
-    int32_t geom, pad1;     // index into the launch's GeomDev table; pad1: column partials per tile (block mat-vec)
+    int32_t geom, pad1;     // index into the launch's GeomDev table
     const int32_t* keep;    // [n] indices into th
     int32_t n, nb;
     cplx* tiles;            // [tile_count(nb)][64][64]

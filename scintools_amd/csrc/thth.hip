@@ -248,7 +248,6 @@ struct RevParams {
     int64_t centre;   // flat index of the pixel the i == j terms poison, or -1
     cplx* recov;      // [ntau, nfd], or its transpose [nfd, ntau] when `transposed`
     int transposed;   // column-major output: every workgroup writes one contiguous run (chi^2 sweep)
-    int lo_grid;      // keep the second (fine) accumulation grid; 0: experiments only
     const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
 };
 
@@ -439,11 +438,9 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
             const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
             atomicAdd(&rev_lds[by], rh);
             atomicAdd(&rev_lds[2 * slab + by], ih);
-            if (p.lo_grid) {
-                const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
-                atomicAdd(&rev_lds[slab + by], rl);
-                atomicAdd(&rev_lds[3 * slab + by], il);
-            }
+            const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
+            atomicAdd(&rev_lds[slab + by], rl);
+            atomicAdd(&rev_lds[3 * slab + by], il);
         } else {
             atomicAdd(&rev_lds[by], wr); atomicAdd(&rev_lds[2 * slab + by], wi);
         }
@@ -514,7 +511,6 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     p.centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
     p.recov = recov;
     p.transposed = 0;
-    p.lo_grid = 1;
     p.bound = nullptr;
     return p;
 }
@@ -530,21 +526,13 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     p.bound = bound;
     // equal slabs, the fewest that fit the LDS (a 4096-row conjugate spectrum is ONE slab: no pair is
     // looked at twice); the accumulators of a slab take more than the default 64 KiB of dynamic LDS
-    static const int small = [] { const char* e = getenv("SCINT_REV_SMALL"); return e ? atoi(e) : 0; }();   // experiments
-    static const int nolo = [] { const char* e = getenv("SCINT_REV_NOLO"); return e ? atoi(e) : 0; }();
-    if (nolo) p.lo_grid = 0;
-    const int64_t slab_max = small ? 1792 : kRevSlab;
-    p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, slab_max));
+    p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    if (small) {
-        hipLaunchKernelGGL(rev_gather_kernel<256>, grid, dim3(256), (size_t)p.slab * 36, stream, p, g);
-    } else {
-        static const hipError_t lds_ok = hipFuncSetAttribute((const void*)rev_gather_kernel<1024>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, kRevSlab * 36);
-        SCINT_HIP(lds_ok);
-        hipLaunchKernelGGL(rev_gather_kernel<1024>, grid, dim3(1024), (size_t)p.slab * 36, stream, p, g);
-    }
+    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)rev_gather_kernel<1024>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRevSlab * 36);
+    SCINT_HIP(lds_ok);
+    hipLaunchKernelGGL(rev_gather_kernel<1024>, grid, dim3(1024), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

@@ -17,6 +17,7 @@ reference ``Dynspec``, or plain arrays) with
 Cleaning, velocity / trapezoid rescaling and plotting are out of scope.
 """
 import ctypes
+import functools
 import os
 import warnings
 
@@ -46,6 +47,26 @@ def get_window(nt, nf, window="hanning", frac=0.1):
     return chan_window, subint_window
 
 
+@functools.lru_cache(maxsize=32)
+def _window_tables(nt, nf, window, frac, device):
+    """The two taper vectors in HBM, kept per (shape, window, device): a repeated calc_sspec (the
+    per-chunk loops of fit_thetatheta / the arc fits) re-uses them instead of rebuilding and
+    uploading them on every call."""
+    if window is None:
+        return None, None
+    cw, sw = get_window(nt, nf, window=window, frac=frac)
+    return to_device(cw, torch.float64), to_device(sw, torch.float64)
+
+
+@functools.lru_cache(maxsize=32)
+def _postdark_tables(nrfft, ncfft, device):
+    """Post-darkening factors of the prewhitened spectrum (dynspec.py:3700-3714), per device."""
+    fd = np.array(list(range(int(-ncfft / 2), int(ncfft / 2))))
+    td = np.array(list(range(0, int(nrfft / 2))))
+    return (to_device(np.power(np.sin(np.multiply(sc.pi / ncfft, fd)), 2), torch.float64),
+            to_device(np.power(np.sin(np.multiply(sc.pi / nrfft, td)), 2), torch.float64))
+
+
 def sspec_device(dyn_t, prewhite=False, halve=True, window="hanning", window_frac=0.1):
     """Secondary spectrum of a device dynamic spectrum [nf, nt] float64 -> device
     tensor in dB, shape [(nrfft/2 if halve else nrfft), ncfft] (dynspec.py:3665-3721)."""
@@ -56,15 +77,8 @@ def sspec_device(dyn_t, prewhite=False, halve=True, window="hanning", window_fra
     ncfft = int(2 ** (np.ceil(np.log2(nt)) + 1))      # dynspec.py:3678
     if prewhite and not halve:
         raise RuntimeError("Cannot apply prewhite to full frame")   # dynspec.py:3717
-    wt = wf = pd_fd = pd_td = None
-    if window is not None:
-        cw, sw = get_window(nt, nf, window=window, frac=window_frac)
-        wt, wf = to_device(cw, torch.float64), to_device(sw, torch.float64)
-    if prewhite:
-        fd = np.array(list(range(int(-ncfft / 2), int(ncfft / 2))))
-        td = np.array(list(range(0, int(nrfft / 2))))
-        pd_fd = to_device(np.power(np.sin(np.multiply(sc.pi / ncfft, fd)), 2), torch.float64)
-        pd_td = to_device(np.power(np.sin(np.multiply(sc.pi / nrfft, td)), 2), torch.float64)
+    wt, wf = _window_tables(nt, nf, window, window_frac, torch.cuda.current_device())
+    pd_fd, pd_td = _postdark_tables(nrfft, ncfft, torch.cuda.current_device()) if prewhite else (None, None)
     need = ctypes.c_size_t()
     _lib.check(lib.scint_sspec_workspace_bytes(nf, nt, ctypes.byref(need)), "sspec_workspace_bytes")
     ws = workspace.get(need.value)
