@@ -629,25 +629,20 @@ struct DecimStore {
     }
 };
 
-// FFT of power-of-two length n of `nrows` rows produced by `in`, into dst[row][0..n)
-// (row stride ld).  dst must not alias what `in` reads when n > 8192.
-static int32_t rows_fft_pow2(const RowSource& in, int64_t nrows, int64_t n, cplx* dst, int64_t ld,
-                             hipStream_t stream) {
+// FFT of power-of-two length n of `nrows` rows produced by the source functor `src` (value at
+// (row, j)), into dst[row][0..n) (row stride ld).  dst must not alias what `src` reads when n > 8192.
+template <class Src>
+static int32_t rows_fft_src(Src src, int64_t nrows, int64_t n, cplx* dst, int64_t ld, hipStream_t stream) {
     SCINT_REQUIRE(is_pow2(n) && n >= 16, "rows_fft: n must be a power of two >= 16");
     SCINT_REQUIRE(nrows < (1 << 30) && ld < (1 << 30), "rows_fft: extent beyond the 32-bit index range");
-    if (n <= 8192)
-        return with_source(in, [&](auto src) {
-            return launch_fft_rows(n, nrows, SlotIsRow<decltype(src)>{src}, RowStoreC{dst, (int)ld}, stream);
-        });
+    if (n <= 8192) return launch_fft_rows(n, nrows, SlotIsRow<Src>{src}, RowStoreC{dst, (int)ld}, stream);
     const int64_t n2 = 4096, n1 = n / n2;
     SCINT_REQUIRE(n1 <= 32, "rows_fft: n too large (max 131072)");
     SCINT_REQUIRE(nrows * n1 < ((int64_t)1 << 32), "rows_fft: too many decimated rows");
     const cplx* tw_n = twiddle_table(n);
     if (!tw_n) return SCINT_E_HIP;
-    int32_t rc = with_source(in, [&](auto src) {
-        return launch_fft_rows(n2, nrows * n1, DecimLoad<decltype(src)>{src, (int)n1},
-                               DecimStore{dst, (int)ld, (int)n1, (int)n2, tw_n}, stream);
-    });
+    int32_t rc = launch_fft_rows<12, 12>(n2, nrows * n1, DecimLoad<Src>{src, (int)n1},
+                                         DecimStore{dst, (int)ld, (int)n1, (int)n2, tw_n}, stream);
     if (rc != SCINT_OK) return rc;
     // radix-n1 pass over j1 (stride n2) for every (row, k2): view dst as [nrows][n1][n2];
     // grid.z is limited to 65535, so chunk the rows
@@ -660,6 +655,33 @@ static int32_t rows_fft_pow2(const RowSource& in, int64_t nrows, int64_t n, cplx
     }
     return SCINT_OK;
 }
+static int32_t rows_fft_pow2(const RowSource& in, int64_t nrows, int64_t n, cplx* dst, int64_t ld,
+                             hipStream_t stream) {
+    return with_source(in, [&](auto src) { return rows_fft_src(src, nrows, n, dst, ld, stream); });
+}
+
+// Real rows longer than the in-LDS limit, two at a time: z[s] = x[2s] + i x[2s+1] goes through the
+// (decimated) row transform at full width; the first strided pass separates
+//   X_{2s}[c] = (Z[c] + conj Z[C-c]) / 2,   X_{2s+1}[c] = (Z[c] - conj Z[C-c]) / (2i),   c <= C/2
+// while it loads (two reads per value: the row-transform result is read exactly once in all).
+template <class Src>
+struct PairRows {
+    Src in; int nrows;
+    __device__ inline cplx operator()(int s, int j) const {
+        const int r0 = 2 * s;
+        return mk(in(r0, j).x, r0 + 1 < nrows ? in(r0 + 1, j).x : 0.0);
+    }
+};
+struct PairSplitSource {
+    const cplx* z; int ld; int C; int nvalid; double fill0;
+    __device__ inline cplx operator()(int64_t, int r, int c) const {
+        if (r >= nvalid) return mk(c == 0 ? fill0 : 0.0, 0.0);
+        const cplx* row = z + (int64_t)(r >> 1) * ld;
+        const cplx zk = row[c], zc = conj(row[c == 0 ? 0 : C - c]);
+        return (r & 1) ? mk(0.5 * (zk.y - zc.y), -0.5 * (zk.x - zc.x))
+                       : mk(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+    }
+};
 
 // ------------------------------------------------------------------------------
 // generic 2-D driver
@@ -725,6 +747,23 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
         });
         if (rc != SCINT_OK) return rc;
         ColSourcePlain hs{rowA, ChL, (int)nvalid, fill0};
+        sink.R = (int)R; sink.C = (int)C; sink.col_post_w = nullptr; sink.col_post_scale = 1.0; sink.half = 1;
+        ArrayLoad mid_ld{colA, ChL, 0};
+        ArrayStore mid_st{colA, ChL, 0};
+        return with_sink(sink, [&](auto sk) { return run_cols_fft(R, Ch, 1, hs, mid_ld, mid_st, sk, stream); });
+    }
+
+    if (real_input && !p.blue_r && !p.blue_c && C > 8192 && R >= 2) {
+        // long real rows (C = 16384 .. 131072): pairs of rows through the decimated row transform
+        const int64_t Ch = C / 2 + 1;
+        const int ChL = (int)((Ch + 7) & ~(int64_t)7);
+        src.n_in = (int)C;
+        src.chirp = nullptr;
+        rc = with_source(src, [&](auto s) {
+            return rows_fft_src(PairRows<decltype(s)>{s, (int)nvalid}, (nvalid + 1) / 2, C, rowA, C, stream);
+        });
+        if (rc != SCINT_OK) return rc;
+        PairSplitSource hs{rowA, (int)C, (int)C, (int)nvalid, fill0};
         sink.R = (int)R; sink.C = (int)C; sink.col_post_w = nullptr; sink.col_post_scale = 1.0; sink.half = 1;
         ArrayLoad mid_ld{colA, ChL, 0};
         ArrayStore mid_st{colA, ChL, 0};
@@ -885,7 +924,7 @@ static int32_t model_from_recov(const cplx* recov, int64_t R, int64_t C, double*
     int32_t rc = run_cols_fft(R, Ch, 1, ModelSymSource{recov, (int)R, (int)C}, mid_ld, mid_st, last, stream);
     if (rc != SCINT_OK) return rc;
     const int64_t rows_out = std::min<int64_t>(crop_r, R);
-    return launch_fft_rows(C, (rows_out + 1) / 2, HermPairLoad{half, ChL, (int)C},
+    return launch_fft_rows<5, 13>(C, (rows_out + 1) / 2, HermPairLoad{half, ChL, (int)C},
                            RealPairStore{out, (int)ld, (int)crop_r, (int)crop_c, scale}, stream);
 }
 

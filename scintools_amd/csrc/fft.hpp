@@ -299,8 +299,10 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
     }
 }
 
-// Host-side launcher: picks the stage sequence for n and launches.
-template <class Loader, class Storer>
+// Host-side launcher: picks the stage sequence for n and launches.  LO..HI bounds log2(n) at compile
+// time: only those kernels are instantiated for the (Loader, Storer) pair (the tiled column passes
+// use 16..128 points, the decimated long rows 4096).
+template <int LO = 4, int HI = 13, class Loader, class Storer>
 int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStream_t stream) {
     SCINT_REQUIRE(is_pow2(n) && n >= 16 && n <= 8192, "fft rows: n must be a power of two in [16, 8192]");
     if (nslots <= 0) return SCINT_OK;
@@ -338,19 +340,25 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
         }                                                                                       \
         SCINT_ROWS_K(R0, R1, R2, R3, false);                                                    \
     } while (0)
+#define SCINT_CASE(L, MAC, R0, R1, R2, R3)                                                      \
+    case L:                                                                                     \
+        if constexpr (LO <= L && L <= HI) { MAC(R0, R1, R2, R3); }                               \
+        else { SCINT_REQUIRE(false, "fft rows: length outside the instantiated range"); }       \
+        break;
     switch (sh.log2n) {
-        case 4: SCINT_ROWS(16, 1, 1, 1); break;
-        case 5: SCINT_ROWS_SHORT(16, 2, 1, 1); break;
-        case 6: SCINT_ROWS_SHORT(16, 4, 1, 1); break;
-        case 7: SCINT_ROWS_SHORT(16, 8, 1, 1); break;
-        case 8: SCINT_ROWS(16, 16, 1, 1); break;
-        case 9: SCINT_ROWS(16, 16, 2, 1); break;
-        case 10: SCINT_ROWS(16, 16, 4, 1); break;
-        case 11: SCINT_ROWS(16, 16, 8, 1); break;
-        case 12: SCINT_ROWS(16, 16, 16, 1); break;
-        case 13: SCINT_ROWS(16, 16, 16, 2); break;
+        SCINT_CASE(4, SCINT_ROWS, 16, 1, 1, 1)
+        SCINT_CASE(5, SCINT_ROWS_SHORT, 16, 2, 1, 1)
+        SCINT_CASE(6, SCINT_ROWS_SHORT, 16, 4, 1, 1)
+        SCINT_CASE(7, SCINT_ROWS_SHORT, 16, 8, 1, 1)
+        SCINT_CASE(8, SCINT_ROWS, 16, 16, 1, 1)
+        SCINT_CASE(9, SCINT_ROWS, 16, 16, 2, 1)
+        SCINT_CASE(10, SCINT_ROWS, 16, 16, 4, 1)
+        SCINT_CASE(11, SCINT_ROWS, 16, 16, 8, 1)
+        SCINT_CASE(12, SCINT_ROWS, 16, 16, 16, 1)
+        SCINT_CASE(13, SCINT_ROWS, 16, 16, 16, 2)
         default: SCINT_REQUIRE(false, "fft rows: unsupported length");
     }
+#undef SCINT_CASE
 #undef SCINT_ROWS_SHORT
 #undef SCINT_ROWS
 #undef SCINT_ROWS_K
@@ -549,9 +557,6 @@ struct ColsBStore {
     __device__ inline Slot open(int64_t slot) const { return Slot{*this, tile_slot(slot, l1, ntiles, ncols, tile_fast)}; }
 };
 
-template <class Loader, class Storer>
-int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStream_t stream);
-
 // Runs a strided-axis FFT.  `first` loads the source, `mid_ld/mid_st` are the plain in-place
 // accessors of the working array, `last` stores the final (natural-order) result.
 // Lengths >= 256: two tiled passes (above); shorter ones: radix passes of fft_cols_kernel.
@@ -573,11 +578,11 @@ int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader fi
         const int64_t ntiles = ceil_div(ncols, 16);
         static const int tile_fast = [] { const char* e = getenv("SCINT_FFT_TILE_ORDER"); return e ? atoi(e) : 1; }();
         SCINT_REQUIRE(batches * ntiles * 128 < ((int64_t)1 << 32), "fft cols: too many tile slots");
-        int32_t rc = launch_fft_rows((int64_t)1 << l1, batches * ntiles * ((int64_t)1 << l2) * 16,
+        int32_t rc = launch_fft_rows<4, 7>((int64_t)1 << l1, batches * ntiles * ((int64_t)1 << l2) * 16,
                                      ColsALoad<FirstLoader>{first, (int)ncols, (int)ntiles, tile_fast, l2},
                                      ColsAStore<MidStorer>{mid_st, (int)ncols, (int)ntiles, tile_fast, l2, tw}, stream);
         if (rc != SCINT_OK) return rc;
-        return launch_fft_rows((int64_t)1 << l2, batches * ntiles * ((int64_t)1 << l1) * 16,
+        return launch_fft_rows<4, 7>((int64_t)1 << l2, batches * ntiles * ((int64_t)1 << l1) * 16,
                                ColsBLoad<MidLoader>{mid_ld, (int)ncols, (int)ntiles, tile_fast, l1, l2},
                                ColsBStore<LastStorer>{last, (int)ncols, (int)ntiles, tile_fast, l1}, stream);
     }

@@ -268,6 +268,36 @@ def test_sspec_vs_reference_golden(golden):
     assert np.abs(lin - lref).max() <= 1e-5 * lref.max()
 
 
+@pytest.mark.parametrize("nf,nt", [(48, 5000), (33, 8192), (128, 9001)])
+def test_sspec_long_rows_vs_oracle(nf, nt):
+    """Rows longer than 4096 samples pad to 16384+ points: the real-to-complex path that sends
+    PAIRS of rows through the decimated row transform (fft.hip, PairRows / PairSplitSource)."""
+    import torch
+    from oracle import sspec_oracle as so
+    from scintools_amd.dynspec import sspec_device
+    from scintools_amd.device import to_device
+    rng = np.random.default_rng(nf + nt)
+    dyn = rng.standard_normal((nf, nt)) + 3.0 + np.cos(np.arange(nt) / 37.0)[None, :]
+    for kw in (dict(), dict(prewhite=True), dict(halve=False), dict(window=None)):
+        sec = sspec_device(to_device(dyn, torch.float64), **kw).cpu().numpy()
+        ref = so.calc_sspec(dyn, 30.0, 0.1, **kw)[2]
+        assert sec.shape == ref.shape
+        lin, lref = 10 ** (sec / 10), 10 ** (ref / 10)
+        assert np.abs(lin - lref).max() <= 1e-10 * lref.max(), kw
+        strong = lref > 1e-6 * lref.max()
+        assert np.abs(sec - ref)[strong].max() <= 1e-8, kw
+
+
+@pytest.mark.parametrize("nf,nt,npad", [(32, 16384, 0), (16, 8192, 1), (64, 4096, 3), (31, 16384, 0)])
+def test_conjugate_spectrum_long_rows(thth, to, nf, nt, npad):
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, _ = arc_dynspec(nf, nt, seed=nf + npad, nimg=8)
+    ref = to.conjugate_spectrum(dyn, npad)
+    got = thth.conjugate_spectrum(dyn, npad).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 def test_fit_thetatheta_vs_reference_golden(golden):
     """The Dynspec entry point of the tutorial (dynspec_thth.rst:146-170): 16 chunks of 64
     channels, 52 curvatures each, npad=3, auto-sized edges -- against the reference's own
