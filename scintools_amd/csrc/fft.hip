@@ -754,6 +754,7 @@ static int32_t fft2_general(RowSource src, int64_t nvalid, double fill0, int64_t
     }
 
     if (real_input && !p.blue_r && !p.blue_c && C > 8192 && R >= 2) {
+        // (for rows that fit the LDS the in-kernel separation above is faster: sspec 4096^2 0.72 vs 0.80 ms)
         // long real rows (C = 16384 .. 131072): pairs of rows through the decimated row transform
         const int64_t Ch = C / 2 + 1;
         const int ChL = (int)((Ch + 7) & ~(int64_t)7);
