@@ -2,7 +2,7 @@
 //   scint_fft2              plain complex 2-D FFT (tests, building block)
 //   scint_sspec             Dynspec.calc_sspec core      (dynspec.py:3665-3721)
 //   scint_cs                conjugate spectrum of a chunk (ththmod.py:777-787)
-//   scint_model_from_recov  ifft2(ifftshift(recov)).real  (ththmod.py:322-324)
+//   scint_model_from_recov  ifft2(ifftshift(recov)).real  (ththmod.py:322-324), complex-to-real
 //   scint_mean / scint_chisq  small deterministic reductions
 //
 // Every transform is "source -> row FFT -> column FFT -> sink":
@@ -13,8 +13,11 @@
 //              row pass never computed (all-zero or constant padding rows);
 //   ColSink    consumes the final value at natural frequency (k1, k2): fftshift, |.|^2,
 //              post-darkening, 10 log10, delay mask, abs, real-part scaling.
-// The descriptors are plain structs switched at run time (wave-uniform branches) so that the
-// FFT kernels are instantiated once.
+// The descriptors are plain structs with a run-time mode (wave-uniform branches); the hot modes
+// (calc_sspec, conjugate spectrum, model) are additionally instantiated with the mode as a template
+// argument, which takes the 16x-unrolled switch out of those kernels.
+// Real input goes two rows per complex transform; the model step is the matching complex-to-real
+// transform (model_from_recov below).
 //
 // Axis lengths that are not powers of two go through Bluestein's chirp-z identity
 //   X[k] = w[k] * IFFT_m( FFT_m(x w) * FFT_m(conj w) )[k],   w[j] = exp(-i pi j^2 / n),

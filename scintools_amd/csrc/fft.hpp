@@ -9,7 +9,9 @@
 //                     buffer.  The first stage loads straight from global through a
 //                     Loader functor (this is where mean-subtract / window /
 //                     prewhiten / zero-pad are fused), the last stage stores
-//                     straight to global through a Storer functor.
+//                     straight to global through a Storer functor.  Both expose
+//                     open(slot) -> per-slot accessor, so the slot is decoded once per
+//                     thread and an element access costs one address.
 //
 //   fft_cols_kernel   one decimation-in-frequency radix-R pass along the STRIDED
 //                     axis.  Lanes run along the contiguous axis, so every load and
