@@ -193,7 +193,10 @@ int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const doubl
                       const scint_cs_geom* geom /*HOST*/, double eta, int32_t hermitian,
                       scint_c128* recov_out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- model dynamic spectrum: ifft2(ifftshift(recov)).real (ththmod.py:322-324) */
+/* ---- model dynamic spectrum: ifft2(ifftshift(recov)).real (ththmod.py:322-324) ----------
+ * recov[ntau, nfd] -> model_out[ntau, nfd].  Computed as a complex-to-real transform of the
+ * Hermitian part of ifftshift(recov) when both lengths are powers of two (nfd in 32..8192): an
+ * identity for any input, equal to the complex transform's real part up to rounding. */
 int32_t scint_model_workspace_bytes(int64_t ntau, int64_t nfd, size_t* bytes /*HOST*/);
 int32_t scint_model_from_recov(const scint_c128* recov, int64_t ntau, int64_t nfd,
                                double* model_out, void* workspace, size_t workspace_bytes,
