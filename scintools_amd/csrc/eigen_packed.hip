@@ -47,6 +47,8 @@ namespace scint {
 constexpr int kCheckEvery = 4;   // Lanczos steps per chunk (between convergence checks); SCINT_CHECK_EVERY overrides.
                                  // Measured at 4096^2 / 256 eta: every 1 / 2 / 4 steps -> 39.6 / 40.1 / 41.1 steps per eta but
                                  // 1081 / 1085 / 1093 eta/s: the saved steps do not pay for the extra checks and read-backs
+constexpr int kCheckEveryBlock = 3;   // two-vector recurrence (a pass is worth more): every 2 / 3 / 4 / 5 passes ->
+                                      // 31.2 / 31.6 / 32.1 / 32.7 passes per eta, 1203 / 1211 / 1196 / 1198 eta/s (3 interleaved runs each)
 constexpr int kFirstCheck = 8;
 constexpr int kMaxK = 512;   // upper bound on Lanczos steps held in LDS by the check kernel
 
@@ -1329,10 +1331,10 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.depth = forced_depth >= 1 && forced_depth <= 2 ? forced_depth : 2;
     const char* every_env = getenv("SCINT_CHECK_EVERY");
     const int forced_every = every_env ? atoi(every_env) : 0;
-    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEvery;
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     const char* block_env = getenv("SCINT_LANCZOS_BLOCK");
     S.block = (block_env && atoi(block_env) == 1) ? 1 : 2;
+    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block == 2 ? kCheckEveryBlock : kCheckEvery);
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
