@@ -169,6 +169,14 @@ def _pool_worker(job):
     return i, val
 
 
+def _pool_warm(path):
+    """Worker warm-up: the imports and the page cache of the shared conjugate spectrum, no eta."""
+    import numpy as _np
+    from oracle import thth_oracle  # noqa: F401
+    z = _np.load(path, mmap_mode="r")
+    return float(_np.abs(z[::64, ::64]).sum())
+
+
 def pool_size(requested, nedge):
     """Workers for the eta-parallel baseline: every core, capped by host memory (one oracle
     gather holds about 80 M^2 bytes of temporaries) and by 64."""
@@ -211,7 +219,7 @@ def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
     ctx = mp.get_context("spawn")
     try:
         with ctx.Pool(nproc) as pool:
-            pool.map(_pool_worker, [(path, idx[0])] * nproc)          # warm the workers (imports, page cache)
+            pool.map(_pool_warm, [path] * nproc, chunksize=1)          # warm the workers (imports, page cache)
             t0 = time.perf_counter()
             pool.map_async(_pool_worker, [(path, i) for i in idx]).get(timeout=900)
             dt = time.perf_counter() - t0
