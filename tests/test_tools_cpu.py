@@ -1,0 +1,44 @@
+"""Host-side tooling that the numbers in DESIGN.md / profiles/ go through (CPU only)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+
+
+def test_interval_union_and_co_residency():
+    """tools/rocpd_summary.py: the union of launch intervals (what bytes / time must use when two
+    streams run the same kernel) and the time spent at each overlap depth."""
+    from rocpd_summary import union_and_depth
+    # two streams: [0,10) and [5,15) overlap on [5,10); a third launch [20,30) is alone
+    union, hist = union_and_depth([(0, 10), (5, 15), (20, 30)])
+    assert union == 25
+    assert hist == {1: 20, 2: 5}
+    # back-to-back launches on one stream: union == plain sum
+    spans = [(i * 10, i * 10 + 10) for i in range(7)]
+    union, hist = union_and_depth(spans)
+    assert union == 70 and hist == {1: 70}
+    # nested launch
+    union, hist = union_and_depth([(0, 100), (10, 20)])
+    assert union == 100 and hist == {1: 90, 2: 10}
+
+
+def test_bench_pool_size_is_bounded_by_memory_and_cores():
+    import bench
+    n = bench.pool_size(-1, 4096)
+    assert 1 <= n <= 64
+    assert bench.pool_size(5, 4096) == 5          # an explicit request is honoured
+    # a bigger problem never gets more workers than a smaller one
+    assert bench.pool_size(-1, 16384) <= bench.pool_size(-1, 1024)
+
+
+def test_bench_workload_is_the_baseline_config():
+    import bench
+    dyn, freqs, times, fd, tau, edges, etas, eta_true = bench.make_workload(256, 32, 256, seed=3)
+    assert dyn.shape == (256, 256) and abs(dyn.mean()) < 1e-9      # mean-subtracted chunk (dynspec.py:1692)
+    assert edges.shape == (256,) and np.allclose(edges, -edges[::-1])
+    assert etas.shape == (32,) and np.isclose(etas[0], 0.25 * eta_true) and np.isclose(etas[-1], 4.0 * eta_true)
+    assert np.all(np.diff(fd) > 0) and np.all(np.diff(tau) > 0)
