@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE ONLY: build the kernel sources for the x86 host on top of the workgroup
+interpreter in this directory (tests/emu/_build/libscint_emu_test.so).
+
+    python tests/emu/build_emu.py [--force]
+
+The product library (scintools_amd/libscint_hip.so) is built by scintools_amd/build.py with hipcc
+for gfx950 and is the only thing scintools_amd ever loads; this host build is loaded by
+tests/test_emu_cpu.py alone, through its own ctypes handle, to exercise the kernels' control flow
+and arithmetic where no GPU exists.  The sources are compiled unchanged except for one textual
+substitution: `extern __shared__` (dynamic LDS) becomes a plain `extern` of an array the
+interpreter owns.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(REPO, "scintools_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libscint_emu_test.so")
+
+# same per-unit floating-point contraction as the product build (scintools_amd/build.py)
+UNITS = {
+    "capi.hip": [],
+    "fft.hip": [],
+    "thth.hip": ["-ffp-contract=off"],
+    "eigen.hip": [],
+    "eigen_packed.hip": [],
+    "arcnorm.hip": ["-ffp-contract=off"],
+}
+
+
+def _clang():
+    for exe in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++") or ""):
+        if exe and os.path.exists(exe):
+            return exe
+    raise RuntimeError("clang++ not found (the kernel sources use clang vector / address-space extensions)")
+
+
+def _stage_sources():
+    """Copy csrc into the build directory with the dynamic-LDS declarations rewritten."""
+    src_out = os.path.join(OUT, "scintools_amd", "csrc")
+    os.makedirs(src_out, exist_ok=True)
+    changed = False
+    for name in sorted(os.listdir(CSRC)):
+        if not name.endswith((".hip", ".hpp")):
+            continue
+        with open(os.path.join(CSRC, name)) as fh:
+            text = fh.read()
+        text = re.sub(r"\bextern\s+__shared__", "extern", text)
+        dst = os.path.join(src_out, name.replace(".hip", ".hip.cpp"))
+        old = None
+        if os.path.exists(dst):
+            with open(dst) as fh:
+                old = fh.read()
+        if old != text:
+            with open(dst, "w") as fh:
+                fh.write(text)
+            changed = True
+    inc_out = os.path.join(OUT, "include")
+    os.makedirs(inc_out, exist_ok=True)
+    shutil.copy2(os.path.join(REPO, "include", "scint_hip.h"), os.path.join(inc_out, "scint_hip.h"))
+    return src_out, changed
+
+
+def build(force=False, verbose=False):
+    cxx = _clang()
+    os.makedirs(OUT, exist_ok=True)
+    src_out, _ = _stage_sources()
+    common = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-fno-omit-frame-pointer",
+              "-I", os.path.join(HERE, "include"), "-Wno-unused-result", "-Wno-unknown-attributes",
+              "-Wno-ignored-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
+    deps = [os.path.join(HERE, "include", "hip", "hip_runtime.h"), __file__]
+    deps += [os.path.join(src_out, f) for f in os.listdir(src_out) if f.endswith(".hpp")]
+    jobs, objs = [], []
+    units = [(os.path.join(src_out, u.replace(".hip", ".hip.cpp")), extra) for u, extra in UNITS.items()]
+    units.append((os.path.join(HERE, "emu_runtime.cpp"), []))
+    for src, extra in units:
+        obj = os.path.join(OUT, os.path.basename(src) + ".o")
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or any(
+            os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + deps)
+        if stale:
+            jobs.append(common + extra + ["-c", src, "-o", obj])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))
