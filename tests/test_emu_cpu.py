@@ -1,0 +1,131 @@
+"""The kernel SOURCES, interpreted on the host (tests/emu), against the oracle -- runs without a GPU.
+
+What this is: scintools_amd/csrc/*.hip compiled for x86 on top of a small workgroup interpreter
+(fibers for threads, 64-lane waves, barriers and cross-lane operations as scheduling points) and
+driven through the same C ABI and the same Python wrappers as the GPU library.  It checks the
+control flow and arithmetic of the kernels and of the host-side sweep scheduler in the build
+container.  What it is not: a product path (scintools_amd never loads it and still raises without
+a GPU) or parity evidence for the GPU (that is `pytest -m gpu`, which runs the gfx950 build of the
+same sources; the two agree to rounding because they ARE the same sources).
+Sizes are tiny: the interpreter runs ~10^4 times slower than the GPU.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    import emulated
+    try:
+        emulated.install(monkeypatch)
+    except RuntimeError as exc:          # no clang++ on this machine
+        pytest.skip(str(exc))
+    from scintools_amd import ththmod
+    return ththmod
+
+
+@pytest.fixture(scope="module")
+def to():
+    from oracle import thth_oracle
+    return thth_oracle
+
+
+@pytest.fixture(scope="module")
+def case():
+    """A 96 x 80 arc dynamic spectrum with its axes, edges and a few curvatures."""
+    from oracle import thth_oracle
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(96, 80, seed=5, nimg=12)
+    dyn = dyn - dyn.mean()
+    fd = thth_oracle.fft_axis(times, 1000.0, 1)
+    tau = thth_oracle.fft_axis(freqs, 1.0, 1)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 100)
+    etas = np.geomspace(0.5, 2.0, 5) * eta_true
+    CS = thth_oracle.conjugate_spectrum(dyn, 1)
+    return dict(dyn=dyn, fd=fd, tau=tau, edges=edges, etas=etas, CS=CS)
+
+
+def test_interpreted_library_is_not_the_product(emu):
+    from scintools_amd import _lib
+    assert os.path.basename(_lib.load()._name) == "libscint_emu_test.so"
+    assert "tests" in _lib.load()._name.split(os.sep)
+
+
+@pytest.mark.parametrize("hermetian", [True, False])
+def test_gather_bit_equal(emu, to, case, hermetian):
+    c = case
+    for eta in c["etas"][[0, 2, 4]]:
+        got, e_got = emu.thth_redmap(c["CS"], c["tau"], c["fd"], eta, c["edges"], hermetian)
+        ref, e_ref = to.thth_redmap(c["CS"], c["tau"], c["fd"], eta, c["edges"], hermetian)
+        assert np.array_equal(got, ref, equal_nan=True)
+        assert np.array_equal(e_got, e_ref)
+
+
+@pytest.mark.parametrize("nf,nt,npad", [(96, 80, 1), (64, 64, 0), (50, 20, 2)])
+def test_conjugate_spectrum(emu, to, nf, nt, npad):
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, _, _ = arc_dynspec(nf, nt, seed=nf + nt, nimg=6)
+    tau = to.fft_axis(freqs, 1.0, npad)
+    mask = 2.5 * (tau[1] - tau[0])
+    ref = to.conjugate_spectrum(dyn, npad, tau, mask)
+    got = emu.conjugate_spectrum(dyn, npad, tau, mask, True).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_secondary_spectrum(emu):
+    import torch
+    from oracle import sspec_oracle
+    from scintools_amd.dynspec import sspec_device
+    from scintools_amd.synth import arc_dynspec
+    dyn = arc_dynspec(64, 96, seed=2, nimg=6)[0]
+    sec = sspec_device(emu.to_device(dyn, torch.float64)).cpu().numpy()
+    ref = sspec_oracle.calc_sspec(dyn, 30.0, 1.0)[2]
+    lin, lref = 10 ** (sec / 10), 10 ** (ref / 10)
+    assert np.abs(lin - lref).max() <= 1e-10 * lref.max()
+
+
+def test_eigenvalue_sweep_vs_arpack(emu, to, case):
+    """The batched two-vector Lanczos sweep incl. its two-stream scheduler (run here in enqueue
+    order) against the oracle's ARPACK eigsh, and independent of the batch size."""
+    c = case
+    eigs, info = emu.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], return_info=True)
+    ref = np.array([to.Eval_calc(c["CS"], c["tau"], c["fd"], e, c["edges"]) for e in c["etas"]])
+    assert np.all(info["status"] == 0)
+    np.testing.assert_allclose(eigs, ref, rtol=1e-9)
+    eigs2 = emu.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], batch=2)
+    assert np.array_equal(eigs, eigs2)
+
+
+def test_modeler_and_chisq_sweep(emu, to, case):
+    c = case
+    eta = c["etas"][2]
+    got = emu.modeler(c["CS"], c["tau"], c["fd"], eta, c["edges"])
+    ref = to.modeler(c["CS"], c["tau"], c["fd"], eta, c["edges"])
+    assert np.array_equal(got[0], ref[0])                                  # thth_red
+    assert abs(got[5] - ref[5]) <= 1e-9 * abs(ref[5])                      # w
+    for k in (2, 3):                                                        # recov, model
+        g, r = np.nan_to_num(got[k]), np.nan_to_num(ref[k])
+        assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k]))
+        assert np.abs(g - r).max() <= 1e-9 * np.abs(r).max()
+    chis = emu.chisq_sweep(c["dyn"], c["CS"], c["tau"], c["fd"], c["etas"][1:4], c["edges"], 1.0)
+    refc = np.array([to.chisq_calc(c["dyn"], c["CS"], c["tau"], c["fd"], e, c["edges"], 1.0) for e in c["etas"][1:4]])
+    np.testing.assert_allclose(chis, refc, rtol=1e-9)
+
+
+def test_rev_map_explicit_matrix(emu, to, case):
+    c = case
+    rng = np.random.default_rng(0)
+    n = c["edges"].shape[0] - 1
+    a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    herm = a + a.conj().T
+    for hermetian, mat in ((True, herm), (False, a)):
+        got = emu.rev_map(mat, c["tau"], c["fd"], c["etas"][2], c["edges"], hermetian)
+        ref = to.rev_map(mat, c["tau"], c["fd"], c["etas"][2], c["edges"], hermetian)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.abs(np.nan_to_num(got) - np.nan_to_num(ref)).max() <= 1e-9 * np.abs(np.nan_to_num(ref)).max()
