@@ -117,22 +117,35 @@ __host__ __device__ inline void bw_qbh_row(const BlkW<W>& k, const cplx (&q)[W],
 
 // ---- the band matrix T ------------------------------------------------------------
 // band[i * (W + 1) + k] = T[i + k][i], k = 0..W (k = 0: the real diagonal in .x); n rows.
-// pa[j], pb[j]: packed A_j and packed B_j (B_j couples blocks j and j + 1), nblk blocks.
+// Entry k of row r of block j from the packed A_j and the packed B_j (B_j couples blocks j and j + 1;
+// nullptr for the last block).
 template <int W>
-__host__ __device__ inline cplx bw_band_entry(const double* pa, const double* pb, int nblk, int i, int k) {
-    const int j = i / W, r = i - j * W;
-    const double* A = pa + (size_t)j * W * W;
+__host__ __device__ inline cplx bw_band_entry(const double* A, const double* B, int r, int k) {
     if (k == 0) return mk(A[r], 0.0);
     if (r + k < W) {                                   // inside the diagonal block: A_j[r + k][r] = conj(A_j[r][r + k])
         const int idx = bw_upper<W>(r, r + k);
         return mk(A[idx], -A[idx + 1]);
     }
-    if (j + 1 >= nblk) return mk(0.0, 0.0);
+    if (!B) return mk(0.0, 0.0);
     const int rp = r + k - W;                          // row of B_j, rp <= r: entry B_j[rp][r]
-    const double* B = pb + (size_t)j * W * W;
     if (rp == r) return mk(B[r], 0.0);
     const int idx = bw_upper<W>(rp, r);
     return mk(B[idx], B[idx + 1]);
+}
+
+// packed forms of the coefficients of a step
+template <int W>
+__host__ __device__ inline void bw_pack(const BlkW<W>& k, double* pa, double* pb) {
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+        pa[r] = k.a[r][r].x;
+        pb[r] = k.b[r][r].x;
+#pragma unroll
+        for (int c = r + 1; c < W; ++c) {
+            pa[bw_upper<W>(r, c)] = k.a[r][c].x; pa[bw_upper<W>(r, c) + 1] = k.a[r][c].y;
+            pb[bw_upper<W>(r, c)] = k.b[r][c].x; pb[bw_upper<W>(r, c) + 1] = k.b[r][c].y;
+        }
+    }
 }
 
 // LDL^H pivots of T - x for a Hermitian band matrix of half width W: returns the number of negative

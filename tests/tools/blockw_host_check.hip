@@ -31,7 +31,8 @@ static void band(const double* pa, const double* pb, int nblk, double* band_out)
     const int n = W * nblk;
     for (int i = 0; i < n; ++i)
         for (int k = 0; k <= W; ++k) {
-            const cplx v = bw_band_entry<W>(pa, pb, nblk, i, k);
+            const int j = i / W, r = i - j * W;
+            const cplx v = bw_band_entry<W>(pa + (size_t)j * W * W, j + 1 < nblk ? pb + (size_t)j * W * W : nullptr, r, k);
             band_out[2 * (i * (W + 1) + k)] = v.x; band_out[2 * (i * (W + 1) + k) + 1] = v.y;
         }
 }
