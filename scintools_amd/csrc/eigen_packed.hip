@@ -908,41 +908,58 @@ __global__ void __launch_bounds__(64) pk2_ritz_kernel(const PackedJob* jobs, con
     if (e == 0) jb.upart[0][K] = p;   // the job is finished: its partial arrays are free
 }
 
+}  // namespace scint
+#include "blockw_kernels.hpp"
+namespace scint {
+
 // ------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------
+// vectors per Lanczos step: 2 (default), 1 (SCINT_LANCZOS_BLOCK=1, the round-1 recurrence) or 4
+// (SCINT_LANCZOS_BLOCK=4, blockw_kernels.hpp -- not yet validated on a GPU).  Read per call.
+static int sweep_block_width() {
+    const char* e = getenv("SCINT_LANCZOS_BLOCK");
+    const int v = e ? atoi(e) : 2;
+    return (v == 1 || v == 4) ? v : 2;
+}
+static int strip_len_block(int nb, int block) {
+    const int s = strip_len_for(nb);
+    return block == 4 ? std::min(s, kStripW) : s;
+}
+
 struct SlabLayout {
     size_t tiles, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
         alpha, beta, result, total;
     int qslots;
 };
 
-static int max_strips(int nb) {
-    const int S = strip_len_for(nb);
+static int max_strips(int nb, int block) {
+    const int S = strip_len_block(nb, block);
     int n = 0;
     for (int I = 0; I < nb; ++I) n += strips_in_row(nb, I, S);
     return n;
 }
 
-static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
+static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block) {
     SlabLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     // the strip count is not monotone in nb across the strip-length thresholds: take the max
     int smax = 0;
-    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb));
+    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb, block));
     L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
     // vectors, partial vectors and scalar histories are sized for the two-vector (block) recurrence:
     // 2 columns, 4 scalars per coefficient (they are small next to the tiles); the single-vector
     // recurrence (SCINT_LANCZOS_BLOCK=1) uses half of each
-    const size_t bw = 2, sc = 4;
+    // (SCINT_LANCZOS_BLOCK=4: 4 columns, 16 scalars, column partials per quarter tile)
+    const size_t bw = block == 4 ? 4 : 2, sc = bw * bw, cparts = block == 4 ? kQuarters : 1;
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.qslots = want_vec ? max_steps + 1 : 2;        // (block steps when two vectors run: <= kMaxKB + 1 are used)
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
-    L.svec = take(sizeof(cplx) * 2 * (size_t)(max_steps + 2));    // eigenvector of T_k (complex, 2 per block step)
+    L.svec = take(sizeof(cplx) * bw * (size_t)(max_steps + 2));   // eigenvector of T_k (complex, bw per block step)
     L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
-    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
+    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw * cparts);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
     L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
     L.apart1 = take(sizeof(double) * (size_t)nbmax * sc);
@@ -964,11 +981,11 @@ struct BatchLayout {
     size_t jobs_stride, strips_stride, list_stride, fin_eta_stride;
 };
 
-static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs) {
+static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs, int block) {
     BatchLayout B;
-    B.slab = slab_layout(nbmax, max_steps, want_vec);
+    B.slab = slab_layout(nbmax, max_steps, want_vec, block);
     B.smax = 0;
-    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb));
+    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb, block));
     size_t off = B.slab.total * (size_t)nbatch;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     B.jobs_stride = align_up(sizeof(PackedJob) * (size_t)nbatch, 256);
@@ -994,7 +1011,7 @@ int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t ma
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, sweep_block_width()).total + 4096;
     return SCINT_OK;
 }
 
@@ -1120,9 +1137,10 @@ struct SweepGroup {
             const int64_t c = S.cs_index ? S.cs_index[e] : 0;
             J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
             J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            J.max_steps = S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
-                                       : std::min(S.steps_cap, std::max(n, 1));
-            J.strip_len = strip_len_for(J.nb);
+            J.max_steps = S.block == 4   ? std::min(std::min(S.steps_cap, kMaxKW), std::max((n + 3) / 4, 1))
+                          : S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
+                                         : std::min(S.steps_cap, std::max(n, 1));
+            J.strip_len = strip_len_block(J.nb, S.block);
             J.start = launch0;
             J.gen = ++slot_gen[(size_t)s];
             J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
@@ -1203,7 +1221,10 @@ struct SweepGroup {
                                             hipMemcpyHostToDevice, stream);
                     if (he != hipSuccess) return hip_fail(he, "sweep eigenvector export", __FILE__, __LINE__);
                     const dim3 grid((unsigned)nb_fin, (unsigned)nfin);
-                    if (S.block == 2)
+                    if (S.block == 4)
+                        hipLaunchKernelGGL(pkw_ritz_kernel<4>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                           S.vec_out, S.vstride);
+                    else if (S.block == 2)
                         hipLaunchKernelGGL(pk2_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
                                            S.vec_out, S.vstride);
                     else
@@ -1226,7 +1247,10 @@ struct SweepGroup {
             if (!fresh.empty()) {
                 int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream);
                 if (rc != SCINT_OK) return rc;
-                if (S.block == 2)
+                if (S.block == 4)
+                    hipLaunchKernelGGL(pkw_init_kernel<4>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                                       d_jobs(tab), d_fresh(tab));
+                else if (S.block == 2)
                     hipLaunchKernelGGL(pk2_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
                                        d_jobs(tab), d_fresh(tab));
                 else
@@ -1241,12 +1265,18 @@ struct SweepGroup {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
                 const int slot = profiler().begin(kProfMatvec, stream);
-                if (S.block == 2)
+                if (S.block == 4)
+                    hipLaunchKernelGGL(pkw_matvec_kernel<4>, dim3((unsigned)(kQuarters * nstrips)), dim3(256), 0, stream,
+                                       d_jobs(tab), d_strips(tab), launch);
+                else if (S.block == 2)
                     hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 else
                     hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 profiler().end(kProfMatvec, slot, stream);
-                if (S.block == 2)
+                if (S.block == 4)
+                    hipLaunchKernelGGL(pkw_reduce_kernel<4>, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroupsW), 0,
+                                       stream, d_jobs(tab), launch);
+                else if (S.block == 2)
                     hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
                                        stream, d_jobs(tab), launch);
                 else
@@ -1254,7 +1284,9 @@ struct SweepGroup {
                                        stream, d_jobs(tab), launch);
             }
         }
-        if (S.block == 2)
+        if (S.block == 4)
+            hipLaunchKernelGGL(pkw_check_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+        else if (S.block == 2)
             hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
         else
             hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
@@ -1332,12 +1364,11 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const char* every_env = getenv("SCINT_CHECK_EVERY");
     const int forced_every = every_env ? atoi(every_env) : 0;
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
-    const char* block_env = getenv("SCINT_LANCZOS_BLOCK");
-    S.block = (block_env && atoi(block_env) == 1) ? 1 : 2;
-    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block == 2 ? kCheckEveryBlock : kCheckEvery);
+    S.block = sweep_block_width();
+    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block >= 2 ? kCheckEveryBlock : kCheckEvery);
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
-    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
+    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs, S.block);
     const SlabLayout& L = S.BL.slab;
     S.base = (char*)workspace;
     S.states_dev = (int32_t*)(S.base + S.BL.states);

@@ -115,6 +115,37 @@ def test_sweep_is_schedule_invariant(env):
         assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
 
 
+def test_four_vector_block_matches_two_vector(env):
+    """SCINT_LANCZOS_BLOCK=4 (blockw_kernels.hpp): same eigenvalues / eigenvectors as the default
+    two-vector recurrence to the stopping tolerance, in fewer matrix passes.  The four-vector kernels
+    are opt-in and have so far only run on the host interpreter (`pytest --emu`, green there): on a
+    GPU this test runs when SCINT_TEST_BLOCK4=1 asks for it."""
+    import os
+    from scintools_amd import _lib
+    if os.environ.get("SCINT_TEST_BLOCK4") != "1" and "emu" not in os.path.basename(_lib.load()._name):
+        pytest.skip("opt-in four-vector path: set SCINT_TEST_BLOCK4=1")
+    thth, to, p = env
+    etas = np.geomspace(0.5, 2.0, 12) * p["eta"]
+    ref, i2 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
+    w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+    os.environ["SCINT_LANCZOS_BLOCK"] = "4"
+    try:
+        got, i4 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
+        again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
+        w4, V4, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+    finally:
+        del os.environ["SCINT_LANCZOS_BLOCK"]
+    assert np.all(i4["status"] == 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-10)
+    assert np.array_equal(again, got)                       # batch-invariant bits
+    assert i4["iters"].mean() < i2["iters"].mean()
+    np.testing.assert_allclose(w4, w2, rtol=1e-10)
+    V2n, V4n = V2.cpu().numpy(), V4.cpu().numpy()
+    for k in range(len(etas)):
+        n = int(i2["N"][k])
+        assert 1 - abs(np.vdot(V2n[k, :n], V4n[k, :n])) <= 1e-9
+
+
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
     from scintools_amd.dynspec import Dynspec
     thth, to, p = env
