@@ -19,7 +19,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "scintools_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# SCINT_EMU_SANITIZE=address: an AddressSanitizer build (global and LDS arrays get red zones, so an
+# out-of-bounds access of a kernel is reported instead of silently reading a neighbour).  Run as
+#   LD_PRELOAD=$(python tests/emu/build_emu.py --asan-runtime) ASAN_OPTIONS=detect_leaks=0 \
+#   SCINT_EMU_SANITIZE=address python -m pytest tests/test_emu_cpu.py
+SANITIZE = os.environ.get("SCINT_EMU_SANITIZE", "")
+OUT = os.path.join(HERE, "_build" + ("_" + SANITIZE if SANITIZE else ""))
 LIB = os.path.join(OUT, "libscint_emu_test.so")
 
 # same per-unit floating-point contraction as the product build (scintools_amd/build.py)
@@ -73,6 +78,10 @@ def build(force=False, verbose=False):
     common = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-fno-omit-frame-pointer",
               "-I", os.path.join(HERE, "include"), "-Wno-unused-result", "-Wno-unknown-attributes",
               "-Wno-ignored-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
+    link_extra = []
+    if SANITIZE:
+        common += [f"-fsanitize={SANITIZE}", "-shared-libsan"]
+        link_extra = [f"-fsanitize={SANITIZE}", "-shared-libsan"]
     deps = [os.path.join(HERE, "include", "hip", "hip_runtime.h"), __file__]
     deps += [os.path.join(src_out, f) for f in os.listdir(src_out) if f.endswith(".hpp")]
     jobs, objs = [], []
@@ -95,12 +104,20 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"]
+        cmd = [cxx, "-shared", "-fPIC", "-o", LIB] + link_extra + objs + ["-lm", "-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     return LIB
 
 
+def asan_runtime():
+    out = subprocess.run([_clang(), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    return out.stdout.strip()
+
+
 if __name__ == "__main__":
+    if "--asan-runtime" in sys.argv:
+        print(asan_runtime())
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

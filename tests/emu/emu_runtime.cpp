@@ -121,13 +121,25 @@ void resolve_wave(int lo, int hi) {
         if (fibers[l].state == kAtWave) fibers[l].state = kRun;
 }
 
+// SCINT_EMU_ORDER=rev runs the waves of a block, the lanes of a wave and the blocks of a grid in
+// the opposite order.  Every order is a legal schedule, so results must not depend on it: a
+// difference means a missing barrier, an inter-block dependence, or reliance on lock-step lanes.
+bool reversed_order() {
+    static const bool rev = [] { const char* e = getenv("SCINT_EMU_ORDER"); return e && e[0] == 'r'; }();
+    return rev;
+}
+
 void run_block(int nthreads) {
+    const bool rev = reversed_order();
+    const int nwaves = (nthreads + 63) / 64;
     for (;;) {
-        for (int w0 = 0; w0 < nthreads; w0 += 64) {
+        for (int wi = 0; wi < nwaves; ++wi) {
+            const int w0 = 64 * (rev ? nwaves - 1 - wi : wi);
             const int w1 = std::min(nthreads, w0 + 64);
             for (;;) {
                 bool parked_at_wave = false;
-                for (int l = w0; l < w1; ++l) {
+                for (int li = 0; li < w1 - w0; ++li) {
+                    const int l = rev ? w1 - 1 - li : w0 + li;
                     if (fibers[l].state == kRun) resume(l);
                     if (fibers[l].state == kAtWave) parked_at_wave = true;
                 }
@@ -165,9 +177,12 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, void (*thunk)(void*), void* c
     if (cur >= 0) { fprintf(stderr, "emu: nested launch\n"); abort(); }
     g_thunk = thunk; g_ctx = ctx;
     gridDim = grid; blockDim = block;
-    for (uint32_t bz = 0; bz < grid.z; ++bz)
-        for (uint32_t by = 0; by < grid.y; ++by)
-            for (uint32_t bx = 0; bx < grid.x; ++bx) {
+    const bool rev = reversed_order();
+    for (uint32_t iz = 0; iz < grid.z; ++iz)
+        for (uint32_t iy = 0; iy < grid.y; ++iy)
+            for (uint32_t ix = 0; ix < grid.x; ++ix) {
+                const uint32_t bx = rev ? grid.x - 1 - ix : ix, by = rev ? grid.y - 1 - iy : iy,
+                               bz = rev ? grid.z - 1 - iz : iz;
                 blockIdx = dim3(bx, by, bz);
                 int t = 0;
                 for (uint32_t z = 0; z < block.z; ++z)

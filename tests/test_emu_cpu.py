@@ -129,3 +129,34 @@ def test_rev_map_explicit_matrix(emu, to, case):
         ref = to.rev_map(mat, c["tau"], c["fd"], c["etas"][2], c["edges"], hermetian)
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         assert np.abs(np.nan_to_num(got) - np.nan_to_num(ref)).max() <= 1e-9 * np.abs(np.nan_to_num(ref)).max()
+
+
+def test_results_do_not_depend_on_the_schedule(tmp_path):
+    """Waves, lanes and blocks interpreted in the opposite order (SCINT_EMU_ORDER=rev) must give the
+    same bits for every product of the path (FFT, gather, the three Lanczos block widths incl. the
+    opt-in four-vector kernels, eigenvectors, rev_map, model, chi^2): any order is a legal GPU
+    schedule, so a difference would be a missing barrier or an inter-block dependence."""
+    import subprocess
+    try:
+        import emulated
+        emulated.load()                      # build once, before the two children race for it
+    except RuntimeError as exc:
+        pytest.skip(str(exc))
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "order_probe.py")
+    procs = []
+    for tag, order in (("fwd", ""), ("rev", "rev")):
+        env = dict(os.environ, SCINT_EMU_ORDER=order, OPENBLAS_NUM_THREADS="1")
+        env.pop("SCINT_LANCZOS_BLOCK", None)
+        procs.append((tag, subprocess.Popen([sys.executable, probe, str(tmp_path / f"{tag}.npz")], env=env,
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for tag, p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, out.decode(errors="replace")[-2000:]
+    a, b = np.load(tmp_path / "fwd.npz"), np.load(tmp_path / "rev.npz")
+    assert set(a.files) == set(b.files) and len(a.files) >= 20
+    for k in a.files:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    # the three recurrences agree with each other, the wider blocks in fewer matrix passes
+    np.testing.assert_allclose(a["eigs_b1"], a["eigs_b2"], rtol=1e-10)
+    np.testing.assert_allclose(a["eigs_b4"], a["eigs_b2"], rtol=1e-10)
+    assert a["iters_b4"].mean() < a["iters_b2"].mean() < a["iters_b1"].mean()
