@@ -210,9 +210,142 @@ pkw_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
     }
 }
 
+// ---- matrix-core form of the W-vector mat-vec -------------------------------------------------
+// STATUS: checked on the host interpreter only (tests/emu, incl. its model of v_mfma_f64_16x16x4_f64
+// taken from the programming guide's operand layout); selected by SCINT_MATVEC_MFMA=1 together with
+// SCINT_LANCZOS_BLOCK=4.  Never run on a GPU.
+//
+// Why: with vector FMAs the row partials sum_j a[r][j] x_J[j][v] live in rows x W complex accumulators
+// PER LANE (lane = column j), which is what caps the block width (256 registers for 16 rows x 4
+// vectors) or forces the quarter strips above (whose column partials cost 25 % extra traffic each
+// way).  v_mfma_f64_16x16x4 contracts over the lanes instead: a 16-row x 64-column slab of a tile
+// against the W vectors (2 W <= 16 real columns) accumulates in FOUR doubles per lane.  A complex
+// product is two real ones, with X as the B operand:
+//   rows:     D[r][n] += Re a[r][j] * X1[j][n] + Im a[r][j] * X2[j][n],   X1 = (xr, xi) interleaved, X2 = i X
+//   columns:  D[j][n] += Re a[r][j] * Y1[r][n] + Im a[r][j] * Y3[r][n],   Y1 = (xr, xi),  Y3 = -i X_I  (conj(a) x)
+// The matrix operand wants the contracted index in lane >> 4 and the free one in lane & 15, so a wave
+// reads its 16 rows of a tile twice: as 16 x 4 patches (row part) and as 4 x 16 patches (column part);
+// the second read hits L1/L2.  One workgroup (4 waves, 16 tile rows each) per strip of <= kStripW
+// tiles; column partials are summed across the waves through LDS per tile -> ONE partial per tile.
+// For W = 4 half of the 16 B-columns are zero (the same instruction count would carry W = 8).
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ inline v4d mfma_f64_16x16x4(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+template <int W>
+__global__ void __launch_bounds__(256, 2)
+pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
+    constexpr int NR = 2 * W;                      // real B columns in use (of 16)
+    static_assert(NR <= 16 && (NR & (NR - 1)) == 0, "block width must be 1, 2, 4 or 8");
+    __shared__ double xs[kStripW][kTB][NR];        // the blocks X_J of the strip as real columns (re0, im0, re1, ...)
+    __shared__ double xI[kTB][NR];                 // the block X_I
+    __shared__ double cred[4][kTB][NR];            // per-wave column partials of the current tile
+    const Strip st = strips[blockIdx.x];
+    const PackedJob* __restrict__ jp = jobs + st.job;
+    const int step = launch - jp->start;
+    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
+    const int par = step & 1;
+    const int nb = jp->nb;
+    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
+    const int qs = jp->qslots;
+    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride * W;   // Q_{j-1}
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k4 = lane >> 4, n16 = lane & 15;     // contracted index / free index of the matrix-core operands
+    const bool odd = n16 & 1;
+    const double live = n16 < NR ? 1.0 : 0.0;      // B columns >= 2 W are zero
+    const int npair = (n16 & (NR - 1)) & ~1;       // this lane's (re, im) pair in a row of xs
+    const int I = st.I;
+    const int64_t t0 = tile_offset(nb, I);
+    const int ntile = st.J1 - st.J0;
+    const cplx* __restrict__ tb = jp->tiles + (t0 + (st.J0 - I)) * kTileElems;
+    // row-part operand g of a tile:    a[16 w + n16][4 g + k4]            g = 0..15
+    // column-part operand (c, kk):     a[16 w + 4 kk + k4][16 c + n16]    c, kk = 0..3
+    const cplx* __restrict__ rp = tb + (16 * w + n16) * kTB + k4;
+    const cplx* __restrict__ cp = tb + (16 * w + k4) * kTB + n16;
+    cplx ra[16], ca[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) ra[g] = gload(rp + 4 * g);
+    const BlkW<W> sc = bw_uniform<W>(bw_step_wave<W>(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
+    for (int idx = threadIdx.x; idx < (ntile + 1) * kTB; idx += 256) {
+        const bool own = idx >= ntile * kTB;       // the last 64 entries build X_I
+        cplx x[W];
+        bw_q_row_at<W>(sc, Up, Qp, own ? I * kTB + (idx - ntile * kTB) : st.J0 * kTB + idx, x);
+        double* dst = own ? &xI[idx - ntile * kTB][0] : &xs[idx >> 6][idx & 63][0];
+#pragma unroll
+        for (int v = 0; v < W; ++v) { dst[2 * v] = x[v].x; dst[2 * v + 1] = x[v].y; }
+    }
+    __syncthreads();
+    // B operands of the column part, fixed for the strip: rows 16 w + 4 kk + k4 of X_I
+    double y1[4], y3[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const double pr = xI[16 * w + 4 * kk + k4][npair], pi = xI[16 * w + 4 * kk + k4][npair + 1];
+        y1[kk] = live * (odd ? pi : pr);           // conj(a) x = (ar xr + ai xi) + i (ar xi - ai xr)
+        y3[kk] = live * (odd ? -pr : pi);
+    }
+    v4d accr0 = {0.0, 0.0, 0.0, 0.0}, accr1 = {0.0, 0.0, 0.0, 0.0};
+    double* __restrict__ colpart = (double*)jp->colpart;
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+        const int64_t toff = (int64_t)t * kTileElems;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ca[q] = gload(cp + toff + (4 * (q & 3)) * kTB + 16 * (q >> 2));   // q = 4 c + kk
+        // rows: 16 patches of 16 rows x 4 columns against X_J
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const double pr = xs[t][4 * g + k4][npair], pi = xs[t][4 * g + k4][npair + 1];
+            const double x1 = live * (odd ? pi : pr);          // a x = (ar xr - ai xi) + i (ar xi + ai xr)
+            const double x2 = live * (odd ? pr : -pi);
+            if (g & 1) { accr1 = mfma_f64_16x16x4(ra[g].x, x1, accr1); accr1 = mfma_f64_16x16x4(ra[g].y, x2, accr1); }
+            else       { accr0 = mfma_f64_16x16x4(ra[g].x, x1, accr0); accr0 = mfma_f64_16x16x4(ra[g].y, x2, accr0); }
+        }
+        if (t + 1 < ntile) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) ra[g] = gload(rp + toff + kTileElems + 4 * g);      // row patches of the next tile
+        }
+        // columns: for each block of 16 columns, 4 patches of 4 rows x 16 columns against X_I
+        v4d accc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accc[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                accc[c] = mfma_f64_16x16x4(ca[4 * c + kk].x, y1[kk], accc[c]);
+                accc[c] = mfma_f64_16x16x4(ca[4 * c + kk].y, y3[kk], accc[c]);
+            }
+        }
+        if (n16 < NR) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cred[w][16 * c + k4 + 4 * r][n16] = accc[c][r];
+        }
+        __syncthreads();
+        const int Jt = st.J0 + t;
+        if (Jt != I) {
+            // cross-wave sum, fixed order; the tile's partial as [64 columns][W] complex
+            for (int idx = threadIdx.x; idx < kTB * NR; idx += 256) {
+                const int col = idx / NR, nn = idx - col * NR;
+                const double sum = ((cred[0][col][nn] + cred[1][col][nn]) + cred[2][col][nn]) + cred[3][col][nn];
+                gstore(colpart + NR * ((t0 + (Jt - I)) * kTB + col) + nn, sum);
+            }
+        }
+        __syncthreads();
+    }
+    // row r = 16 w + k4 + 4 reg of the strip's row partial, real column n16
+    double* __restrict__ rowpart = (double*)jp->rowpart;
+    if (n16 < NR) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            gstore(rowpart + NR * ((int64_t)st.index * kTB + 16 * w + k4 + 4 * r) + n16, accr0[r] + accr1[r]);
+    }
+}
+
 template <int W>
 __global__ void __launch_bounds__(64 * kRedGroupsW)
-pkw_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
+pkw_reduce_kernel(const PackedJob* __restrict__ jobs, int launch, int cparts) {
     constexpr int S = W * W;
     __shared__ cplx part[kRedGroupsW][kTB][W];
     const PackedJob jb = jobs[blockIdx.y];
@@ -222,16 +355,17 @@ pkw_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
     // fixed summation order: the strips of block row K, then the column partials of the tiles
-    // (cI, K), cI < K, quarter by quarter
+    // (cI, K), cI < K, part by part (cparts = kQuarters for the quarter-strip mat-vec, 1 for the
+    // matrix-core one)
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc[W];
 #pragma unroll
     for (int v = 0; v < W; ++v) acc[v] = mk(0.0, 0.0);
-    for (int idx = g; idx < nrow + kQuarters * K; idx += kRedGroupsW) {
+    for (int idx = g; idx < nrow + cparts * K; idx += kRedGroupsW) {
         const int ci = idx - nrow;
-        const int cI = ci / kQuarters, cq = ci - cI * kQuarters;
+        const int cI = ci / cparts, cq = ci - cI * cparts;
         const cplx* src = idx < nrow ? jb.rowpart + W * ((int64_t)(s0 + idx) * kTB + e)
-                                     : jb.colpart + W * (((tile_offset(jb.nb, cI) + (K - cI)) * kQuarters + cq) * kTB + e);
+                                     : jb.colpart + W * (((tile_offset(jb.nb, cI) + (K - cI)) * cparts + cq) * kTB + e);
 #pragma unroll
         for (int v = 0; v < W; ++v) acc[v] = acc[v] + gload(src + v);
     }

@@ -922,6 +922,11 @@ static int sweep_block_width() {
     const int v = e ? atoi(e) : 2;
     return (v == 1 || v == 4) ? v : 2;
 }
+// SCINT_MATVEC_MFMA=1 (with SCINT_LANCZOS_BLOCK=4): the matrix-core mat-vec of blockw_kernels.hpp
+static bool sweep_matvec_mfma() {
+    const char* e = getenv("SCINT_MATVEC_MFMA");
+    return e && atoi(e) == 1;
+}
 static int strip_len_block(int nb, int block) {
     const int s = strip_len_for(nb);
     return block == 4 ? std::min(s, kStripW) : s;
@@ -1074,7 +1079,8 @@ struct SweepProblem {
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
     SweepTail* tail_hook; hipStream_t tail[2]; int tail_rr = 0;   // retired curvatures alternate between two tail streams
-    int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1 or 2)
+    int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1, 2 or 4)
+    bool mfma = false;                                 // block == 4: matrix-core mat-vec (SCINT_MATVEC_MFMA=1)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1265,7 +1271,10 @@ struct SweepGroup {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
                 const int slot = profiler().begin(kProfMatvec, stream);
-                if (S.block == 4)
+                if (S.block == 4 && S.mfma)
+                    hipLaunchKernelGGL(pkw_matvec_mfma_kernel<4>, dim3((unsigned)nstrips), dim3(256), 0, stream,
+                                       d_jobs(tab), d_strips(tab), launch);
+                else if (S.block == 4)
                     hipLaunchKernelGGL(pkw_matvec_kernel<4>, dim3((unsigned)(kQuarters * nstrips)), dim3(256), 0, stream,
                                        d_jobs(tab), d_strips(tab), launch);
                 else if (S.block == 2)
@@ -1275,7 +1284,7 @@ struct SweepGroup {
                 profiler().end(kProfMatvec, slot, stream);
                 if (S.block == 4)
                     hipLaunchKernelGGL(pkw_reduce_kernel<4>, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroupsW), 0,
-                                       stream, d_jobs(tab), launch);
+                                       stream, d_jobs(tab), launch, S.mfma ? 1 : kQuarters);
                 else if (S.block == 2)
                     hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
                                        stream, d_jobs(tab), launch);
@@ -1365,6 +1374,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const int forced_every = every_env ? atoi(every_env) : 0;
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     S.block = sweep_block_width();
+    S.mfma = S.block == 4 && sweep_matvec_mfma();
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block >= 2 ? kCheckEveryBlock : kCheckEvery);
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;

@@ -46,8 +46,10 @@ struct Fiber {
     int state = kDone;
     dim3 tid;
     int op = 0, arg = 0, width = 64;
-    uint64_t value = 0, result = 0;
+    uint64_t value = 0, value2 = 0, result = 0;
 };
+constexpr int kGather = 100;
+uint64_t snapshots[kMaxThreads / 64][64][2];
 Fiber fibers[kMaxThreads];
 void* sched_sp = nullptr;
 int cur = -1;
@@ -98,6 +100,16 @@ void resolve_wave(int lo, int hi) {
             abort();
         }
         if (fibers[l].value) ballot |= 1ull << (l - lo);
+    }
+    if (op0 == kGather) {
+        uint64_t (*snap)[2] = snapshots[lo / 64];
+        for (int l = lo; l < lo + 64; ++l) {
+            const bool on = l < hi && fibers[l].state == kAtWave;
+            snap[l - lo][0] = on ? fibers[l].value : 0;
+            snap[l - lo][1] = on ? fibers[l].value2 : 0;
+            if (on) fibers[l].state = kRun;
+        }
+        return;
     }
     for (int l = lo; l < hi; ++l) {
         Fiber& f = fibers[l];
@@ -162,6 +174,17 @@ uint64_t wave_op(int op, uint64_t value, int arg, int width) {
     to_scheduler();
     return f.result;
 }
+
+const uint64_t (*wave_gather2(uint64_t v0, uint64_t v1))[2] {
+    Fiber& f = fibers[cur];
+    f.op = kGather; f.value = v0; f.value2 = v1;
+    f.state = kAtWave;
+    const int wave = cur / 64;
+    to_scheduler();
+    return snapshots[wave];
+}
+
+int lane_id() { return cur & 63; }
 
 void block_barrier() {
     fibers[cur].state = kAtBarrier;

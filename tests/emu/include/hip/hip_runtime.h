@@ -89,6 +89,10 @@ hipError_t hipFuncSetAttribute(const void* func, hipFuncAttribute attr, int valu
 namespace emu {
 enum WaveOp { kShfl = 1, kShflXor, kShflDown, kShflUp, kBallot, kReadFirst };
 uint64_t wave_op(int op, uint64_t value, int arg, int width);
+// every active lane deposits two values; returns the wave's snapshot [64][2] (valid until the wave's
+// next gather) -- the building block of the matrix-core instructions
+const uint64_t (*wave_gather2(uint64_t v0, uint64_t v1))[2];
+int lane_id();
 void block_barrier();
 void run_grid(dim3 grid, dim3 block, size_t shmem, void (*thunk)(void*), void* ctx);
 
@@ -142,6 +146,24 @@ inline int emu_readlane(int v, int lane) {
 inline int emu_readfirstlane(int v) {
     return ::emu::from_bits<int>(::emu::wave_op(::emu::kReadFirst, ::emu::to_bits(v), 0, 64));
 }
+// v_mfma_f64_16x16x4_f64: D = C + A(16x4) B(4x16).  Operand layout (cdna_hip_programming.md, f64
+// MFMA): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, C/D register r of lane l holds
+// row (l >> 4) + 4 r, column l & 15.
+typedef double emu_v4d __attribute__((ext_vector_type(4)));
+inline emu_v4d emu_mfma_f64_16x16x4(double a, double b, emu_v4d c) {
+    const uint64_t (*snap)[2] = ::emu::wave_gather2(::emu::to_bits(a), ::emu::to_bits(b));
+    const int lane = ::emu::lane_id(), j = lane & 15;
+    emu_v4d d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = (lane >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k)
+            acc = __builtin_fma(::emu::from_bits<double>(snap[16 * k + i][0]), ::emu::from_bits<double>(snap[16 * k + j][1]), acc);
+        d[r] = acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) emu_mfma_f64_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 

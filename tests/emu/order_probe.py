@@ -37,13 +37,14 @@ def main(out_path):
     res["sspec_pw"] = sspec_device(ththmod.to_device(dyn, torch.float64), prewhite=True).cpu().numpy()
     res["red"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges)[0]
     res["red_nh"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges, False)[0]
-    for block in ("2", "1", "4"):
-        os.environ["SCINT_LANCZOS_BLOCK"] = block
+    for block in ("2", "1", "4", "4m"):                      # 4m: four vectors, matrix-core mat-vec
+        os.environ["SCINT_LANCZOS_BLOCK"] = block[0]
+        os.environ["SCINT_MATVEC_MFMA"] = "1" if block.endswith("m") else "0"
         eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, return_info=True)
         res["eigs_b" + block], res["iters_b" + block] = eigs, info["iters"]
         w, V, _ = ththmod.eigvec_sweep(cs_t, tau, fd, etas[1:4], edges)
         res["w_b" + block], res["V_b" + block] = w, V.cpu().numpy()
-    del os.environ["SCINT_LANCZOS_BLOCK"]
+    del os.environ["SCINT_LANCZOS_BLOCK"], os.environ["SCINT_MATVEC_MFMA"]
     m = ththmod.modeler(CS, tau, fd, etas[2], edges)
     res["recov"], res["model"], res["V1"] = m[2], m[3], m[6]
     res["chisq"] = ththmod.chisq_sweep(dyn, cs_t, tau, fd, etas[1:4], edges, 1.0)

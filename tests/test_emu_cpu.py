@@ -147,6 +147,7 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     for tag, order in (("fwd", ""), ("rev", "rev")):
         env = dict(os.environ, SCINT_EMU_ORDER=order, OPENBLAS_NUM_THREADS="1")
         env.pop("SCINT_LANCZOS_BLOCK", None)
+        env.pop("SCINT_MATVEC_MFMA", None)
         procs.append((tag, subprocess.Popen([sys.executable, probe, str(tmp_path / f"{tag}.npz")], env=env,
                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for tag, p in procs:
@@ -159,4 +160,6 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     # the three recurrences agree with each other, the wider blocks in fewer matrix passes
     np.testing.assert_allclose(a["eigs_b1"], a["eigs_b2"], rtol=1e-10)
     np.testing.assert_allclose(a["eigs_b4"], a["eigs_b2"], rtol=1e-10)
+    np.testing.assert_allclose(a["eigs_b4m"], a["eigs_b4"], rtol=1e-12)     # matrix-core mat-vec of the same recurrence
+    assert np.array_equal(a["iters_b4m"], a["iters_b4"])
     assert a["iters_b4"].mean() < a["iters_b2"].mean() < a["iters_b1"].mean()

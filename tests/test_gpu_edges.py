@@ -128,22 +128,25 @@ def test_four_vector_block_matches_two_vector(env):
     etas = np.geomspace(0.5, 2.0, 12) * p["eta"]
     ref, i2 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
     w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
-    os.environ["SCINT_LANCZOS_BLOCK"] = "4"
-    try:
-        got, i4 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
-        again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
-        w4, V4, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
-    finally:
-        del os.environ["SCINT_LANCZOS_BLOCK"]
-    assert np.all(i4["status"] == 0)
-    np.testing.assert_allclose(got, ref, rtol=1e-10)
-    assert np.array_equal(again, got)                       # batch-invariant bits
-    assert i4["iters"].mean() < i2["iters"].mean()
-    np.testing.assert_allclose(w4, w2, rtol=1e-10)
-    V2n, V4n = V2.cpu().numpy(), V4.cpu().numpy()
-    for k in range(len(etas)):
-        n = int(i2["N"][k])
-        assert 1 - abs(np.vdot(V2n[k, :n], V4n[k, :n])) <= 1e-9
+    V2n = V2.cpu().numpy()
+    for mfma in ("0", "1"):                                 # vector-FMA quarter strips / matrix-core mat-vec
+        os.environ["SCINT_LANCZOS_BLOCK"] = "4"
+        os.environ["SCINT_MATVEC_MFMA"] = mfma
+        try:
+            got, i4 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
+            again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
+            w4, V4, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+        finally:
+            del os.environ["SCINT_LANCZOS_BLOCK"], os.environ["SCINT_MATVEC_MFMA"]
+        assert np.all(i4["status"] == 0), mfma
+        np.testing.assert_allclose(got, ref, rtol=1e-10)
+        assert np.array_equal(again, got), mfma             # batch-invariant bits
+        assert i4["iters"].mean() < i2["iters"].mean()
+        np.testing.assert_allclose(w4, w2, rtol=1e-10)
+        V4n = V4.cpu().numpy()
+        for k in range(len(etas)):
+            n = int(i2["N"][k])
+            assert 1 - abs(np.vdot(V2n[k, :n], V4n[k, :n])) <= 1e-9
 
 
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
