@@ -22,6 +22,10 @@
 
 namespace scint {
 
+// relative size (against the column's Gram entry) below which a Cholesky pivot counts as zero; the
+// rounding noise of G - A^H A - sum |B|^2 is a few 1e-16 of the Gram entry
+constexpr double kBwPivotFloor = 1e-13;
+
 template <int W>
 __host__ __device__ constexpr int bw_upper(int r, int c) {   // index of Re of entry (r, c), r < c
     return W + 2 * (r * W - r * (r + 1) / 2 + (c - r - 1));
@@ -75,7 +79,10 @@ __host__ __device__ inline BlkW<W> bw_from_sums(const double* sa, const double* 
         double d = h[c][c].x;
 #pragma unroll
         for (int m = 0; m < c; ++m) d -= norm2(k.b[m][c]);
-        const double piv = d > 0.0 ? sqrt(d) : 0.0;
+        // a pivot at the rounding level of the Gram entry it was subtracted from is a direction that
+        // is exhausted (duplicate start rows, block wider than the matrix, converged directions): its
+        // normalised column would be amplified noise, not orthogonal to the others
+        const double piv = d > kBwPivotFloor * g[c][c].x ? sqrt(d) : 0.0;
         k.b[c][c] = mk(piv, 0.0);
         k.inv[c] = piv > 0.0 ? 1.0 / piv : 0.0;
 #pragma unroll
@@ -146,6 +153,22 @@ __host__ __device__ inline void bw_pack(const BlkW<W>& k, double* pa, double* pb
             pb[bw_upper<W>(r, c)] = k.b[r][c].x; pb[bw_upper<W>(r, c) + 1] = k.b[r][c].y;
         }
     }
+}
+
+// Block steps after which the Krylov space of a job is complete.  Block i contributes rank(Q_i) =
+// the nonzero pivots of B_{i-1} (beta[i], packed) independent directions; once their sum reaches n
+// the projection T is the whole matrix and later steps only add noise.  Returns min(k, that step
+// count) and the accumulated rank.  A start block can be rank deficient (block wider than the
+// matrix, dependent rows), so W k >= n alone proves nothing.
+template <int W>
+__host__ __device__ inline int bw_complete_steps(const double* beta, int k, int n, int* rank_out) {
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+        for (int r = 0; r < W; ++r) rank += beta[W * W * j + r] > 0.0;
+        if (rank >= n) { *rank_out = rank; return j + 1; }
+    }
+    *rank_out = rank;
+    return k;
 }
 
 // LDL^H pivots of T - x for a Hermitian band matrix of half width W: returns the number of negative

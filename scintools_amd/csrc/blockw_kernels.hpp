@@ -475,11 +475,20 @@ __global__ void __launch_bounds__(64) pkw_check_kernel(const PackedJob* jobs, in
         return;
     }
     if (k_done < 2 && k_done < jb.max_steps) return;
-    const int k = min(k_done, jb.max_steps);
-    const int n = W * k;
+    const int k_run = min(k_done, jb.max_steps);
     // A_{k-1}, B_{k-1} are still in the partials of the last reduce kernel
-    const BlkW<W> last = bw_step_wave<W>((k & 1) ? jb.apart[1] : jb.apart[0], (k & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane);
-    if (lane == 0) bw_pack<W>(last, lastA, lastB);
+    const BlkW<W> last = bw_step_wave<W>((k_run & 1) ? jb.apart[1] : jb.apart[0], (k_run & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane);
+    // blocks that make the Krylov space complete (all of them unless the space is saturated)
+    int rank = 0;
+    const int k = bw_complete_steps<W>(jb.beta, k_run, jb.n, &rank);
+    const bool complete = rank >= jb.n;
+    const int n = W * k;
+    if (lane == 0) {
+        bw_pack<W>(last, lastA, lastB);
+        if (k < k_run) {                       // saturated before the last step: its diagonal block is in the history
+            for (int c = 0; c < S; ++c) lastA[c] = jb.alpha[S * (k - 1) + c];
+        }
+    }
     __syncthreads();
     for (int i = lane; i < n; i += 64) {
         const int j = i / W, r = i - j * W;
@@ -545,14 +554,16 @@ __global__ void __launch_bounds__(64) pkw_check_kernel(const PackedJob* jobs, in
         const double prev = jb.result[3];
         const double at = fmax(fabs(theta), 1e-300);
         const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
-        const bool exact = finite && (n >= jb.n || bnorm == 0.0);
+        // the projection is the whole matrix (accumulated rank, bw_complete_steps) or the last block
+        // is exhausted (invariant subspace)
+        const bool exact = finite && (complete || bnorm == 0.0);
         // eigenvector wanted: same gap-aware rule as the other check kernels
         const double prev2 = jb.result[1], gap2 = theta - theta2;
         const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
         const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= 30.0 * jb.tol * gap2);
         const bool ok = jb.want_vec ? vec_ok : (err <= jb.tol * at && settled);
         const bool conv = finite && (ok || exact);
-        const bool stop = conv || !finite || k >= jb.max_steps;
+        const bool stop = conv || !finite || k_run >= jb.max_steps;
         jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
         if (stop) {
             jb.state[1] = k;

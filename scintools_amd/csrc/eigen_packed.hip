@@ -910,31 +910,36 @@ __global__ void __launch_bounds__(64) pk2_ritz_kernel(const PackedJob* jobs, con
 
 }  // namespace scint
 #include "blockw_kernels.hpp"
+#include "blockq_kernels.hpp"
 namespace scint {
 
 // ------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------
-// vectors per Lanczos step: 2 (default), 1 (SCINT_LANCZOS_BLOCK=1, the round-1 recurrence) or 4
-// (SCINT_LANCZOS_BLOCK=4, blockw_kernels.hpp -- not yet validated on a GPU).  Read per call.
+// vectors per Lanczos step: 2 (default), 1 (SCINT_LANCZOS_BLOCK=1, the round-1 recurrence), 4
+// (blockw_kernels.hpp) or 8 (blockq_kernels.hpp) -- the last two not yet validated on a GPU.  Read per call.
 static int sweep_block_width() {
     const char* e = getenv("SCINT_LANCZOS_BLOCK");
     const int v = e ? atoi(e) : 2;
-    return (v == 1 || v == 4) ? v : 2;
+    return (v == 1 || v == 4 || v == 8) ? v : 2;
 }
 // SCINT_MATVEC_MFMA=1 (with SCINT_LANCZOS_BLOCK=4): the matrix-core mat-vec of blockw_kernels.hpp
-static bool sweep_matvec_mfma() {
+static int sweep_matvec_mode() {
     const char* e = getenv("SCINT_MATVEC_MFMA");
-    return e && atoi(e) == 1;
+    return e ? atoi(e) : 0;
 }
+// the "q" kernel family (coefficients and Q_j once per step, blockq_kernels.hpp): always for 8 vectors,
+// for 4 vectors with SCINT_MATVEC_MFMA=2 (cross-check of the family against the pkw_* kernels)
+static bool sweep_q_family(int block) { return block == 8 || (block == 4 && sweep_matvec_mode() == 2); }
 static int strip_len_block(int nb, int block) {
     const int s = strip_len_for(nb);
+    if (block == 8) return std::min(s, QShape<8>::strip);
     return block == 4 ? std::min(s, kStripW) : s;
 }
 
 struct SlabLayout {
     size_t tiles, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
-        alpha, beta, result, total;
+        alpha, beta, result, coef, total;
     int qslots;
 };
 
@@ -957,7 +962,7 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block
     // 2 columns, 4 scalars per coefficient (they are small next to the tiles); the single-vector
     // recurrence (SCINT_LANCZOS_BLOCK=1) uses half of each
     // (SCINT_LANCZOS_BLOCK=4: 4 columns, 16 scalars, column partials per quarter tile)
-    const size_t bw = block == 4 ? 4 : 2, sc = bw * bw, cparts = block == 4 ? kQuarters : 1;
+    const size_t bw = block >= 4 ? (size_t)block : 2, sc = bw * bw, cparts = block == 4 ? kQuarters : 1;
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.qslots = want_vec ? max_steps + 1 : 2;        // (block steps when two vectors run: <= kMaxKB + 1 are used)
@@ -973,6 +978,7 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block
     L.alpha = take(sizeof(double) * (size_t)(max_steps + 2) * sc);
     L.beta = take(sizeof(double) * (size_t)(max_steps + 3) * sc);
     L.result = take(sizeof(double) * 4);
+    L.coef = take(sizeof(double) * (6 * sc + bw));       // QCoef<W>::total (wide-block family only)
     L.total = align_up(off, 256);
     return L;
 }
@@ -1081,6 +1087,7 @@ struct SweepProblem {
     SweepTail* tail_hook; hipStream_t tail[2]; int tail_rr = 0;   // retired curvatures alternate between two tail streams
     int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1, 2 or 4)
     bool mfma = false;                                 // block == 4: matrix-core mat-vec (SCINT_MATVEC_MFMA=1)
+    bool qfam = false;                                 // wide-block kernel family (blockq_kernels.hpp)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1143,7 +1150,11 @@ struct SweepGroup {
             const int64_t c = S.cs_index ? S.cs_index[e] : 0;
             J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
             J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            J.max_steps = S.block == 4   ? std::min(std::min(S.steps_cap, kMaxKW), std::max((n + 3) / 4, 1))
+            // wide blocks: W extra steps beyond ceil(n / W) -- a rank-deficient start block (tiny or
+            // rank-deficient matrices) grows the Krylov space by fewer than W dimensions per step
+            J.max_steps = S.block == 8   ? std::min(std::min(S.steps_cap, kMaxKQ), (n + 7) / 8 + 8)
+                          : S.qfam       ? std::min(std::min(S.steps_cap, kMaxKQ), (n + 3) / 4 + 4)
+                          : S.block == 4 ? std::min(std::min(S.steps_cap, kMaxKW), (n + 3) / 4 + 4)
                           : S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
                                          : std::min(S.steps_cap, std::max(n, 1));
             J.strip_len = strip_len_block(J.nb, S.block);
@@ -1227,7 +1238,10 @@ struct SweepGroup {
                                             hipMemcpyHostToDevice, stream);
                     if (he != hipSuccess) return hip_fail(he, "sweep eigenvector export", __FILE__, __LINE__);
                     const dim3 grid((unsigned)nb_fin, (unsigned)nfin);
-                    if (S.block == 4)
+                    if (S.block == 8)
+                        hipLaunchKernelGGL(pkw_ritz_kernel<8>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                           S.vec_out, S.vstride);
+                    else if (S.block == 4)
                         hipLaunchKernelGGL(pkw_ritz_kernel<4>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
                                            S.vec_out, S.vstride);
                     else if (S.block == 2)
@@ -1253,7 +1267,10 @@ struct SweepGroup {
             if (!fresh.empty()) {
                 int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream);
                 if (rc != SCINT_OK) return rc;
-                if (S.block == 4)
+                if (S.block == 8)
+                    hipLaunchKernelGGL(pkw_init_kernel<8>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                                       d_jobs(tab), d_fresh(tab));
+                else if (S.block == 4)
                     hipLaunchKernelGGL(pkw_init_kernel<4>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
                                        d_jobs(tab), d_fresh(tab));
                 else if (S.block == 2)
@@ -1270,6 +1287,30 @@ struct SweepGroup {
         if (nstrips > 0) {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
+                if (S.qfam) {
+                    // wide-block family: coefficients and Q_j once per step, then mat-vec and reduce
+                    const dim3 gq((unsigned)nb_run, (unsigned)nslots);
+                    if (S.block == 8) {
+                        hipLaunchKernelGGL(pkq_coef_kernel<8>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch);
+                        hipLaunchKernelGGL(pkq_qbuild_kernel<8>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
+                    } else {
+                        hipLaunchKernelGGL(pkq_coef_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch);
+                        hipLaunchKernelGGL(pkq_qbuild_kernel<4>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
+                    }
+                    const int slotq = profiler().begin(kProfMatvec, stream);
+                    if (S.block == 8)
+                        hipLaunchKernelGGL(pkq_matvec_mfma_kernel<8>, dim3((unsigned)nstrips), dim3(256), pkq_matvec_lds_bytes<8>(),
+                                           stream, d_jobs(tab), d_strips(tab), launch);
+                    else
+                        hipLaunchKernelGGL(pkq_matvec_mfma_kernel<4>, dim3((unsigned)nstrips), dim3(256), pkq_matvec_lds_bytes<4>(),
+                                           stream, d_jobs(tab), d_strips(tab), launch);
+                    profiler().end(kProfMatvec, slotq, stream);
+                    if (S.block == 8)
+                        hipLaunchKernelGGL(pkq_reduce_kernel<8>, gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    else
+                        hipLaunchKernelGGL(pkq_reduce_kernel<4>, gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    continue;
+                }
                 const int slot = profiler().begin(kProfMatvec, stream);
                 if (S.block == 4 && S.mfma)
                     hipLaunchKernelGGL(pkw_matvec_mfma_kernel<4>, dim3((unsigned)nstrips), dim3(256), 0, stream,
@@ -1293,7 +1334,15 @@ struct SweepGroup {
                                        stream, d_jobs(tab), launch);
             }
         }
-        if (S.block == 4)
+        if (S.qfam && S.block == 8) {
+            hipLaunchKernelGGL(pkq_coef_kernel<8>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+            hipLaunchKernelGGL(pkq_check_kernel<8>, dim3((unsigned)nslots), dim3(64), QCheckLds<8>::total, stream, d_jobs(tab),
+                               launch0 + S.check_every);
+        } else if (S.qfam) {
+            hipLaunchKernelGGL(pkq_coef_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+            hipLaunchKernelGGL(pkq_check_kernel<4>, dim3((unsigned)nslots), dim3(64), QCheckLds<4>::total, stream, d_jobs(tab),
+                               launch0 + S.check_every);
+        } else if (S.block == 4)
             hipLaunchKernelGGL(pkw_check_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
         else if (S.block == 2)
             hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
@@ -1374,7 +1423,20 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const int forced_every = every_env ? atoi(every_env) : 0;
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     S.block = sweep_block_width();
-    S.mfma = S.block == 4 && sweep_matvec_mfma();
+    S.qfam = sweep_q_family(S.block);
+    S.mfma = S.block == 4 && (S.qfam || sweep_matvec_mode() == 1);
+    if (S.qfam) {
+        // kernels of the family with more than the default 64 KiB of dynamic LDS
+        static const hipError_t lds_ok = [] {
+            hipError_t e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)pkq_matvec_lds_bytes<8>());
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)pkq_check_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)QCheckLds<8>::total);
+            return e;
+        }();
+        if (lds_ok != hipSuccess) return hip_fail(lds_ok, "wide-block LDS attributes", __FILE__, __LINE__);
+    }
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block >= 2 ? kCheckEveryBlock : kCheckEvery);
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
@@ -1440,6 +1502,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
             J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
             J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * (grp.slot0 + s);
+            J.coef = (double*)(sl + L.coef);
             J.tol = tol; J.gen = 0;
             J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
             J.eta = 0; J.two_eta = 0; J.keep = keep_idx;

@@ -67,6 +67,7 @@ struct PackedJob {
     int32_t* state;         // [4] last FINISHED generation of the slot (job done <=> state[0] >= gen), steps, -, -
     double* eig_out; int32_t* status_out; int32_t* iters_out;
     double tol;             // target relative accuracy of the eigenvalue
+    double* coef;           // wide-block family (blockq_kernels.hpp): coefficients of the current step, QCoef<W> layout
 };
 
 struct Strip {

@@ -37,9 +37,10 @@ def main(out_path):
     res["sspec_pw"] = sspec_device(ththmod.to_device(dyn, torch.float64), prewhite=True).cpu().numpy()
     res["red"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges)[0]
     res["red_nh"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges, False)[0]
-    for block in ("2", "1", "4", "4m"):                      # 4m: four vectors, matrix-core mat-vec
+    # 4m: four vectors with the matrix-core mat-vec; 4q: four vectors, wide-block kernel family; 8: eight vectors
+    for block, mode in (("2", "0"), ("1", "0"), ("4", "0"), ("4m", "1"), ("4q", "2"), ("8", "0")):
         os.environ["SCINT_LANCZOS_BLOCK"] = block[0]
-        os.environ["SCINT_MATVEC_MFMA"] = "1" if block.endswith("m") else "0"
+        os.environ["SCINT_MATVEC_MFMA"] = mode
         eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, return_info=True)
         res["eigs_b" + block], res["iters_b" + block] = eigs, info["iters"]
         w, V, _ = ththmod.eigvec_sweep(cs_t, tau, fd, etas[1:4], edges)

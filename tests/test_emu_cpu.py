@@ -133,8 +133,8 @@ def test_rev_map_explicit_matrix(emu, to, case):
 
 def test_results_do_not_depend_on_the_schedule(tmp_path):
     """Waves, lanes and blocks interpreted in the opposite order (SCINT_EMU_ORDER=rev) must give the
-    same bits for every product of the path (FFT, gather, the three Lanczos block widths incl. the
-    opt-in four-vector kernels, eigenvectors, rev_map, model, chi^2): any order is a legal GPU
+    same bits for every product of the path (FFT, gather, every Lanczos block width incl. the opt-in
+    four- and eight-vector kernels, eigenvectors, rev_map, model, chi^2): any order is a legal GPU
     schedule, so a difference would be a missing barrier or an inter-block dependence."""
     import subprocess
     try:
@@ -162,4 +162,10 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     np.testing.assert_allclose(a["eigs_b4"], a["eigs_b2"], rtol=1e-10)
     np.testing.assert_allclose(a["eigs_b4m"], a["eigs_b4"], rtol=1e-12)     # matrix-core mat-vec of the same recurrence
     assert np.array_equal(a["iters_b4m"], a["iters_b4"])
+    np.testing.assert_allclose(a["eigs_b4q"], a["eigs_b4"], rtol=1e-12)     # wide-block kernel family, four vectors
+    np.testing.assert_allclose(a["eigs_b8"], a["eigs_b2"], rtol=1e-10)      # ... eight vectors
+    assert a["iters_b8"].mean() <= a["iters_b4"].mean()
+    for tag in ("b1", "b4", "b4m", "b4q", "b8"):                            # eigenvectors up to a phase
+        for k in range(a["V_b2"].shape[0]):
+            assert 1 - abs(np.vdot(a["V_" + tag][k], a["V_b2"][k])) <= 1e-9, (tag, k)
     assert a["iters_b4"].mean() < a["iters_b2"].mean() < a["iters_b1"].mean()

@@ -115,38 +115,43 @@ def test_sweep_is_schedule_invariant(env):
         assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
 
 
-def test_four_vector_block_matches_two_vector(env):
-    """SCINT_LANCZOS_BLOCK=4 (blockw_kernels.hpp): same eigenvalues / eigenvectors as the default
-    two-vector recurrence to the stopping tolerance, in fewer matrix passes.  The four-vector kernels
-    are opt-in and have so far only run on the host interpreter (`pytest --emu`, green there): on a
-    GPU this test runs when SCINT_TEST_BLOCK4=1 asks for it."""
+@pytest.mark.parametrize("block,matvec", [("4", "0"), ("4", "1"), ("4", "2"), ("8", "0")])
+def test_wide_blocks_match_two_vector(env, block, matvec):
+    """The opt-in wider Lanczos blocks -- SCINT_LANCZOS_BLOCK=4 with the vector-FMA quarter strips
+    (SCINT_MATVEC_MFMA=0), the matrix-core mat-vec (=1) or the wide-block kernel family (=2), and
+    SCINT_LANCZOS_BLOCK=8 (wide-block family, blockq_kernels.hpp): same eigenvalues / eigenvectors as
+    the default two-vector recurrence to the stopping tolerance, in fewer matrix passes.  These
+    kernels have so far only run on the host interpreter (`pytest --emu`, green there): on a GPU this
+    test runs when SCINT_TEST_WIDE_BLOCKS=1 asks for it."""
     import os
     from scintools_amd import _lib
-    if os.environ.get("SCINT_TEST_BLOCK4") != "1" and "emu" not in os.path.basename(_lib.load()._name):
-        pytest.skip("opt-in four-vector path: set SCINT_TEST_BLOCK4=1")
+    if os.environ.get("SCINT_TEST_WIDE_BLOCKS") != "1" and "emu" not in os.path.basename(_lib.load()._name):
+        pytest.skip("opt-in wide-block paths: set SCINT_TEST_WIDE_BLOCKS=1")
     thth, to, p = env
     etas = np.geomspace(0.5, 2.0, 12) * p["eta"]
-    ref, i2 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
-    w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
-    V2n = V2.cpu().numpy()
-    for mfma in ("0", "1"):                                 # vector-FMA quarter strips / matrix-core mat-vec
-        os.environ["SCINT_LANCZOS_BLOCK"] = "4"
-        os.environ["SCINT_MATVEC_MFMA"] = mfma
-        try:
-            got, i4 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
-            again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
-            w4, V4, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
-        finally:
-            del os.environ["SCINT_LANCZOS_BLOCK"], os.environ["SCINT_MATVEC_MFMA"]
-        assert np.all(i4["status"] == 0), mfma
-        np.testing.assert_allclose(got, ref, rtol=1e-10)
-        assert np.array_equal(again, got), mfma             # batch-invariant bits
-        assert i4["iters"].mean() < i2["iters"].mean()
-        np.testing.assert_allclose(w4, w2, rtol=1e-10)
-        V4n = V4.cpu().numpy()
-        for k in range(len(etas)):
-            n = int(i2["N"][k])
-            assert 1 - abs(np.vdot(V2n[k, :n], V4n[k, :n])) <= 1e-9
+    saved = {k: os.environ.pop(k, None) for k in ("SCINT_LANCZOS_BLOCK", "SCINT_MATVEC_MFMA")}
+    try:
+        ref, i2 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
+        w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+        os.environ["SCINT_LANCZOS_BLOCK"] = block
+        os.environ["SCINT_MATVEC_MFMA"] = matvec
+        got, iw = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
+        again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
+        ww, Vw, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert np.all(iw["status"] == 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-10)
+    assert np.array_equal(again, got)                           # batch-invariant bits
+    assert iw["iters"].mean() < i2["iters"].mean()
+    np.testing.assert_allclose(ww, w2, rtol=1e-10)
+    V2n, Vwn = V2.cpu().numpy(), Vw.cpu().numpy()
+    for k in range(len(etas)):
+        n = int(i2["N"][k])
+        assert 1 - abs(np.vdot(V2n[k, :n], Vwn[k, :n])) <= 1e-9
 
 
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
