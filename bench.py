@@ -129,6 +129,22 @@ def make_workload(size, neta, nedge, seed, npad=0, npz=None):
     return dyn, freqs, times, fd, tau, edges, etas, eta_true
 
 
+def lanczos_block():
+    """(vectors per Lanczos step, name of the mat-vec kernel) as the library will choose them from the
+    environment: 2 by default; SCINT_LANCZOS_BLOCK=1 / 4 / 8 and SCINT_MATVEC_MFMA select the
+    experimental paths (eigen_packed.hip, sweep_block_width)."""
+    b = os.environ.get("SCINT_LANCZOS_BLOCK", "2")
+    m = os.environ.get("SCINT_MATVEC_MFMA", "0")
+    if b == "1":
+        return 1, "pk_matvec_kernel"
+    if b == "8":
+        return 8, "pkq_matvec_mfma_kernel<8> (eight-vector block Lanczos, matrix cores; experimental)"
+    if b == "4":
+        name = {"1": "pkw_matvec_mfma_kernel<4>", "2": "pkq_matvec_mfma_kernel<4>"}.get(m, "pkw_matvec_kernel<4>")
+        return 4, name + " (four-vector block Lanczos; experimental)"
+    return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec)"
+
+
 def blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -405,11 +421,10 @@ def main():
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
-                       "lanczos_vectors_per_step": 1 if os.environ.get("SCINT_LANCZOS_BLOCK") == "1" else 2,
+                       "lanczos_vectors_per_step": lanczos_block()[0],
                        "batch": int(info["batch"]), "failed_etas": int(np.sum(info["status"] != 0)),
                        "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
-            "roofline": {"kernel": "pk_matvec_kernel" if os.environ.get("SCINT_LANCZOS_BLOCK") == "1" else
-                         "pk2_matvec_kernel (two-vector block Lanczos mat-vec)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": lanczos_block()[1], "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg_per_launch,
                          "traffic": (ratio * alg_per_launch) if ratio else None,

@@ -236,7 +236,7 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cred[w][16 * c + k4 + 4 * r][n16] = accc[c][r];
+                for (int r = 0; r < 4; ++r) cred[w][16 * c + mfma_d_row(lane, r)][n16] = accc[c][r];
         }
         __syncthreads();
         const int Jt = st.J0 + t;
@@ -253,7 +253,7 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
     if (n16 < NR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            gstore(rowpart + NR * ((int64_t)st.index * kTB + 16 * w + k4 + 4 * r) + n16, accr0[r] + accr1[r]);
+            gstore(rowpart + NR * ((int64_t)st.index * kTB + 16 * w + mfma_d_row(lane, r)) + n16, accr0[r] + accr1[r]);
     }
 }
 

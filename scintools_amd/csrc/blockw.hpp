@@ -48,8 +48,10 @@ __host__ __device__ inline cplx bw_a(const BlkW<W>& k, int r, int c) {
 
 // From the SUMMED partials sa = pack(Q^H W), sg = pack(W^H W): A, the Cholesky factor B of
 // G - A^H A, and the inverse pivots.
+// `room`: directions the Krylov space can still take (n minus the rank of the blocks so far); what
+// survives the pivot floor beyond that is the noise of a saturated space.
 template <int W>
-__host__ __device__ inline BlkW<W> bw_from_sums(const double* sa, const double* sg) {
+__host__ __device__ inline BlkW<W> bw_from_sums(const double* sa, const double* sg, int room = 1 << 30) {
     BlkW<W> k;
     cplx g[W][W];
 #pragma unroll
@@ -82,7 +84,8 @@ __host__ __device__ inline BlkW<W> bw_from_sums(const double* sa, const double* 
         // a pivot at the rounding level of the Gram entry it was subtracted from is a direction that
         // is exhausted (duplicate start rows, block wider than the matrix, converged directions): its
         // normalised column would be amplified noise, not orthogonal to the others
-        const double piv = d > kBwPivotFloor * g[c][c].x ? sqrt(d) : 0.0;
+        const double piv = (room > 0 && d > kBwPivotFloor * g[c][c].x) ? sqrt(d) : 0.0;
+        room -= piv > 0.0;
         k.b[c][c] = mk(piv, 0.0);
         k.inv[c] = piv > 0.0 ? 1.0 / piv : 0.0;
 #pragma unroll

@@ -31,8 +31,11 @@ __device__ inline int bw_start_row(int n, int v) {
     return (n / 2 + v) % max(n, 1);
 }
 
+// `beta`, `step`, `n`: the history of the B factors (their nonzero pivots are the ranks of the blocks
+// 0 .. step-1) and the matrix size -- the room left in the Krylov space for the block being formed
 template <int W>
-__device__ inline BlkW<W> bw_step_wave(const double* __restrict__ ap, const double* __restrict__ up, int nb, int lane) {
+__device__ inline BlkW<W> bw_step_wave(const double* __restrict__ ap, const double* __restrict__ up, int nb, int lane,
+                                       const double* __restrict__ beta, int step, int n) {
     constexpr int S = W * W;
     double sa[S], sg[S];
 #pragma unroll
@@ -43,7 +46,11 @@ __device__ inline BlkW<W> bw_step_wave(const double* __restrict__ ap, const doub
     }
 #pragma unroll
     for (int c = 0; c < S; ++c) { sa[c] = wave_sum(sa[c]); sg[c] = wave_sum(sg[c]); }
-    return bw_from_sums<W>(sa, sg);
+    int room = n;
+    for (int j = 0; j < step; ++j)
+#pragma unroll
+        for (int r = 0; r < W; ++r) room -= gload(beta + S * j + r) > 0.0;
+    return bw_from_sums<W>(sa, sg, room);
 }
 
 // the coefficients are wave-uniform: keep them in scalar registers
@@ -138,7 +145,7 @@ pkw_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
     cplx a0[4], a1[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) a0[r] = gload_nt(tp + r * kTB);
-    const BlkW<W> sc = bw_uniform<W>(bw_step_wave<W>(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
+    const BlkW<W> sc = bw_uniform<W>(bw_step_wave<W>(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane, jp->beta, step, jp->n));
     // lanes 0..15 of every wave hold rows 16 q .. 16 q + 15 of the block X_I; rows read them back with v_readlane
     cplx xI[W];
     bw_q_row_at<W>(sc, Up, Qp, I * kTB + 16 * qr + (lane & 15), xI);
@@ -232,6 +239,11 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ inline v4d mfma_f64_16x16x4(double a, double b, v4d c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// Operand layout the kernels assume (cdna_hip_programming.md, "f64 MFMA"): A[i][k] in lane 16 k + i,
+// B[k][j] in lane 16 k + j, and register r of lane l of C/D holds row mfma_d_row(l, r), column l & 15.
+// If a GPU run of the wide-block test fails only for the matrix-core forms, this is the one place
+// (with its mirror in tests/emu/include/hip/hip_runtime.h) to look at first.
+__device__ inline int mfma_d_row(int lane, int r) { return (lane >> 4) + 4 * r; }
 
 template <int W>
 __global__ void __launch_bounds__(256, 2)
@@ -266,7 +278,7 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
     cplx ra[16], ca[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) ra[g] = gload(rp + 4 * g);
-    const BlkW<W> sc = bw_uniform<W>(bw_step_wave<W>(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
+    const BlkW<W> sc = bw_uniform<W>(bw_step_wave<W>(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane, jp->beta, step, jp->n));
     for (int idx = threadIdx.x; idx < (ntile + 1) * kTB; idx += 256) {
         const bool own = idx >= ntile * kTB;       // the last 64 entries build X_I
         cplx x[W];
@@ -320,7 +332,7 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cred[w][16 * c + k4 + 4 * r][n16] = accc[c][r];
+                for (int r = 0; r < 4; ++r) cred[w][16 * c + mfma_d_row(lane, r)][n16] = accc[c][r];
         }
         __syncthreads();
         const int Jt = st.J0 + t;
@@ -339,7 +351,7 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
     if (n16 < NR) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            gstore(rowpart + NR * ((int64_t)st.index * kTB + 16 * w + k4 + 4 * r) + n16, accr0[r] + accr1[r]);
+            gstore(rowpart + NR * ((int64_t)st.index * kTB + 16 * w + mfma_d_row(lane, r)) + n16, accr0[r] + accr1[r]);
     }
 }
 
@@ -373,7 +385,7 @@ pkw_reduce_kernel(const PackedJob* __restrict__ jobs, int launch, int cparts) {
     for (int v = 0; v < W; ++v) part[g][e][v] = acc[v];
     __syncthreads();
     if (g == 0) {
-        const BlkW<W> sc = bw_step_wave<W>(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, e);
+        const BlkW<W> sc = bw_step_wave<W>(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, e, jb.beta, step, jb.n);
         cplx tot[W];
 #pragma unroll
         for (int v = 0; v < W; ++v) {
@@ -477,7 +489,7 @@ __global__ void __launch_bounds__(64) pkw_check_kernel(const PackedJob* jobs, in
     if (k_done < 2 && k_done < jb.max_steps) return;
     const int k_run = min(k_done, jb.max_steps);
     // A_{k-1}, B_{k-1} are still in the partials of the last reduce kernel
-    const BlkW<W> last = bw_step_wave<W>((k_run & 1) ? jb.apart[1] : jb.apart[0], (k_run & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane);
+    const BlkW<W> last = bw_step_wave<W>((k_run & 1) ? jb.apart[1] : jb.apart[0], (k_run & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane, jb.beta, k_run, jb.n);
     // blocks that make the Krylov space complete (all of them unless the space is saturated)
     int rank = 0;
     const int k = bw_complete_steps<W>(jb.beta, k_run, jb.n, &rank);
