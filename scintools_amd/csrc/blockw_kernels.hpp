@@ -239,7 +239,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ inline v4d mfma_f64_16x16x4(double a, double b, v4d c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
-// Operand layout the kernels assume (cdna_hip_programming.md, "f64 MFMA"): A[i][k] in lane 16 k + i,
+// Operand layout the kernels assume (cdna_hip_programming.md, "f64 MFMA"; the same follows from
+// composable_kernel's descriptor of this instruction, xdlops_gemm.hpp mfma_type<mfma_f64_16x16x4f64>:
+// group_size 1, 4 groups, 16 threads per block, 4 input blocks, k reduction): A[i][k] in lane 16 k + i,
 // B[k][j] in lane 16 k + j, and register r of lane l of C/D holds row mfma_d_row(l, r), column l & 15.
 // If a GPU run of the wide-block test fails only for the matrix-core forms, this is the one place
 // (with its mirror in tests/emu/include/hip/hip_runtime.h) to look at first.
