@@ -87,6 +87,7 @@ def build(force=False, verbose=False):
     jobs, objs = [], []
     units = [(os.path.join(src_out, u.replace(".hip", ".hip.cpp")), extra) for u, extra in UNITS.items()]
     units.append((os.path.join(HERE, "emu_runtime.cpp"), []))
+    units.append((os.path.join(HERE, "emu_selftest.cpp"), []))
     for src, extra in units:
         obj = os.path.join(OUT, os.path.basename(src) + ".o")
         objs.append(obj)

@@ -56,6 +56,37 @@ def test_interpreted_library_is_not_the_product(emu):
     assert "tests" in _lib.load()._name.split(os.sep)
 
 
+def test_interpreter_semantics(emu):
+    """The interpreter's own model of the hardware: cross-lane operations incl. a ballot that only
+    part of the wave executes, a block barrier across four waves, and v_mfma_f64_16x16x4 with the
+    operand layout of the programming guide (A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j,
+    result register r of lane l = row (l >> 4) + 4 r, column l & 15)."""
+    import ctypes
+    import emulated
+    lib = emulated.load()
+    rng = np.random.default_rng(1)
+    a, b, c = rng.standard_normal(64), rng.standard_normal(64), rng.standard_normal(256)
+    d = np.zeros(256)
+    ptr = lambda x: ctypes.c_void_p(x.ctypes.data)
+    lib.emu_selftest_mfma(ptr(a), ptr(b), ptr(c), ptr(d))
+    A = a.reshape(4, 16).T                      # A[i][k] = a[16 k + i]
+    B = b.reshape(4, 16)                        # B[k][j] = b[16 k + j]
+    C = np.zeros((16, 16))
+    lanes, regs = np.meshgrid(np.arange(64), np.arange(4), indexing="ij")
+    C[(lanes >> 4) + 4 * regs, lanes & 15] = c.reshape(64, 4)
+    D = C + A @ B
+    np.testing.assert_allclose(d.reshape(64, 4), D[(lanes >> 4) + 4 * regs, lanes & 15], rtol=1e-12, atol=1e-14)
+    x = rng.standard_normal(256)
+    out = np.zeros(320)
+    lib.emu_selftest_wave(ptr(x), ptr(out), ctypes.c_int(40))
+    l = np.arange(64)
+    np.testing.assert_allclose(out[:64], x[:64].sum(), rtol=1e-13)
+    assert np.array_equal(out[64:128], x[(l * 7) % 64])
+    assert np.all(out[128:192] == float(int(x[5] * 1000.0)))
+    assert np.array_equal(out[192:256], np.where(l < 40, np.sum(np.arange(40) % 3 == 0), -1))
+    assert np.array_equal(out[256:320], x[64:128])
+
+
 @pytest.mark.parametrize("hermetian", [True, False])
 def test_gather_bit_equal(emu, to, case, hermetian):
     c = case
