@@ -20,11 +20,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu
 
 @pytest.fixture()
 def emu(monkeypatch):
+    import subprocess
     import emulated
     try:
         emulated.install(monkeypatch)
-    except RuntimeError as exc:          # no clang++ on this machine
-        pytest.skip(str(exc))
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:    # no usable clang++ on this machine
+        pytest.skip(f"host interpreter could not be built: {exc}")
     from scintools_amd import ththmod
     return ththmod
 
@@ -171,8 +172,8 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     try:
         import emulated
         emulated.load()                      # build once, before the two children race for it
-    except RuntimeError as exc:
-        pytest.skip(str(exc))
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:
+        pytest.skip(f"host interpreter could not be built: {exc}")
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "order_probe.py")
     procs = []
     for tag, order in (("fwd", ""), ("rev", "rev")):
