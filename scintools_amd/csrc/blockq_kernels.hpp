@@ -27,7 +27,10 @@ namespace scint {
 
 constexpr int kMaxKQ = 40;          // block steps the check kernel holds in LDS (T up to 320 x 320 for W = 8)
 constexpr int kRedGroupsQ = 4;      // wavefronts per reduce block (LDS: groups x 64 x W complex)
-template <int W> struct QShape { static constexpr int strip = W >= 8 ? 4 : 8; };   // tiles per strip (LDS of the mat-vec)
+// tiles per strip of the mat-vec (its X_J blocks live in LDS): 8 for four vectors; for eight vectors 4
+// (72 KiB, two workgroups per CU) or, with SCINT_Q_STRIP=8, 8 (104 KiB, one workgroup per CU, half the
+// X_J / row-partial traffic) -- to be decided by measurement
+template <int W> struct QShape { static constexpr int strip = W >= 8 ? 4 : 8; };
 
 // layout of PackedJob::coef (doubles): A full [W][W] complex | B upper [W][W] complex (zeros below)
 // | 1/diag(B) [W] | packed A [W*W] | packed B [W*W]
@@ -153,13 +156,13 @@ __global__ void __launch_bounds__(64) pkq_qbuild_kernel(const PackedJob* jobs, i
 
 // The matrix-core mat-vec (see pkw_matvec_mfma_kernel for the operand algebra) with X_J and X_I copied
 // from the stored Q_j.  Dynamic LDS: xs[STRIP][64][2W] | xI[64][2W] | cred[4][64][2W] doubles.
-template <int W> constexpr size_t pkq_matvec_lds_bytes() {
-    return sizeof(double) * (size_t)(QShape<W>::strip + 1 + 4) * kTB * 2 * W;
+template <int W, int STRIP> constexpr size_t pkq_matvec_lds_bytes() {
+    return sizeof(double) * (size_t)(STRIP + 1 + 4) * kTB * 2 * W;
 }
-template <int W>
+template <int W, int STRIP>
 __global__ void __launch_bounds__(256, 2)
 pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    constexpr int NR = 2 * W, STRIP = QShape<W>::strip;
+    constexpr int NR = 2 * W;
     static_assert(NR <= 16 && (NR & (NR - 1)) == 0, "block width must be 1, 2, 4 or 8");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double (*xs)[kTB][NR] = (double (*)[kTB][NR])smem_raw;

@@ -930,10 +930,15 @@ static int sweep_matvec_mode() {
 }
 // the "q" kernel family (coefficients and Q_j once per step, blockq_kernels.hpp): always for 8 vectors,
 // for 4 vectors with SCINT_MATVEC_MFMA=2 (cross-check of the family against the pkw_* kernels)
+// strip length of the eight-vector mat-vec: 4 (default) or 8 (SCINT_Q_STRIP=8)
+static int sweep_q_strip8() {
+    const char* e = getenv("SCINT_Q_STRIP");
+    return (e && atoi(e) == 8) ? 8 : QShape<8>::strip;
+}
 static bool sweep_q_family(int block) { return block == 8 || (block == 4 && sweep_matvec_mode() == 2); }
 static int strip_len_block(int nb, int block) {
     const int s = strip_len_for(nb);
-    if (block == 8) return std::min(s, QShape<8>::strip);
+    if (block == 8) return std::min(s, sweep_q_strip8());
     return block == 4 ? std::min(s, kStripW) : s;
 }
 
@@ -1088,6 +1093,7 @@ struct SweepProblem {
     int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1, 2 or 4)
     bool mfma = false;                                 // block == 4: matrix-core mat-vec (SCINT_MATVEC_MFMA=1)
     bool qfam = false;                                 // wide-block kernel family (blockq_kernels.hpp)
+    int qstrip = 4;                                    // its strip length for eight vectors (SCINT_Q_STRIP)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1298,11 +1304,14 @@ struct SweepGroup {
                         hipLaunchKernelGGL(pkq_qbuild_kernel<4>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
                     }
                     const int slotq = profiler().begin(kProfMatvec, stream);
-                    if (S.block == 8)
-                        hipLaunchKernelGGL(pkq_matvec_mfma_kernel<8>, dim3((unsigned)nstrips), dim3(256), pkq_matvec_lds_bytes<8>(),
+                    if (S.block == 8 && S.qstrip == 8)
+                        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<8, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<8, 8>()),
+                                           stream, d_jobs(tab), d_strips(tab), launch);
+                    else if (S.block == 8)
+                        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<8, 4>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<8, 4>()),
                                            stream, d_jobs(tab), d_strips(tab), launch);
                     else
-                        hipLaunchKernelGGL(pkq_matvec_mfma_kernel<4>, dim3((unsigned)nstrips), dim3(256), pkq_matvec_lds_bytes<4>(),
+                        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<4, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<4, 8>()),
                                            stream, d_jobs(tab), d_strips(tab), launch);
                     profiler().end(kProfMatvec, slotq, stream);
                     if (S.block == 8)
@@ -1424,12 +1433,16 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     S.block = sweep_block_width();
     S.qfam = sweep_q_family(S.block);
+    S.qstrip = sweep_q_strip8();
     S.mfma = S.block == 4 && (S.qfam || sweep_matvec_mode() == 1);
     if (S.qfam) {
         // kernels of the family with more than the default 64 KiB of dynamic LDS
         static const hipError_t lds_ok = [] {
-            hipError_t e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)pkq_matvec_lds_bytes<8>());
+            hipError_t e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)pkq_matvec_lds_bytes<8, 4>());
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)pkq_matvec_lds_bytes<8, 8>());
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)pkq_check_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)QCheckLds<8>::total);

@@ -16,6 +16,7 @@ run() {  # tag, block, matvec mode
 for rep in 1 2; do
   run default_$rep 2 0
   run b8_$rep 8 0
+  SCINT_Q_STRIP=8 run b8s8_$rep 8 0
   run b4q_$rep 4 2
   run b4m_$rep 4 1
   run b4v_$rep 4 0
