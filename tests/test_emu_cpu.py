@@ -201,3 +201,36 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
         for k in range(a["V_b2"].shape[0]):
             assert 1 - abs(np.vdot(a["V_" + tag][k], a["V_b2"][k])) <= 1e-9, (tag, k)
     assert a["iters_b4"].mean() < a["iters_b2"].mean() < a["iters_b1"].mean()
+
+
+def test_gather_fuzz_bit_equal(emu, to):
+    """Random small geometries (sizes, padding, edge counts and ranges, curvatures from far below to far
+    above the arc, both Hermitian settings): the gather kernel's index arithmetic (exact floor, crop,
+    wrap-around) against the oracle, bit for bit."""
+    from scintools_amd.synth import arc_dynspec
+    rng = np.random.default_rng(20260921)
+    checked = 0
+    for trial in range(40):
+        nf, nt = int(rng.integers(8, 72)), int(rng.integers(8, 72))
+        npad = int(rng.integers(0, 3))
+        dyn, freqs, times, eta_true = arc_dynspec(nf, nt, seed=trial, nimg=5)
+        fd = to.fft_axis(times, 1000.0, npad)
+        tau = to.fft_axis(freqs, 1.0, npad)
+        CS = to.conjugate_spectrum(dyn - dyn.mean(), npad)
+        nedge = 2 * int(rng.integers(2, 40))                          # even: an odd count has two centres of equal |theta|
+        lim = fd.max() * float(rng.uniform(0.2, 1.2))
+        edges = np.linspace(-lim, lim, nedge)
+        eta = eta_true * float(10 ** rng.uniform(-1.5, 1.5))
+        hermetian = bool(trial % 2 == 0)
+        try:
+            ref, e_ref = to.thth_redmap(CS, tau, fd, eta, edges, hermetian)
+        except (IndexError, ValueError):
+            with pytest.raises((IndexError, ValueError)):
+                emu.thth_redmap(CS, tau, fd, eta, edges, hermetian)
+            continue
+        got, e_got = emu.thth_redmap(CS, tau, fd, eta, edges, hermetian)
+        assert got.shape == ref.shape, (trial, nf, nt, npad, nedge)
+        assert np.array_equal(got, ref, equal_nan=True), (trial, nf, nt, npad, nedge, eta / eta_true, hermetian)
+        assert np.array_equal(e_got, e_ref)
+        checked += 1
+    assert checked >= 25
