@@ -1436,8 +1436,12 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.qstrip = sweep_q_strip8();
     S.mfma = S.block == 4 && (S.qfam || sweep_matvec_mode() == 1);
     if (S.qfam) {
-        // kernels of the family with more than the default 64 KiB of dynamic LDS
-        static const hipError_t lds_ok = [] {
+        // kernels of the family with more than the default 64 KiB of dynamic LDS; the attribute is per
+        // device, so it is set once per (host thread, device)
+        thread_local std::map<int, hipError_t> lds_set;
+        int dev = 0;
+        SCINT_HIP(hipGetDevice(&dev));
+        if (lds_set.find(dev) == lds_set.end()) {
             hipError_t e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)pkq_matvec_lds_bytes<8, 4>());
             if (e == hipSuccess)
@@ -1446,8 +1450,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)pkq_check_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)QCheckLds<8>::total);
-            return e;
-        }();
+            lds_set[dev] = e;
+        }
+        const hipError_t lds_ok = lds_set[dev];
         if (lds_ok != hipSuccess) return hip_fail(lds_ok, "wide-block LDS attributes", __FILE__, __LINE__);
     }
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block >= 2 ? kCheckEveryBlock : kCheckEvery);

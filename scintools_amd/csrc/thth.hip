@@ -5,6 +5,7 @@
 // falls in is decided by a floor / an ordered comparison of float64 expressions,
 // and the reference evaluates those expressions with one IEEE rounding per NumPy
 // ufunc.  A fused multiply-add would flip pixels.
+#include <map>
 #include <float.h>
 #include <math.h>
 
@@ -529,9 +530,14 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)rev_gather_kernel<1024>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRevSlab * 36);
-    SCINT_HIP(lds_ok);
+    // the attribute belongs to the function ON A DEVICE: set it once per (host thread, device)
+    thread_local std::map<int, hipError_t> lds_set;
+    int dev = 0;
+    SCINT_HIP(hipGetDevice(&dev));
+    if (lds_set.find(dev) == lds_set.end())
+        lds_set[dev] = hipFuncSetAttribute((const void*)rev_gather_kernel<1024>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kRevSlab * 36);
+    SCINT_HIP(lds_set[dev]);
     hipLaunchKernelGGL(rev_gather_kernel<1024>, grid, dim3(1024), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
