@@ -260,6 +260,236 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
     }
 }
 
+// the last stage of both reduce kernels (wave 0 of the block): W_j = total - Q_{j-1} B_{j-1}^H for the
+// block's 64 rows and the partials of the next coefficients
+template <int W>
+__device__ inline void pkq_reduce_tail(const PackedJob& jb, int K, int step, int par, int e,
+                                       cplx (*part)[kTB][W], cplx (*Bs)[W]) {
+    constexpr int S = W * W;
+    const int qs = jb.qslots, r = K * kTB + e;
+    const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + qs - 1) % qs) * jb.qstride * W;
+    const cplx* __restrict__ Qj = jb.Q + (int64_t)(step % qs) * jb.qstride * W;
+    cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
+    cplx q[W], x[W], t[W];
+#pragma unroll
+    for (int v = 0; v < W; ++v) { q[v] = gload(Qp + W * r + v); x[v] = gload(Qj + W * r + v); }
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+        cplx tot = part[0][e][c];
+#pragma unroll
+        for (int k = 1; k < kRedGroupsQ; ++k) tot = tot + part[k][e][c];
+        cplx s = mk(0.0, 0.0);                        // row of Q_{j-1} B_{j-1}^H: sum_{m >= c} q_m conj(B[c][m])
+#pragma unroll
+        for (int m = c; m < W; ++m) s = s + mulc(q[m], Bs[c][m]);
+        t[c] = tot - s;                               // row of W_j = A Q_j - Q_{j-1} B_{j-1}^H
+        gstore(Un + W * r + c, t[c]);
+    }
+    // packed partials of A_j = Q_j^H W_j and of W_j^H W_j, written as they are produced
+    double* __restrict__ an = (par ? jb.apart[0] : jb.apart[1]) + S * K;
+    double* __restrict__ un = (par ? jb.upart[0] : jb.upart[1]) + S * K;
+#pragma unroll
+    for (int a = 0; a < W; ++a) {
+        const double da = wave_sum(x[a].x * t[a].x + x[a].y * t[a].y);
+        const double dg = wave_sum(norm2(t[a]));
+        if (e == 0) { an[a] = da; un[a] = dg; }
+#pragma unroll
+        for (int b = a + 1; b < W; ++b) {
+            const cplx za = wave_sum(mulc(t[b], x[a]));            // conj(x_a) t_b
+            const cplx zg = wave_sum(mulc(t[b], t[a]));            // conj(t_a) t_b
+            if (e == 0) {
+                an[bw_upper<W>(a, b)] = za.x; an[bw_upper<W>(a, b) + 1] = za.y;
+                un[bw_upper<W>(a, b)] = zg.x; un[bw_upper<W>(a, b) + 1] = zg.y;
+            }
+        }
+    }
+}
+
+// ---- banded form: R block rows per workgroup -------------------------------------------------------
+// The strip kernel above pays per TILE for what could be paid per group of tiles: one column partial
+// (64 x W complex) written and read back, and the copy of X_J.  At W = 8 that is 8 KiB + 8 KiB + 8 KiB
+// per 64-KiB tile; with the row partials and the X_I copies the extra traffic is ~0.47 of the matrix
+// stream (model: 65 MB on 133 MB per pass at N = 4095), which would eat most of the 0.62x passes.  The
+// matrix cores make the cure cheap: a row block's accumulator is 8 registers, so one workgroup can
+// take R block rows (I0 .. I0+R-1) of a column chunk J0..J1: for every column J the column parts of
+// the R tiles accumulate in the same four accumulators before ONE cross-wave reduction and ONE partial
+// per (band, column); X_J is copied once for R tiles.  R = 4, chunks of 4: extra traffic 0.21.
+// Tile columns left of a row's diagonal do not exist (packed upper triangle): row r takes part from
+// column I0 + r on; the chunk grid starts at J0 = I0, and R <= STRIP makes every workgroup of a band
+// produce a row partial for every row of the band.
+// Dynamic LDS: xs[STRIP][64][2W] | xI[R][64][2W] | cred[4][64][min(2W, 8)] doubles.
+template <int W, int STRIP, int R> constexpr size_t pkq_band_lds_bytes() {
+    return sizeof(double) * ((size_t)(STRIP + R) * kTB * 2 * W + (size_t)4 * kTB * (2 * W > 8 ? 8 : 2 * W));
+}
+template <int W, int STRIP, int R>
+__global__ void __launch_bounds__(256, 2)
+pkq_matvec_band_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
+    constexpr int NR = 2 * W, NRH = NR > 8 ? 8 : NR, PHASES = NR / NRH;
+    static_assert(NR <= 16 && (NR & (NR - 1)) == 0 && R <= STRIP, "bad band shape");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double (*xs)[kTB][NR] = (double (*)[kTB][NR])smem_raw;
+    double (*xI)[kTB][NR] = (double (*)[kTB][NR])(smem_raw + sizeof(double) * STRIP * kTB * NR);
+    double (*cred)[kTB][NRH] = (double (*)[kTB][NRH])(smem_raw + sizeof(double) * (STRIP + R) * kTB * NR);
+    const Strip st = strips[blockIdx.x];
+    const PackedJob* __restrict__ jp = jobs + st.job;
+    const int step = launch - jp->start;
+    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
+    const int nb = jp->nb;
+    const cplx* __restrict__ Qj = jp->Q + (int64_t)(step % jp->qslots) * jp->qstride * W;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k4 = lane >> 4, n16 = lane & 15;
+    const bool odd = n16 & 1;
+    const double live = n16 < NR ? 1.0 : 0.0;
+    const int npair = (n16 & (NR - 1)) & ~1;
+    const int I0 = st.I, J0 = st.J0;
+    const int nrow = min(R, nb - I0), ntile = st.J1 - J0;
+    const cplx* __restrict__ tiles = jp->tiles;
+    // tile (I0 + r, J0 + t) of the packed upper triangle (exists iff I0 + r <= J0 + t)
+    auto tile_at = [&](int t, int r) { return tiles + (tile_offset(nb, I0 + r) + (J0 + t - I0 - r)) * kTileElems; };
+    const int row_off = (16 * w + n16) * kTB + k4;       // row-part operand g:  + 4 g
+    const int col_off = (16 * w + k4) * kTB + n16;       // column-part operand (c, kk): + 4 kk * 64 + 16 c
+    cplx ra[16], ca[16];
+    {
+        const cplx* __restrict__ p0 = tile_at(0, 0) + row_off;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) ra[g] = gload(p0 + 4 * g);
+    }
+    {
+        cplx* xsc = (cplx*)smem_raw;
+        const cplx* __restrict__ srcJ = Qj + (int64_t)J0 * kTB * W;
+        for (int idx = threadIdx.x; idx < ntile * kTB * W; idx += 256) xsc[idx] = gload(srcJ + idx);
+        cplx* xIc = (cplx*)&xI[0][0][0];
+        const cplx* __restrict__ srcI = Qj + (int64_t)I0 * kTB * W;
+        for (int idx = threadIdx.x; idx < nrow * kTB * W; idx += 256) xIc[idx] = gload(srcI + idx);
+    }
+    __syncthreads();
+    v4d accr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) accr[r] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double* __restrict__ colpart = (double*)jp->colpart;
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+        const int J = J0 + t;
+        v4d accc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accc[c] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r >= nrow || I0 + r > J) continue;                 // wave-uniform
+            const cplx* __restrict__ tp = tile_at(t, r);
+            const bool offdiag = I0 + r < J;
+            if (offdiag) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) ca[q] = gload(tp + col_off + (4 * (q & 3)) * kTB + 16 * (q >> 2));   // q = 4 c + kk
+            }
+            v4d a0 = accr[r], a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const double pr = xs[t][4 * g + k4][npair], pi = xs[t][4 * g + k4][npair + 1];
+                const double x1 = live * (odd ? pi : pr);          // a x = (ar xr - ai xi) + i (ar xi + ai xr)
+                const double x2 = live * (odd ? pr : -pi);
+                if (g & 1) { a1 = mfma_f64_16x16x4(ra[g].x, x1, a1); a1 = mfma_f64_16x16x4(ra[g].y, x2, a1); }
+                else       { a0 = mfma_f64_16x16x4(ra[g].x, x1, a0); a0 = mfma_f64_16x16x4(ra[g].y, x2, a0); }
+            }
+            accr[r] = a0 + a1;
+            // row patches of the next tile of the sequence: the next row of this column, else row 0 of the next one
+            {
+                int tn = t, rn = r + 1;
+                if (rn >= nrow || I0 + rn > J) { rn = 0; tn = t + 1; }
+                if (tn < ntile) {
+                    const cplx* __restrict__ pn = tile_at(tn, rn) + row_off;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) ra[g] = gload(pn + 4 * g);
+                }
+            }
+            if (offdiag) {
+                // B operands of the column part: rows 16 w + 4 kk + k4 of X_{I0 + r};  conj(a) x = (ar xr + ai xi) + i (ar xi - ai xr)
+                double y1[4], y3[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double pr = xI[r][16 * w + 4 * kk + k4][npair], pi = xI[r][16 * w + 4 * kk + k4][npair + 1];
+                    y1[kk] = live * (odd ? pi : pr);
+                    y3[kk] = live * (odd ? -pr : pi);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        accc[c] = mfma_f64_16x16x4(ca[4 * c + kk].x, y1[kk], accc[c]);
+                        accc[c] = mfma_f64_16x16x4(ca[4 * c + kk].y, y3[kk], accc[c]);
+                    }
+                }
+            }
+        }
+        if (J > I0) {
+            // cross-wave sum of the column's partial (all rows of the band), fixed order, one half of the
+            // real columns per phase
+#pragma unroll
+            for (int ph = 0; ph < PHASES; ++ph) {
+                if (n16 < NR && (n16 / NRH) == ph) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) cred[w][16 * c + mfma_d_row(lane, r4)][n16 - ph * NRH] = accc[c][r4];
+                }
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < kTB * NRH; idx += 256) {
+                    const int col = idx / NRH, nn = idx - col * NRH;
+                    const double sum = ((cred[0][col][nn] + cred[1][col][nn]) + cred[2][col][nn]) + cred[3][col][nn];
+                    gstore(colpart + NR * ((tile_offset(nb, I0) + (J - I0)) * kTB + col) + ph * NRH + nn, sum);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    double* __restrict__ rowpart = (double*)jp->rowpart;
+    if (n16 < NR) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (r >= nrow) continue;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                gstore(rowpart + NR * (((int64_t)st.index * R + r) * kTB + 16 * w + mfma_d_row(lane, r4)) + n16, accr[r][r4]);
+        }
+    }
+}
+
+// reduce for the banded mat-vec: block row K = R b + r sums the row partials (slot R * workgroup + r)
+// of the workgroups of band b -- row_strip0[b] .. row_strip0[b + 1] -- and the column partials of
+// the bands that start above it (I0' = R b' < K), stored at the tile slot (I0', K)
+template <int W, int R>
+__global__ void __launch_bounds__(64 * kRedGroupsQ)
+pkq_reduce_band_kernel(const PackedJob* __restrict__ jobs, int launch) {
+    constexpr int S = W * W;
+    typedef QCoef<W> C;
+    __shared__ cplx part[kRedGroupsQ][kTB][W];
+    __shared__ cplx Bs[W][W];
+    const PackedJob jb = jobs[blockIdx.y];
+    const int K = blockIdx.x;
+    const int step = launch - jb.start;
+    if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
+    const int par = step & 1;
+    const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
+    const int b = K / R, r = K - R * b;
+    const int w0 = jb.row_strip0[b], nwg = jb.row_strip0[b + 1] - w0;
+    const int nabove = (K + R - 1) / R;
+    cplx acc[W];
+#pragma unroll
+    for (int v = 0; v < W; ++v) acc[v] = mk(0.0, 0.0);
+    for (int idx = g; idx < nwg + nabove; idx += kRedGroupsQ) {
+        const int I0p = R * (idx - nwg);
+        const cplx* src = idx < nwg ? jb.rowpart + W * (((int64_t)(w0 + idx) * R + r) * kTB + e)
+                                    : jb.colpart + W * ((tile_offset(jb.nb, I0p) + (K - I0p)) * kTB + e);
+#pragma unroll
+        for (int v = 0; v < W; ++v) acc[v] = acc[v] + gload(src + v);
+    }
+#pragma unroll
+    for (int v = 0; v < W; ++v) part[g][e][v] = acc[v];
+    for (int i = threadIdx.x; i < S; i += 64 * kRedGroupsQ)
+        Bs[i / W][i % W] = mk(gload(jb.coef + C::b_up + 2 * i), gload(jb.coef + C::b_up + 2 * i + 1));
+    __syncthreads();
+    if (g == 0) pkq_reduce_tail<W>(jb, K, step, par, e, part, Bs);
+}
+
 template <int W>
 __global__ void __launch_bounds__(64 * kRedGroupsQ)
 pkq_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
@@ -290,44 +520,7 @@ pkq_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     for (int i = threadIdx.x; i < S; i += 64 * kRedGroupsQ)
         Bs[i / W][i % W] = mk(gload(jb.coef + C::b_up + 2 * i), gload(jb.coef + C::b_up + 2 * i + 1));
     __syncthreads();
-    if (g == 0) {
-        const int qs = jb.qslots, r = K * kTB + e;
-        const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + qs - 1) % qs) * jb.qstride * W;
-        const cplx* __restrict__ Qj = jb.Q + (int64_t)(step % qs) * jb.qstride * W;
-        cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
-        cplx q[W], x[W], t[W];
-#pragma unroll
-        for (int v = 0; v < W; ++v) { q[v] = gload(Qp + W * r + v); x[v] = gload(Qj + W * r + v); }
-#pragma unroll
-        for (int c = 0; c < W; ++c) {
-            cplx tot = part[0][e][c];
-#pragma unroll
-            for (int k = 1; k < kRedGroupsQ; ++k) tot = tot + part[k][e][c];
-            cplx s = mk(0.0, 0.0);                        // row of Q_{j-1} B_{j-1}^H: sum_{m >= c} q_m conj(B[c][m])
-#pragma unroll
-            for (int m = c; m < W; ++m) s = s + mulc(q[m], Bs[c][m]);
-            t[c] = tot - s;                               // row of W_j = A Q_j - Q_{j-1} B_{j-1}^H
-            gstore(Un + W * r + c, t[c]);
-        }
-        // packed partials of A_j = Q_j^H W_j and of W_j^H W_j, written as they are produced
-        double* __restrict__ an = (par ? jb.apart[0] : jb.apart[1]) + S * K;
-        double* __restrict__ un = (par ? jb.upart[0] : jb.upart[1]) + S * K;
-#pragma unroll
-        for (int a = 0; a < W; ++a) {
-            const double da = wave_sum(x[a].x * t[a].x + x[a].y * t[a].y);
-            const double dg = wave_sum(norm2(t[a]));
-            if (e == 0) { an[a] = da; un[a] = dg; }
-#pragma unroll
-            for (int b = a + 1; b < W; ++b) {
-                const cplx za = wave_sum(mulc(t[b], x[a]));            // conj(x_a) t_b
-                const cplx zg = wave_sum(mulc(t[b], t[a]));            // conj(t_a) t_b
-                if (e == 0) {
-                    an[bw_upper<W>(a, b)] = za.x; an[bw_upper<W>(a, b) + 1] = za.y;
-                    un[bw_upper<W>(a, b)] = zg.x; un[bw_upper<W>(a, b) + 1] = zg.y;
-                }
-            }
-        }
-    }
+    if (g == 0) pkq_reduce_tail<W>(jb, K, step, par, e, part, Bs);
 }
 
 // LDL^H pivots of T - x (bw_band_count) with the sliding window of the last W columns in memory:

@@ -935,10 +935,17 @@ static int sweep_q_strip8() {
     const char* e = getenv("SCINT_Q_STRIP");
     return (e && atoi(e) == 8) ? 8 : QShape<8>::strip;
 }
+// block rows per workgroup of the wide-block mat-vec (banded form, blockq_kernels.hpp): 4 for eight
+// vectors, 1 (plain strips) for the four-vector cross-check; SCINT_Q_BAND=1 / 4 overrides
+static int sweep_q_band(int block) {
+    const char* e = getenv("SCINT_Q_BAND");
+    const int v = e ? atoi(e) : (block == 8 ? 4 : 1);
+    return v == 4 ? 4 : 1;
+}
 static bool sweep_q_family(int block) { return block == 8 || (block == 4 && sweep_matvec_mode() == 2); }
 static int strip_len_block(int nb, int block) {
     const int s = strip_len_for(nb);
-    if (block == 8) return std::min(s, sweep_q_strip8());
+    if (block == 8) return std::min(s, sweep_q_band(8) == 4 ? 4 : sweep_q_strip8());
     return block == 4 ? std::min(s, kStripW) : s;
 }
 
@@ -973,7 +980,8 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block
     L.qslots = want_vec ? max_steps + 1 : 2;        // (block steps when two vectors run: <= kMaxKB + 1 are used)
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
     L.svec = take(sizeof(cplx) * bw * (size_t)(max_steps + 2));   // eigenvector of T_k (complex, bw per block step)
-    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
+    // (banded wide-block mat-vec: one row partial per workgroup AND row of its band, at most 4 rows)
+    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw * (block >= 4 ? 4 : 1));
     L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw * cparts);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
     L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
@@ -1094,6 +1102,7 @@ struct SweepProblem {
     bool mfma = false;                                 // block == 4: matrix-core mat-vec (SCINT_MATVEC_MFMA=1)
     bool qfam = false;                                 // wide-block kernel family (blockq_kernels.hpp)
     int qstrip = 4;                                    // its strip length for eight vectors (SCINT_Q_STRIP)
+    int qband = 1;                                     // block rows per workgroup of its mat-vec (SCINT_Q_BAND)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1193,6 +1202,19 @@ struct SweepGroup {
                 nb_run = std::max(nb_run, J.nb);
                 int32_t* rs0 = hrs + (size_t)s * (size_t)(S.nbmax + 1);
                 int idx = 0;
+                if (S.qfam && S.qband > 1) {
+                    // banded mat-vec: workgroups per band of qband block rows; rs0[b] = first workgroup of band b
+                    int bands = 0;
+                    for (int I0 = 0; I0 < J.nb; I0 += S.qband, ++bands) {
+                        rs0[bands] = idx;
+                        for (int J0 = I0; J0 < J.nb; J0 += J.strip_len) {
+                            Strip& st = hs[nstrips++];
+                            st.job = s; st.I = I0; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
+                        }
+                    }
+                    rs0[bands] = idx;
+                    continue;
+                }
                 for (int I = 0; I < J.nb; ++I) {
                     rs0[I] = idx;
                     for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
@@ -1304,7 +1326,14 @@ struct SweepGroup {
                         hipLaunchKernelGGL(pkq_qbuild_kernel<4>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
                     }
                     const int slotq = profiler().begin(kProfMatvec, stream);
-                    if (S.block == 8 && S.qstrip == 8)
+                    if (S.qband == 4) {
+                        if (S.block == 8)
+                            hipLaunchKernelGGL((pkq_matvec_band_kernel<8, 4, 4>), dim3((unsigned)nstrips), dim3(256),
+                                               (pkq_band_lds_bytes<8, 4, 4>()), stream, d_jobs(tab), d_strips(tab), launch);
+                        else
+                            hipLaunchKernelGGL((pkq_matvec_band_kernel<4, 8, 4>), dim3((unsigned)nstrips), dim3(256),
+                                               (pkq_band_lds_bytes<4, 8, 4>()), stream, d_jobs(tab), d_strips(tab), launch);
+                    } else if (S.block == 8 && S.qstrip == 8)
                         hipLaunchKernelGGL((pkq_matvec_mfma_kernel<8, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<8, 8>()),
                                            stream, d_jobs(tab), d_strips(tab), launch);
                     else if (S.block == 8)
@@ -1314,7 +1343,11 @@ struct SweepGroup {
                         hipLaunchKernelGGL((pkq_matvec_mfma_kernel<4, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<4, 8>()),
                                            stream, d_jobs(tab), d_strips(tab), launch);
                     profiler().end(kProfMatvec, slotq, stream);
-                    if (S.block == 8)
+                    if (S.qband == 4 && S.block == 8)
+                        hipLaunchKernelGGL((pkq_reduce_band_kernel<8, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    else if (S.qband == 4)
+                        hipLaunchKernelGGL((pkq_reduce_band_kernel<4, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    else if (S.block == 8)
                         hipLaunchKernelGGL(pkq_reduce_kernel<8>, gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
                     else
                         hipLaunchKernelGGL(pkq_reduce_kernel<4>, gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
@@ -1434,6 +1467,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.block = sweep_block_width();
     S.qfam = sweep_q_family(S.block);
     S.qstrip = sweep_q_strip8();
+    S.qband = S.qfam ? sweep_q_band(S.block) : 1;
     S.mfma = S.block == 4 && (S.qfam || sweep_matvec_mode() == 1);
     if (S.qfam) {
         // kernels of the family with more than the default 64 KiB of dynamic LDS; the attribute is per
@@ -1447,6 +1481,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)pkq_matvec_lds_bytes<8, 8>());
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)pkq_matvec_band_kernel<8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)pkq_band_lds_bytes<8, 4, 4>());
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)pkq_check_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)QCheckLds<8>::total);

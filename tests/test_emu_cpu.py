@@ -180,6 +180,7 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
         env = dict(os.environ, SCINT_EMU_ORDER=order, OPENBLAS_NUM_THREADS="1")
         env.pop("SCINT_LANCZOS_BLOCK", None)
         env.pop("SCINT_MATVEC_MFMA", None)
+        env.pop("SCINT_Q_BAND", None)
         procs.append((tag, subprocess.Popen([sys.executable, probe, str(tmp_path / f"{tag}.npz")], env=env,
                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for tag, p in procs:
@@ -197,7 +198,10 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     np.testing.assert_allclose(a["eigs_b4q"], a["eigs_b4"], rtol=1e-12)     # wide-block kernel family, four vectors
     np.testing.assert_allclose(a["eigs_b8"], a["eigs_b2"], rtol=1e-10)      # ... eight vectors
     assert a["iters_b8"].mean() <= a["iters_b4"].mean()
-    for tag in ("b1", "b4", "b4m", "b4q", "b8"):                            # eigenvectors up to a phase
+    np.testing.assert_allclose(a["eigs_b8s"], a["eigs_b8"], rtol=1e-12)     # strips / bands of the same recurrence
+    np.testing.assert_allclose(a["eigs_b4b"], a["eigs_b4q"], rtol=1e-12)
+    assert np.array_equal(a["iters_b8s"], a["iters_b8"]) and np.array_equal(a["iters_b4b"], a["iters_b4q"])
+    for tag in ("b1", "b4", "b4m", "b4q", "b4b", "b8", "b8s"):              # eigenvectors up to a phase
         for k in range(a["V_b2"].shape[0]):
             assert 1 - abs(np.vdot(a["V_" + tag][k], a["V_b2"][k])) <= 1e-9, (tag, k)
     assert a["iters_b4"].mean() < a["iters_b2"].mean() < a["iters_b1"].mean()

@@ -115,12 +115,14 @@ def test_sweep_is_schedule_invariant(env):
         assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
 
 
-@pytest.mark.parametrize("block,matvec", [("4", "0"), ("4", "1"), ("4", "2"), ("8", "0")])
-def test_wide_blocks_match_two_vector(env, block, matvec):
+@pytest.mark.parametrize("block,matvec,band", [("4", "0", "1"), ("4", "1", "1"), ("4", "2", "1"), ("4", "2", "4"),
+                                               ("8", "0", "4"), ("8", "0", "1")])
+def test_wide_blocks_match_two_vector(env, block, matvec, band):
     """The opt-in wider Lanczos blocks -- SCINT_LANCZOS_BLOCK=4 with the vector-FMA quarter strips
     (SCINT_MATVEC_MFMA=0), the matrix-core mat-vec (=1) or the wide-block kernel family (=2), and
     SCINT_LANCZOS_BLOCK=8 (wide-block family, blockq_kernels.hpp): same eigenvalues / eigenvectors as
-    the default two-vector recurrence to the stopping tolerance, in fewer matrix passes.  These
+    the default two-vector recurrence to the stopping tolerance, in fewer matrix passes; `band` = block
+    rows per workgroup of the wide-block mat-vec (SCINT_Q_BAND: 4 = banded, 1 = plain strips).  These
     kernels have so far only run on the host interpreter (`pytest --emu`, green there): on a GPU this
     test runs when SCINT_TEST_WIDE_BLOCKS=1 asks for it."""
     import os
@@ -129,12 +131,13 @@ def test_wide_blocks_match_two_vector(env, block, matvec):
         pytest.skip("opt-in wide-block paths: set SCINT_TEST_WIDE_BLOCKS=1")
     thth, to, p = env
     etas = np.geomspace(0.5, 2.0, 12) * p["eta"]
-    saved = {k: os.environ.pop(k, None) for k in ("SCINT_LANCZOS_BLOCK", "SCINT_MATVEC_MFMA")}
+    saved = {k: os.environ.pop(k, None) for k in ("SCINT_LANCZOS_BLOCK", "SCINT_MATVEC_MFMA", "SCINT_Q_BAND")}
     try:
         ref, i2 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
         w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
         os.environ["SCINT_LANCZOS_BLOCK"] = block
         os.environ["SCINT_MATVEC_MFMA"] = matvec
+        os.environ["SCINT_Q_BAND"] = band
         got, iw = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
         again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
         ww, Vw, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])

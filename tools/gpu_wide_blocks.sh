@@ -15,8 +15,10 @@ run() {  # tag, block, matvec mode
 }
 for rep in 1 2; do
   run default_$rep 2 0
-  run b8_$rep 8 0
-  SCINT_Q_STRIP=8 run b8s8_$rep 8 0
+  run b8_$rep 8 0                                  # banded mat-vec (4 block rows per workgroup)
+  SCINT_Q_BAND=1 run b8strip4_$rep 8 0             # plain strips of 4 tiles
+  SCINT_Q_BAND=1 SCINT_Q_STRIP=8 run b8strip8_$rep 8 0
+  SCINT_Q_BAND=4 run b4band_$rep 4 2
   run b4q_$rep 4 2
   run b4m_$rep 4 1
   run b4v_$rep 4 0
