@@ -138,9 +138,12 @@ def lanczos_block():
     if b == "1":
         return 1, "pk_matvec_kernel"
     if b == "8":
-        return 8, "pkq_matvec_mfma_kernel<8> (eight-vector block Lanczos, matrix cores; experimental)"
+        name = "pkq_matvec_mfma_kernel<8>" if os.environ.get("SCINT_Q_BAND") == "1" else "pkq_matvec_band_kernel<8, 4, 4>"
+        return 8, name + " (eight-vector block Lanczos, matrix cores; experimental)"
     if b == "4":
         name = {"1": "pkw_matvec_mfma_kernel<4>", "2": "pkq_matvec_mfma_kernel<4>"}.get(m, "pkw_matvec_kernel<4>")
+        if m == "2" and os.environ.get("SCINT_Q_BAND") == "4":
+            name = "pkq_matvec_band_kernel<4, 8, 4>"
         return 4, name + " (four-vector block Lanczos; experimental)"
     return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec)"
 
