@@ -25,7 +25,8 @@
 
 namespace scint {
 
-constexpr int kMaxKQ = 40;          // block steps the check kernel holds in LDS (T up to 320 x 320 for W = 8)
+// block steps the check kernel holds in LDS: 40 for eight vectors (T up to 320 x 320), 64 for four
+template <int W> constexpr int kq_max_steps() { return W >= 8 ? 40 : 64; }
 constexpr int kRedGroupsQ = 4;      // wavefronts per reduce block (LDS: groups x 64 x W complex)
 // tiles per strip of the mat-vec (its X_J blocks live in LDS): 8 for four vectors; for eight vectors 4
 // (72 KiB, two workgroups per CU) or, with SCINT_Q_STRIP=8, 8 (104 KiB, one workgroup per CU, half the
@@ -593,7 +594,7 @@ __device__ inline double bq_multisect(const cplx* band, int n, int target, doubl
 // dynamic LDS of the check kernel (bytes): band | sv | fd | window (64 lanes; later the factor M of the
 // inverse iteration) | rinv | lane-0 window | packed A, B and B upper of the last step
 template <int W> struct QCheckLds {
-    static constexpr int NMAX = W * kMaxKQ, S = W * W;
+    static constexpr int NMAX = W * kq_max_steps<W>(), S = W * W;
     static constexpr size_t band = 0;
     static constexpr size_t sv = band + sizeof(cplx) * NMAX * (W + 1);
     static constexpr size_t fd = sv + sizeof(cplx) * NMAX;

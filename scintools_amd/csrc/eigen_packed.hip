@@ -1167,8 +1167,8 @@ struct SweepGroup {
             J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
             // wide blocks: W extra steps beyond ceil(n / W) -- a rank-deficient start block (tiny or
             // rank-deficient matrices) grows the Krylov space by fewer than W dimensions per step
-            J.max_steps = S.block == 8   ? std::min(std::min(S.steps_cap, kMaxKQ), (n + 7) / 8 + 8)
-                          : S.qfam       ? std::min(std::min(S.steps_cap, kMaxKQ), (n + 3) / 4 + 4)
+            J.max_steps = S.block == 8   ? std::min(std::min(S.steps_cap, kq_max_steps<8>()), (n + 7) / 8 + 8)
+                          : S.qfam       ? std::min(std::min(S.steps_cap, kq_max_steps<4>()), (n + 3) / 4 + 4)
                           : S.block == 4 ? std::min(std::min(S.steps_cap, kMaxKW), (n + 3) / 4 + 4)
                           : S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
                                          : std::min(S.steps_cap, std::max(n, 1));
