@@ -1,6 +1,8 @@
-"""World-size-2 gloo tests (CPU) of the multi-GPU sharding logic.  The per-rank compute is
-the oracle here (local_fn), so this checks partitioning + all-gather, not kernels: the
-gathered result must equal the single-process result bit for bit."""
+"""World-size-2 gloo tests (CPU) of the multi-GPU sharding logic.  In the first test the per-rank
+compute is the oracle (local_fn), so it checks partitioning + all-gather, not kernels; in the second
+every rank runs the product's own wrappers and kernel sources on the host interpreter (tests/emu) --
+the default local_fn, i.e. what a rank does on its GPU.  Either way the gathered result must equal the
+single-process result bit for bit."""
 import os
 import socket
 import sys
@@ -96,3 +98,56 @@ def test_single_process_path_needs_no_process_group():
     to, CS, tau, fd, etas, edges = _problem()
     got = sweep.sharded_eval_sweep(CS, tau, fd, etas[:2], edges, local_fn=_oracle_sweep)
     assert np.array_equal(got, _oracle_sweep(CS, tau, fd, etas[:2], edges))
+
+
+def _worker_emu(rank, world, port, q):
+    """A rank whose "GPU" is the host interpreter: the default local_fn (ththmod.eval_sweep through the
+    C ABI) under torch.distributed."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
+    import torch.distributed as dist
+    from _pytest.monkeypatch import MonkeyPatch
+    import emulated
+    patch = MonkeyPatch()
+    emulated.install(patch)
+    from scintools_amd import sweep, ththmod
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    to, CS, tau, fd, etas, edges = _problem()
+    full = sweep.sharded_eval_sweep(CS, tau, fd, etas, edges)
+
+    def one_obs(i):
+        return ththmod.eval_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges)
+    obs = sweep.sharded_observations(3, one_obs, 3)
+    q.put((rank, full, obs))
+    dist.barrier()
+    dist.destroy_process_group()
+    patch.undo()
+
+
+@pytest.mark.timeout(600)
+def test_world2_gloo_with_the_interpreted_kernels(monkeypatch):
+    import subprocess
+    sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
+    import emulated
+    try:
+        emulated.install(monkeypatch)                 # also builds the interpreted library once, before the ranks start
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:
+        pytest.skip(f"host interpreter could not be built: {exc}")
+    from scintools_amd import ththmod
+    to, CS, tau, fd, etas, edges = _problem()
+    single = ththmod.eval_sweep(CS, tau, fd, etas, edges)
+    single_obs = np.stack([ththmod.eval_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges) for i in range(3)])
+    np.testing.assert_allclose(single, _oracle_sweep(CS, tau, fd, etas, edges), rtol=1e-9)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_emu, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=480) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, full, obs in results:
+        assert np.array_equal(full, single), rank     # same bits on every rank as in one process
+        assert np.array_equal(obs, single_obs), rank
