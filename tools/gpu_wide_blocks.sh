@@ -6,6 +6,9 @@
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
+# 0. the matrix-core instruction itself: operand layout and rate on this GPU
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/mfma_f64_probe.hip -o /tmp/mfma_probe 2> /dev/null \
+  && timeout 60 /tmp/mfma_probe | tee $O/wb_mfma_probe.txt
 SCINT_TEST_WIDE_BLOCKS=1 timeout 300 python -m pytest tests/test_gpu_edges.py -m gpu -q -k "wide_blocks or tiny" \
     > $O/wb_pytest.log 2>&1; echo "pytest rc=$?" >> $O/wb_pytest.log
 grep -E "passed|failed|^FAILED|rc=" $O/wb_pytest.log | tail -8
