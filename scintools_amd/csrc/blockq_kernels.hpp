@@ -25,8 +25,9 @@
 
 namespace scint {
 
-// block steps the check kernel holds in LDS: 40 for eight vectors (T up to 320 x 320), 64 for four
-template <int W> constexpr int kq_max_steps() { return W >= 8 ? 40 : 64; }
+// block steps the check kernel holds in LDS: 64 (T up to 512 x 512 for eight vectors: 155 KiB of the
+// 160 KiB of LDS; the two-vector path allows 128 steps = 256 Krylov dimensions)
+template <int W> constexpr int kq_max_steps() { return 64; }
 constexpr int kRedGroupsQ = 4;      // wavefronts per reduce block (LDS: groups x 64 x W complex)
 // tiles per strip of the mat-vec (its X_J blocks live in LDS): 8 for four vectors; for eight vectors 4
 // (72 KiB, two workgroups per CU) or, with SCINT_Q_STRIP=8, 8 (104 KiB, one workgroup per CU, half the
@@ -606,6 +607,7 @@ template <int W> struct QCheckLds {
     static constexpr size_t rinv0 = win0 + sizeof(cplx) * W * W;
     static constexpr size_t last = rinv0 + sizeof(double) * W;          // packed A | packed B | B upper (complex)
     static constexpr size_t total = last + sizeof(double) * (2 * S + 2 * S);
+    static_assert(total <= 160 * 1024, "the check kernel's LDS must fit one CU");
 };
 
 template <int W>
