@@ -529,7 +529,7 @@ pkq_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
 // column i lives in slot i % W, element (slot, k) at win[(slot * W + k) * stride], 1 / d at
 // rinv[slot * stride].  stride = 64 interleaves the windows of the 64 lanes (conflict-free LDS).
 template <int W>
-__device__ inline int bq_band_count(const cplx* band, int n, double x, double tiny, cplx* win, double* rinv, int stride,
+__device__ __forceinline__ int bq_band_count(const cplx* band, int n, double x, double tiny, cplx* win, double* rinv, int stride,
                                     double* d_out = nullptr, cplx* m_out = nullptr) {
     for (int s = 0; s < W; ++s) {
         rinv[s * stride] = 0.0;
@@ -569,7 +569,7 @@ __device__ inline int bq_band_count(const cplx* band, int n, double x, double ti
 }
 
 template <int W>
-__device__ inline double bq_multisect(const cplx* band, int n, int target, double lo, double hi, double tiny, int lane,
+__device__ __forceinline__ double bq_multisect(const cplx* band, int n, int target, double lo, double hi, double tiny, int lane,
                                       cplx* win, double* rinv) {
     for (int round = 0; round < 48; ++round) {
         const double wdt = hi - lo;
