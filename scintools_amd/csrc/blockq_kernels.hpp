@@ -265,7 +265,7 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 // the last stage of both reduce kernels (wave 0 of the block): W_j = total - Q_{j-1} B_{j-1}^H for the
 // block's 64 rows and the partials of the next coefficients
 template <int W>
-__device__ inline void pkq_reduce_tail(const PackedJob& jb, int K, int step, int par, int e,
+__device__ __forceinline__ void pkq_reduce_tail(const PackedJob& jb, int K, int step, int par, int e,
                                        cplx (*part)[kTB][W], cplx (*Bs)[W]) {
     constexpr int S = W * W;
     const int qs = jb.qslots, r = K * kTB + e;
@@ -293,14 +293,14 @@ __device__ inline void pkq_reduce_tail(const PackedJob& jb, int K, int step, int
     for (int a = 0; a < W; ++a) {
         const double da = wave_sum(x[a].x * t[a].x + x[a].y * t[a].y);
         const double dg = wave_sum(norm2(t[a]));
-        if (e == 0) { an[a] = da; un[a] = dg; }
+        if (e == 0) { gstore(an + a, da); gstore(un + a, dg); }
 #pragma unroll
         for (int b = a + 1; b < W; ++b) {
             const cplx za = wave_sum(mulc(t[b], x[a]));            // conj(x_a) t_b
             const cplx zg = wave_sum(mulc(t[b], t[a]));            // conj(t_a) t_b
             if (e == 0) {
-                an[bw_upper<W>(a, b)] = za.x; an[bw_upper<W>(a, b) + 1] = za.y;
-                un[bw_upper<W>(a, b)] = zg.x; un[bw_upper<W>(a, b) + 1] = zg.y;
+                gstore(an + bw_upper<W>(a, b), za.x); gstore(an + bw_upper<W>(a, b) + 1, za.y);
+                gstore(un + bw_upper<W>(a, b), zg.x); gstore(un + bw_upper<W>(a, b) + 1, zg.y);
             }
         }
     }
