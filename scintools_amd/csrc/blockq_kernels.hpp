@@ -222,9 +222,11 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
             if (g & 1) { accr1 = mfma_f64_16x16x4(ra[g].x, x1, accr1); accr1 = mfma_f64_16x16x4(ra[g].y, x2, accr1); }
             else       { accr0 = mfma_f64_16x16x4(ra[g].x, x1, accr0); accr0 = mfma_f64_16x16x4(ra[g].y, x2, accr0); }
         }
-        if (t + 1 < ntile) {
+        {   // row patches of the next tile (of this one again after the last: an unconditional load keeps
+            // the compiler's wait counts exact)
+            const int64_t noff = t + 1 < ntile ? toff + kTileElems : toff;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) ra[g] = gload(rp + toff + kTileElems + 4 * g);
+            for (int g = 0; g < 16; ++g) ra[g] = gload(rp + noff + 4 * g);
         }
         v4d accc[4];
 #pragma unroll
@@ -379,10 +381,11 @@ pkq_matvec_band_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
             if (r >= nrow || I0 + r > J) continue;                 // wave-uniform
             const cplx* __restrict__ tp = tile_at(t, r);
             const bool offdiag = I0 + r < J;
-            if (offdiag) {
+            // (loads are issued unconditionally -- the diagonal tile's column patches are read and not
+            // used, the last tile's "next" is itself: a load under a branch makes the compiler's
+            // wait counts pessimistic for everything queued behind it, and the pipeline collapses)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) ca[q] = gload(tp + col_off + (4 * (q & 3)) * kTB + 16 * (q >> 2));   // q = 4 c + kk
-            }
+            for (int q = 0; q < 16; ++q) ca[q] = gload(tp + col_off + (4 * (q & 3)) * kTB + 16 * (q >> 2));   // q = 4 c + kk
             v4d a0 = accr[r], a1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -397,11 +400,9 @@ pkq_matvec_band_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
             {
                 int tn = t, rn = r + 1;
                 if (rn >= nrow || I0 + rn > J) { rn = 0; tn = t + 1; }
-                if (tn < ntile) {
-                    const cplx* __restrict__ pn = tile_at(tn, rn) + row_off;
+                const cplx* __restrict__ pn = (tn < ntile ? tile_at(tn, rn) : tp) + row_off;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) ra[g] = gload(pn + 4 * g);
-                }
+                for (int g = 0; g < 16; ++g) ra[g] = gload(pn + 4 * g);
             }
             if (offdiag) {
                 // B operands of the column part: rows 16 w + 4 kk + k4 of X_{I0 + r};  conj(a) x = (ar xr + ai xi) + i (ar xi - ai xr)

@@ -314,9 +314,11 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
             if (g & 1) { accr1 = mfma_f64_16x16x4(ra[g].x, x1, accr1); accr1 = mfma_f64_16x16x4(ra[g].y, x2, accr1); }
             else       { accr0 = mfma_f64_16x16x4(ra[g].x, x1, accr0); accr0 = mfma_f64_16x16x4(ra[g].y, x2, accr0); }
         }
-        if (t + 1 < ntile) {
+        {   // row patches of the next tile (of this one again after the last: an unconditional load keeps
+            // the compiler's wait counts exact -- a load under a branch makes them pessimistic)
+            const int64_t noff = t + 1 < ntile ? toff + kTileElems : toff;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) ra[g] = gload(rp + toff + kTileElems + 4 * g);      // row patches of the next tile
+            for (int g = 0; g < 16; ++g) ra[g] = gload(rp + noff + 4 * g);
         }
         // columns: for each block of 16 columns, 4 patches of 4 rows x 16 columns against X_I
         v4d accc[4];
