@@ -536,6 +536,12 @@ __global__ void __launch_bounds__(64) pk2_init_kernel(const PackedJob* jobs, con
 // were measured and removed: half strips (8 rows per wave, 168 registers, three waves per SIMD:
 // 1075 eta/s against 1183) and two sweeps per strip (1147 eta/s); DESIGN.md section 6.
 constexpr int kFlushF = 4;     // its column partials are reduced across the waves every 4 tiles (a barrier pair each)
+// UNCOND = true (SCINT_PK2_PREFETCH=1, unmeasured): the next tile's first-half loads are issued
+// unconditionally (of this tile again after the last one).  With the load under `if (t + 1 < ntile)`
+// the compiler must assume it may not have been issued and makes the waits of the second half
+// pessimistic: the half ends on vmcnt(0), i.e. it also waits for the loads it has just prefetched,
+// and every tile iteration drains the wave's loads (seen in the assembly: tools/isa_stats.py).
+template <bool UNCOND>
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
     __shared__ cplx cred[4][kFlushF][kTB][2];   // per-wave column partials of kFlushF tiles, 2 vectors (32 KiB)
@@ -592,7 +598,11 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
             c1 = mk(c1.x + a0[r].x * x1.x + a0[r].y * x1.y, c1.y + a0[r].x * x1.y - a0[r].y * x1.x);   // conj(a) x_I
             c2 = mk(c2.x + a0[r].x * x2.x + a0[r].y * x2.y, c2.y + a0[r].x * x2.y - a0[r].y * x2.x);
         }
-        if (t + 1 < ntile) {
+        if (UNCOND) {
+            const cplx* __restrict__ nx = t + 1 < ntile ? tc + kTileElems : tc;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(nx + r * kTB);
+        } else if (t + 1 < ntile) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + kTileElems + r * kTB);   // first half of the next tile
         }
@@ -1103,6 +1113,7 @@ struct SweepProblem {
     bool qfam = false;                                 // wide-block kernel family (blockq_kernels.hpp)
     int qstrip = 4;                                    // its strip length for eight vectors (SCINT_Q_STRIP)
     int qband = 1;                                     // block rows per workgroup of its mat-vec (SCINT_Q_BAND)
+    bool pk2_uncond = false;                           // two-vector mat-vec with unconditional prefetch (SCINT_PK2_PREFETCH=1)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1360,8 +1371,10 @@ struct SweepGroup {
                 else if (S.block == 4)
                     hipLaunchKernelGGL(pkw_matvec_kernel<4>, dim3((unsigned)(kQuarters * nstrips)), dim3(256), 0, stream,
                                        d_jobs(tab), d_strips(tab), launch);
+                else if (S.block == 2 && S.pk2_uncond)
+                    hipLaunchKernelGGL(pk2_matvec_kernel<true>, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 else if (S.block == 2)
-                    hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
+                    hipLaunchKernelGGL(pk2_matvec_kernel<false>, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 else
                     hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 profiler().end(kProfMatvec, slot, stream);
@@ -1465,6 +1478,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     const int forced_every = every_env ? atoi(every_env) : 0;
     // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
     S.block = sweep_block_width();
+    { const char* e = getenv("SCINT_PK2_PREFETCH"); S.pk2_uncond = e && atoi(e) == 1; }
     S.qfam = sweep_q_family(S.block);
     S.qstrip = sweep_q_strip8();
     S.qband = S.qfam ? sweep_q_band(S.block) : 1;

@@ -181,6 +181,7 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
         env.pop("SCINT_LANCZOS_BLOCK", None)
         env.pop("SCINT_MATVEC_MFMA", None)
         env.pop("SCINT_Q_BAND", None)
+        env.pop("SCINT_PK2_PREFETCH", None)
         procs.append((tag, subprocess.Popen([sys.executable, probe, str(tmp_path / f"{tag}.npz")], env=env,
                                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for tag, p in procs:
@@ -198,6 +199,8 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     np.testing.assert_allclose(a["eigs_b4q"], a["eigs_b4"], rtol=1e-12)     # wide-block kernel family, four vectors
     np.testing.assert_allclose(a["eigs_b8"], a["eigs_b2"], rtol=1e-10)      # ... eight vectors
     assert a["iters_b8"].mean() <= a["iters_b4"].mean()
+    for key in ("eigs", "iters", "w", "V"):                                  # same arithmetic, different load schedule
+        assert np.array_equal(a[f"{key}_b2u"], a[f"{key}_b2"]), key
     np.testing.assert_allclose(a["eigs_b8s"], a["eigs_b8"], rtol=1e-12)     # strips / bands of the same recurrence
     np.testing.assert_allclose(a["eigs_b4b"], a["eigs_b4q"], rtol=1e-12)
     assert np.array_equal(a["iters_b8s"], a["iters_b8"]) and np.array_equal(a["iters_b4b"], a["iters_b4q"])
