@@ -199,7 +199,7 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
         const cplx* __restrict__ srcI = Qj + (int64_t)I * kTB * W;
         for (int idx = threadIdx.x; idx < kTB * W; idx += 256) xIc[idx] = gload(srcI + idx);
     }
-    __syncthreads();
+    lds_barrier();
     double y1[4], y3[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -245,7 +245,7 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cred[w][16 * c + mfma_d_row(lane, r)][n16] = accc[c][r];
         }
-        __syncthreads();
+        lds_barrier();
         const int Jt = st.J0 + t;
         if (Jt != I) {
             for (int idx = threadIdx.x; idx < kTB * NR; idx += 256) {
@@ -254,7 +254,7 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
                 gstore(colpart + NR * ((t0 + (Jt - I)) * kTB + col) + nn, sum);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     double* __restrict__ rowpart = (double*)jp->rowpart;
     if (n16 < NR) {
@@ -365,7 +365,7 @@ pkq_matvec_band_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
         const cplx* __restrict__ srcI = Qj + (int64_t)I0 * kTB * W;
         for (int idx = threadIdx.x; idx < nrow * kTB * W; idx += 256) xIc[idx] = gload(srcI + idx);
     }
-    __syncthreads();
+    lds_barrier();
     v4d accr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) accr[r] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -434,13 +434,13 @@ pkq_matvec_band_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
                         for (int r4 = 0; r4 < 4; ++r4) cred[w][16 * c + mfma_d_row(lane, r4)][n16 - ph * NRH] = accc[c][r4];
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int idx = threadIdx.x; idx < kTB * NRH; idx += 256) {
                     const int col = idx / NRH, nn = idx - col * NRH;
                     const double sum = ((cred[0][col][nn] + cred[1][col][nn]) + cred[2][col][nn]) + cred[3][col][nn];
                     gstore(colpart + NR * ((tile_offset(nb, I0) + (J - I0)) * kTB + col) + ph * NRH + nn, sum);
                 }
-                __syncthreads();
+                lds_barrier();
             }
         }
     }

@@ -289,7 +289,7 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
         for (int v = 0; v < W; ++v) { dst[2 * v] = x[v].x; dst[2 * v + 1] = x[v].y; }
     }
-    __syncthreads();
+    lds_barrier();
     // B operands of the column part, fixed for the strip: rows 16 w + 4 kk + k4 of X_I
     double y1[4], y3[4];
 #pragma unroll
@@ -338,7 +338,7 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cred[w][16 * c + mfma_d_row(lane, r)][n16] = accc[c][r];
         }
-        __syncthreads();
+        lds_barrier();
         const int Jt = st.J0 + t;
         if (Jt != I) {
             // cross-wave sum, fixed order; the tile's partial as [64 columns][W] complex
@@ -348,7 +348,7 @@ pkw_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
                 gstore(colpart + NR * ((t0 + (Jt - I)) * kTB + col) + nn, sum);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // row r = 16 w + k4 + 4 reg of the strip's row partial, real column n16
     double* __restrict__ rowpart = (double*)jp->rowpart;

@@ -59,6 +59,13 @@ __device__ inline void gstore_nt(cplx* p, cplx v) {
     __builtin_nontemporal_store(t, (SCINT_GLOBAL v2d*)p);
 }
 
+// ---- workgroup barrier for LDS hand-offs ---------------------------------------------------------
+// __syncthreads() is a workgroup-scope fence + barrier: the fence also waits for every GLOBAL access
+// in flight (s_waitcnt vmcnt(0)), i.e. it drains the loads a kernel has prefetched for its next
+// tile.  Where the only thing handed from wave to wave is LDS data, waiting for the LDS counter is
+// enough.  (tests/emu turns this line into a plain barrier.)
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- wavefront (64 lanes) reductions ------------------------------------------
 __device__ inline double wave_sum(double v) {
 #pragma unroll

@@ -540,7 +540,8 @@ constexpr int kFlushF = 4;     // its column partials are reduced across the wav
 // unconditionally (of this tile again after the last one).  With the load under `if (t + 1 < ntile)`
 // the compiler must assume it may not have been issued and makes the waits of the second half
 // pessimistic: the half ends on vmcnt(0), i.e. it also waits for the loads it has just prefetched,
-// and every tile iteration drains the wave's loads (seen in the assembly: tools/isa_stats.py).
+// and every tile iteration drains the wave's loads (seen in the assembly: tools/isa_stats.py).  The
+// variant also uses the LDS-only barrier (common.hpp) where the column partials are flushed.
 template <bool UNCOND>
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
@@ -577,7 +578,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
         xs[idx >> 6][idx & 63][0] = x1;
         xs[idx >> 6][idx & 63][1] = x2;
     }
-    __syncthreads();
+    if (UNCOND) lds_barrier(); else __syncthreads();
     cplx acc1[16], acc2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
@@ -620,7 +621,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
         if ((t & (kFlushF - 1)) == kFlushF - 1 || t + 1 == ntile) {
             // cross-wave reduction of the last <= kFlushF tiles' column partials: wave w takes the
             // (tile, vector) pairs w, w + 4 of the 2 kFlushF
-            __syncthreads();
+            if (UNCOND) lds_barrier(); else __syncthreads();
             const int tb = t & ~(kFlushF - 1);
 #pragma unroll
             for (int c = w; c < 2 * kFlushF; c += 4) {
@@ -633,7 +634,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
                     }
                 }
             }
-            __syncthreads();
+            if (UNCOND) lds_barrier(); else __syncthreads();
         }
     }
     cplx* __restrict__ rowpart = jp->rowpart;

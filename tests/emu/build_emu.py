@@ -6,9 +6,10 @@ interpreter in this directory (tests/emu/_build/libscint_emu_test.so).
 The product library (scintools_amd/libscint_hip.so) is built by scintools_amd/build.py with hipcc
 for gfx950 and is the only thing scintools_amd ever loads; this host build is loaded by
 tests/test_emu_cpu.py alone, through its own ctypes handle, to exercise the kernels' control flow
-and arithmetic where no GPU exists.  The sources are compiled unchanged except for one textual
-substitution: `extern __shared__` (dynamic LDS) becomes a plain `extern` of an array the
-interpreter owns.
+and arithmetic where no GPU exists.  The sources are compiled unchanged except for two textual
+substitutions: `extern __shared__` (dynamic LDS) becomes a plain `extern` of an array the
+interpreter owns, and the one line of inline assembly (the LDS-only barrier of common.hpp) becomes
+`__syncthreads()`.
 """
 import os
 import re
@@ -56,6 +57,8 @@ def _stage_sources():
         with open(os.path.join(CSRC, name)) as fh:
             text = fh.read()
         text = re.sub(r"\bextern\s+__shared__", "extern", text)
+        # the LDS-only barrier (inline assembly, common.hpp) is a plain barrier on the interpreter
+        text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\);', "__syncthreads();", text)
         dst = os.path.join(src_out, name.replace(".hip", ".hip.cpp"))
         old = None
         if os.path.exists(dst):
