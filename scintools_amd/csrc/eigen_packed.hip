@@ -947,16 +947,17 @@ static int sweep_q_strip8() {
     return (e && atoi(e) == 8) ? 8 : QShape<8>::strip;
 }
 // block rows per workgroup of the wide-block mat-vec (banded form, blockq_kernels.hpp): 4 for eight
-// vectors, 1 (plain strips) for the four-vector cross-check; SCINT_Q_BAND=1 / 4 overrides
+// vectors, 1 (plain strips) for the four-vector cross-check; SCINT_Q_BAND=1 / 2 / 4 overrides (2: 64 KiB
+// of LDS at W = 8 instead of 80)
 static int sweep_q_band(int block) {
     const char* e = getenv("SCINT_Q_BAND");
     const int v = e ? atoi(e) : (block == 8 ? 4 : 1);
-    return v == 4 ? 4 : 1;
+    return (v == 4 || v == 2) ? v : 1;
 }
 static bool sweep_q_family(int block) { return block == 8 || (block == 4 && sweep_matvec_mode() == 2); }
 static int strip_len_block(int nb, int block) {
     const int s = strip_len_for(nb);
-    if (block == 8) return std::min(s, sweep_q_band(8) == 4 ? 4 : sweep_q_strip8());
+    if (block == 8) return std::min(s, sweep_q_band(8) > 1 ? 4 : sweep_q_strip8());
     return block == 4 ? std::min(s, kStripW) : s;
 }
 
@@ -1338,7 +1339,14 @@ struct SweepGroup {
                         hipLaunchKernelGGL(pkq_qbuild_kernel<4>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
                     }
                     const int slotq = profiler().begin(kProfMatvec, stream);
-                    if (S.qband == 4) {
+                    if (S.qband == 2) {
+                        if (S.block == 8)
+                            hipLaunchKernelGGL((pkq_matvec_band_kernel<8, 4, 2>), dim3((unsigned)nstrips), dim3(256),
+                                               (pkq_band_lds_bytes<8, 4, 2>()), stream, d_jobs(tab), d_strips(tab), launch);
+                        else
+                            hipLaunchKernelGGL((pkq_matvec_band_kernel<4, 8, 2>), dim3((unsigned)nstrips), dim3(256),
+                                               (pkq_band_lds_bytes<4, 8, 2>()), stream, d_jobs(tab), d_strips(tab), launch);
+                    } else if (S.qband == 4) {
                         if (S.block == 8)
                             hipLaunchKernelGGL((pkq_matvec_band_kernel<8, 4, 4>), dim3((unsigned)nstrips), dim3(256),
                                                (pkq_band_lds_bytes<8, 4, 4>()), stream, d_jobs(tab), d_strips(tab), launch);
@@ -1355,7 +1363,11 @@ struct SweepGroup {
                         hipLaunchKernelGGL((pkq_matvec_mfma_kernel<4, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<4, 8>()),
                                            stream, d_jobs(tab), d_strips(tab), launch);
                     profiler().end(kProfMatvec, slotq, stream);
-                    if (S.qband == 4 && S.block == 8)
+                    if (S.qband == 2 && S.block == 8)
+                        hipLaunchKernelGGL((pkq_reduce_band_kernel<8, 2>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    else if (S.qband == 2)
+                        hipLaunchKernelGGL((pkq_reduce_band_kernel<4, 2>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    else if (S.qband == 4 && S.block == 8)
                         hipLaunchKernelGGL((pkq_reduce_band_kernel<8, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
                     else if (S.qband == 4)
                         hipLaunchKernelGGL((pkq_reduce_band_kernel<4, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);

@@ -20,6 +20,7 @@ for rep in 1 2; do
   run default_$rep 2 0
   SCINT_PK2_PREFETCH=1 run default_uncond_$rep 2 0   # same kernel with unconditional prefetch loads (exact wait counts)
   run b8_$rep 8 0                                  # banded mat-vec (4 block rows per workgroup)
+  SCINT_Q_BAND=2 run b8band2_$rep 8 0              # two block rows per workgroup (64 KiB of LDS)
   SCINT_Q_BAND=1 run b8strip4_$rep 8 0             # plain strips of 4 tiles
   SCINT_Q_BAND=1 SCINT_Q_STRIP=8 run b8strip8_$rep 8 0
   SCINT_Q_BAND=4 run b4band_$rep 4 2
