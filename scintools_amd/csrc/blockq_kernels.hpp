@@ -12,8 +12,9 @@
 //   pkq_coef_kernel    one wave per curvature: A_{j-1} = sum of the partials of Q^H W, the Cholesky
 //                      factor B_{j-1} of W^H W - A^H A, 1 / diag(B); also the history the check reads
 //   pkq_qbuild_kernel  Q_j, row by row, written once (3 N W complex of traffic: ~1 % of a pass)
-//   pkq_matvec_mfma_kernel   the matrix-core mat-vec of blockw_kernels.hpp with X_J / X_I simply
-//                      copied from Q_j (no coefficients, no rebuild)
+//   pkq_matvec_band_kernel / pkq_matvec_mfma_kernel   the matrix-core mat-vec of blockw_kernels.hpp
+//                      with X_J / X_I simply copied from Q_j (no coefficients, no rebuild), over bands of
+//                      R block rows (default for eight vectors) or plain strips
 //   pkq_reduce_kernel  W_j = A Q_j - Q_{j-1} B_{j-1}^H and the partials of the next coefficients
 // The convergence check is the same algorithm as pkw_check_kernel (64-shift multisection on the
 // banded LDL^H Sturm count, inverse iteration for the residual) with the per-lane W x W window of

@@ -1,9 +1,10 @@
 // blockw.hpp -- W-vector block Lanczos: the step algebra (host + device, W a template argument) and
 // the kernels of the W > 2 recurrence.
 //
-// STATUS: round-3 groundwork on branch wip/block4.  The algebra below is checked on the CPU against
-// tools/models/blockw_reference.py (tests/tools/blockw_host_check); the kernels have NOT run on a
-// GPU yet.  Nothing in the default path uses this file.
+// STATUS: opt-in (SCINT_LANCZOS_BLOCK=4 / 8).  The algebra below is checked on the CPU against
+// tools/models/blockw_reference.py (tests/test_blockw_cpu.py, tests/tools/blockw_host_check); the
+// kernels that use it (blockw_kernels.hpp, blockq_kernels.hpp) are green on the host interpreter
+// (tests/emu) and have NOT run on a GPU yet.  Nothing in the default path uses this file.
 //
 // Conventions (every matrix W x W complex unless noted), as in tools/models/blockw_reference.py:
 //   W_j   = A Q_j - Q_{j-1} B_{j-1}^H           (N x W; mat-vec + reduce kernel)

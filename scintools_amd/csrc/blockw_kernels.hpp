@@ -1,8 +1,11 @@
 // blockw_kernels.hpp -- kernels of the W-vector block Lanczos recurrence (W = 4), the wider sibling of
 // the pk2_* kernels in eigen_packed.hip.  Included by eigen_packed.hip after its device helpers.
 //
-// STATUS: branch wip/block4, round-3 groundwork.  The step algebra (blockw.hpp) is checked on the
-// CPU; THESE KERNELS HAVE NOT RUN ON A GPU YET.  Selected only by SCINT_LANCZOS_BLOCK=4.
+// STATUS: opt-in, selected only by SCINT_LANCZOS_BLOCK=4 (mat-vec form: SCINT_MATVEC_MFMA=0 vector
+// FMAs, 1 matrix cores; 2 selects the kernel family of blockq_kernels.hpp instead).  Green on the host
+// interpreter (tests/emu); THESE KERNELS HAVE NOT RUN ON A GPU YET.  The traffic model
+// (tools/models/wide_block_traffic.py) predicts that the vector-FMA quarter-strip form below LOSES
+// against the default (1.12x the sweep cost): its column partials are per quarter tile.
 //
 // Why: the sweep is bound by streaming the packed matrix once per pass; the passes per curvature
 // fall with the block width (CPU model at N = 4095: 31.9 passes for W = 2, 24.6 for W = 4), while

@@ -1,5 +1,5 @@
 """Executable specification of the W-vector block Lanczos step algebra, written the way the device
-code computes it (round-3 groundwork, not part of the product).
+code computes it (the specification the opt-in wide-block kernels are checked against; not part of the product).
 
 Conventions (W = block width; every matrix below is W x W complex unless noted):
   W_j   = A Q_j - Q_{j-1} B_{j-1}^H            (N x W; the mat-vec + the reduce kernel)
