@@ -145,6 +145,8 @@ def lanczos_block():
         if m == "2" and os.environ.get("SCINT_Q_BAND") == "4":
             name = "pkq_matvec_band_kernel<4, 8, 4>"
         return 4, name + " (four-vector block Lanczos; experimental)"
+    if m == "2":
+        return 2, "pkq_matvec_band_kernel<2, 16, 4> (two-vector block Lanczos on the matrix cores; experimental)"
     return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec)"
 
 

@@ -27,13 +27,13 @@
 namespace scint {
 
 // block steps the check kernel holds in LDS: 64 (T up to 512 x 512 for eight vectors: 155 KiB of the
-// 160 KiB of LDS; the two-vector path allows 128 steps = 256 Krylov dimensions)
-template <int W> constexpr int kq_max_steps() { return 64; }
+// 160 KiB of LDS); 128 for two vectors, as the pk2 kernels allow
+template <int W> constexpr int kq_max_steps() { return W <= 2 ? 128 : 64; }
 constexpr int kRedGroupsQ = 4;      // wavefronts per reduce block (LDS: groups x 64 x W complex)
-// tiles per strip of the mat-vec (its X_J blocks live in LDS): 8 for four vectors; for eight vectors 4
+// tiles per strip of the mat-vec (its X_J blocks live in LDS): 16 / 8 for two / four vectors; for eight vectors 4
 // (72 KiB, two workgroups per CU) or, with SCINT_Q_STRIP=8, 8 (104 KiB, one workgroup per CU, half the
 // X_J / row-partial traffic) -- to be decided by measurement
-template <int W> struct QShape { static constexpr int strip = W >= 8 ? 4 : 8; };
+template <int W> struct QShape { static constexpr int strip = W >= 8 ? 4 : (W >= 4 ? 8 : 16); };
 
 // layout of PackedJob::coef (doubles): A full [W][W] complex | B upper [W][W] complex (zeros below)
 // | 1/diag(B) [W] | packed A [W*W] | packed B [W*W]

@@ -940,7 +940,7 @@ static int sweep_matvec_mode() {
     return e ? atoi(e) : 0;
 }
 // the "q" kernel family (coefficients and Q_j once per step, blockq_kernels.hpp): always for 8 vectors,
-// for 4 vectors with SCINT_MATVEC_MFMA=2 (cross-check of the family against the pkw_* kernels)
+// for 4 or 2 vectors with SCINT_MATVEC_MFMA=2 (cross-checks of the family against the pkw_* / pk2_* kernels)
 // strip length of the eight-vector mat-vec: 4 (default) or 8 (SCINT_Q_STRIP=8)
 static int sweep_q_strip8() {
     const char* e = getenv("SCINT_Q_STRIP");
@@ -954,11 +954,63 @@ static int sweep_q_band(int block) {
     const int v = e ? atoi(e) : (block == 8 ? 4 : 1);
     return (v == 4 || v == 2) ? v : 1;
 }
-static bool sweep_q_family(int block) { return block == 8 || (block == 4 && sweep_matvec_mode() == 2); }
+static bool sweep_q_family(int block) { return block == 8 || ((block == 4 || block == 2) && sweep_matvec_mode() == 2); }
 static int strip_len_block(int nb, int block) {
     const int s = strip_len_for(nb);
     if (block == 8) return std::min(s, sweep_q_band(8) > 1 ? 4 : sweep_q_strip8());
-    return block == 4 ? std::min(s, kStripW) : s;
+    return block == 4 ? std::min(s, kStripW) : s;          // (two vectors: up to 16 = QHost<2>::strip)
+}
+
+// ---- launches of the wide-block kernel family (blockq_kernels.hpp), one set per width -------------
+// strips of the plain strip form: 16 / 8 / 4 tiles for 2 / 4 / 8 vectors (8 tiles for eight vectors
+// with SCINT_Q_STRIP=8); the banded form uses the same chunk lengths
+template <int W> struct QHost { static constexpr int strip = QShape<W>::strip; };
+
+template <int W>
+static void q_launch_step(int band, int qstrip8, int nstrips, int nb_run, int nslots, hipStream_t stream,
+                          const PackedJob* jobs, const Strip* strips, int launch) {
+    constexpr int ST = QHost<W>::strip;
+    const dim3 gq((unsigned)nb_run, (unsigned)nslots), gs((unsigned)nstrips);
+    hipLaunchKernelGGL(pkq_coef_kernel<W>, dim3((unsigned)nslots), dim3(64), 0, stream, jobs, launch);
+    hipLaunchKernelGGL(pkq_qbuild_kernel<W>, gq, dim3(64), 0, stream, jobs, launch);
+    const int slot = profiler().begin(kProfMatvec, stream);
+    if (band == 4)
+        hipLaunchKernelGGL((pkq_matvec_band_kernel<W, ST, 4>), gs, dim3(256), (pkq_band_lds_bytes<W, ST, 4>()), stream, jobs, strips, launch);
+    else if (band == 2)
+        hipLaunchKernelGGL((pkq_matvec_band_kernel<W, ST, 2>), gs, dim3(256), (pkq_band_lds_bytes<W, ST, 2>()), stream, jobs, strips, launch);
+    else if (W == 8 && qstrip8 == 8)
+        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<W, 8>), gs, dim3(256), (pkq_matvec_lds_bytes<W, 8>()), stream, jobs, strips, launch);
+    else
+        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<W, ST>), gs, dim3(256), (pkq_matvec_lds_bytes<W, ST>()), stream, jobs, strips, launch);
+    profiler().end(kProfMatvec, slot, stream);
+    if (band == 4)
+        hipLaunchKernelGGL((pkq_reduce_band_kernel<W, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, jobs, launch);
+    else if (band == 2)
+        hipLaunchKernelGGL((pkq_reduce_band_kernel<W, 2>), gq, dim3(64 * kRedGroupsQ), 0, stream, jobs, launch);
+    else
+        hipLaunchKernelGGL(pkq_reduce_kernel<W>, gq, dim3(64 * kRedGroupsQ), 0, stream, jobs, launch);
+}
+
+template <int W>
+static void q_launch_check(int nslots, hipStream_t stream, const PackedJob* jobs, int launches_done) {
+    hipLaunchKernelGGL(pkq_coef_kernel<W>, dim3((unsigned)nslots), dim3(64), 0, stream, jobs, launches_done);
+    hipLaunchKernelGGL(pkq_check_kernel<W>, dim3((unsigned)nslots), dim3(64), QCheckLds<W>::total, stream, jobs, launches_done);
+}
+
+// kernels of the family whose dynamic LDS exceeds the default 64 KiB limit
+template <int W>
+static hipError_t q_set_lds_attributes() {
+    constexpr int ST = QHost<W>::strip;
+    hipError_t e = hipSuccess;
+    auto set = [&](const void* f, size_t bytes) {
+        if (e == hipSuccess && bytes > 64 * 1024) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    };
+    set((const void*)pkq_matvec_band_kernel<W, ST, 4>, pkq_band_lds_bytes<W, ST, 4>());
+    set((const void*)pkq_matvec_band_kernel<W, ST, 2>, pkq_band_lds_bytes<W, ST, 2>());
+    set((const void*)pkq_matvec_mfma_kernel<W, ST>, pkq_matvec_lds_bytes<W, ST>());
+    if (W == 8) set((const void*)pkq_matvec_mfma_kernel<W, 8>, pkq_matvec_lds_bytes<W, 8>());
+    set((const void*)pkq_check_kernel<W>, QCheckLds<W>::total);
+    return e;
 }
 
 struct SlabLayout {
@@ -993,7 +1045,7 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
     L.svec = take(sizeof(cplx) * bw * (size_t)(max_steps + 2));   // eigenvector of T_k (complex, bw per block step)
     // (banded wide-block mat-vec: one row partial per workgroup AND row of its band, at most 4 rows)
-    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw * (block >= 4 ? 4 : 1));
+    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw * ((block >= 4 || sweep_q_family(block)) ? 4 : 1));
     L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw * cparts);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
     L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
@@ -1181,6 +1233,7 @@ struct SweepGroup {
             // wide blocks: W extra steps beyond ceil(n / W) -- a rank-deficient start block (tiny or
             // rank-deficient matrices) grows the Krylov space by fewer than W dimensions per step
             J.max_steps = S.block == 8   ? std::min(std::min(S.steps_cap, kq_max_steps<8>()), (n + 7) / 8 + 8)
+                          : S.qfam && S.block == 2 ? std::min(std::min(S.steps_cap, kq_max_steps<2>()), (n + 1) / 2 + 2)
                           : S.qfam       ? std::min(std::min(S.steps_cap, kq_max_steps<4>()), (n + 3) / 4 + 4)
                           : S.block == 4 ? std::min(std::min(S.steps_cap, kMaxKW), (n + 3) / 4 + 4)
                           : S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
@@ -1282,6 +1335,9 @@ struct SweepGroup {
                     if (S.block == 8)
                         hipLaunchKernelGGL(pkw_ritz_kernel<8>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
                                            S.vec_out, S.vstride);
+                    else if (S.block == 2 && S.qfam)
+                        hipLaunchKernelGGL(pkw_ritz_kernel<2>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                           S.vec_out, S.vstride);
                     else if (S.block == 4)
                         hipLaunchKernelGGL(pkw_ritz_kernel<4>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
                                            S.vec_out, S.vstride);
@@ -1311,6 +1367,9 @@ struct SweepGroup {
                 if (S.block == 8)
                     hipLaunchKernelGGL(pkw_init_kernel<8>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
                                        d_jobs(tab), d_fresh(tab));
+                else if (S.block == 2 && S.qfam)
+                    hipLaunchKernelGGL(pkw_init_kernel<2>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                                       d_jobs(tab), d_fresh(tab));
                 else if (S.block == 4)
                     hipLaunchKernelGGL(pkw_init_kernel<4>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
                                        d_jobs(tab), d_fresh(tab));
@@ -1330,51 +1389,9 @@ struct SweepGroup {
                 const int launch = launch0 + i;
                 if (S.qfam) {
                     // wide-block family: coefficients and Q_j once per step, then mat-vec and reduce
-                    const dim3 gq((unsigned)nb_run, (unsigned)nslots);
-                    if (S.block == 8) {
-                        hipLaunchKernelGGL(pkq_coef_kernel<8>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch);
-                        hipLaunchKernelGGL(pkq_qbuild_kernel<8>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
-                    } else {
-                        hipLaunchKernelGGL(pkq_coef_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch);
-                        hipLaunchKernelGGL(pkq_qbuild_kernel<4>, gq, dim3(64), 0, stream, d_jobs(tab), launch);
-                    }
-                    const int slotq = profiler().begin(kProfMatvec, stream);
-                    if (S.qband == 2) {
-                        if (S.block == 8)
-                            hipLaunchKernelGGL((pkq_matvec_band_kernel<8, 4, 2>), dim3((unsigned)nstrips), dim3(256),
-                                               (pkq_band_lds_bytes<8, 4, 2>()), stream, d_jobs(tab), d_strips(tab), launch);
-                        else
-                            hipLaunchKernelGGL((pkq_matvec_band_kernel<4, 8, 2>), dim3((unsigned)nstrips), dim3(256),
-                                               (pkq_band_lds_bytes<4, 8, 2>()), stream, d_jobs(tab), d_strips(tab), launch);
-                    } else if (S.qband == 4) {
-                        if (S.block == 8)
-                            hipLaunchKernelGGL((pkq_matvec_band_kernel<8, 4, 4>), dim3((unsigned)nstrips), dim3(256),
-                                               (pkq_band_lds_bytes<8, 4, 4>()), stream, d_jobs(tab), d_strips(tab), launch);
-                        else
-                            hipLaunchKernelGGL((pkq_matvec_band_kernel<4, 8, 4>), dim3((unsigned)nstrips), dim3(256),
-                                               (pkq_band_lds_bytes<4, 8, 4>()), stream, d_jobs(tab), d_strips(tab), launch);
-                    } else if (S.block == 8 && S.qstrip == 8)
-                        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<8, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<8, 8>()),
-                                           stream, d_jobs(tab), d_strips(tab), launch);
-                    else if (S.block == 8)
-                        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<8, 4>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<8, 4>()),
-                                           stream, d_jobs(tab), d_strips(tab), launch);
-                    else
-                        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<4, 8>), dim3((unsigned)nstrips), dim3(256), (pkq_matvec_lds_bytes<4, 8>()),
-                                           stream, d_jobs(tab), d_strips(tab), launch);
-                    profiler().end(kProfMatvec, slotq, stream);
-                    if (S.qband == 2 && S.block == 8)
-                        hipLaunchKernelGGL((pkq_reduce_band_kernel<8, 2>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
-                    else if (S.qband == 2)
-                        hipLaunchKernelGGL((pkq_reduce_band_kernel<4, 2>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
-                    else if (S.qband == 4 && S.block == 8)
-                        hipLaunchKernelGGL((pkq_reduce_band_kernel<8, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
-                    else if (S.qband == 4)
-                        hipLaunchKernelGGL((pkq_reduce_band_kernel<4, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
-                    else if (S.block == 8)
-                        hipLaunchKernelGGL(pkq_reduce_kernel<8>, gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
-                    else
-                        hipLaunchKernelGGL(pkq_reduce_kernel<4>, gq, dim3(64 * kRedGroupsQ), 0, stream, d_jobs(tab), launch);
+                    if (S.block == 8) q_launch_step<8>(S.qband, S.qstrip, nstrips, nb_run, nslots, stream, d_jobs(tab), d_strips(tab), launch);
+                    else if (S.block == 4) q_launch_step<4>(S.qband, S.qstrip, nstrips, nb_run, nslots, stream, d_jobs(tab), d_strips(tab), launch);
+                    else q_launch_step<2>(S.qband, S.qstrip, nstrips, nb_run, nslots, stream, d_jobs(tab), d_strips(tab), launch);
                     continue;
                 }
                 const int slot = profiler().begin(kProfMatvec, stream);
@@ -1402,14 +1419,10 @@ struct SweepGroup {
                                        stream, d_jobs(tab), launch);
             }
         }
-        if (S.qfam && S.block == 8) {
-            hipLaunchKernelGGL(pkq_coef_kernel<8>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
-            hipLaunchKernelGGL(pkq_check_kernel<8>, dim3((unsigned)nslots), dim3(64), QCheckLds<8>::total, stream, d_jobs(tab),
-                               launch0 + S.check_every);
-        } else if (S.qfam) {
-            hipLaunchKernelGGL(pkq_coef_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
-            hipLaunchKernelGGL(pkq_check_kernel<4>, dim3((unsigned)nslots), dim3(64), QCheckLds<4>::total, stream, d_jobs(tab),
-                               launch0 + S.check_every);
+        if (S.qfam) {
+            if (S.block == 8) q_launch_check<8>(nslots, stream, d_jobs(tab), launch0 + S.check_every);
+            else if (S.block == 4) q_launch_check<4>(nslots, stream, d_jobs(tab), launch0 + S.check_every);
+            else q_launch_check<2>(nslots, stream, d_jobs(tab), launch0 + S.check_every);
         } else if (S.block == 4)
             hipLaunchKernelGGL(pkw_check_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
         else if (S.block == 2)
@@ -1503,17 +1516,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         int dev = 0;
         SCINT_HIP(hipGetDevice(&dev));
         if (lds_set.find(dev) == lds_set.end()) {
-            hipError_t e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)pkq_matvec_lds_bytes<8, 4>());
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)pkq_matvec_mfma_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)pkq_matvec_lds_bytes<8, 8>());
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)pkq_matvec_band_kernel<8, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)pkq_band_lds_bytes<8, 4, 4>());
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)pkq_check_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)QCheckLds<8>::total);
+            hipError_t e = q_set_lds_attributes<8>();
+            if (e == hipSuccess) e = q_set_lds_attributes<4>();
+            if (e == hipSuccess) e = q_set_lds_attributes<2>();
             lds_set[dev] = e;
         }
         const hipError_t lds_ok = lds_set[dev];

@@ -38,9 +38,10 @@ def main(out_path):
     res["red"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges)[0]
     res["red_nh"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges, False)[0]
     # 4m: four vectors with the matrix-core mat-vec; 4q: four vectors, wide-block kernel family; 8: eight vectors
-    # (8: banded mat-vec, four block rows per workgroup -- its default; 8s: plain strips; 4b: four vectors, banded)
+    # (8: banded mat-vec, four block rows per workgroup -- its default; 8s: plain strips; 4b: four vectors, banded;
+    #  2q: TWO vectors in the wide-block family -- the default recurrence on the matrix cores)
     for block, mode, band in (("2", "0", ""), ("2u", "0", ""), ("1", "0", ""), ("4", "0", ""), ("4m", "1", ""), ("4q", "2", "1"),
-                              ("4b", "2", "4"), ("8", "0", "4"), ("8s", "0", "1")):
+                              ("4b", "2", "4"), ("8", "0", "4"), ("8s", "0", "1"), ("2q", "2", "4")):
         os.environ["SCINT_LANCZOS_BLOCK"] = block[0]
         os.environ["SCINT_MATVEC_MFMA"] = mode
         os.environ.pop("SCINT_Q_BAND", None)

@@ -201,10 +201,12 @@ def test_results_do_not_depend_on_the_schedule(tmp_path):
     assert a["iters_b8"].mean() <= a["iters_b4"].mean()
     for key in ("eigs", "iters", "w", "V"):                                  # same arithmetic, different load schedule
         assert np.array_equal(a[f"{key}_b2u"], a[f"{key}_b2"]), key
+    np.testing.assert_allclose(a["eigs_b2q"], a["eigs_b2"], rtol=1e-12)     # two vectors on the matrix cores
+    assert np.array_equal(a["iters_b2q"], a["iters_b2"])
     np.testing.assert_allclose(a["eigs_b8s"], a["eigs_b8"], rtol=1e-12)     # strips / bands of the same recurrence
     np.testing.assert_allclose(a["eigs_b4b"], a["eigs_b4q"], rtol=1e-12)
     assert np.array_equal(a["iters_b8s"], a["iters_b8"]) and np.array_equal(a["iters_b4b"], a["iters_b4q"])
-    for tag in ("b1", "b4", "b4m", "b4q", "b4b", "b8", "b8s"):              # eigenvectors up to a phase
+    for tag in ("b1", "b2q", "b4", "b4m", "b4q", "b4b", "b8", "b8s"):              # eigenvectors up to a phase
         for k in range(a["V_b2"].shape[0]):
             assert 1 - abs(np.vdot(a["V_" + tag][k], a["V_b2"][k])) <= 1e-9, (tag, k)
     assert a["iters_b4"].mean() < a["iters_b2"].mean() < a["iters_b1"].mean()

@@ -116,7 +116,7 @@ def test_sweep_is_schedule_invariant(env):
 
 
 @pytest.mark.parametrize("block,matvec,band", [("4", "0", "1"), ("4", "1", "1"), ("4", "2", "1"), ("4", "2", "4"),
-                                               ("8", "0", "4"), ("8", "0", "1")])
+                                               ("8", "0", "4"), ("8", "0", "1"), ("2", "2", "4")])
 def test_wide_blocks_match_two_vector(env, block, matvec, band):
     """The opt-in wider Lanczos blocks -- SCINT_LANCZOS_BLOCK=4 with the vector-FMA quarter strips
     (SCINT_MATVEC_MFMA=0), the matrix-core mat-vec (=1) or the wide-block kernel family (=2), and
@@ -149,7 +149,7 @@ def test_wide_blocks_match_two_vector(env, block, matvec, band):
     assert np.all(iw["status"] == 0)
     np.testing.assert_allclose(got, ref, rtol=1e-10)
     assert np.array_equal(again, got)                           # batch-invariant bits
-    assert iw["iters"].mean() < i2["iters"].mean()
+    assert iw["iters"].mean() < i2["iters"].mean() or block == "2"      # ("2": the default recurrence on the matrix cores)
     np.testing.assert_allclose(ww, w2, rtol=1e-10)
     V2n, Vwn = V2.cpu().numpy(), Vw.cpu().numpy()
     for k in range(len(etas)):

@@ -24,6 +24,7 @@ for rep in 1 2; do
   SCINT_Q_BAND=1 run b8strip4_$rep 8 0             # plain strips of 4 tiles
   SCINT_Q_BAND=1 SCINT_Q_STRIP=8 run b8strip8_$rep 8 0
   SCINT_Q_BAND=4 run b4band_$rep 4 2
+  SCINT_Q_BAND=4 run b2band_$rep 2 2               # the default two-vector recurrence on the matrix cores, banded
   run b4q_$rep 4 2
   run b4m_$rep 4 1
   run b4v_$rep 4 0
