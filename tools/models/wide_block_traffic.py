@@ -37,6 +37,7 @@ def main():
     nb = -(-n // 64)
     rows = [
         ("W=2 default (strips of 16, rebuild)", 2, dict(strip=16, rebuild=True)),
+        ("W=2 wide-block family, bands of 4 x chunks of 16", 2, dict(strip=16, band=4, q_family=True)),
         ("W=4 vector FMAs, quarter strips of 8", 4, dict(strip=8, col_parts=4, rebuild=True)),
         ("W=4 matrix cores, strips of 8 (rebuild)", 4, dict(strip=8, rebuild=True)),
         ("W=4 wide-block family, strips of 8", 4, dict(strip=8, q_family=True)),
