@@ -57,10 +57,30 @@ __global__ void __launch_bounds__(64) pkq_coef_kernel(const PackedJob* jobs, int
     const double* __restrict__ ap = par ? jb.apart[1] : jb.apart[0];
     const double* __restrict__ up = par ? jb.upart[1] : jb.upart[0];
     // fixed order: lane c owns scalar c and walks the 64-row blocks in order
+    // (eight blocks' loads are issued before their sums are taken, in block order: a loop of load-wait-add
+    // would pay the memory latency nb times)
     for (int c = lane; c < S; c += 64) {
         double a = 0.0, g = 0.0;
-        for (int i = 0; i < jb.nb; ++i) { a += gload(ap + S * i + c); g += gload(up + S * i + c); }
+        for (int i0 = 0; i0 < jb.nb; i0 += 8) {
+            double xa[8], xg[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, jb.nb - 1);
+                xa[u] = gload(ap + S * i + c); xg[u] = gload(up + S * i + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < jb.nb) { a += xa[u]; g += xg[u]; }
+        }
         sa[c] = a; sg[c] = g;
+    }
+    // directions the Krylov space has left: n minus the nonzero pivots of the blocks so far (lanes in parallel)
+    __shared__ int room_s;
+    {
+        double used = 0.0;
+        for (int idx = lane; idx < step * W; idx += 64) used += gload(jb.beta + S * (idx / W) + idx % W) > 0.0 ? 1.0 : 0.0;
+        used = wave_sum(used);
+        if (lane == 0) room_s = jb.n - (int)used;
     }
     __syncthreads();
     for (int idx = lane; idx < S; idx += 64) {
@@ -86,9 +106,7 @@ __global__ void __launch_bounds__(64) pkq_coef_kernel(const PackedJob* jobs, int
         // The Krylov space holds at most n directions: once the blocks so far (their nonzero pivots,
         // bw_complete_steps) and this one have n, whatever else survives the pivot floor is the
         // noise of a saturated space and would enter T as a non-orthogonal column.
-        int room = jb.n;
-        for (int j = 0; j < step; ++j)
-            for (int r = 0; r < W; ++r) room -= jb.beta[S * j + r] > 0.0;
+        int room = room_s;
         for (int c = 0; c < W; ++c) {
             double d = H[c][c].x;
             for (int m = 0; m < c; ++m) d -= norm2(B[m][c]);
@@ -645,8 +663,9 @@ __global__ void __launch_bounds__(64) pkq_check_kernel(const PackedJob* jobs, in
     if (k_done < 2 && k_done < jb.max_steps) return;
     const int k_run = min(k_done, jb.max_steps);
     // blocks that make the Krylov space complete (all of them unless the space is saturated)
+    __shared__ int rk[kq_max_steps<W>()];
     int rank = 0;
-    const int k = bw_complete_steps<W>(jb.beta, k_run, jb.n, &rank);
+    const int k = bw_complete_steps_wave<W>(jb.beta, k_run, jb.n, lane, rk, &rank);
     const bool complete = rank >= jb.n;
     const int n = W * k;
     // A_{k-1}, B_{k-1}: pkq_coef_kernel ran for step k_run just before this kernel; when the space was

@@ -49,10 +49,11 @@ __device__ inline BlkW<W> bw_step_wave(const double* __restrict__ ap, const doub
     }
 #pragma unroll
     for (int c = 0; c < S; ++c) { sa[c] = wave_sum(sa[c]); sg[c] = wave_sum(sg[c]); }
-    int room = n;
-    for (int j = 0; j < step; ++j)
-#pragma unroll
-        for (int r = 0; r < W; ++r) room -= gload(beta + S * j + r) > 0.0;
+    // nonzero pivots of the earlier blocks, counted by the lanes in parallel (a serial loop over
+    // step * W dependent loads would cost their latencies one after the other)
+    double used = 0.0;
+    for (int idx = lane; idx < step * W; idx += 64) used += gload(beta + S * (idx / W) + idx % W) > 0.0 ? 1.0 : 0.0;
+    const int room = n - (int)wave_sum(used);
     return bw_from_sums<W>(sa, sg, room);
 }
 
@@ -448,6 +449,26 @@ pkw_reduce_kernel(const PackedJob* __restrict__ jobs, int launch, int cparts) {
     }
 }
 
+// bw_complete_steps for one wavefront: the ranks of the blocks are read by the lanes in parallel into
+// `rk` (LDS, >= k entries), then scanned (the serial version waits for k * W loads one after the other)
+template <int W>
+__device__ inline int bw_complete_steps_wave(const double* __restrict__ beta, int k, int n, int lane, int* rk, int* rank_out) {
+    for (int j = lane; j < k; j += 64) {
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < W; ++r) c += gload(beta + W * W * j + r) > 0.0;
+        rk[j] = c;
+    }
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < k; ++j) {
+        rank += rk[j];
+        if (rank >= n) { *rank_out = rank; return j + 1; }
+    }
+    *rank_out = rank;
+    return k;
+}
+
 template <int W>
 __device__ inline double bw_multisect(const cplx* band, int n, int target, double lo, double hi, double tiny, int lane) {
     for (int round = 0; round < 48; ++round) {
@@ -498,8 +519,9 @@ __global__ void __launch_bounds__(64) pkw_check_kernel(const PackedJob* jobs, in
     // A_{k-1}, B_{k-1} are still in the partials of the last reduce kernel
     const BlkW<W> last = bw_step_wave<W>((k_run & 1) ? jb.apart[1] : jb.apart[0], (k_run & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane, jb.beta, k_run, jb.n);
     // blocks that make the Krylov space complete (all of them unless the space is saturated)
+    __shared__ int rk[kMaxKW];
     int rank = 0;
-    const int k = bw_complete_steps<W>(jb.beta, k_run, jb.n, &rank);
+    const int k = bw_complete_steps_wave<W>(jb.beta, k_run, jb.n, lane, rk, &rank);
     const bool complete = rank >= jb.n;
     const int n = W * k;
     if (lane == 0) {
