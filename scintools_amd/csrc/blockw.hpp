@@ -228,21 +228,25 @@ __host__ __device__ inline int bw_band_count(const cplx* band, int n, double x, 
 }
 
 // Two steps of inverse iteration with the stored factor of T - sigma (d, m from bw_band_count):
-// s <- (T - sigma)^{-1} s, scaled to max |component| = 1; returns sum |s_i|^2.  s must hold n entries.
+// s <- (T - sigma)^{-1} s, scaled to max |component| = 1; returns sum |s_i|^2.  s must hold n entries;
+// d is overwritten with its reciprocals.
 template <int W>
-__host__ __device__ inline double bw_inverse_iteration(const double* d, const cplx* m, int n, cplx* s, int iters = 2) {
+__host__ __device__ inline double bw_inverse_iteration(double* d, const cplx* m, int n, cplx* s, int iters = 2) {
+    // the pivots are only ever divided by: invert them once, in place (a division per band entry and
+    // sweep would sit in the dependent chain of the substitutions, which one lane runs alone)
+    for (int i = 0; i < n; ++i) d[i] = 1.0 / d[i];
     for (int i = 0; i < n; ++i) s[i] = mk(1.0, 0.0);
     double nrm = (double)n;
     for (int it = 0; it < iters; ++it) {
         for (int i = 0; i < n; ++i) {                      // L y = s, L_{i,i-k} = M_{i,i-k} / d_{i-k}
             cplx y = s[i];
-            for (int k = 1; k <= W && k <= i; ++k) y = y - (m[(size_t)(i - k) * W + k - 1] * s[i - k]) * (1.0 / d[i - k]);
+            for (int k = 1; k <= W && k <= i; ++k) y = y - (m[(size_t)(i - k) * W + k - 1] * s[i - k]) * d[i - k];
             s[i] = y;
         }
-        for (int i = 0; i < n; ++i) s[i] = s[i] * (1.0 / d[i]);
+        for (int i = 0; i < n; ++i) s[i] = s[i] * d[i];
         for (int i = n - 1; i >= 0; --i) {                 // L^H z = y
             cplx z = s[i];
-            for (int k = 1; k <= W && i + k < n; ++k) z = z - mulc(s[i + k], m[(size_t)i * W + k - 1]) * (1.0 / d[i]);
+            for (int k = 1; k <= W && i + k < n; ++k) z = z - mulc(s[i + k], m[(size_t)i * W + k - 1]) * d[i];
             s[i] = z;
         }
         double mx = 0.0;
