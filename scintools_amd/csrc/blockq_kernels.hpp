@@ -175,6 +175,20 @@ __global__ void __launch_bounds__(64) pkq_qbuild_kernel(const PackedJob* jobs, i
     for (int v = 0; v < W; ++v) gstore(Qn + W * r + v, x[v]);
 }
 
+// cooperative copy of `count` complex values (count <= MAXN) from global memory into LDS by 256 threads:
+// every thread issues all its loads before the first LDS store (a load-store loop would pay the memory
+// latency once per 256 values); loads beyond `count` re-read the last element and are dropped
+template <int MAXN>
+__device__ inline void copy_to_lds_256(cplx* __restrict__ dst, const cplx* __restrict__ src, int count, int tid) {
+    constexpr int U = (MAXN + 255) / 256;
+    cplx tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) tmp[u] = gload(src + min(tid + 256 * u, count - 1));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (tid + 256 * u < count) dst[tid + 256 * u] = tmp[u];
+}
+
 // The matrix-core mat-vec (see pkw_matvec_mfma_kernel for the operand algebra) with X_J and X_I copied
 // from the stored Q_j.  Dynamic LDS: xs[STRIP][64][2W] | xI[64][2W] | cred[4][64][2W] doubles.
 template <int W, int STRIP> constexpr size_t pkq_matvec_lds_bytes() {
@@ -210,14 +224,8 @@ pkq_matvec_mfma_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
     for (int g = 0; g < 16; ++g) ra[g] = gload(rp + 4 * g);
     // rows of Q_j are [row][W] complex = [row][2 W] doubles: the blocks are plain copies
-    {
-        cplx* xsc = (cplx*)smem_raw;
-        const cplx* __restrict__ srcJ = Qj + (int64_t)st.J0 * kTB * W;
-        for (int idx = threadIdx.x; idx < ntile * kTB * W; idx += 256) xsc[idx] = gload(srcJ + idx);
-        cplx* xIc = (cplx*)&xI[0][0];
-        const cplx* __restrict__ srcI = Qj + (int64_t)I * kTB * W;
-        for (int idx = threadIdx.x; idx < kTB * W; idx += 256) xIc[idx] = gload(srcI + idx);
-    }
+    copy_to_lds_256<STRIP * kTB * W>((cplx*)smem_raw, Qj + (int64_t)st.J0 * kTB * W, ntile * kTB * W, threadIdx.x);
+    copy_to_lds_256<kTB * W>((cplx*)&xI[0][0], Qj + (int64_t)I * kTB * W, kTB * W, threadIdx.x);
     lds_barrier();
     double y1[4], y3[4];
 #pragma unroll
@@ -376,14 +384,8 @@ pkq_matvec_band_kernel(const PackedJob* __restrict__ jobs, const Strip* __restri
 #pragma unroll
         for (int g = 0; g < 16; ++g) ra[g] = gload(p0 + 4 * g);
     }
-    {
-        cplx* xsc = (cplx*)smem_raw;
-        const cplx* __restrict__ srcJ = Qj + (int64_t)J0 * kTB * W;
-        for (int idx = threadIdx.x; idx < ntile * kTB * W; idx += 256) xsc[idx] = gload(srcJ + idx);
-        cplx* xIc = (cplx*)&xI[0][0][0];
-        const cplx* __restrict__ srcI = Qj + (int64_t)I0 * kTB * W;
-        for (int idx = threadIdx.x; idx < nrow * kTB * W; idx += 256) xIc[idx] = gload(srcI + idx);
-    }
+    copy_to_lds_256<STRIP * kTB * W>((cplx*)smem_raw, Qj + (int64_t)J0 * kTB * W, ntile * kTB * W, threadIdx.x);
+    copy_to_lds_256<R * kTB * W>((cplx*)&xI[0][0][0], Qj + (int64_t)I0 * kTB * W, nrow * kTB * W, threadIdx.x);
     lds_barrier();
     v4d accr[R];
 #pragma unroll
