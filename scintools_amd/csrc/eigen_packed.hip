@@ -1041,7 +1041,9 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block
     const size_t bw = block >= 4 ? (size_t)block : 2, sc = bw * bw, cparts = block == 4 ? kQuarters : 1;
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
-    L.qslots = want_vec ? max_steps + 1 : 2;        // (block steps when two vectors run: <= kMaxKB + 1 are used)
+    // (block steps when two vectors run: <= kMaxKB + 1 are used; the wider blocks stop at 64 steps and
+    // their slots are 2-4 times as large, so their count is capped)
+    L.qslots = want_vec ? (block >= 4 ? std::min(max_steps, 64) : max_steps) + 1 : 2;
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
     L.svec = take(sizeof(cplx) * bw * (size_t)(max_steps + 2));   // eigenvector of T_k (complex, bw per block step)
     // (banded wide-block mat-vec: one row partial per workgroup AND row of its band, at most 4 rows)
