@@ -1,6 +1,6 @@
 """W-vector block Lanczos algebra (scintools_amd/csrc/blockw.hpp, compiled for the HOST) against its
 NumPy specification tools/models/blockw_reference.py.  CPU only; the kernels that use the algebra are
-round-3 work and have no GPU test yet."""
+opt-in, run on the host interpreter (tests/test_emu_cpu.py) and have an opt-in GPU test."""
 import ctypes
 import os
 import shutil
@@ -87,6 +87,24 @@ def test_exhausted_direction_gives_zero_pivot(lib):
     a = np.zeros(2 * W * W); b = np.zeros(2 * W * W); inv = np.zeros(W)
     lib.bw_from_sums_c(W, dp(pack(A, W)), dp(pack(G, W)), dp(a), dp(b), dp(inv))
     assert inv[1] == 0.0 and inv[0] > 0 and inv[2] > 0
+
+
+def test_numerically_dependent_column_is_dropped(lib):
+    """A duplicated column of W_j leaves a pivot of pure rounding noise (either sign): the relative
+    floor must drop it, or its normalised column would be amplified noise in Q_{j+1}."""
+    W, n = 4, 60
+    rng = np.random.default_rng(7)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, W)) + 1j * rng.standard_normal((n, W)))
+    Wj = rng.standard_normal((n, W)) + 1j * rng.standard_normal((n, W))
+    Wj[:, 2] = Wj[:, 0] * (0.3 - 0.4j) + Wj[:, 1] * 1.7            # in the span of the first two
+    A = Q.conj().T @ Wj
+    G = Wj.conj().T @ Wj
+    a = np.zeros(2 * W * W); b = np.zeros(2 * W * W); inv = np.zeros(W)
+    lib.bw_from_sums_c(W, dp(pack((A + A.conj().T) / 2, W)), dp(pack(G, W)), dp(a), dp(b), dp(inv))
+    assert inv[2] == 0.0 and inv[0] > 0 and inv[1] > 0 and inv[3] > 0
+    Ar, Br, invr = ref.step_block((A + A.conj().T) / 2, G)
+    assert invr[2] == 0.0
+    np.testing.assert_allclose(inv, invr, rtol=1e-9)
 
 
 @pytest.mark.parametrize("W", [2, 3, 4])

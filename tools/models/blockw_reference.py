@@ -15,17 +15,26 @@ B_j and a zero column in Q_{j+1} (inverse pivot 0), as the two-vector device cod
 import numpy as np
 
 
-def step_block(Asum, Gsum):
-    """From the summed partials A = Q^H W and G = W^H W: (A, B upper triangular, inverse pivots)."""
+PIVOT_FLOOR = 1e-13      # kBwPivotFloor of blockw.hpp
+
+
+def step_block(Asum, Gsum, room=None):
+    """From the summed partials A = Q^H W and G = W^H W: (A, B upper triangular, inverse pivots).
+    A pivot at the rounding level of its Gram entry (PIVOT_FLOOR, relative) is a direction that is
+    exhausted; so is every direction beyond `room`, the dimensions the Krylov space has left (n minus
+    the rank of the earlier blocks)."""
     W = Asum.shape[0]
     A = Asum.copy()
     H = Gsum - A.conj().T @ A
     B = np.zeros((W, W), complex)
     inv = np.zeros(W)
+    room = W if room is None else room
     for c in range(W):                         # Cholesky, H = B^H B, row c of B at a time
         d = H[c, c].real - sum(abs(B[m, c]) ** 2 for m in range(c))
-        B[c, c] = np.sqrt(d) if d > 0.0 else 0.0
-        inv[c] = 1.0 / B[c, c].real if d > 0.0 else 0.0
+        keep = room > 0 and d > PIVOT_FLOOR * Gsum[c, c].real
+        room -= keep
+        B[c, c] = np.sqrt(d) if keep else 0.0
+        inv[c] = 1.0 / B[c, c].real if keep else 0.0
         for j in range(c + 1, W):
             s = H[c, j] - sum(np.conj(B[m, c]) * B[m, j] for m in range(c))
             B[c, j] = s * inv[c]
