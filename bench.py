@@ -241,9 +241,11 @@ def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
     ctx = mp.get_context("spawn")
     try:
         with ctx.Pool(nproc) as pool:
-            pool.map(_pool_warm, [path] * nproc, chunksize=1)          # warm the workers (imports, page cache)
+            # warm the workers (imports, page cache); bounded waits: a pool whose workers die at start-up
+            # respawns them for ever, and a baseline must never hang the benchmark
+            pool.map_async(_pool_warm, [path] * nproc, chunksize=1).get(timeout=180)
             t0 = time.perf_counter()
-            pool.map_async(_pool_worker, [(path, i) for i in idx]).get(timeout=900)
+            pool.map_async(_pool_worker, [(path, i) for i in idx]).get(timeout=300)
             dt = time.perf_counter() - t0
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
