@@ -243,3 +243,35 @@ def test_gather_fuzz_bit_equal(emu, to):
         assert np.array_equal(e_got, e_ref)
         checked += 1
     assert checked >= 25
+
+
+def test_block_widths_on_noise_spectra_vs_lapack(emu, to):
+    """Noise-like conjugate spectra (no arc: small spectral gaps, and matrices small enough that the
+    Krylov space of the wider blocks becomes complete): the default two-vector sweep and the opt-in
+    four- and eight-vector families against LAPACK's eigvalsh of the oracle's reduced theta-theta."""
+    rng = np.random.default_rng(5)
+    saved = {k: os.environ.pop(k, None) for k in ("SCINT_LANCZOS_BLOCK", "SCINT_MATVEC_MFMA", "SCINT_Q_BAND")}
+    try:
+        for trial in range(2):
+            nf, nt = int(rng.integers(100, 200)), int(rng.integers(100, 200))
+            dyn = rng.standard_normal((nf, nt))
+            if trial % 2:
+                dyn += 5 * np.outer(np.cos(np.arange(nf) * 0.3), np.cos(np.arange(nt) * 0.2))
+            fd = to.fft_axis(np.arange(nt) * 30.0, 1000.0, 0)
+            tau = to.fft_axis(1400 + np.arange(nf) * 0.1, 1.0, 0)
+            CS = to.conjugate_spectrum(dyn - dyn.mean(), 0)
+            edges = np.linspace(-fd.max() / 2, fd.max() / 2, 2 * int(rng.integers(20, 80)))
+            etas = tau.max() / (fd.max() / 2) ** 2 * np.array([0.3, 1.0, 3.0])
+            ref = np.array([np.linalg.eigvalsh(to.thth_redmap(CS, tau, fd, e, edges)[0])[-1] for e in etas])
+            for env in ({}, {"SCINT_LANCZOS_BLOCK": "4", "SCINT_MATVEC_MFMA": "2"}, {"SCINT_LANCZOS_BLOCK": "8"}):
+                for k in saved:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                eigs, info = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
+                assert np.all(info["status"] == 0), env
+                np.testing.assert_allclose(eigs, np.abs(ref), rtol=1e-11, err_msg=str(env))
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
