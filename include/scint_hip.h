@@ -28,7 +28,7 @@
  *     device; an 8 KiB reduction scratch per (device, stream) used by scint_mean /
  *     scint_chisq; per host thread a pinned flag buffer (4 int32 per resident
  *     curvature) and staging for the sweep's job tables, and, per device, the internal
- *     streams mentioned above.
+ *     streams mentioned above and a note of which kernels' LDS-size attribute has been set.
  */
 #ifndef SCINT_HIP_H
 #define SCINT_HIP_H
