@@ -7,6 +7,8 @@
 // operation are the active lanes, exactly the set the hardware would execute it for under
 // structured control flow.  A barrier releases when every fiber of the block is parked at it or
 // finished.  Blocks run one after the other, kernels run synchronously at launch.
+// One host thread at a time: the fiber table and the geometry variables are process-global (the
+// tests drive the library from one thread; ranks of a multi-process test are separate processes).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
