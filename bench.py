@@ -130,23 +130,9 @@ def make_workload(size, neta, nedge, seed, npad=0, npz=None):
 
 
 def lanczos_block():
-    """(vectors per Lanczos step, name of the mat-vec kernel) as the library will choose them from the
-    environment: 2 by default; SCINT_LANCZOS_BLOCK=1 / 4 / 8 and SCINT_MATVEC_MFMA select the
-    experimental paths (eigen_packed.hip, sweep_block_width)."""
-    b = os.environ.get("SCINT_LANCZOS_BLOCK", "2")
-    m = os.environ.get("SCINT_MATVEC_MFMA", "0")
-    if b == "1":
-        return 1, "pk_matvec_kernel"
-    if b == "8":
-        name = "pkq_matvec_mfma_kernel<8>" if os.environ.get("SCINT_Q_BAND") == "1" else "pkq_matvec_band_kernel<8, 4, 4>"
-        return 8, name + " (eight-vector block Lanczos, matrix cores; experimental)"
-    if b == "4":
-        name = {"1": "pkw_matvec_mfma_kernel<4>", "2": "pkq_matvec_mfma_kernel<4>"}.get(m, "pkw_matvec_kernel<4>")
-        if m == "2" and os.environ.get("SCINT_Q_BAND") == "4":
-            name = "pkq_matvec_band_kernel<4, 8, 4>"
-        return 4, name + " (four-vector block Lanczos; experimental)"
-    if m == "2":
-        return 2, "pkq_matvec_band_kernel<2, 16, 4> (two-vector block Lanczos on the matrix cores; experimental)"
+    """(vectors per Lanczos pass, name of the mat-vec kernel): the one recurrence the library ships
+    (eigen_packed.hip); the single-vector and the four- / eight-vector families were measured
+    and removed (profiles/r03_wide_blocks_ab.json)."""
     return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec)"
 
 

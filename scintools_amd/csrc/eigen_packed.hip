@@ -1,38 +1,38 @@
-// eigen_packed.hip -- the eta sweep: packed gather + batched Hermitian Lanczos on the
-// tile-packed theta-theta matrices (packed.hpp).  This is the headline path
+// eigen_packed.hip -- the eta sweep: packed gather + batched two-vector (block) Hermitian Lanczos on
+// the tile-packed theta-theta matrices (packed.hpp).  This is the headline path
 // (scint_eval_sweep); eigen.hip keeps the full-matrix solver for user-supplied matrices.
 //
-// Per Lanczos step j, for all jobs of a batch at once:
+// Per Lanczos pass j, for all jobs of a batch at once (details at the kernels):
 //
-//   pk_matvec_kernel  one workgroup per strip of <= 8 tiles (I, J0..J1): streams the tiles
-//                     once (16 independent 1-KiB wave loads in flight per wave), forms
-//                     the row-block partial  sum_J A_IJ x_J  (64 lanes stride the columns,
-//                     wave-shuffle reduction at the end of the strip) and, per off-diagonal
-//                     tile, the column-block partial  A_IJ^H x_I  (lane-local over rows,
-//                     4-wave LDS reduction every 4 tiles; x_I is broadcast with v_readlane).
-//                     The loop is software-pipelined over half tiles so that >= 8 KiB per
-//                     wave is always in flight.  x = q_j is never stored normalised: every
-//                     workgroup rebuilds x = (u_{j-1} - alpha_{j-1} q_{j-1}) / beta_{j-1}
-//                     from the previous step's vectors and partial dot products.
-//                     HBM bound: 8 N^2 bytes per job-step (algorithmic = actual).
-//   pk_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials,
-//                     u_j = A q_j - beta_{j-1} q_{j-1}, q_j, and the partials of
-//                     alpha_j = q_j^H u_j and |u_j|^2  (beta_j^2 = |u_j|^2 - alpha_j^2).
-//   pk_check_kernel   (every 4 steps) top two Ritz values of T_k by 64-lane multisection on
-//                     the Sturm count, Ritz residual by the backward recurrence, and the
-//                     a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
+//   pk2_matvec_kernel  one workgroup per strip of <= 16 tiles (I, J0..J1): streams the tiles once
+//                      (16 independent 1-KiB wave loads in flight per wave) and multiplies BOTH vectors
+//                      of the block: row partials sum_J A_IJ X_J (64 lanes stride the columns,
+//                      wave-shuffle reduction at the end of the strip) and, per off-diagonal tile, the
+//                      column partials A_IJ^H X_I (lane-local over rows, 4-wave LDS reduction every 4
+//                      tiles; X_I broadcast with v_readlane).  HBM bound: 8 N (N + 1) bytes per pass.
+//   pk2_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials -> W_j, Q_j and the
+//                      partial sums of A_j = Q_j^H W_j and of the Gram matrix W_j^H W_j.
+//   pk2_check_kernel   (every 3 passes) top two eigenvalues of the pentadiagonal T_k by 64-lane
+//                      multisection on a banded LDL^H Sturm count, Ritz residual by inverse iteration,
+//                      a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
 //
 // Scheduling (SweepGroup below): the `batch` slots are kept full -- when a curvature converges its
 // slot is re-filled with the next eta of the sweep (continuous batching; every job carries the
 // launch index it started at, so jobs at different Lanczos steps share one launch).  Two groups of
-// slots run on two streams and fill each other's gaps; in each, the steps are queued in chunks of
-// 4 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
+// slots run on two streams and fill each other's gaps; in each, the passes are queued in chunks of
+// 3 + a convergence check, two chunks ahead of the state the host has seen, so a stream never
 // waits for the host.  Per-job arithmetic does not depend on the schedule.
 //
 // Stopping: err <= tol * |theta_1| (tol = 1e-12 by default, i.e. 1000x tighter than the
 // 1e-9 parity target against ARPACK) and the Ritz value moved by < 1e3 tol |theta_1| since the
 // previous check.  No atomics anywhere: results are bit-reproducible and independent of how the
 // etas are batched.
+//
+// History (measured, then removed -- profiles/r03_wide_blocks_ab.json): the
+// single-vector recurrence of round 1 (41.1 passes per eta against 31.6, 1079-1094 eta/s against
+// 1183-1233) and the four- / eight-vector families of round 2 (vector-FMA quarter strips 587 eta/s,
+// matrix-core strips 960, matrix-core bands 1163 with four vectors and 967 with eight, against 1201
+// for this kernel in the same interleaved A/B on one MI355X).
 #include <math.h>
 
 #include <algorithm>
@@ -44,15 +44,11 @@
 
 namespace scint {
 
-constexpr int kCheckEvery = 4;   // Lanczos steps per chunk (between convergence checks); SCINT_CHECK_EVERY overrides.
-                                 // Measured at 4096^2 / 256 eta: every 1 / 2 / 4 steps -> 39.6 / 40.1 / 41.1 steps per eta but
-                                 // 1081 / 1085 / 1093 eta/s: the saved steps do not pay for the extra checks and read-backs
-constexpr int kCheckEveryBlock = 3;   // two-vector recurrence (a pass is worth more): every 2 / 3 / 4 / 5 passes ->
+constexpr int kCheckEveryBlock = 3;   // passes per chunk (between convergence checks); SCINT_CHECK_EVERY overrides (tests).
+                                      // Measured at 4096^2 / 256 eta: every 2 / 3 / 4 / 5 passes ->
                                       // 31.2 / 31.6 / 32.1 / 32.7 passes per eta, 1203 / 1211 / 1196 / 1198 eta/s (3 interleaved runs each)
 constexpr int kFirstCheck = 8;
-constexpr int kMaxK = 512;   // upper bound on Lanczos steps held in LDS by the check kernel
-
-struct StepScalars { double alpha, beta, inv; };
+constexpr int kMaxK = 512;   // upper bound on the Lanczos steps a caller may ask for
 
 // Element (row, col) of the packed Hermitian matrix, row != col blocks handled by symmetry.
 __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
@@ -61,42 +57,7 @@ __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
     return conj(jb.tiles[(tile_offset(jb.nb, bc) + (br - bc)) * kTileElems + (c % kTB) * kTB + (r % kTB)]);
 }
 
-// u_{-1} := v0 = row n/2 of theta-theta (Eval_calc, ththmod.py:398), q_{-1} := 0
-__global__ void __launch_bounds__(64) pk_init_kernel(const PackedJob* jobs, const int32_t* slots) {
-    const PackedJob jb = jobs[slots[blockIdx.y]];
-    const int K = blockIdx.x, e = threadIdx.x;
-    if (K == 0 && e == 0) { jb.state[1] = 0; jb.result[1] = -INFINITY; jb.result[3] = -INFINITY; }   // state[0] keeps the finished generation
-    if (K >= jb.nb) return;
-    const int r = K * kTB + e;
-    cplx v = mk(0.0, 0.0);
-    if (r < jb.n && jb.n >= 2) v = packed_at(jb, jb.n / 2, r);
-    jb.U[0][r] = v;
-    jb.U[1][r] = mk(0.0, 0.0);
-    jb.Q[(int64_t)(jb.qslots - 1) * jb.qstride + r] = mk(0.0, 0.0);   // "q_{-1}" = 0
-    jb.Q[r] = mk(0.0, 0.0);
-    const double p = wave_sum(norm2(v));
-    if (e == 0) {
-        jb.apart[0][K] = 0.0; jb.upart[0][K] = p;
-        jb.apart[1][K] = 0.0; jb.upart[1][K] = 0.0;
-    }
-}
-
 constexpr int kMaxStrip = 16;
-constexpr int kFlush = 4;      // column partials are reduced across the 4 waves every kFlush tiles
-
-// alpha_{j-1}, beta_{j-1} by ONE wavefront (no barriers): nb <= 64*k entries, fixed order
-__device__ inline StepScalars step_scalars_wave(const double* __restrict__ ap, const double* __restrict__ up,
-                                                int nb, int lane) {
-    double a = 0.0, uu = 0.0;
-    for (int i = lane; i < nb; i += 64) { a += gload(ap + i); uu += gload(up + i); }
-    StepScalars s;
-    s.alpha = wave_sum(a);
-    uu = wave_sum(uu);
-    const double b2 = uu - s.alpha * s.alpha;
-    s.beta = b2 > 0.0 ? sqrt(b2) : 0.0;
-    s.inv = s.beta > 0.0 ? 1.0 / s.beta : 0.0;
-    return s;
-}
 
 // wave-uniform broadcast of lane `src`'s double through the scalar unit (no LDS, no VGPR)
 __device__ inline double readlane_f64(double v, int src) {
@@ -105,317 +66,8 @@ __device__ inline double readlane_f64(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(256, 2)
-pk_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx cred[4][kFlush][kTB];      // per-wave column partials of kFlush tiles (16 KiB)
-    const Strip st = strips[blockIdx.x];
-    const PackedJob* __restrict__ jp = jobs + st.job;
-    const int step = launch - jp->start;
-    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
-    const int par = step & 1;
-    const int nb = jp->nb;
-    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
-    const int qs = jp->qslots;
-    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride;   // q_{j-1}
-    const cplx* __restrict__ tiles = jp->tiles;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int I = st.I;
-    const int64_t t0 = tile_offset(nb, I);
-    const int ntile = st.J1 - st.J0;
-    // Software pipeline over half tiles (8 rows x 64 columns = 8 KiB per wave): the next half
-    // tile's loads are always in flight while the current one is consumed.  The first loads go
-    // out before anything else -- they do not depend on the step scalars.
-    const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
-    cplx a0[8], a1[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
-    const StepScalars sc = step_scalars_wave(par ? jp->apart[1] : jp->apart[0],
-                                             par ? jp->upart[1] : jp->upart[0], nb, lane);
-    // lane l of every wave holds x_I[l]; rows read it back with v_readlane (scalar broadcast)
-    cplx xIr;
-    {
-        const cplx u = gload(Up + I * kTB + lane), q = gload(Qp + I * kTB + lane);
-        xIr = mk((u.x - sc.alpha * q.x) * sc.inv, (u.y - sc.alpha * q.y) * sc.inv);
-    }
-    cplx accR[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accR[r] = mk(0.0, 0.0);
-    cplx* __restrict__ colpart = jp->colpart;
-#pragma unroll 1
-    for (int t = 0; t < ntile; ++t) {
-        const int J = st.J0 + t;
-        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) a1[r] = gload_nt(tc + (8 + r) * kTB);   // second half of this tile
-        const cplx uj = gload(Up + J * kTB + lane), qj = gload(Qp + J * kTB + lane);
-        const cplx xJ = mk((uj.x - sc.alpha * qj.x) * sc.inv, (uj.y - sc.alpha * qj.y) * sc.inv);
-        cplx c = mk(0.0, 0.0);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            accR[r] = accR[r] + a0[r] * xJ;
-            const cplx xi = mk(readlane_f64(xIr.x, 16 * w + r), readlane_f64(xIr.y, 16 * w + r));
-            c = mk(c.x + a0[r].x * xi.x + a0[r].y * xi.y, c.y + a0[r].x * xi.y - a0[r].y * xi.x);   // conj(a) x_I
-        }
-        if (t + 1 < ntile) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + kTileElems + r * kTB);   // first half of the next tile
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            accR[8 + r] = accR[8 + r] + a1[r] * xJ;
-            const cplx xi = mk(readlane_f64(xIr.x, 16 * w + 8 + r), readlane_f64(xIr.y, 16 * w + 8 + r));
-            c = mk(c.x + a1[r].x * xi.x + a1[r].y * xi.y, c.y + a1[r].x * xi.y - a1[r].y * xi.x);
-        }
-        cred[w][t & (kFlush - 1)][lane] = c;   // this wave's own slot
-        if ((t & (kFlush - 1)) == kFlush - 1 || t + 1 == ntile) {
-            // cross-wave reduction of the last <= kFlush tiles' column partials: wave w takes tile w
-            __syncthreads();
-            const int tb = t & ~(kFlush - 1);
-            const int tt = tb + w;
-            if (tt <= t) {
-                const int Jt = st.J0 + tt;
-                if (Jt != I) {
-                    const cplx s = ((cred[0][w][lane] + cred[1][w][lane]) + cred[2][w][lane]) + cred[3][w][lane];
-                    gstore(colpart + (t0 + (Jt - I)) * kTB + lane, s);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    cplx* __restrict__ rowpart = jp->rowpart;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const cplx s = wave_sum(accR[r]);
-        if (lane == 0) gstore(rowpart + (int64_t)st.index * kTB + 16 * w + r, s);
-    }
-}
-
 constexpr int kRedGroups = 16;   // wavefronts per reduce block: each sums every 16th partial vector
 
-__global__ void __launch_bounds__(64 * kRedGroups)
-pk_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
-    __shared__ cplx part[kRedGroups][kTB];
-    const PackedJob jb = jobs[blockIdx.y];
-    const int K = blockIdx.x;
-    const int step = launch - jb.start;
-    if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
-    const int par = step & 1;
-    const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
-    // fixed summation order: group g adds entries g, g+16, g+32, ... of the list
-    // [row-strip partials of block row K, then column partials of tiles (0..K-1, K)];
-    // the 16 group sums are then added in group order.  Few entries per group keeps the
-    // dependent-load chain short.
-    const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
-    cplx acc = mk(0.0, 0.0);
-    for (int idx = g; idx < nrow + K; idx += kRedGroups) {
-        if (idx < nrow) acc = acc + gload(jb.rowpart + (int64_t)(s0 + idx) * kTB + e);
-        else {
-            const int I = idx - nrow;
-            acc = acc + gload(jb.colpart + (tile_offset(jb.nb, I) + (K - I)) * kTB + e);
-        }
-    }
-    part[g][e] = acc;
-    __syncthreads();
-    if (g == 0) {
-        // the same fixed-order scalar sums the mat-vec kernel evaluated
-        const StepScalars sc = step_scalars_wave(par ? jb.apart[1] : jb.apart[0],
-                                                 par ? jb.upart[1] : jb.upart[0], jb.nb, e);
-        cplx total = part[0][e];
-#pragma unroll
-        for (int k = 1; k < kRedGroups; ++k) total = total + part[k][e];
-        const int r = K * kTB + e;
-        const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
-        const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + jb.qslots - 1) % jb.qslots) * jb.qstride;
-        cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
-        cplx* __restrict__ Qn = jb.Q + (int64_t)(step % jb.qslots) * jb.qstride;
-        const cplx up = gload(Up + r), qp = gload(Qp + r);
-        const cplx qn = mk((up.x - sc.alpha * qp.x) * sc.inv, (up.y - sc.alpha * qp.y) * sc.inv);
-        const cplx t = mk(total.x - sc.beta * qp.x, total.y - sc.beta * qp.y);
-        gstore(Un + r, t);
-        gstore(Qn + r, qn);
-        const double pa = wave_sum(qn.x * t.x + qn.y * t.y);   // Re(conj(q) u)
-        const double pu = wave_sum(norm2(t));
-        if (e == 0) {
-            (par ? jb.apart[0] : jb.apart[1])[K] = pa;
-            (par ? jb.upart[0] : jb.upart[1])[K] = pu;
-            if (K == 0) {
-                if (step > 0) jb.alpha[step - 1] = sc.alpha;
-                jb.beta[step] = sc.beta;
-            }
-        }
-    }
-}
-
-// eigenvalues of T_k (diag a[0..k), off-diagonal b[1..k)) strictly below x
-__device__ inline int sturm_count(const double* a, const double* b, int k, double x, double tiny) {
-    int cnt = 0;
-    double d = a[0] - x;
-    if (fabs(d) < tiny) d = -tiny;
-    cnt += d < 0.0;
-    for (int i = 1; i < k; ++i) {
-        d = (a[i] - x) - b[i] * b[i] / d;
-        if (fabs(d) < tiny) d = -tiny;
-        cnt += d < 0.0;
-    }
-    return cnt;
-}
-
-// smallest x in (lo, hi] with count(x) >= target, by 64-lane multisection; requires
-// count(lo) < target <= count(hi).  Returns the midpoint of the final bracket.
-__device__ inline double multisect(const double* a, const double* b, int k, int target, double lo,
-                                   double hi, double tiny, int lane) {
-    for (int round = 0; round < 48; ++round) {
-        const double wdt = hi - lo;
-        if (!(wdt > 0.0)) break;
-        const double x = lo + wdt * ((double)(lane + 1) / 65.0);
-        const int ok = (x > lo && x < hi) ? (sturm_count(a, b, k, x, tiny) >= target) : 0;
-        const unsigned long long m = __ballot(ok);
-        double nlo, nhi;
-        if (m == 0ull) { nlo = __shfl(x, 63, 64); nhi = hi; }
-        else {
-            const int first = __ffsll((long long)m) - 1;
-            nhi = __shfl(x, first, 64);
-            nlo = first > 0 ? __shfl(x, first - 1, 64) : lo;
-        }
-        if (!(nlo > lo) && !(nhi < hi)) break;
-        if (nlo > lo) lo = nlo;
-        if (nhi < hi) hi = nhi;
-        if (hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi))) break;
-    }
-    return 0.5 * (lo + hi);
-}
-
-__global__ void __launch_bounds__(64) pk_check_kernel(const PackedJob* jobs, int launches_done) {
-    __shared__ double a[kMaxK + 1];
-    __shared__ double b[kMaxK + 2];
-    const PackedJob jb = jobs[blockIdx.x];
-    if (jb.gen <= 0 || jb.state[0] >= jb.gen) return;      // idle slot / finished job
-    const int lane = threadIdx.x;
-    const int k_done = launches_done - jb.start;   // Lanczos steps this job has completed
-    if (jb.n < 2) {
-        if (lane == 0) {
-            jb.state[0] = jb.gen;
-            jb.status_out[0] = SCINT_E_EMPTY;
-            jb.eig_out[0] = nan("");
-            if (jb.iters_out) jb.iters_out[0] = 0;
-        }
-        return;
-    }
-    if (k_done < kFirstCheck && k_done < jb.max_steps) return;
-    const int k = min(k_done, jb.max_steps);
-    // alpha_{k-1}, beta_{k-1} are still in the partials of the last reduce kernel
-    const int par = k & 1;
-    double al = 0.0, uu = 0.0;
-    const double* __restrict__ ap = par ? jb.apart[1] : jb.apart[0];
-    const double* __restrict__ upp = par ? jb.upart[1] : jb.upart[0];
-    for (int i = lane; i < jb.nb; i += 64) { al += ap[i]; uu += upp[i]; }
-    al = wave_sum(al);
-    uu = wave_sum(uu);
-    const double b2 = uu - al * al;
-    const double beta_k = b2 > 0.0 ? sqrt(b2) : 0.0;
-    for (int i = lane; i < k - 1; i += 64) a[i] = jb.alpha[i];
-    for (int i = lane + 1; i < k; i += 64) b[i] = jb.beta[i];
-    if (lane == 0) { a[k - 1] = al; b[0] = 0.0; }
-    __syncthreads();
-
-    double lo = INFINITY, hi = -INFINITY, scale = 0.0;
-    for (int i = lane; i < k; i += 64) {
-        const double off = (i > 0 ? fabs(b[i]) : 0.0) + (i + 1 < k ? fabs(b[i + 1]) : 0.0);
-        lo = fmin(lo, a[i] - off);
-        hi = fmax(hi, a[i] + off);
-        scale = fmax(scale, fabs(a[i]) + off);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, o, 64));
-        hi = fmax(hi, __shfl_xor(hi, o, 64));
-        scale = fmax(scale, __shfl_xor(scale, o, 64));
-    }
-    const bool finite = isfinite(lo) && isfinite(hi) && isfinite(beta_k);
-    double theta = nan(""), theta2 = -INFINITY, resid = nan(""), err = nan("");
-    if (finite && scale == 0.0 && beta_k == 0.0) {
-        // T_k = 0: an all-zero theta-theta (e.g. every delay masked); ARPACK returns 0 as well
-        theta = 0.0; theta2 = 0.0; resid = 0.0; err = 0.0;
-    } else if (finite) {
-        const double tiny = scale * 1e-300 + 1e-300;
-        lo = lo - 1e-15 * fabs(lo) - 1e-300;   // count(lo) == 0
-        hi = hi + 1e-15 * fabs(hi) + 1e-300;   // count(hi) == k
-        theta = multisect(a, b, k, k, lo, hi, tiny, lane);
-        if (k >= 2) theta2 = multisect(a, b, k, k - 1, lo, theta, tiny, lane);
-        // Ritz residual beta_k |s_{k-1}|, s = eigenvector of T_k by the backward recurrence
-        if (lane == 0) {
-            double* __restrict__ sv = jb.want_vec ? jb.svec : nullptr;
-            double sk = 1.0, skp1 = 0.0, nrm = 1.0, last = 1.0;
-            if (sv) sv[k - 1] = 1.0;
-            for (int i = k - 1; i >= 1; --i) {
-                const double bi = b[i];
-                double sm1 = (bi != 0.0) ? ((theta - a[i]) * sk - (i + 1 < k ? b[i + 1] * skp1 : 0.0)) / bi : 0.0;
-                if (!isfinite(sm1)) sm1 = 0.0;
-                if (fabs(sm1) > 1e150) {
-                    const double f = 1e-150;
-                    sm1 *= f; sk *= f; last *= f; nrm *= f * f;
-                    if (sv) for (int t = i; t < k; ++t) sv[t] *= f;
-                }
-                if (sv) sv[i - 1] = sm1;
-                nrm += sm1 * sm1;
-                skp1 = sk;
-                sk = sm1;
-            }
-            const double inv = 1.0 / sqrt(nrm);
-            if (sv) for (int t = 0; t < k; ++t) sv[t] *= inv;
-            resid = beta_k * fabs(last) * inv;
-        }
-        resid = __shfl(resid, 0, 64);
-        const double gap = theta - theta2;
-        err = (gap > resid) ? resid * resid / gap : resid;
-    }
-    if (lane == 0) {
-        const double prev = jb.result[3], prev2 = jb.result[1];
-        const double at = fmax(fabs(theta), 1e-300);
-        const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
-        const bool exact = finite && (k >= jb.n || beta_k == 0.0);
-        // eigenvalue only: a-posteriori bound on theta.  Eigenvector wanted: the error of the Ritz
-        // vector is ~ resid / gap; ask for 30 tol (3e-11 at the default) of it, with the gap taken
-        // from the two top Ritz values once the second one has stopped moving (theta_2 <= lambda_2
-        // approaches from below, so an unsettled theta_2 would flatter the gap); resid <= tol
-        // |theta| always suffices.
-        const double gap2 = theta - theta2;
-        const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
-        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= 30.0 * jb.tol * gap2);
-        const bool ok = jb.want_vec ? vec_ok : (err <= jb.tol * at && settled);
-        const bool conv = finite && (ok || exact);
-        const bool stop = conv || !finite || k >= jb.max_steps;
-        jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
-        if (stop) {
-            jb.state[1] = k;
-            jb.state[0] = jb.gen;
-            jb.eig_out[0] = jb.want_vec ? theta : fabs(theta);   // modeler keeps the sign of w
-            if (jb.iters_out) jb.iters_out[0] = k;
-            jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
-        }
-    }
-}
-
-// Ritz vector of finished jobs: y = sum_j s_j q_j, then normalised (fixed-order reductions).
-// grid (nb, njobs); vec_out rows are `vstride` apart and indexed by the job's eta index.
-__global__ void __launch_bounds__(64) pk_ritz_kernel(const PackedJob* jobs, const int32_t* slots,
-                                                     const int64_t* eta_index, cplx* vec_out,
-                                                     int64_t vstride) {
-    const PackedJob jb = jobs[slots[blockIdx.y]];
-    const int K = blockIdx.x, e = threadIdx.x;
-    if (K >= jb.nb) return;
-    const int k = jb.state[1];
-    const int r = K * kTB + e;
-    cplx y = mk(0.0, 0.0);
-    for (int j = 0; j < k; ++j) {
-        const cplx q = jb.Q[(int64_t)j * jb.qstride + r];
-        const double s = jb.svec[j];
-        y = mk(y.x + s * q.x, y.y + s * q.y);
-    }
-    cplx* out = vec_out + eta_index[blockIdx.y] * vstride;
-    if (r < jb.n) out[r] = y;
-    const double p = wave_sum(r < jb.n ? norm2(y) : 0.0);
-    if (e == 0) jb.upart[0][K] = p;   // the job is finished: its partial arrays are free
-}
 
 __global__ void __launch_bounds__(64) pk_ritz_scale_kernel(const PackedJob* jobs, const int32_t* slots,
                                                            const int64_t* eta_index, cplx* vec_out,
@@ -536,13 +188,9 @@ __global__ void __launch_bounds__(64) pk2_init_kernel(const PackedJob* jobs, con
 // were measured and removed: half strips (8 rows per wave, 168 registers, three waves per SIMD:
 // 1075 eta/s against 1183) and two sweeps per strip (1147 eta/s); DESIGN.md section 6.
 constexpr int kFlushF = 4;     // its column partials are reduced across the waves every 4 tiles (a barrier pair each)
-// UNCOND = true (SCINT_PK2_PREFETCH=1, unmeasured): the next tile's first-half loads are issued
-// unconditionally (of this tile again after the last one).  With the load under `if (t + 1 < ntile)`
-// the compiler must assume it may not have been issued and makes the waits of the second half
-// pessimistic: the half ends on vmcnt(0), i.e. it also waits for the loads it has just prefetched,
-// and every tile iteration drains the wave's loads (seen in the assembly: tools/isa_stats.py).  The
-// variant also uses the LDS-only barrier (common.hpp) where the column partials are flushed.
-template <bool UNCOND>
+// (The same kernel with its prefetch loads issued unconditionally -- exact wait counts -- and LDS-only
+// barriers in the flush was measured in round 3: 1169 against 1201 eta/s; tools/probes/pk2_probe.hip
+// shows the body at 6.1-6.2 TB/s on synthetic strips in either form, so it was removed.)
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
     __shared__ cplx cred[4][kFlushF][kTB][2];   // per-wave column partials of kFlushF tiles, 2 vectors (32 KiB)
@@ -578,7 +226,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
         xs[idx >> 6][idx & 63][0] = x1;
         xs[idx >> 6][idx & 63][1] = x2;
     }
-    if (UNCOND) lds_barrier(); else __syncthreads();
+    __syncthreads();
     cplx acc1[16], acc2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
@@ -599,11 +247,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
             c1 = mk(c1.x + a0[r].x * x1.x + a0[r].y * x1.y, c1.y + a0[r].x * x1.y - a0[r].y * x1.x);   // conj(a) x_I
             c2 = mk(c2.x + a0[r].x * x2.x + a0[r].y * x2.y, c2.y + a0[r].x * x2.y - a0[r].y * x2.x);
         }
-        if (UNCOND) {
-            const cplx* __restrict__ nx = t + 1 < ntile ? tc + kTileElems : tc;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(nx + r * kTB);
-        } else if (t + 1 < ntile) {
+        if (t + 1 < ntile) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + kTileElems + r * kTB);   // first half of the next tile
         }
@@ -621,7 +265,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
         if ((t & (kFlushF - 1)) == kFlushF - 1 || t + 1 == ntile) {
             // cross-wave reduction of the last <= kFlushF tiles' column partials: wave w takes the
             // (tile, vector) pairs w, w + 4 of the 2 kFlushF
-            if (UNCOND) lds_barrier(); else __syncthreads();
+            __syncthreads();
             const int tb = t & ~(kFlushF - 1);
 #pragma unroll
             for (int c = w; c < 2 * kFlushF; c += 4) {
@@ -634,7 +278,7 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
                     }
                 }
             }
-            if (UNCOND) lds_barrier(); else __syncthreads();
+            __syncthreads();
         }
     }
     cplx* __restrict__ rowpart = jp->rowpart;
@@ -919,136 +563,41 @@ __global__ void __launch_bounds__(64) pk2_ritz_kernel(const PackedJob* jobs, con
     if (e == 0) jb.upart[0][K] = p;   // the job is finished: its partial arrays are free
 }
 
-}  // namespace scint
-#include "blockw_kernels.hpp"
-#include "blockq_kernels.hpp"
-namespace scint {
-
 // ------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------
-// vectors per Lanczos step: 2 (default), 1 (SCINT_LANCZOS_BLOCK=1, the round-1 recurrence), 4
-// (blockw_kernels.hpp) or 8 (blockq_kernels.hpp) -- the last two not yet validated on a GPU.  Read per call.
-static int sweep_block_width() {
-    const char* e = getenv("SCINT_LANCZOS_BLOCK");
-    const int v = e ? atoi(e) : 2;
-    return (v == 1 || v == 4 || v == 8) ? v : 2;
-}
-// SCINT_MATVEC_MFMA=1 (with SCINT_LANCZOS_BLOCK=4): the matrix-core mat-vec of blockw_kernels.hpp
-static int sweep_matvec_mode() {
-    const char* e = getenv("SCINT_MATVEC_MFMA");
-    return e ? atoi(e) : 0;
-}
-// the "q" kernel family (coefficients and Q_j once per step, blockq_kernels.hpp): always for 8 vectors,
-// for 4 or 2 vectors with SCINT_MATVEC_MFMA=2 (cross-checks of the family against the pkw_* / pk2_* kernels)
-// strip length of the eight-vector mat-vec: 4 (default) or 8 (SCINT_Q_STRIP=8)
-static int sweep_q_strip8() {
-    const char* e = getenv("SCINT_Q_STRIP");
-    return (e && atoi(e) == 8) ? 8 : QShape<8>::strip;
-}
-// block rows per workgroup of the wide-block mat-vec (banded form, blockq_kernels.hpp): 4 for eight
-// vectors, 1 (plain strips) for the four-vector cross-check; SCINT_Q_BAND=1 / 2 / 4 overrides (2: 64 KiB
-// of LDS at W = 8 instead of 80)
-static int sweep_q_band(int block) {
-    const char* e = getenv("SCINT_Q_BAND");
-    const int v = e ? atoi(e) : (block == 8 ? 4 : 1);
-    return (v == 4 || v == 2) ? v : 1;
-}
-static bool sweep_q_family(int block) { return block == 8 || ((block == 4 || block == 2) && sweep_matvec_mode() == 2); }
-static int strip_len_block(int nb, int block) {
-    const int s = strip_len_for(nb);
-    if (block == 8) return std::min(s, sweep_q_band(8) > 1 ? 4 : sweep_q_strip8());
-    return block == 4 ? std::min(s, kStripW) : s;          // (two vectors: up to 16 = QHost<2>::strip)
-}
-
-// ---- launches of the wide-block kernel family (blockq_kernels.hpp), one set per width -------------
-// strips of the plain strip form: 16 / 8 / 4 tiles for 2 / 4 / 8 vectors (8 tiles for eight vectors
-// with SCINT_Q_STRIP=8); the banded form uses the same chunk lengths
-template <int W> struct QHost { static constexpr int strip = QShape<W>::strip; };
-
-template <int W>
-static void q_launch_step(int band, int qstrip8, int nstrips, int nb_run, int nslots, hipStream_t stream,
-                          const PackedJob* jobs, const Strip* strips, int launch) {
-    constexpr int ST = QHost<W>::strip;
-    const dim3 gq((unsigned)nb_run, (unsigned)nslots), gs((unsigned)nstrips);
-    hipLaunchKernelGGL(pkq_coef_kernel<W>, dim3((unsigned)nslots), dim3(64), 0, stream, jobs, launch);
-    hipLaunchKernelGGL(pkq_qbuild_kernel<W>, gq, dim3(64), 0, stream, jobs, launch);
-    const int slot = profiler().begin(kProfMatvec, stream);
-    if (band == 4)
-        hipLaunchKernelGGL((pkq_matvec_band_kernel<W, ST, 4>), gs, dim3(256), (pkq_band_lds_bytes<W, ST, 4>()), stream, jobs, strips, launch);
-    else if (band == 2)
-        hipLaunchKernelGGL((pkq_matvec_band_kernel<W, ST, 2>), gs, dim3(256), (pkq_band_lds_bytes<W, ST, 2>()), stream, jobs, strips, launch);
-    else if (W == 8 && qstrip8 == 8)
-        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<W, 8>), gs, dim3(256), (pkq_matvec_lds_bytes<W, 8>()), stream, jobs, strips, launch);
-    else
-        hipLaunchKernelGGL((pkq_matvec_mfma_kernel<W, ST>), gs, dim3(256), (pkq_matvec_lds_bytes<W, ST>()), stream, jobs, strips, launch);
-    profiler().end(kProfMatvec, slot, stream);
-    if (band == 4)
-        hipLaunchKernelGGL((pkq_reduce_band_kernel<W, 4>), gq, dim3(64 * kRedGroupsQ), 0, stream, jobs, launch);
-    else if (band == 2)
-        hipLaunchKernelGGL((pkq_reduce_band_kernel<W, 2>), gq, dim3(64 * kRedGroupsQ), 0, stream, jobs, launch);
-    else
-        hipLaunchKernelGGL(pkq_reduce_kernel<W>, gq, dim3(64 * kRedGroupsQ), 0, stream, jobs, launch);
-}
-
-template <int W>
-static void q_launch_check(int nslots, hipStream_t stream, const PackedJob* jobs, int launches_done) {
-    hipLaunchKernelGGL(pkq_coef_kernel<W>, dim3((unsigned)nslots), dim3(64), 0, stream, jobs, launches_done);
-    hipLaunchKernelGGL(pkq_check_kernel<W>, dim3((unsigned)nslots), dim3(64), QCheckLds<W>::total, stream, jobs, launches_done);
-}
-
-// kernels of the family whose dynamic LDS exceeds the default 64 KiB limit
-template <int W>
-static hipError_t q_set_lds_attributes() {
-    constexpr int ST = QHost<W>::strip;
-    hipError_t e = hipSuccess;
-    auto set = [&](const void* f, size_t bytes) {
-        if (e == hipSuccess && bytes > 64 * 1024) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    };
-    set((const void*)pkq_matvec_band_kernel<W, ST, 4>, pkq_band_lds_bytes<W, ST, 4>());
-    set((const void*)pkq_matvec_band_kernel<W, ST, 2>, pkq_band_lds_bytes<W, ST, 2>());
-    set((const void*)pkq_matvec_mfma_kernel<W, ST>, pkq_matvec_lds_bytes<W, ST>());
-    if (W == 8) set((const void*)pkq_matvec_mfma_kernel<W, 8>, pkq_matvec_lds_bytes<W, 8>());
-    set((const void*)pkq_check_kernel<W>, QCheckLds<W>::total);
-    return e;
-}
-
 struct SlabLayout {
     size_t tiles, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
-        alpha, beta, result, coef, total;
+        alpha, beta, result, total;
     int qslots;
 };
 
-static int max_strips(int nb, int block) {
-    const int S = strip_len_block(nb, block);
+static int max_strips(int nb) {
+    const int S = strip_len_for(nb);
     int n = 0;
     for (int I = 0; I < nb; ++I) n += strips_in_row(nb, I, S);
     return n;
 }
 
-static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block) {
+static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     SlabLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     // the strip count is not monotone in nb across the strip-length thresholds: take the max
     int smax = 0;
-    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb, block));
+    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb));
     L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
-    // vectors, partial vectors and scalar histories are sized for the two-vector (block) recurrence:
-    // 2 columns, 4 scalars per coefficient (they are small next to the tiles); the single-vector
-    // recurrence (SCINT_LANCZOS_BLOCK=1) uses half of each
-    // (SCINT_LANCZOS_BLOCK=4: 4 columns, 16 scalars, column partials per quarter tile)
-    const size_t bw = block >= 4 ? (size_t)block : 2, sc = bw * bw, cparts = block == 4 ? kQuarters : 1;
+    // vectors, partial vectors and scalar histories of the two-vector (block) recurrence: 2 columns,
+    // 4 scalars per coefficient (all small next to the tiles)
+    const size_t bw = 2, sc = bw * bw;
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
-    // (block steps when two vectors run: <= kMaxKB + 1 are used; the wider blocks stop at 64 steps and
-    // their slots are 2-4 times as large, so their count is capped)
-    L.qslots = want_vec ? (block >= 4 ? std::min(max_steps, 64) : max_steps) + 1 : 2;
+    // (block steps: <= kMaxKB + 1 are used)
+    L.qslots = want_vec ? max_steps + 1 : 2;
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
     L.svec = take(sizeof(cplx) * bw * (size_t)(max_steps + 2));   // eigenvector of T_k (complex, bw per block step)
-    // (banded wide-block mat-vec: one row partial per workgroup AND row of its band, at most 4 rows)
-    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw * ((block >= 4 || sweep_q_family(block)) ? 4 : 1));
-    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw * cparts);
+    L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
+    L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
     L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
     L.apart1 = take(sizeof(double) * (size_t)nbmax * sc);
@@ -1057,7 +606,6 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, int block
     L.alpha = take(sizeof(double) * (size_t)(max_steps + 2) * sc);
     L.beta = take(sizeof(double) * (size_t)(max_steps + 3) * sc);
     L.result = take(sizeof(double) * 4);
-    L.coef = take(sizeof(double) * (6 * sc + bw));       // QCoef<W>::total (wide-block family only)
     L.total = align_up(off, 256);
     return L;
 }
@@ -1071,11 +619,11 @@ struct BatchLayout {
     size_t jobs_stride, strips_stride, list_stride, fin_eta_stride;
 };
 
-static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs, int block) {
+static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs) {
     BatchLayout B;
-    B.slab = slab_layout(nbmax, max_steps, want_vec, block);
+    B.slab = slab_layout(nbmax, max_steps, want_vec);
     B.smax = 0;
-    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb, block));
+    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb));
     size_t off = B.slab.total * (size_t)nbatch;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     B.jobs_stride = align_up(sizeof(PackedJob) * (size_t)nbatch, 256);
@@ -1101,7 +649,7 @@ int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t ma
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, sweep_block_width()).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs).total + 4096;
     return SCINT_OK;
 }
 
@@ -1146,7 +694,7 @@ static SideStreams* side_streams() {
 // The scheduler.  The `batch` slots are split into two GROUPS, each driven on its own stream (the
 // caller's and `aux`): the gaps of one stream -- launch boundaries, the latency-bound reduce and
 // check kernels, refills -- are filled by the other stream's kernels.  Inside a group the Lanczos
-// steps are queued in CHUNKS of kCheckEvery steps + one convergence check + the read-back of the
+// steps are queued in CHUNKS of kCheckEveryBlock passes + one convergence check + the read-back of the
 // per-slot state words, and the host runs `depth` chunks ahead of the state it has seen (depth 2
 // by default): while chunk c executes, chunk c+1 is already queued, so a stream never waits for
 // the host.  Retiring and refilling therefore lag: a curvature that converges in chunk k is seen
@@ -1164,12 +712,7 @@ struct SweepProblem {
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
     SweepTail* tail_hook; hipStream_t tail[2]; int tail_rr = 0;   // retired curvatures alternate between two tail streams
-    int nbmax, steps_cap, depth, check_every, block;   // block: vectors per Lanczos step (1, 2 or 4)
-    bool mfma = false;                                 // block == 4: matrix-core mat-vec (SCINT_MATVEC_MFMA=1)
-    bool qfam = false;                                 // wide-block kernel family (blockq_kernels.hpp)
-    int qstrip = 4;                                    // its strip length for eight vectors (SCINT_Q_STRIP)
-    int qband = 1;                                     // block rows per workgroup of its mat-vec (SCINT_Q_BAND)
-    bool pk2_uncond = false;                           // two-vector mat-vec with unconditional prefetch (SCINT_PK2_PREFETCH=1)
+    int nbmax, steps_cap, depth, check_every;
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
 };
@@ -1215,7 +758,7 @@ struct SweepGroup {
         }
     }
 
-    // prepare and enqueue chunk `chunk`: refill idle slots, then kCheckEvery steps + check + read-back
+    // prepare and enqueue chunk `chunk`: refill idle slots, then kCheckEveryBlock passes + check + read-back
     int32_t enqueue(int fin_chunk) {
         SweepProblem& S = *P;
         const SlabLayout& L = S.BL.slab;
@@ -1232,15 +775,8 @@ struct SweepGroup {
             const int64_t c = S.cs_index ? S.cs_index[e] : 0;
             J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
             J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
-            // wide blocks: W extra steps beyond ceil(n / W) -- a rank-deficient start block (tiny or
-            // rank-deficient matrices) grows the Krylov space by fewer than W dimensions per step
-            J.max_steps = S.block == 8   ? std::min(std::min(S.steps_cap, kq_max_steps<8>()), (n + 7) / 8 + 8)
-                          : S.qfam && S.block == 2 ? std::min(std::min(S.steps_cap, kq_max_steps<2>()), (n + 1) / 2 + 2)
-                          : S.qfam       ? std::min(std::min(S.steps_cap, kq_max_steps<4>()), (n + 3) / 4 + 4)
-                          : S.block == 4 ? std::min(std::min(S.steps_cap, kMaxKW), (n + 3) / 4 + 4)
-                          : S.block == 2 ? std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1))
-                                         : std::min(S.steps_cap, std::max(n, 1));
-            J.strip_len = strip_len_block(J.nb, S.block);
+            J.max_steps = std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1));
+            J.strip_len = strip_len_for(J.nb);
             J.start = launch0;
             J.gen = ++slot_gen[(size_t)s];
             J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
@@ -1270,19 +806,6 @@ struct SweepGroup {
                 nb_run = std::max(nb_run, J.nb);
                 int32_t* rs0 = hrs + (size_t)s * (size_t)(S.nbmax + 1);
                 int idx = 0;
-                if (S.qfam && S.qband > 1) {
-                    // banded mat-vec: workgroups per band of qband block rows; rs0[b] = first workgroup of band b
-                    int bands = 0;
-                    for (int I0 = 0; I0 < J.nb; I0 += S.qband, ++bands) {
-                        rs0[bands] = idx;
-                        for (int J0 = I0; J0 < J.nb; J0 += J.strip_len) {
-                            Strip& st = hs[nstrips++];
-                            st.job = s; st.I = I0; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
-                        }
-                    }
-                    rs0[bands] = idx;
-                    continue;
-                }
                 for (int I = 0; I < J.nb; ++I) {
                     rs0[I] = idx;
                     for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
@@ -1334,21 +857,8 @@ struct SweepGroup {
                                             hipMemcpyHostToDevice, stream);
                     if (he != hipSuccess) return hip_fail(he, "sweep eigenvector export", __FILE__, __LINE__);
                     const dim3 grid((unsigned)nb_fin, (unsigned)nfin);
-                    if (S.block == 8)
-                        hipLaunchKernelGGL(pkw_ritz_kernel<8>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                           S.vec_out, S.vstride);
-                    else if (S.block == 2 && S.qfam)
-                        hipLaunchKernelGGL(pkw_ritz_kernel<2>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                           S.vec_out, S.vstride);
-                    else if (S.block == 4)
-                        hipLaunchKernelGGL(pkw_ritz_kernel<4>, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                           S.vec_out, S.vstride);
-                    else if (S.block == 2)
-                        hipLaunchKernelGGL(pk2_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                           S.vec_out, S.vstride);
-                    else
-                        hipLaunchKernelGGL(pk_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
-                                           S.vec_out, S.vstride);
+                    hipLaunchKernelGGL(pk2_ritz_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab), d_fin_eta(tab),
+                                       S.vec_out, S.vstride);
                     hipLaunchKernelGGL(pk_ritz_scale_kernel, grid, dim3(64), 0, stream, d_jobs(ft), d_fin(tab),
                                        d_fin_eta(tab), S.vec_out, S.vstride);
                 }
@@ -1366,21 +876,8 @@ struct SweepGroup {
             if (!fresh.empty()) {
                 int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream);
                 if (rc != SCINT_OK) return rc;
-                if (S.block == 8)
-                    hipLaunchKernelGGL(pkw_init_kernel<8>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                                       d_jobs(tab), d_fresh(tab));
-                else if (S.block == 2 && S.qfam)
-                    hipLaunchKernelGGL(pkw_init_kernel<2>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                                       d_jobs(tab), d_fresh(tab));
-                else if (S.block == 4)
-                    hipLaunchKernelGGL(pkw_init_kernel<4>, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                                       d_jobs(tab), d_fresh(tab));
-                else if (S.block == 2)
-                    hipLaunchKernelGGL(pk2_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                                       d_jobs(tab), d_fresh(tab));
-                else
-                    hipLaunchKernelGGL(pk_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
-                                       d_jobs(tab), d_fresh(tab));
+                hipLaunchKernelGGL(pk2_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
+                                   d_jobs(tab), d_fresh(tab));
             }
             he = hipGetLastError();
             if (he != hipSuccess) return hip_fail(he, "sweep refill", __FILE__, __LINE__);
@@ -1389,48 +886,14 @@ struct SweepGroup {
         if (nstrips > 0) {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
-                if (S.qfam) {
-                    // wide-block family: coefficients and Q_j once per step, then mat-vec and reduce
-                    if (S.block == 8) q_launch_step<8>(S.qband, S.qstrip, nstrips, nb_run, nslots, stream, d_jobs(tab), d_strips(tab), launch);
-                    else if (S.block == 4) q_launch_step<4>(S.qband, S.qstrip, nstrips, nb_run, nslots, stream, d_jobs(tab), d_strips(tab), launch);
-                    else q_launch_step<2>(S.qband, S.qstrip, nstrips, nb_run, nslots, stream, d_jobs(tab), d_strips(tab), launch);
-                    continue;
-                }
                 const int slot = profiler().begin(kProfMatvec, stream);
-                if (S.block == 4 && S.mfma)
-                    hipLaunchKernelGGL(pkw_matvec_mfma_kernel<4>, dim3((unsigned)nstrips), dim3(256), 0, stream,
-                                       d_jobs(tab), d_strips(tab), launch);
-                else if (S.block == 4)
-                    hipLaunchKernelGGL(pkw_matvec_kernel<4>, dim3((unsigned)(kQuarters * nstrips)), dim3(256), 0, stream,
-                                       d_jobs(tab), d_strips(tab), launch);
-                else if (S.block == 2 && S.pk2_uncond)
-                    hipLaunchKernelGGL(pk2_matvec_kernel<true>, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
-                else if (S.block == 2)
-                    hipLaunchKernelGGL(pk2_matvec_kernel<false>, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
-                else
-                    hipLaunchKernelGGL(pk_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
+                hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
                 profiler().end(kProfMatvec, slot, stream);
-                if (S.block == 4)
-                    hipLaunchKernelGGL(pkw_reduce_kernel<4>, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroupsW), 0,
-                                       stream, d_jobs(tab), launch, S.mfma ? 1 : kQuarters);
-                else if (S.block == 2)
-                    hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
-                                       stream, d_jobs(tab), launch);
-                else
-                    hipLaunchKernelGGL(pk_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
-                                       stream, d_jobs(tab), launch);
+                hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
+                                   stream, d_jobs(tab), launch);
             }
         }
-        if (S.qfam) {
-            if (S.block == 8) q_launch_check<8>(nslots, stream, d_jobs(tab), launch0 + S.check_every);
-            else if (S.block == 4) q_launch_check<4>(nslots, stream, d_jobs(tab), launch0 + S.check_every);
-            else q_launch_check<2>(nslots, stream, d_jobs(tab), launch0 + S.check_every);
-        } else if (S.block == 4)
-            hipLaunchKernelGGL(pkw_check_kernel<4>, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
-        else if (S.block == 2)
-            hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
-        else
-            hipLaunchKernelGGL(pk_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+        hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
         he = hipGetLastError();
         if (he == hipSuccess)
             he = hipMemcpyAsync(h_flags[chunk % kTabs], S.states_dev + 4 * slot0, sizeof(int32_t) * 4 * (size_t)nslots,
@@ -1504,32 +967,10 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.depth = forced_depth >= 1 && forced_depth <= 2 ? forced_depth : 2;
     const char* every_env = getenv("SCINT_CHECK_EVERY");
     const int forced_every = every_env ? atoi(every_env) : 0;
-    // two-vector (block) recurrence by default; SCINT_LANCZOS_BLOCK=1 keeps the single-vector one
-    S.block = sweep_block_width();
-    { const char* e = getenv("SCINT_PK2_PREFETCH"); S.pk2_uncond = e && atoi(e) == 1; }
-    S.qfam = sweep_q_family(S.block);
-    S.qstrip = sweep_q_strip8();
-    S.qband = S.qfam ? sweep_q_band(S.block) : 1;
-    S.mfma = S.block == 4 && (S.qfam || sweep_matvec_mode() == 1);
-    if (S.qfam) {
-        // kernels of the family with more than the default 64 KiB of dynamic LDS; the attribute is per
-        // device, so it is set once per (host thread, device)
-        thread_local std::map<int, hipError_t> lds_set;
-        int dev = 0;
-        SCINT_HIP(hipGetDevice(&dev));
-        if (lds_set.find(dev) == lds_set.end()) {
-            hipError_t e = q_set_lds_attributes<8>();
-            if (e == hipSuccess) e = q_set_lds_attributes<4>();
-            if (e == hipSuccess) e = q_set_lds_attributes<2>();
-            lds_set[dev] = e;
-        }
-        const hipError_t lds_ok = lds_set[dev];
-        if (lds_ok != hipSuccess) return hip_fail(lds_ok, "wide-block LDS attributes", __FILE__, __LINE__);
-    }
-    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : (S.block >= 2 ? kCheckEveryBlock : kCheckEvery);
+    S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEveryBlock;
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
-    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs, S.block);
+    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
     const SlabLayout& L = S.BL.slab;
     S.base = (char*)workspace;
     S.states_dev = (int32_t*)(S.base + S.BL.states);
@@ -1591,7 +1032,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
             J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
             J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * (grp.slot0 + s);
-            J.coef = (double*)(sl + L.coef);
             J.tol = tol; J.gen = 0;
             J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
             J.eta = 0; J.two_eta = 0; J.keep = keep_idx;

@@ -33,7 +33,7 @@ __host__ __device__ inline int64_t tile_count(int nb) { return (int64_t)nb * (nb
 // the summation order -- and every bit of the result -- is independent of the batch)
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced > 16 ? 16 : forced;   // experiments only (16 = kMaxStrip of the mat-vec kernels)
+    if (forced > 0) return forced > 16 ? 16 : forced;   // tests of schedule independence (16 = kMaxStrip of the mat-vec kernel)
     return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
 }
 inline int strips_in_row(int nb, int I, int S) { return (nb - I + S - 1) / S; }
@@ -67,7 +67,6 @@ struct PackedJob {
     int32_t* state;         // [4] last FINISHED generation of the slot (job done <=> state[0] >= gen), steps, -, -
     double* eig_out; int32_t* status_out; int32_t* iters_out;
     double tol;             // target relative accuracy of the eigenvalue
-    double* coef;           // wide-block family (blockq_kernels.hpp): coefficients of the current step, QCoef<W> layout
 };
 
 struct Strip {

@@ -252,8 +252,16 @@ struct RevParams {
     const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
 };
 
-constexpr int kRevSlab = 4096;     // most tau rows accumulated per workgroup: 4096 * 36 B = 144 KiB of LDS
-// (workgroups of 1024 threads: one per CU then, 16 wavefronts share the column's accumulators)
+constexpr int kRevSlab = 1024;     // most tau rows accumulated per workgroup: 1024 * 36 B = 36 KiB of LDS
+constexpr int kRevThreadsK = 256;  // threads per workgroup
+// Round 2 ran one 1024-thread workgroup with 144 KiB of LDS per Doppler column (all 4096 delay rows):
+// alone 0.41 ms per 4096^2 image, but inside the chi^2 sweep 1.95 ms -- a workgroup that needs a whole
+// CU never finds one while the mat-vec keeps two 64-KiB workgroups on every CU
+// (profiles/r02_modeler_kernel_stats.csv).  A 256-thread / 36-KiB workgroup fits beside ONE mat-vec
+// workgroup, i.e. it starts whenever any mat-vec workgroup retires.  A column then takes several
+// workgroups (slabs of <= 1024 delay rows); each still walks all theta_i, but the delay a pair can reach
+// is bounded from theta_i and the column's Doppler interval alone, so the lanes whose pairs cannot fall
+// in the slab leave before they load anything (a slab is a contiguous run of i).
 
 // ---- order-independent (bit-reproducible) accumulation ---------------------------------------
 // Many (i, j) pairs fall in one CS pixel and arrive in scheduling order.  Plain float64 adds
@@ -448,8 +456,22 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
         atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
     };
 
+    const double lo_hi_min = fmin(lo, hi), lo_hi_max = fmax(lo, hi);
     for (int i = threadIdx.x; usable && i < N; i += kRevThreads) {
         const double th_i = gload(p.th + i);
+        {
+            // every pair of this lane has x = th_j - th_i in [lo, hi] and y = eta x (2 th_i + x): a parabola
+            // in x, extremal at the interval ends or at its vertex x = -th_i.  If that range of y misses the
+            // slab by more than a row on either side of the slack `contribute` already allows, no pair of
+            // this lane lands here.  (NaNs compare false: the lane goes on.)
+            const double ya = p.eta * (lo * (2.0 * th_i + lo)), yb = p.eta * (hi * (2.0 * th_i + hi));
+            double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
+            if (-th_i >= lo_hi_min && -th_i <= lo_hi_max) {
+                const double yv = -(p.eta * (th_i * th_i));
+                ymin = fmin(ymin, yv); ymax = fmax(ymax, yv);
+            }
+            if ((ymax - g.tau0) * inv_tstep < row_lo - 1.0 || (ymin - g.tau0) * inv_tstep > row_hi + 1.0) continue;
+        }
         const int g0 = i + s0;                                         // first candidate
         double tj[kRevWin + 2];                                        // th[g0 - 1 .. g0 + W]
 #pragma unroll
@@ -519,26 +541,19 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
 // Enqueue the back-map: bound pre-pass (max |value|, min theta spacing) + the column gather.
 int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound /*[2] device scratch*/,
                        hipStream_t stream) {
-    static const unsigned long long init[2] = {0ull, 0x7ff0000000000000ull};   // 0.0, +inf
-    SCINT_HIP(hipMemcpyAsync(bound, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    // bound[0] = 0.0, bound[1] = +inf as bit patterns, written by the device (no host buffer involved:
+    // a pageable source would make this an in-line staged copy on the tail stream)
+    SCINT_HIP(hipMemsetAsync(bound, 0, 12, stream));
+    SCINT_HIP(hipMemsetD32Async((hipDeviceptr_t)((char*)bound + 12), 0x7ff00000, 1, stream));
     const int64_t nvals = p.rank1 ? (int64_t)p.N : (int64_t)p.N * p.N;
     const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
     hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
     p.bound = bound;
-    // equal slabs, the fewest that fit the LDS (a 4096-row conjugate spectrum is ONE slab: no pair is
-    // looked at twice); the accumulators of a slab take more than the default 64 KiB of dynamic LDS
+    // equal slabs of at most kRevSlab delay rows
     p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    // the attribute belongs to the function ON A DEVICE: set it once per (host thread, device)
-    thread_local std::map<int, hipError_t> lds_set;
-    int dev = 0;
-    SCINT_HIP(hipGetDevice(&dev));
-    if (lds_set.find(dev) == lds_set.end())
-        lds_set[dev] = hipFuncSetAttribute((const void*)rev_gather_kernel<1024>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kRevSlab * 36);
-    SCINT_HIP(lds_set[dev]);
-    hipLaunchKernelGGL(rev_gather_kernel<1024>, grid, dim3(1024), (size_t)p.slab * 36, stream, p, g);
+    hipLaunchKernelGGL(rev_gather_kernel<kRevThreadsK>, grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

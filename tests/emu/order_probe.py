@@ -37,24 +37,10 @@ def main(out_path):
     res["sspec_pw"] = sspec_device(ththmod.to_device(dyn, torch.float64), prewhite=True).cpu().numpy()
     res["red"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges)[0]
     res["red_nh"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges, False)[0]
-    # 4m: four vectors with the matrix-core mat-vec; 4q: four vectors, wide-block kernel family; 8: eight vectors
-    # (8: banded mat-vec, four block rows per workgroup -- its default; 8s: plain strips; 4b: four vectors, banded;
-    #  2q: TWO vectors in the wide-block family -- the default recurrence on the matrix cores)
-    for block, mode, band in (("2", "0", ""), ("2u", "0", ""), ("1", "0", ""), ("4", "0", ""), ("4m", "1", ""), ("4q", "2", "1"),
-                              ("4b", "2", "4"), ("8", "0", "4"), ("8s", "0", "1"), ("2q", "2", "4")):
-        os.environ["SCINT_LANCZOS_BLOCK"] = block[0]
-        os.environ["SCINT_MATVEC_MFMA"] = mode
-        os.environ.pop("SCINT_Q_BAND", None)
-        if band:
-            os.environ["SCINT_Q_BAND"] = band
-        os.environ["SCINT_PK2_PREFETCH"] = "1" if block == "2u" else "0"     # 2u: unconditional prefetch form
-        eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, return_info=True)
-        res["eigs_b" + block], res["iters_b" + block] = eigs, info["iters"]
-        w, V, _ = ththmod.eigvec_sweep(cs_t, tau, fd, etas[1:4], edges)
-        res["w_b" + block], res["V_b" + block] = w, V.cpu().numpy()
-    del os.environ["SCINT_LANCZOS_BLOCK"], os.environ["SCINT_MATVEC_MFMA"]
-    os.environ.pop("SCINT_Q_BAND", None)
-    os.environ.pop("SCINT_PK2_PREFETCH", None)
+    eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, return_info=True)
+    res["eigs_b2"], res["iters_b2"] = eigs, info["iters"]
+    w, V, _ = ththmod.eigvec_sweep(cs_t, tau, fd, etas[1:4], edges)
+    res["w_b2"], res["V_b2"] = w, V.cpu().numpy()
     m = ththmod.modeler(CS, tau, fd, etas[2], edges)
     res["recov"], res["model"], res["V1"] = m[2], m[3], m[6]
     res["chisq"] = ththmod.chisq_sweep(dyn, cs_t, tau, fd, etas[1:4], edges, 1.0)

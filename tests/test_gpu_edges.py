@@ -115,48 +115,6 @@ def test_sweep_is_schedule_invariant(env):
         assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
 
 
-@pytest.mark.parametrize("block,matvec,band", [("4", "0", "1"), ("4", "1", "1"), ("4", "2", "1"), ("4", "2", "4"),
-                                               ("8", "0", "4"), ("8", "0", "1"), ("2", "2", "4")])
-def test_wide_blocks_match_two_vector(env, block, matvec, band):
-    """The opt-in wider Lanczos blocks -- SCINT_LANCZOS_BLOCK=4 with the vector-FMA quarter strips
-    (SCINT_MATVEC_MFMA=0), the matrix-core mat-vec (=1) or the wide-block kernel family (=2), and
-    SCINT_LANCZOS_BLOCK=8 (wide-block family, blockq_kernels.hpp): same eigenvalues / eigenvectors as
-    the default two-vector recurrence to the stopping tolerance, in fewer matrix passes; `band` = block
-    rows per workgroup of the wide-block mat-vec (SCINT_Q_BAND: 4 = banded, 1 = plain strips).  These
-    kernels have so far only run on the host interpreter (`pytest --emu`, green there): on a GPU this
-    test runs when SCINT_TEST_WIDE_BLOCKS=1 asks for it."""
-    import os
-    from scintools_amd import _lib
-    if os.environ.get("SCINT_TEST_WIDE_BLOCKS") != "1" and "emu" not in os.path.basename(_lib.load()._name):
-        pytest.skip("opt-in wide-block paths: set SCINT_TEST_WIDE_BLOCKS=1")
-    thth, to, p = env
-    etas = np.geomspace(0.5, 2.0, 12) * p["eta"]
-    saved = {k: os.environ.pop(k, None) for k in ("SCINT_LANCZOS_BLOCK", "SCINT_MATVEC_MFMA", "SCINT_Q_BAND")}
-    try:
-        ref, i2 = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
-        w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
-        os.environ["SCINT_LANCZOS_BLOCK"] = block
-        os.environ["SCINT_MATVEC_MFMA"] = matvec
-        os.environ["SCINT_Q_BAND"] = band
-        got, iw = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], return_info=True)
-        again = thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=5)
-        ww, Vw, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"])
-    finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
-    assert np.all(iw["status"] == 0)
-    np.testing.assert_allclose(got, ref, rtol=1e-10)
-    assert np.array_equal(again, got)                           # batch-invariant bits
-    assert iw["iters"].mean() < i2["iters"].mean() or block == "2"      # ("2": the default recurrence on the matrix cores)
-    np.testing.assert_allclose(ww, w2, rtol=1e-10)
-    V2n, Vwn = V2.cpu().numpy(), Vw.cpu().numpy()
-    for k in range(len(etas)):
-        n = int(i2["N"][k])
-        assert 1 - abs(np.vdot(V2n[k, :n], Vwn[k, :n])) <= 1e-9
-
-
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
     from scintools_amd.dynspec import Dynspec
     thth, to, p = env

@@ -1,0 +1,81 @@
+#!/bin/bash
+# The ONE script behind every GPU measurement of this repository (profiles/README.md names the
+# sub-command and tag of each committed file).  Run from the repository root on the GPU box:
+#   gpurun --timeout 900 -- 'bash tools/gpu_run.sh <sub-command> [tag] [extra bench.py arguments]'
+# Output goes to gpurun_out/<tag>_*; summaries worth keeping are copied into profiles/ by hand.
+#   suite    [tag]          pytest -m gpu (whole suite, durations)
+#   bench    [tag] [args]   the driver's bench command (--gpus 1 --steps 20 --warmup 5) + extra args
+#   quick    [tag] [args]   bench.py --steps 5 --warmup 2 --no-cpu-baseline --modeler-steps 0 + extra args
+#   configs  [tag]          BASELINE configs 4 / 5, npad = 3 and the 4096^2 reference-Simulation screen
+#   trace    [tag] [args]   rocprofv3 --kernel-trace --stats of a 3-step bench -> per-kernel stats + interval unions
+#   modeler  [tag]          the same trace of the chi^2 (modeler) objective
+#   pmc      [tag] [args]   FETCH_SIZE / WRITE_SIZE in separate --pmc passes of a 1-step bench (256 eta)
+#   fft      [tag]          kernel trace + PMC passes of tools/time_fft.py (calc_sspec and CS, 2048^2 .. 8192^2)
+#   probes   [tag]          tools/probes/*.hip (stream ceiling, pk2 body, f64 MFMA layout)
+#   all      [tag]          suite, bench, configs, trace, modeler, pmc, fft  (the closing call of a round)
+set -u
+R=$PWD; O=$R/gpurun_out; mkdir -p $O
+export TMPDIR=/tmp
+CMD=${1:-all}; TAG=${2:-m}; shift; shift || true
+EXTRA="$*"
+QUICK="--no-cpu-baseline --modeler-steps 0"
+
+suite() {
+  timeout 1200 python -m pytest tests -m gpu -q --durations=8 > $O/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest.log
+  grep -E "passed|failed|^FAILED|^ERROR|rc=" $O/${TAG}_pytest.log | tail -8
+}
+bench() {
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 $EXTRA > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"
+  head -c 400 $O/${TAG}_bench_n1.json; echo; tail -2 $O/${TAG}_bench.err
+}
+quick() {
+  timeout 300 python bench.py --steps 5 --warmup 2 $QUICK $EXTRA > $O/${TAG}_quick.json 2> $O/${TAG}_quick.err; echo "quick rc=$?"
+  python tools/bench_line.py $O/${TAG}_quick.json
+}
+configs() {
+  timeout 300 python bench.py --size 2048 --obs-total 64 --steps 2 --warmup 1 $QUICK > $O/${TAG}_bench_cfg4_64obs.json 2>> $O/${TAG}_bench.err
+  timeout 300 python bench.py --size 8192 --neta 64 --steps 2 --warmup 1 $QUICK > $O/${TAG}_bench_cfg5_8192.json 2>> $O/${TAG}_bench.err
+  timeout 300 python bench.py --npad 3 --steps 2 --warmup 1 $QUICK > $O/${TAG}_bench_npad3.json 2>> $O/${TAG}_bench.err
+  timeout 600 python tests/tools/make_sim_input.py 4096 3 /tmp/sim4096.npz > $O/${TAG}_sim_input.txt 2>&1
+  timeout 300 python bench.py --dyn-npz /tmp/sim4096.npz --steps 3 --warmup 1 --cpu-pool 0 --cpu-sample 2 --modeler-steps 0 > $O/${TAG}_bench_sim4096.json 2>> $O/${TAG}_bench.err
+  for f in cfg4_64obs cfg5_8192 npad3 sim4096; do python tools/bench_line.py $O/${TAG}_bench_$f.json; done
+}
+trace_of() {  # name, bench arguments
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_$1 -o bench -- python $R/bench.py $2 > $O/${TAG}_prof_$1.log 2>&1 )
+  db=$(find $O/${TAG}_prof_$1 -name "*.db" | head -1)
+  python tools/rocpd_summary.py $db $O/${TAG}_$1_kernel_stats.csv $O/${TAG}_$1_kernel_overlap.json > /dev/null
+  head -12 $O/${TAG}_$1_kernel_stats.csv | cut -c1-220
+}
+trace()   { trace_of bench "--steps 3 --warmup 1 $QUICK $EXTRA"; }
+modeler() { trace_of modeler "--objective chisq --steps 2 --warmup 1 --no-cpu-baseline"; }
+pmc_of() {  # name, command (relative to the repo root), description
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace -d $O/${TAG}_pmc_$1_$c -o pmc -- python $R/$2 > $O/${TAG}_pmc_$1_$c.log 2>&1 )
+  done
+  python tools/pmc_kernels.py $(find $O/${TAG}_pmc_$1_FETCH_SIZE -name "*.db" | head -1) $(find $O/${TAG}_pmc_$1_WRITE_SIZE -name "*.db" | head -1) \
+      $O/${TAG}_pmc_$1_kernels.json "$3" > $O/${TAG}_pmc_$1.txt 2>&1
+  head -24 $O/${TAG}_pmc_$1.txt
+}
+pmc() {
+  pmc_of bench "bench.py --steps 1 --warmup 0 $QUICK $EXTRA" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 0 $QUICK $EXTRA (256 eta, 4096^2)"
+  python tools/pmc_summary.py $(find $O/${TAG}_pmc_bench_FETCH_SIZE -name "*.db" | head -1) $(find $O/${TAG}_pmc_bench_WRITE_SIZE -name "*.db" | head -1) \
+      $O/${TAG}_pmc_bench_FETCH_SIZE.log $O/${TAG}_pmc_summary.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 0 $QUICK (256 eta, 4096^2)" > $O/${TAG}_pmc_summary.txt 2>&1
+  head -12 $O/${TAG}_pmc_summary.txt
+}
+fft() {
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_fft -o fft -- python $R/tools/time_fft.py > $O/${TAG}_prof_fft.log 2>&1 )
+  db=$(find $O/${TAG}_prof_fft -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/${TAG}_fft_kernel_stats.csv > /dev/null
+  grep -E "sspec|cs " $O/${TAG}_prof_fft.log | head -12
+  pmc_of fft "tools/time_fft.py" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/time_fft.py"
+}
+probes() {
+  for p in stream_probe pk2_probe mfma_f64_probe; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/$p.hip -o /tmp/$p 2> /dev/null && timeout 120 /tmp/$p | tee $O/${TAG}_$p.txt
+  done
+}
+case $CMD in
+  suite|bench|quick|configs|trace|modeler|pmc|fft|probes) $CMD ;;
+  all) suite; bench; configs; trace; modeler; pmc; fft ;;
+  *) echo "unknown sub-command $CMD"; exit 2 ;;
+esac
+find $O -name "*.db" -size +20M -delete
