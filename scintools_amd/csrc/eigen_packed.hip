@@ -675,8 +675,11 @@ static char* pinned_staging(size_t bytes) {
 }
 
 // Internal streams, one set per (host thread, device): `aux` drives the second group of slots;
-// `tail[2]` (chi^2 sweep only) run the per-curvature model steps of the retired curvatures, alternately.
-struct SideStreams { hipStream_t aux = nullptr, tail[2] = {nullptr, nullptr}; };
+// `tail[kTailLanes]` (chi^2 sweep only) run the per-curvature model steps of the retired curvatures, round robin.
+// (Measured in round 3, profiles/r03_tail_schedule_ab.json: highest stream priority for the tail streams costs
+// 6 %, 1 / 2 / 4 lanes and 36-KiB / 144-KiB back-map workgroups are within 3 % of each other -- the chi^2 sweep
+// is bound by the SUM of the mat-vec's and the tail kernels' GPU time, not by how they interleave.)
+struct SideStreams { hipStream_t aux = nullptr, tail[kTailLanes] = {}; };
 static SideStreams* side_streams() {
     thread_local std::map<int, SideStreams> streams;
     int dev = 0;
@@ -711,7 +714,7 @@ struct SweepProblem {
     const int32_t* keep_idx; const int32_t* keep_n; const double* etas; int64_t neta;
     double* eigs_out; int32_t* status_out; int32_t* iters_out;
     bool want_vec; cplx* vec_out; int64_t vstride;
-    SweepTail* tail_hook; hipStream_t tail[2]; int tail_rr = 0;   // retired curvatures alternate between two tail streams
+    SweepTail* tail_hook; hipStream_t tail[kTailLanes]; int tail_rr = 0;   // retired curvatures go round the tail streams
     int nbmax, steps_cap, depth, check_every;
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
@@ -865,10 +868,10 @@ struct SweepGroup {
             }
             if (S.tail_hook && !fin_eta.empty()) {
                 he = hipEventRecord(export_done[tab], stream);
-                for (int l = 0; l < 2 && he == hipSuccess; ++l) he = hipStreamWaitEvent(S.tail[l], export_done[tab], 0);
+                for (int l = 0; l < kTailLanes && he == hipSuccess; ++l) he = hipStreamWaitEvent(S.tail[l], export_done[tab], 0);
                 if (he != hipSuccess) return hip_fail(he, "sweep tail hand-off", __FILE__, __LINE__);
                 for (int64_t e : fin_eta) {
-                    const int l = S.tail_rr++ & 1;
+                    const int l = S.tail_rr++ % kTailLanes;
                     const int32_t rc = S.tail_hook->retire(e, S.tail[l], l);
                     if (rc != SCINT_OK) return rc;
                 }
@@ -958,7 +961,8 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
     S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
     S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
-    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook; S.tail[0] = side->tail[0]; S.tail[1] = side->tail[1];
+    S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook;
+    for (int l = 0; l < kTailLanes; ++l) S.tail[l] = side->tail[l];
     S.nbmax = (int)ceil_div(M, kTB);
     S.steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nslots = (int)std::min(batch, neta);
@@ -1045,7 +1049,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
         if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream);
         if (he == hipSuccess) he = hipEventRecord(start_ev, stream);
-        for (int l = 0; l < 2 && he == hipSuccess; ++l) he = hipStreamWaitEvent(side->tail[l], start_ev, 0);
+        for (int l = 0; l < kTailLanes && he == hipSuccess; ++l) he = hipStreamWaitEvent(side->tail[l], start_ev, 0);
         if (he == hipSuccess) he = hipStreamWaitEvent(side->aux, start_ev, 0);
         if (he != hipSuccess) rc = hip_fail(he, "sweep setup", __FILE__, __LINE__);
     }
@@ -1058,10 +1062,16 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         }
         if (!any) break;
     }
-    // leave nothing running on the internal streams, and nothing pending on the caller's
-    (void)hipStreamSynchronize(stream);
-    (void)hipStreamSynchronize(side->aux);
-    for (int l = 0; l < 2; ++l) (void)hipStreamSynchronize(side->tail[l]);
+    // leave nothing running on the internal streams, and nothing pending on the caller's; an
+    // asynchronous fault in the last queued chunk or in a tail step surfaces here and nowhere else
+    hipError_t sync_err = hipStreamSynchronize(stream);
+    { const hipError_t e2 = hipStreamSynchronize(side->aux); if (sync_err == hipSuccess) sync_err = e2; }
+    for (int l = 0; l < kTailLanes; ++l) {
+        const hipError_t e2 = hipStreamSynchronize(side->tail[l]);
+        if (sync_err == hipSuccess) sync_err = e2;
+    }
+    { const hipError_t e2 = hipGetLastError(); if (sync_err == hipSuccess) sync_err = e2; }
+    if (rc == SCINT_OK && sync_err != hipSuccess) rc = hip_fail(sync_err, "sweep completion", __FILE__, __LINE__);
     for (int g = 0; g < ngroups; ++g)
         for (int t = 0; t < kTabs; ++t) {
             if (G[g].chunk_done[t]) (void)hipEventDestroy(G[g].chunk_done[t]);

@@ -1262,7 +1262,8 @@ struct ChisqTail : SweepTail {
     const cplx* vec; int64_t vstride; const double* w; const double* th_red; int64_t M;
     const double* dspecT; int64_t nf, nt; const uint8_t* maskT; double noise_n; double* chisq_out;
     // one set of scratch buffers per tail lane
-    cplx* recovT_[2]; double* modelT_[2]; void* fft_ws_[2]; size_t fft_ws_bytes; double* partial_[2]; void* rev_scratch_[2];
+    cplx* recovT_[kTailLanes]; double* modelT_[kTailLanes]; void* fft_ws_[kTailLanes]; size_t fft_ws_bytes;
+    double* partial_[kTailLanes]; void* rev_scratch_[kTailLanes];
 
     int32_t retire(int64_t e, hipStream_t tail, int lane) override {
         const int64_t n = keep_n[e];
@@ -1278,7 +1279,9 @@ struct ChisqTail : SweepTail {
     }
 };
 
-struct ChisqSweepLayout { size_t recov[2], model[2], dspecT, maskT, fft[2], partial[2], rev[2], sweep, total, fft_bytes, sweep_bytes; };
+struct ChisqSweepLayout {
+    size_t recov[kTailLanes], model[kTailLanes], dspecT, maskT, fft[kTailLanes], partial[kTailLanes], rev[kTailLanes], sweep, total, fft_bytes, sweep_bytes;
+};
 static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, int64_t ntau, int64_t nfd,
                                   int64_t nf, int64_t nt, ChisqSweepLayout* L) {
     size_t off = 0;
@@ -1286,7 +1289,7 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
     L->dspecT = take(sizeof(double) * (size_t)nf * (size_t)nt);
     L->maskT = take((size_t)nf * (size_t)nt);
     L->fft_bytes = fft2_general_ws(nfd, ntau, nfd);
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < kTailLanes; ++l) {
         L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
         L->model[l] = take(sizeof(double) * (size_t)nf * (size_t)nt);
         L->fft[l] = take(L->fft_bytes);
@@ -1345,7 +1348,7 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
     t.vec = (const cplx*)vec_out; t.vstride = vec_stride; t.w = w_out; t.th_red = th_red; t.M = M;
     t.dspecT = dspecT; t.nf = nf; t.nt = nt; t.maskT = maskT; t.noise_n = noise_n; t.chisq_out = chisq_out;
     t.fft_ws_bytes = L.fft_bytes;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < kTailLanes; ++l) {
         t.recovT_[l] = (cplx*)(base + L.recov[l]); t.modelT_[l] = (double*)(base + L.model[l]);
         t.fft_ws_[l] = base + L.fft[l];
         t.partial_[l] = (double*)(base + L.partial[l]); t.rev_scratch_[l] = base + L.rev[l];

@@ -81,8 +81,9 @@ int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJo
 
 // What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
 // on the host while the sweep runs; enqueues on a tail stream that already waits for the export.
+constexpr int kTailLanes = 4;   // tail streams of the chi^2 sweep (model steps of retired curvatures in flight at once)
 struct SweepTail {
-    // `lane` (0 or 1) names the tail stream: work of one lane is ordered, the two lanes overlap, so
+    // `lane` (0 .. kTailLanes-1) names the tail stream: work of one lane is ordered, the lanes overlap, so
     // an implementation keeps one set of scratch buffers per lane
     virtual int32_t retire(int64_t eta_index, hipStream_t tail, int lane) = 0;
     virtual ~SweepTail() {}

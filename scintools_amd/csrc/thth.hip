@@ -238,6 +238,23 @@ __host__ __device__ inline int64_t hist_bin(double x, double x0, double step, in
     return k;
 }
 
+// The same bin for the gather kernel: the first guess comes from a multiplication by 1/step (the two
+// fix-up loops make the result exact whatever the guess), 32-bit index.
+__device__ inline int hist_bin_rcp(double x, double x0, double step, double inv_step, int n) {
+    if (!(step > 0.0) || x != x) return -1;
+    const double guess = floor((x - x0) * inv_step + 0.5);
+    if (guess < -1.0) return -1;
+    if (guess > (double)n + 1.0) return -1;
+    int k = (int)guess;
+    if (k < 0) k = 0;
+    if (k > n) k = n;
+    while (k < n && (((double)(k + 1) - 0.5) * step + x0) <= x) ++k;
+    while (k >= 0 && (((double)k - 0.5) * step + x0) > x) --k;
+    if (k < 0) return -1;
+    if (k == n) return (x == (((double)n - 0.5) * step + x0)) ? n - 1 : -1;
+    return k;
+}
+
 struct RevParams {
     const cplx* thth; int64_t ld;      // explicit matrix (rank1 == 0)
     const cplx* vec; const double* w;  // rank-1: |w| v v^H (rank1 == 1)
@@ -418,19 +435,24 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
     const double inv_tstep = 1.0 / g.tau1_step;
     const double row_lo = (double)row0 - 2.0, row_hi = (double)(row0 + rows) + 1.0;   // estimate of bin + 0.5
     auto beyond = [&](double x) { return last ? (x > hi) : (x >= hi); };
-    auto contribute = [&](int i, int j, double th_i, double th_j) {
-        if (i == j) return;                                            // lands in the poisoned centre bin
+    // what pair (i, j) adds to which row of the slab (by < 0: nothing)
+    struct Contrib { int by; uint32_t c; double rh, rl, ih, il; };
+    auto evaluate = [&](int i, int j, double th_i, double th_j) -> Contrib {
+        Contrib t; t.by = -1; t.c = 0u; t.rh = t.rl = t.ih = t.il = 0.0;
+        if (i == j) return t;                                          // lands in the poisoned centre bin
         const double y = p.eta * (th_j * th_j - th_i * th_i);          // tau_map[i, j] (ththmod.py:208-210)
         // cheap slab test first (two rows of slack cover the rounding of this estimate): the exact
         // bin, the weight and the loads are only paid for by the slab that owns the pixel
         const double est = (y - g.tau0) * inv_tstep;
-        if (est < row_lo || est > row_hi) return;
-        const int64_t by = hist_bin(y, g.tau0, g.tau1_step, g.ntau) - row0;
-        if (by < 0 || by >= rows) return;
+        if (est < row_lo || est > row_hi) return t;
+        const int bin = hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, (int)g.ntau);
+        if (bin < 0) return t;
+        const int by = bin - (int)row0;
+        if (by < 0 || by >= rows) return t;
         // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
         const double scl = 1.0 / sqrt(fabs(p.two_eta * (th_i - th_j)));
         double wr, wi;
-        uint32_t c = 1u;
+        t.c = 1u;
         if (p.rank1) {
             const cplx o = mulc(gload(p.vec + i), gload(p.vec + j));   // outer(V, conj(V)) * |w|  (:312-313)
             wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
@@ -440,29 +462,40 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
             if (p.hermitian) {
                 const cplx u = gload(p.thth + (int64_t)j * p.ld + i);
                 wr += u.x * scl; wi += -(u.y * scl);
-                c = 2u;
+                t.c = 2u;
             }
         }
+        t.by = by;
         if (sp.exact) {
-            const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
-            atomicAdd(&rev_lds[by], rh);
-            atomicAdd(&rev_lds[2 * slab + by], ih);
-            const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
-            atomicAdd(&rev_lds[slab + by], rl);
-            atomicAdd(&rev_lds[3 * slab + by], il);
+            t.rh = (wr + sp.s1) - sp.s1; t.ih = (wi + sp.s1) - sp.s1;
+            t.rl = ((wr - t.rh) + sp.s2) - sp.s2; t.il = ((wi - t.ih) + sp.s2) - sp.s2;
         } else {
-            atomicAdd(&rev_lds[by], wr); atomicAdd(&rev_lds[2 * slab + by], wi);
+            t.rh = wr; t.ih = wi;
         }
-        atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
+        return t;
     };
-
+    auto deposit = [&](const Contrib& t) {
+        atomicAdd(&rev_lds[t.by], t.rh);
+        atomicAdd(&rev_lds[2 * slab + t.by], t.ih);
+        if (sp.exact) {
+            atomicAdd(&rev_lds[slab + t.by], t.rl);
+            atomicAdd(&rev_lds[3 * slab + t.by], t.il);
+        }
+        atomicAdd((uint32_t*)(rev_lds + 4 * slab) + t.by, t.c);
+    };
+    // (Summing the runs of lanes that hit one accumulator in registers first -- a segmented scan over the
+    // wave, legal because the grid-split addends sum exactly in any association -- was measured in round 3:
+    // 0.58 ms against 0.38 ms per 4096^2 image.  The kernel is bound by its fp64 arithmetic per pair
+    // (exact bin, 1/sqrt, split), not by the LDS atomics.)
     const double lo_hi_min = fmin(lo, hi), lo_hi_max = fmax(lo, hi);
-    for (int i = threadIdx.x; usable && i < N; i += kRevThreads) {
-        const double th_i = gload(p.th + i);
-        {
+    for (int base = 0; usable && base < N; base += kRevThreads) {      // trip count uniform over the workgroup
+        const int i = base + (int)threadIdx.x;
+        bool active = i < N;
+        const double th_i = active ? gload(p.th + i) : 0.0;
+        if (active) {
             // every pair of this lane has x = th_j - th_i in [lo, hi] and y = eta x (2 th_i + x): a parabola
             // in x, extremal at the interval ends or at its vertex x = -th_i.  If that range of y misses the
-            // slab by more than a row on either side of the slack `contribute` already allows, no pair of
+            // slab by more than a row on either side of the slack `evaluate` already allows, no pair of
             // this lane lands here.  (NaNs compare false: the lane goes on.)
             const double ya = p.eta * (lo * (2.0 * th_i + lo)), yb = p.eta * (hi * (2.0 * th_i + hi));
             double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
@@ -470,8 +503,9 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
                 const double yv = -(p.eta * (th_i * th_i));
                 ymin = fmin(ymin, yv); ymax = fmax(ymax, yv);
             }
-            if ((ymax - g.tau0) * inv_tstep < row_lo - 1.0 || (ymin - g.tau0) * inv_tstep > row_hi + 1.0) continue;
+            if ((ymax - g.tau0) * inv_tstep < row_lo - 1.0 || (ymin - g.tau0) * inv_tstep > row_hi + 1.0) active = false;
         }
+        if (__ballot(active) == 0ull) continue;                        // wave-uniform
         const int g0 = i + s0;                                         // first candidate
         double tj[kRevWin + 2];                                        // th[g0 - 1 .. g0 + W]
 #pragma unroll
@@ -480,28 +514,32 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
             // the two guards are clamped into the array: a guard at the array's end that is still
             // outside the column speaks for everything beyond it
             const int cl = k == 0 ? min(idx, N - 1) : (k == W + 1 ? max(idx, 0) : idx);
-            tj[k] = (k <= W + 1 && cl >= 0 && cl < N) ? gload(p.th + cl) : nan("");
+            tj[k] = (active && k <= W + 1 && cl >= 0 && cl < N) ? gload(p.th + cl) : nan("");
         }
         double t_hi = tj[1];                                           // tj[W + 1] without dynamic indexing
 #pragma unroll
         for (int k = 2; k < kRevWin + 2; ++k) t_hi = (k == W + 1) ? tj[k] : t_hi;
         const bool below_ok = (g0 - 1 < 0) || !(tj[0] - th_i >= lo);
         const bool above_ok = (g0 + W >= N) || beyond(t_hi - th_i);
-        if (W > 0 && below_ok && above_ok) {
-#pragma unroll
-            for (int k = 1; k <= kRevWin; ++k) {
-                const int j = g0 - 1 + k;
-                if (k > W || j < 0 || j >= N) continue;
-                const double x = tj[k] - th_i;                         // fd_map[i, j]  (ththmod.py:207)
-                if (!(x >= lo) || beyond(x)) continue;
-                contribute(i, j, th_i, tj[k]);
-            }
-        } else {
+        const bool windowed = active && W > 0 && below_ok && above_ok;
+        if (active && !windowed) {                                     // irregular grid: search, deposit pair by pair
             for (int j = rev_first_ge(p.th, N, th_i, lo, g0); j < N; ++j) {
                 const double th_j = gload(p.th + j);
                 if (beyond(th_j - th_i)) break;
-                contribute(i, j, th_i, th_j);
+                const Contrib t = evaluate(i, j, th_i, th_j);
+                if (t.by >= 0) deposit(t);
             }
+        }
+#pragma unroll
+        for (int k = 1; k <= kRevWin; ++k) {
+            if (k > W) break;                                          // W is uniform over the workgroup
+            const int j = g0 - 1 + k;
+            Contrib t; t.by = -1; t.c = 0u; t.rh = t.rl = t.ih = t.il = 0.0;
+            if (windowed && j >= 0 && j < N) {
+                const double x = tj[k] - th_i;                         // fd_map[i, j]  (ththmod.py:207)
+                if (x >= lo && !beyond(x)) t = evaluate(i, j, th_i, tj[k]);
+            }
+            if (t.by >= 0) deposit(t);
         }
     }
     __syncthreads();
@@ -541,10 +579,11 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
 // Enqueue the back-map: bound pre-pass (max |value|, min theta spacing) + the column gather.
 int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound /*[2] device scratch*/,
                        hipStream_t stream) {
-    // bound[0] = 0.0, bound[1] = +inf as bit patterns, written by the device (no host buffer involved:
-    // a pageable source would make this an in-line staged copy on the tail stream)
-    SCINT_HIP(hipMemsetAsync(bound, 0, 12, stream));
-    SCINT_HIP(hipMemsetD32Async((hipDeviceptr_t)((char*)bound + 12), 0x7ff00000, 1, stream));
+    // bound[0] = 0.0 (max), bound[1] = 0x7f7f7f7f7f7f7f7f = 1.4e306 (min: above any spacing) as bit patterns,
+    // written by the device (no host buffer involved: a pageable source would make this an in-line staged
+    // copy on the tail stream)
+    SCINT_HIP(hipMemsetAsync(bound, 0, 8, stream));
+    SCINT_HIP(hipMemsetAsync((char*)bound + 8, 0x7f, 8, stream));
     const int64_t nvals = p.rank1 ? (int64_t)p.N : (int64_t)p.N * p.N;
     const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
     hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
