@@ -66,6 +66,11 @@ __device__ inline void gstore_nt(cplx* p, cplx v) {
 // enough.  (tests/emu turns this line into a plain barrier.)
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Lanes of ONE wavefront exchanging data through LDS: the LDS executes a wave's instructions in order,
+// so the hardware needs no barrier; this only pins the order for the compiler (and is a wave-level
+// meeting point on the host interpreter of tests/emu).
+__device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // ---- wavefront (64 lanes) reductions ------------------------------------------
 __device__ inline double wave_sum(double v) {
 #pragma unroll

@@ -4,13 +4,16 @@
 //
 // Per Lanczos pass j, for all jobs of a batch at once (details at the kernels):
 //
-//   pk2_matvec_kernel  one workgroup per strip of <= 16 tiles (I, J0..J1): streams the tiles once
-//                      (16 independent 1-KiB wave loads in flight per wave) and multiplies BOTH vectors
-//                      of the block: row partials sum_J A_IJ X_J (64 lanes stride the columns,
-//                      wave-shuffle reduction at the end of the strip) and, per off-diagonal tile, the
-//                      column partials A_IJ^H X_I (lane-local over rows, 4-wave LDS reduction every 4
-//                      tiles; X_I broadcast with v_readlane).  HBM bound: 8 N (N + 1) bytes per pass.
-//   pk2_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials -> W_j, Q_j and the
+//   pk2_coef_kernel    the step's 2x2 coefficients A_{j-1}, B_{j-1} from the previous step's fixed-order partial
+//                      sums and the block Q_j they define, once per job (1024 rows per workgroup).
+//   pk2_matvec_kernel  one workgroup per strip of <= 16 tiles (I, J0..J1), described by ONE 80-byte record:
+//                      streams the tiles once (16 independent 1-KiB wave loads in flight per wave) and
+//                      multiplies BOTH vectors of the block Q_j: row partials sum_J A_IJ X_J (64 lanes stride
+//                      the columns; reduced over the lanes through LDS at the end of the strip) and, per
+//                      off-diagonal tile, the column partials A_IJ^H X_I (lane-local over rows, 4-wave LDS
+//                      reduction every 4 tiles; X_I broadcast with v_readlane).  HBM bound: 8 N (N + 1)
+//                      bytes per pass.
+//   pk2_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials -> W_j and the
 //                      partial sums of A_j = Q_j^H W_j and of the Gram matrix W_j^H W_j.
 //   pk2_check_kernel   (every 3 passes) top two eigenvalues of the pentadiagonal T_k by 64-lane
 //                      multisection on a banded LDL^H Sturm count, Ritz residual by inverse iteration,
@@ -103,8 +106,7 @@ __global__ void __launch_bounds__(64) pk_ritz_scale_kernel(const PackedJob* jobs
 // come from a Sturm count on the banded LDL^H factorisation, the Ritz vector's last block (for
 // the residual ||B_{k-1} s_last||) from inverse iteration on the same factorisation.
 //
-// The kernels mirror the single-vector ones: Q_j is never stored ahead of its use -- every
-// consumer rebuilds  Q_j = (W_{j-1} - Q_{j-1} A_{j-1}) B_{j-1}^{-1}  from the previous step's
+// Q_j = (W_{j-1} - Q_{j-1} A_{j-1}) B_{j-1}^{-1} is built by pk2_coef_kernel from the previous step's
 // vectors and the fixed-order partial sums of A_{j-1} = Q^H W and of the Gram matrix W^H W
 // (G' = W^H W - A^H A, as beta^2 = |u|^2 - alpha^2 in the single-vector form).  Vectors are
 // stored interleaved, [row][2]; scalar partials as 4 doubles per 64-row block.
@@ -135,19 +137,6 @@ __device__ inline Blk2 step_block_wave(const double* __restrict__ ap, const doub
     const double d = h22 - norm2(b.b12);
     b.b22 = d > 0.0 ? sqrt(d) : 0.0;
     b.i22 = b.b22 > 0.0 ? 1.0 / b.b22 : 0.0;
-    return b;
-}
-
-// the step scalars are wave-uniform (results of wave_sum): moving them to the scalar registers
-// frees two dozen vector registers in the mat-vec
-__device__ inline double uniform_f64(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-__device__ inline Blk2 uniform_blk(Blk2 b) {
-    b.a11 = uniform_f64(b.a11); b.a22 = uniform_f64(b.a22); b.a12 = mk(uniform_f64(b.a12.x), uniform_f64(b.a12.y));
-    b.b11 = uniform_f64(b.b11); b.b22 = uniform_f64(b.b22); b.b12 = mk(uniform_f64(b.b12.x), uniform_f64(b.b12.y));
-    b.i11 = uniform_f64(b.i11); b.i22 = uniform_f64(b.i22);
     return b;
 }
 
@@ -184,6 +173,66 @@ __global__ void __launch_bounds__(64) pk2_init_kernel(const PackedJob* jobs, con
     }
 }
 
+// The step's 2x2 coefficients, computed ONCE per job and step (pk2_coef_kernel) and read back as ten
+// scalars by the consumers (reduce: B_{j-1}).  Layout of jb.coef + 16 * parity:
+//   a11 a22 a12.x a12.y  b11 b22 b12.x b12.y  i11 i22
+__device__ inline Blk2 load_blk(const double* __restrict__ c) {
+    Blk2 b;
+    b.a11 = gload(c + 0); b.a22 = gload(c + 1); b.a12 = mk(gload(c + 2), gload(c + 3));
+    b.b11 = gload(c + 4); b.b22 = gload(c + 5); b.b12 = mk(gload(c + 6), gload(c + 7));
+    b.i11 = gload(c + 8); b.i22 = gload(c + 9);
+    return b;
+}
+
+// Step j, first launch: A_{j-1}, B_{j-1} from the fixed-order partial sums of the previous reduce
+// kernel, then Q_j = (W_{j-1} - Q_{j-1} A_{j-1}) B_{j-1}^{-1} for 1024 rows per workgroup.  Every
+// workgroup of a job recomputes the (identical) coefficients; the first one also writes them out.
+// Until round 3 every mat-vec workgroup did this itself -- five dependent memory round trips before
+// its tile loads could start, 18 % of the streaming rate (5.0 TB/s in the sweep against 6.2 TB/s for
+// the same loop on synthetic strips, profiles/r03_pk2_probe.txt).
+constexpr int kCoefRows = 1024;
+__global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __restrict__ jobs, int launch) {
+    __shared__ double sh[16];
+    const PackedJob jb = jobs[blockIdx.y];
+    const int step = launch - jb.start;
+    if (jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
+    if ((int)blockIdx.x * kCoefRows >= jb.nb * kTB) return;
+    const int par = step & 1;
+    if (threadIdx.x < 64) {
+        const Blk2 sc = step_block_wave(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, threadIdx.x);
+        if (threadIdx.x == 0) {
+            sh[0] = sc.a11; sh[1] = sc.a22; sh[2] = sc.a12.x; sh[3] = sc.a12.y;
+            sh[4] = sc.b11; sh[5] = sc.b22; sh[6] = sc.b12.x; sh[7] = sc.b12.y;
+            sh[8] = sc.i11; sh[9] = sc.i22;
+            if (blockIdx.x == 0) {
+                double* c = jb.coef + 16 * par;
+#pragma unroll
+                for (int i = 0; i < 10; ++i) gstore(c + i, sh[i]);
+                if (step > 0) {
+                    double* A = jb.alpha + 4 * (step - 1);
+                    A[0] = sc.a11; A[1] = sc.a22; A[2] = sc.a12.x; A[3] = sc.a12.y;
+                }
+                double* B = jb.beta + 4 * step;                      // B[step] couples blocks step-1 and step
+                B[0] = sc.b11; B[1] = sc.b22; B[2] = sc.b12.x; B[3] = sc.b12.y;
+            }
+        }
+    }
+    __syncthreads();
+    Blk2 sc;
+    sc.a11 = sh[0]; sc.a22 = sh[1]; sc.a12 = mk(sh[2], sh[3]);
+    sc.b11 = sh[4]; sc.b22 = sh[5]; sc.b12 = mk(sh[6], sh[7]);
+    sc.i11 = sh[8]; sc.i22 = sh[9];
+    const int r = (int)blockIdx.x * kCoefRows + (int)threadIdx.x;
+    if (r >= jb.nb * kTB) return;
+    const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
+    const int qs = jb.qslots;
+    const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + qs - 1) % qs) * jb.qstride * 2;
+    cplx* __restrict__ Qn = jb.Q + (int64_t)(step % qs) * jb.qstride * 2;
+    cplx x1, x2;
+    blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), x1, x2);
+    gstore(Qn + 2 * r, x1); gstore(Qn + 2 * r + 1, x2);
+}
+
 // 16 rows per wave, 256 registers, two waves per SIMD, two workgroups per CU.  Two other shapes
 // were measured and removed: half strips (8 rows per wave, 168 registers, three waves per SIMD:
 // 1075 eta/s against 1183) and two sweeps per strip (1147 eta/s); DESIGN.md section 6.
@@ -192,45 +241,38 @@ constexpr int kFlushF = 4;     // its column partials are reduced across the wav
 // barriers in the flush was measured in round 3: 1169 against 1201 eta/s; tools/probes/pk2_probe.hip
 // shows the body at 6.1-6.2 TB/s on synthetic strips in either form, so it was removed.)
 __global__ void __launch_bounds__(256, 2)
-pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx cred[4][kFlushF][kTB][2];   // per-wave column partials of kFlushF tiles, 2 vectors (32 KiB)
-    __shared__ cplx xs[kMaxStrip][kTB][2];      // the blocks X_J of the strip, rebuilt once per workgroup (32 KiB)
-    const Strip st = strips[blockIdx.x];
-    const PackedJob* __restrict__ jp = jobs + st.job;
-    const int step = launch - jp->start;
-    if (jp->n < 2 || step < 0 || step >= jp->max_steps || gload(jp->state) >= jp->gen) return;
-    const int par = step & 1;
-    const int nb = jp->nb;
-    const cplx* __restrict__ Up = par ? jp->U[1] : jp->U[0];
-    const int qs = jp->qslots;
-    const cplx* __restrict__ Qp = jp->Q + (int64_t)((step + qs - 1) % qs) * jp->qstride * 2;   // Q_{j-1}
-    const cplx* __restrict__ tiles = jp->tiles;
+pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
+    __shared__ cplx lds[4096];                   // 64 KiB: two workgroups per CU
+    cplx (*cred)[kFlushF][kTB][2] = reinterpret_cast<cplx (*)[kFlushF][kTB][2]>(lds);      // [4]: per-wave column partials of kFlushF tiles, 2 vectors (32 KiB)
+    cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 2048);                     // [kMaxStrip]: the blocks X_J = rows of Q_j of the strip (32 KiB)
+    const Strip* __restrict__ sp = strips + blockIdx.x;
+    const int step = launch - sp->start;
+    if (step < 0 || step >= sp->max_steps) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int I = st.I;
-    const int64_t t0 = tile_offset(nb, I);
-    const int ntile = st.J1 - st.J0;
-    const cplx* __restrict__ tp = tiles + (t0 + (st.J0 - I)) * kTileElems + (16 * w) * kTB + lane;
+    const int ntile = sp->ntile;
+    const cplx* __restrict__ tp = sp->tiles + (16 * w) * kTB + lane;
     cplx a0[8], a1[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
-    const Blk2 sc = uniform_blk(step_block_wave(par ? jp->apart[1] : jp->apart[0], par ? jp->upart[1] : jp->upart[0], nb, lane));
+    const int32_t done = gload(sp->state);
+    const cplx* __restrict__ X = sp->Q + (int64_t)(step % sp->qslots) * sp->qstride * 2;   // Q_j
+    const int I = sp->I, J0 = sp->J0;
     // lane l of every wave holds row l of the block X_I (both vectors); rows read it back with v_readlane
-    cplx xI1, xI2;
-    blk_q_row(sc, gload(Up + 2 * (I * kTB + lane)), gload(Up + 2 * (I * kTB + lane) + 1),
-              gload(Qp + 2 * (I * kTB + lane)), gload(Qp + 2 * (I * kTB + lane) + 1), xI1, xI2);
-    // X_J = rows J0*64 .. J1*64 of Q_j, once per workgroup (the first tile's loads stay in flight)
+    const cplx xI1 = gload(X + 2 * (I * kTB + lane)), xI2 = gload(X + 2 * (I * kTB + lane) + 1);
+    // X_J = rows J0*64 .. of Q_j into LDS, once per workgroup (the first tile's loads stay in flight)
     for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
-        const int r = st.J0 * kTB + idx;
-        cplx x1, x2;
-        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), gload(Qp + 2 * r), gload(Qp + 2 * r + 1), x1, x2);
+        const int r = J0 * kTB + idx;
+        const cplx x1 = gload(X + 2 * r), x2 = gload(X + 2 * r + 1);
         xs[idx >> 6][idx & 63][0] = x1;
         xs[idx >> 6][idx & 63][1] = x2;
     }
+    if (done >= sp->gen) return;                 // finished job (workgroup-uniform): its loads were harmless
     __syncthreads();
     cplx acc1[16], acc2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
-    cplx* __restrict__ colpart = jp->colpart;
+    cplx* __restrict__ colpart = sp->colpart;
+    const int tdiag = I - J0;                    // the strip's diagonal tile (if any) stores no column partial
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
         const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
@@ -270,24 +312,38 @@ pk2_matvec_kernel(const PackedJob* __restrict__ jobs, const Strip* __restrict__ 
 #pragma unroll
             for (int c = w; c < 2 * kFlushF; c += 4) {
                 const int k = c >> 1, v = c & 1, tt = tb + k;
-                if (tt <= t) {
-                    const int Jt = st.J0 + tt;
-                    if (Jt != I) {
-                        const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
-                        gstore(colpart + 2 * ((t0 + (Jt - I)) * kTB + lane) + v, sum);
-                    }
+                if (tt <= t && tt != tdiag) {
+                    const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
+                    gstore(colpart + 2 * (tt * kTB + lane) + v, sum);
                 }
             }
             __syncthreads();
         }
     }
-    cplx* __restrict__ rowpart = jp->rowpart;
+    // Row partials: the sum over the 64 lanes of each of the wave's 16 rows x 2 vectors.  Through LDS
+    // (cred and xs are free: every wave is past the last flush barrier), eight rows at a time: the wave
+    // stores 8 x 64 values, lane L adds the eight consecutive values L*8 .. L*8+7 of row L/8, and
+    // three shuffle steps finish the row.  (The 64 six-step shuffle reductions this replaces were 1700
+    // of the kernel's 2500 instructions and kept a wave 4 us off the memory system per strip.)
+    cplx* __restrict__ rowpart = sp->rowpart;
+    cplx* __restrict__ red = lds + w * 1024;     // this wave's 16 KiB; 576 elements used (one pad element per 8)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const cplx s1 = wave_sum(acc1[r]), s2 = wave_sum(acc2[r]);
-        if (lane == 0) {
-            gstore(rowpart + 2 * ((int64_t)st.index * kTB + 16 * w + r), s1);
-            gstore(rowpart + 2 * ((int64_t)st.index * kTB + 16 * w + r) + 1, s2);
+    for (int v = 0; v < 2; ++v) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int e = rr * 64 + lane;
+                red[e + (e >> 3)] = v ? acc2[8 * h + rr] : acc1[8 * h + rr];
+            }
+            wave_lds_sync();
+            cplx s = red[lane * 9];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) s = s + red[lane * 9 + k];
+            wave_lds_sync();
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) s = mk(s.x + __shfl_xor(s.x, o, 64), s.y + __shfl_xor(s.y, o, 64));
+            if ((lane & 7) == 0) gstore(rowpart + 2 * (16 * w + 8 * h + (lane >> 3)) + v, s);
         }
     }
 }
@@ -301,7 +357,8 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
-    // fixed summation order as in pk_reduce_kernel, for both vectors
+    // fixed summation order: the row partials of block row K strip by strip, then the column
+    // partials of the tiles above the diagonal in column K; sixteen wavefronts take every 16th
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc1 = mk(0.0, 0.0), acc2 = mk(0.0, 0.0);
     for (int idx = g; idx < nrow + K; idx += kRedGroups) {
@@ -315,23 +372,20 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     part[g][e][1] = acc2;
     __syncthreads();
     if (g == 0) {
-        const Blk2 sc = step_block_wave(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, e);
+        const Blk2 sc = load_blk(jb.coef + 16 * par);               // B_{j-1} (pk2_coef_kernel of this step)
         cplx tot1 = part[0][e][0], tot2 = part[0][e][1];
 #pragma unroll
         for (int k = 1; k < kRedGroups; ++k) { tot1 = tot1 + part[k][e][0]; tot2 = tot2 + part[k][e][1]; }
         const int r = K * kTB + e;
-        const cplx* __restrict__ Up = par ? jb.U[1] : jb.U[0];
         const cplx* __restrict__ Qp = jb.Q + (int64_t)((step + jb.qslots - 1) % jb.qslots) * jb.qstride * 2;
+        const cplx* __restrict__ Qn = jb.Q + (int64_t)(step % jb.qslots) * jb.qstride * 2;
         cplx* __restrict__ Un = par ? jb.U[0] : jb.U[1];
-        cplx* __restrict__ Qn = jb.Q + (int64_t)(step % jb.qslots) * jb.qstride * 2;
         const cplx q1 = gload(Qp + 2 * r), q2 = gload(Qp + 2 * r + 1);
-        cplx x1, x2;
-        blk_q_row(sc, gload(Up + 2 * r), gload(Up + 2 * r + 1), q1, q2, x1, x2);       // row of Q_j
+        const cplx x1 = gload(Qn + 2 * r), x2 = gload(Qn + 2 * r + 1);       // row of Q_j
         // row of W_j = A Q_j - Q_{j-1} B_{j-1}^H:  (q1 b11 + q2 conj(b12), q2 b22)
         const cplx t1 = tot1 - (q1 * sc.b11 + mulc(q2, sc.b12));
         const cplx t2 = tot2 - q2 * sc.b22;
         gstore(Un + 2 * r, t1); gstore(Un + 2 * r + 1, t2);
-        gstore(Qn + 2 * r, x1); gstore(Qn + 2 * r + 1, x2);
         const double pa11 = wave_sum(x1.x * t1.x + x1.y * t1.y);      // Re(conj(x1) t1)
         const double pa22 = wave_sum(x2.x * t2.x + x2.y * t2.y);
         const cplx pa12 = wave_sum(mulc(t2, x1));                     // conj(x1) t2
@@ -342,14 +396,6 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
             double* un = par ? jb.upart[0] : jb.upart[1];
             an[4 * K] = pa11; an[4 * K + 1] = pa22; an[4 * K + 2] = pa12.x; an[4 * K + 3] = pa12.y;
             un[4 * K] = pg11; un[4 * K + 1] = pg22; un[4 * K + 2] = pg12.x; un[4 * K + 3] = pg12.y;
-            if (K == 0) {
-                if (step > 0) {
-                    double* A = jb.alpha + 4 * (step - 1);
-                    A[0] = sc.a11; A[1] = sc.a22; A[2] = sc.a12.x; A[3] = sc.a12.y;
-                }
-                double* B = jb.beta + 4 * step;                      // B[step] couples blocks step-1 and step
-                B[0] = sc.b11; B[1] = sc.b22; B[2] = sc.b12.x; B[3] = sc.b12.y;
-            }
         }
     }
 }
@@ -568,7 +614,7 @@ __global__ void __launch_bounds__(64) pk2_ritz_kernel(const PackedJob* jobs, con
 // ------------------------------------------------------------------------------
 struct SlabLayout {
     size_t tiles, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
-        alpha, beta, result, total;
+        coef, alpha, beta, result, total;
     int qslots;
 };
 
@@ -603,6 +649,7 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
     L.apart1 = take(sizeof(double) * (size_t)nbmax * sc);
     L.upart0 = take(sizeof(double) * (size_t)nbmax * sc);
     L.upart1 = take(sizeof(double) * (size_t)nbmax * sc);
+    L.coef = take(sizeof(double) * 32);
     L.alpha = take(sizeof(double) * (size_t)(max_steps + 2) * sc);
     L.beta = take(sizeof(double) * (size_t)(max_steps + 3) * sc);
     L.result = take(sizeof(double) * 4);
@@ -812,14 +859,23 @@ struct SweepGroup {
                 for (int I = 0; I < J.nb; ++I) {
                     rs0[I] = idx;
                     for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
+                        if (J.n < 2) { ++idx; continue; }          // nothing to multiply (the check kernel reports it)
                         Strip& st = hs[nstrips++];
-                        st.job = s; st.I = I; st.J0 = J0; st.J1 = std::min(J.nb, J0 + J.strip_len); st.index = idx++;
+                        const int64_t t0 = tile_offset(J.nb, I) + (J0 - I);
+                        st.tiles = J.tiles + t0 * kTileElems;
+                        st.Q = J.Q; st.qstride = J.qstride; st.qslots = J.qslots;
+                        st.rowpart = J.rowpart + 2 * (int64_t)idx * kTB;
+                        st.colpart = J.colpart + 2 * t0 * kTB;
+                        st.state = J.state;
+                        st.I = I; st.J0 = J0; st.ntile = std::min(J.nb, J0 + J.strip_len) - J0;
+                        st.start = J.start; st.gen = J.gen; st.max_steps = J.max_steps; st.job = s;
+                        ++idx;
                     }
                 }
                 rs0[J.nb] = idx;
             }
             std::stable_sort(hs, hs + nstrips, [](const Strip& a, const Strip& b) {
-                return (a.J1 - a.J0) > (b.J1 - b.J0);
+                return a.ntile > b.ntile;
             });
             std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
             std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
@@ -889,8 +945,10 @@ struct SweepGroup {
         if (nstrips > 0) {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
+                hipLaunchKernelGGL(pk2_coef_kernel, dim3((unsigned)ceil_div(nb_run * kTB, kCoefRows), (unsigned)nslots),
+                                   dim3(kCoefRows), 0, stream, d_jobs(tab), launch);
                 const int slot = profiler().begin(kProfMatvec, stream);
-                hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_jobs(tab), d_strips(tab), launch);
+                hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_strips(tab), launch);
                 profiler().end(kProfMatvec, slot, stream);
                 hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
                                    stream, d_jobs(tab), launch);
@@ -1034,6 +1092,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
             J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
             J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
+            J.coef = (double*)(sl + L.coef);
             J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
             J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * (grp.slot0 + s);
             J.tol = tol; J.gen = 0;

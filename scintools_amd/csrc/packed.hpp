@@ -61,6 +61,7 @@ struct PackedJob {
     const int32_t* row_strip0;  // [nb+1] first strip index of each block row
     double* apart[2];       // [nb] partial q_j^H u_j      (ping-pong by step parity)
     double* upart[2];       // [nb] partial |u_j|^2
+    double* coef;           // [2][16] the step's 2x2 coefficients A_{j-1}, B_{j-1}, 1/diag(B_{j-1}) (by step parity)
     double* alpha;          // [max_steps + 1]
     double* beta;           // [max_steps + 2]   beta[i] couples i-1 and i
     double* result;         // [4] theta, err estimate, resid, theta2
@@ -69,9 +70,18 @@ struct PackedJob {
     double tol;             // target relative accuracy of the eigenvalue
 };
 
-struct Strip {
-    int32_t job, I, J0, J1;   // tiles (I, J0 .. J1-1)
-    int32_t index;            // strip index inside the job (row of rowpart)
+// One mat-vec workgroup's work: tiles (I, J0 .. J0+ntile-1) of one job.  The record carries every
+// pointer the workgroup needs, so that its tile loads are issued after ONE dependent load (this
+// record) instead of three (strip -> job table -> state word); measured in round 3.
+struct __attribute__((aligned(16))) Strip {
+    const cplx* tiles;        // first tile of the strip
+    const cplx* Q;            // the job's Q ring (slot j % qslots holds Q_j, slots qstride*2 elements apart)
+    cplx* rowpart;            // this strip's [64][2] row partials
+    cplx* colpart;            // [ntile][64][2] column partials, first tile of the strip first
+    const int32_t* state;     // the slot's state word (job done <=> state[0] >= gen)
+    int64_t qstride;
+    int32_t I, J0, ntile, qslots;
+    int32_t start, gen, max_steps, job;
 };
 
 // Gather for the jobs in slots[0..njobs) (device array of indices into jobs_dev); every job

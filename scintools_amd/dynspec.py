@@ -471,9 +471,14 @@ class Dynspec:
         if pool is not None:
             res = pool.map(thth.single_search, [self._search_params(cf, ct, verbose) for cf, ct in chunks])
             for (cf, ct), r in zip(chunks, res):
-                self.eta_evo[cf, ct] = r[0]
-                self.eta_evo_err[cf, ct] = r[1]
-                self.thth_eigs[cf, ct] = np.nan
+                # with astropy present single_search returns Quantities (s**3): strip before the
+                # plain-float arrays take them (a NumPy scalar assignment of a Quantity raises)
+                self.eta_evo[cf, ct] = float(units.strip(r[0], 'eta', 's3', warn=False))
+                self.eta_evo_err[cf, ct] = float(units.strip(r[1], 'eta_sig', 's3', warn=False))
+                # single_search drops failed curvatures from the curve it returns (ththmod.py:817):
+                # only a complete curve can be put back on the eta grid
+                curve = np.asarray(r[4], dtype=float)
+                self.thth_eigs[cf, ct] = curve if curve.shape == (self.neta,) else np.nan
         else:
             from . import sweep
             fits = sweep.sharded_chunks(len(chunks), lambda idx: self._fit_chunks([chunks[i] for i in idx]),

@@ -75,3 +75,44 @@ def test_quantity_path_with_astropy_like_units():
     out = subprocess.run([sys.executable, "-c", CHILD, shim, REPO], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "quantity path ok" in out.stdout
+
+
+POOL_CHILD = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np
+import astropy.units as u
+from scintools_amd import dynspec, units
+assert units.HAVE_ASTROPY
+
+
+class FakePool:                 # what sweep.gpu_pool's workers hand back when astropy is importable
+    def map(self, fn, pars):
+        out = []
+        for k, p in enumerate(pars):
+            curve = np.arange(4.0) + k if k != 1 else np.arange(3.0)     # chunk 1: one curvature failed
+            out.append(((0.02 + 0.001 * k) * u.s**3, 0.002 * u.s**3, 1400.0 * u.MHz, 10.0 * u.s, curve))
+        return out
+
+
+d = object.__new__(dynspec.Dynspec)
+d.cwf = 1; d.ncf_fit = 2; d.nct_fit = 2; d.neta = 4; d.fref = 1400.0
+d.freqs = 1400.0 + np.arange(8.0); d.times = 30.0 * np.arange(8.0)
+d._chunk = lambda cf, ct: (slice(4 * cf, 4 * cf + 4), slice(4 * ct, 4 * ct + 4))
+d._search_params = lambda cf, ct, verbose: [cf, ct]
+d.fit_thetatheta(pool=FakePool())
+assert d.eta_evo.dtype == np.float64 and np.allclose(d.eta_evo.ravel(), 0.02 + 0.001 * np.arange(4))
+assert np.allclose(d.eta_evo_err, 0.002)
+assert np.array_equal(d.thth_eigs[0, 0], np.arange(4.0)) and np.all(np.isnan(d.thth_eigs[0, 1]))
+assert np.isfinite(d.ththeta) and np.isfinite(d.ththetaerr)
+print("pool path ok")
+'''
+
+
+def test_fit_thetatheta_pool_path_strips_quantities():
+    """ADVICE r2: with astropy importable single_search returns Quantities; the pool path must strip
+    them before the plain-float arrays take them, and keep complete curves."""
+    shim = os.path.join(REPO, "tests", "golden", "refshim")
+    out = subprocess.run([sys.executable, "-c", POOL_CHILD, shim, REPO], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "pool path ok" in out.stdout
