@@ -21,6 +21,7 @@ ARCH = "gfx950"
 UNITS = {
     "capi.hip": [],
     "fft.hip": [],
+    "sspec.hip": [],
     "thth.hip": ["-ffp-contract=off"],
     "eigen.hip": [],
     "eigen_packed.hip": [],

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 
 #include "../../include/scint_hip.h"
 
@@ -70,6 +71,23 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 // so the hardware needs no barrier; this only pins the order for the compiler (and is a wave-level
 // meeting point on the host interpreter of tests/emu).
 __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Lane K of every 16-lane row to all lanes of that row (v_mov_b32_dpp row_newbcast:K, VALU only)
+template <int K>
+__device__ inline double row_bcast_f64(double v) {
+    static_assert(K >= 0 && K < 16, "row_newbcast lane");
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (DPP controls are immediates)
+template <int B, int E, class F>
+__device__ inline void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // ---- wavefront (64 lanes) reductions ------------------------------------------
 __device__ inline double wave_sum(double v) {

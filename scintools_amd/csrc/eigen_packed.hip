@@ -233,118 +233,149 @@ __global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __
     gstore(Qn + 2 * r, x1); gstore(Qn + 2 * r + 1, x2);
 }
 
-// 16 rows per wave, 256 registers, two waves per SIMD, two workgroups per CU.  Two other shapes
-// were measured and removed: half strips (8 rows per wave, 168 registers, three waves per SIMD:
-// 1075 eta/s against 1183) and two sweeps per strip (1147 eta/s); DESIGN.md section 6.
-constexpr int kFlushF = 4;     // its column partials are reduced across the waves every 4 tiles (a barrier pair each)
-// (The same kernel with its prefetch loads issued unconditionally -- exact wait counts -- and LDS-only
-// barriers in the flush was measured in round 3: 1169 against 1201 eta/s; tools/probes/pk2_probe.hip
-// shows the body at 6.1-6.2 TB/s on synthetic strips in either form, so it was removed.)
+// One workgroup = one strip of <= 16 tiles; wave w owns the 16-column slice 16w .. 16w+15 of every tile,
+// ALL 64 rows.  A wave load is eight 128-byte row segments: lane l = 8 rg + cg reads row 8j + rg,
+// columns 16w + 8cc + cg for the sixteen (j, cc), j = 0..7 row steps, cc = 0..1 column chunks.  So
+//   * the COLUMN part  c_J[col] = sum_rows conj(a[row][col]) x_I[row]  is lane-local over 8 rows and
+//     finishes inside the wave (three shuffle steps over the eight row groups): no LDS, no barrier;
+//   * the ROW part  y_I[row] = sum_J sum_col a[row][col] x_J[col]  keeps 8 rows x 2 vectors of per-lane
+//     accumulators for the whole strip and is reduced once at its end (8 lanes through LDS, then the four
+//     waves through LDS): two barriers per STRIP.
+// Until round 3 a wave owned 16 rows x 64 columns: the column partials then needed a 4-wave LDS reduction
+// with two barriers every 4 tiles, and on synthetic strips that flush took the loop from 6.56 to 5.51 TB/s
+// (barriers + LDS 12 %, its stores under a branch another 4.5 %: a memory operation under a branch makes
+// the compiler's wait counts pessimistic for everything behind it; profiles/r03_pk2_probe.txt).  Hence
+// the loop below is branch-free: the last tile is peeled (no conditional prefetch) and every lane stores
+// its column partial unconditionally (the diagonal tile's goes to a scratch row nobody reads).
+// x_I: eight distinct rows per instruction, read from LDS.
+__device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (*__restrict__ xir)[2],
+                                        const cplx (&xJ1)[2], const cplx (&xJ2)[2], cplx (&acc1)[8], cplx (&acc2)[8],
+                                        cplx (&c1)[2], cplx (&c2)[2]) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * h + jj;
+        const cplx x1 = xir[8 * j][0], x2 = xir[8 * j][1];             // row 8j + rg of X_I
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const cplx e = a[2 * jj + cc];
+            acc1[j] = acc1[j] + e * xJ1[cc];
+            acc2[j] = acc2[j] + e * xJ2[cc];
+            c1[cc] = mk(c1[cc].x + e.x * x1.x + e.y * x1.y, c1[cc].y + e.x * x1.y - e.y * x1.x);   // conj(a) x_I
+            c2[cc] = mk(c2[cc].x + e.x * x2.x + e.y * x2.y, c2[cc].y + e.x * x2.y - e.y * x2.x);
+        }
+    }
+}
+// the eight row groups of a column (lanes l ^ 8, ^ 16, ^ 32; fixed order), then one 16-byte store per lane:
+// row groups 0..3 hold (chunk, vector) = (rg >> 1, rg & 1), groups 4..7 store the same values again
+__device__ __forceinline__ void pk2_colstore(cplx (&c1)[2], cplx (&c2)[2], int rg, cplx* __restrict__ dst) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            c1[cc] = mk(c1[cc].x + __shfl_xor(c1[cc].x, o, 64), c1[cc].y + __shfl_xor(c1[cc].y, o, 64));
+            c2[cc] = mk(c2[cc].x + __shfl_xor(c2[cc].x, o, 64), c2[cc].y + __shfl_xor(c2[cc].y, o, 64));
+        }
+    }
+    const cplx lo = (rg & 1) ? c2[0] : c1[0], hi = (rg & 1) ? c2[1] : c1[1];
+    gstore(dst, (rg & 2) ? hi : lo);
+}
+
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
     __shared__ cplx lds[4096];                   // 64 KiB: two workgroups per CU
-    cplx (*cred)[kFlushF][kTB][2] = reinterpret_cast<cplx (*)[kFlushF][kTB][2]>(lds);      // [4]: per-wave column partials of kFlushF tiles, 2 vectors (32 KiB)
-    cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 2048);                     // [kMaxStrip]: the blocks X_J = rows of Q_j of the strip (32 KiB)
+    cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds);          // [kMaxStrip]: the blocks X_J = rows of Q_j (32 KiB)
+    cplx (*xi)[2] = reinterpret_cast<cplx (*)[2]>(lds + 2048);             // [64]: the block X_I (2 KiB)
     const Strip* __restrict__ sp = strips + blockIdx.x;
     const int step = launch - sp->start;
     if (step < 0 || step >= sp->max_steps) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cg = lane & 7, rg = lane >> 3, col = 16 * w + cg;
     const int ntile = sp->ntile;
-    const cplx* __restrict__ tp = sp->tiles + (16 * w) * kTB + lane;
-    cplx a0[8], a1[8];
+    const cplx* __restrict__ tp = sp->tiles + rg * kTB + col;               // row rg, first column of the lane
+    cplx a0[8], a1[8];                                                      // element 2 jj + cc: row 8 (4h + jj) + rg, column col + 8 cc
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tp + r * kTB);
+    for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tp + (8 * (k >> 1)) * kTB + 8 * (k & 1));
     const int32_t done = gload(sp->state);
     const cplx* __restrict__ X = sp->Q + (int64_t)(step % sp->qslots) * sp->qstride * 2;   // Q_j
     const int I = sp->I, J0 = sp->J0;
-    // lane l of every wave holds row l of the block X_I (both vectors); rows read it back with v_readlane
-    const cplx xI1 = gload(X + 2 * (I * kTB + lane)), xI2 = gload(X + 2 * (I * kTB + lane) + 1);
-    // X_J = rows J0*64 .. of Q_j into LDS, once per workgroup (the first tile's loads stay in flight)
-    for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
-        const int r = J0 * kTB + idx;
-        const cplx x1 = gload(X + 2 * r), x2 = gload(X + 2 * r + 1);
-        xs[idx >> 6][idx & 63][0] = x1;
-        xs[idx >> 6][idx & 63][1] = x2;
-    }
+    // X_I and the strip's X_J blocks: contiguous copies of rows of Q_j (the first tile's loads stay in flight)
+    if (threadIdx.x < 2 * kTB) lds[2048 + threadIdx.x] = gload(X + 2 * I * kTB + threadIdx.x);
+    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) lds[idx] = gload(X + 2 * J0 * kTB + idx);
     if (done >= sp->gen) return;                 // finished job (workgroup-uniform): its loads were harmless
     __syncthreads();
-    cplx acc1[16], acc2[16];
+    cplx acc1[8], acc2[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc1[r] = mk(0.0, 0.0); acc2[r] = mk(0.0, 0.0); }
-    cplx* __restrict__ colpart = sp->colpart;
-    const int tdiag = I - J0;                    // the strip's diagonal tile (if any) stores no column partial
+    for (int j = 0; j < 8; ++j) { acc1[j] = mk(0.0, 0.0); acc2[j] = mk(0.0, 0.0); }
+    const cplx (*__restrict__ xir)[2] = xi + rg;
+    // this lane's slot in a tile's [64][2] column partial: column col + 8 (rg >> 1 & 1), vector rg & 1
+    const int cslot = 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
+    cplx* __restrict__ colpart = sp->colpart + cslot;
+    // the diagonal tile (block I of this strip, if any) has no column partial: its store goes to the strip's
+    // row-partial block, which this workgroup overwrites at the end
+    cplx* __restrict__ dummy = sp->rowpart + cslot;
+    const int tdiag = I - J0;
 #pragma unroll 1
-    for (int t = 0; t < ntile; ++t) {
+    for (int t = 0; t + 1 < ntile; ++t) {
         const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a1[r] = gload_nt(tc + (8 + r) * kTB);   // second half of this tile
-        const cplx xJ1 = xs[t][lane][0], xJ2 = xs[t][lane][1];
-        cplx c1 = mk(0.0, 0.0), c2 = mk(0.0, 0.0);
+        for (int k = 0; k < 8; ++k) a1[k] = gload_nt(tc + (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1));   // rows 32 .. 63
+        cplx xJ1[2], xJ2[2], c1[2], c2[2];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            acc1[r] = acc1[r] + a0[r] * xJ1;
-            acc2[r] = acc2[r] + a0[r] * xJ2;
-            const cplx x1 = mk(readlane_f64(xI1.x, 16 * w + r), readlane_f64(xI1.y, 16 * w + r));
-            const cplx x2 = mk(readlane_f64(xI2.x, 16 * w + r), readlane_f64(xI2.y, 16 * w + r));
-            c1 = mk(c1.x + a0[r].x * x1.x + a0[r].y * x1.y, c1.y + a0[r].x * x1.y - a0[r].y * x1.x);   // conj(a) x_I
-            c2 = mk(c2.x + a0[r].x * x2.x + a0[r].y * x2.y, c2.y + a0[r].x * x2.y - a0[r].y * x2.x);
+        for (int cc = 0; cc < 2; ++cc) {
+            xJ1[cc] = xs[t][col + 8 * cc][0]; xJ2[cc] = xs[t][col + 8 * cc][1];
+            c1[cc] = mk(0.0, 0.0); c2[cc] = mk(0.0, 0.0);
         }
-        if (t + 1 < ntile) {
+        pk2_half(a0, 0, xir, xJ1, xJ2, acc1, acc2, c1, c2);
+        // (scheduling fences: left alone, the compiler sinks these loads below the second half to save
+        // registers, and the next tile then starts with nothing in flight)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) a0[r] = gload_nt(tc + kTileElems + r * kTB);   // first half of the next tile
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            acc1[8 + r] = acc1[8 + r] + a1[r] * xJ1;
-            acc2[8 + r] = acc2[8 + r] + a1[r] * xJ2;
-            const cplx x1 = mk(readlane_f64(xI1.x, 16 * w + 8 + r), readlane_f64(xI1.y, 16 * w + 8 + r));
-            const cplx x2 = mk(readlane_f64(xI2.x, 16 * w + 8 + r), readlane_f64(xI2.y, 16 * w + 8 + r));
-            c1 = mk(c1.x + a1[r].x * x1.x + a1[r].y * x1.y, c1.y + a1[r].x * x1.y - a1[r].y * x1.x);
-            c2 = mk(c2.x + a1[r].x * x2.x + a1[r].y * x2.y, c2.y + a1[r].x * x2.y - a1[r].y * x2.x);
-        }
-        cred[w][t & (kFlushF - 1)][lane][0] = c1;   // this wave's own slot
-        cred[w][t & (kFlushF - 1)][lane][1] = c2;
-        if ((t & (kFlushF - 1)) == kFlushF - 1 || t + 1 == ntile) {
-            // cross-wave reduction of the last <= kFlushF tiles' column partials: wave w takes the
-            // (tile, vector) pairs w, w + 4 of the 2 kFlushF
-            __syncthreads();
-            const int tb = t & ~(kFlushF - 1);
-#pragma unroll
-            for (int c = w; c < 2 * kFlushF; c += 4) {
-                const int k = c >> 1, v = c & 1, tt = tb + k;
-                if (tt <= t && tt != tdiag) {
-                    const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
-                    gstore(colpart + 2 * (tt * kTB + lane) + v, sum);
-                }
-            }
-            __syncthreads();
-        }
+        for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tc + kTileElems + (8 * (k >> 1)) * kTB + 8 * (k & 1));   // rows 0 .. 31 of the next tile
+        __builtin_amdgcn_sched_barrier(0);
+        pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
+        pk2_colstore(c1, c2, rg, t == tdiag ? dummy : colpart + 2 * (t * kTB));
     }
-    // Row partials: the sum over the 64 lanes of each of the wave's 16 rows x 2 vectors.  Through LDS
-    // (cred and xs are free: every wave is past the last flush barrier), eight rows at a time: the wave
-    // stores 8 x 64 values, lane L adds the eight consecutive values L*8 .. L*8+7 of row L/8, and
-    // three shuffle steps finish the row.  (The 64 six-step shuffle reductions this replaces were 1700
-    // of the kernel's 2500 instructions and kept a wave 4 us off the memory system per strip.)
-    cplx* __restrict__ rowpart = sp->rowpart;
-    cplx* __restrict__ red = lds + w * 1024;     // this wave's 16 KiB; 576 elements used (one pad element per 8)
+    {   // the last tile: nothing left to prefetch
+        const int t = ntile - 1;
+        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a1[k] = gload_nt(tc + (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1));
+        cplx xJ1[2], xJ2[2], c1[2], c2[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            xJ1[cc] = xs[t][col + 8 * cc][0]; xJ2[cc] = xs[t][col + 8 * cc][1];
+            c1[cc] = mk(0.0, 0.0); c2[cc] = mk(0.0, 0.0);
+        }
+        pk2_half(a0, 0, xir, xJ1, xJ2, acc1, acc2, c1, c2);
+        pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
+        pk2_colstore(c1, c2, rg, t == tdiag ? dummy : colpart + 2 * (t * kTB));
+    }
+    // Row partials.  (1) inside the wave, over the 8 lanes of a row group: the wave stores 8 j x 64 lanes,
+    // lane L adds the eight consecutive values L*8 .. L*8+7 = row step L / 8, row group L % 8: row L of the
+    // block; (2) across the four waves (column slices) through LDS, fixed order.  xs / xi are dead once
+    // every wave has left the loop, and so are the scratch stores into rowpart.
+    __syncthreads();
+    cplx* __restrict__ red = lds + w * 576;      // 8 x 64 values + one pad element per 8
+    cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 2560);   // [4 waves][64 rows][2]
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int e = rr * 64 + lane;
-                red[e + (e >> 3)] = v ? acc2[8 * h + rr] : acc1[8 * h + rr];
-            }
-            wave_lds_sync();
-            cplx s = red[lane * 9];
-#pragma unroll
-            for (int k = 1; k < 8; ++k) s = s + red[lane * 9 + k];
-            wave_lds_sync();
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) s = mk(s.x + __shfl_xor(s.x, o, 64), s.y + __shfl_xor(s.y, o, 64));
-            if ((lane & 7) == 0) gstore(rowpart + 2 * (16 * w + 8 * h + (lane >> 3)) + v, s);
+        for (int j = 0; j < 8; ++j) {
+            const int e = j * 64 + lane;
+            red[e + (e >> 3)] = v ? acc2[j] : acc1[j];
         }
+        wave_lds_sync();
+        cplx s = red[lane * 9];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) s = s + red[lane * 9 + k];
+        wave_lds_sync();
+        rsum[w][lane][v] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * kTB) {
+        const int row = threadIdx.x >> 1, v = threadIdx.x & 1;
+        const cplx tot = ((rsum[0][row][v] + rsum[1][row][v]) + rsum[2][row][v]) + rsum[3][row][v];
+        gstore(sp->rowpart + threadIdx.x, tot);
     }
 }
 

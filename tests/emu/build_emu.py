@@ -32,6 +32,7 @@ LIB = os.path.join(OUT, "libscint_emu_test.so")
 UNITS = {
     "capi.hip": [],
     "fft.hip": [],
+    "sspec.hip": [],
     "thth.hip": ["-ffp-contract=off"],
     "eigen.hip": [],
     "eigen_packed.hip": [],

@@ -164,6 +164,13 @@ inline emu_v4d emu_mfma_f64_16x16x4(double a, double b, emu_v4d c) {
     return d;
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, cbsz, abid, blgp) emu_mfma_f64_16x16x4((a), (b), (c))
+// v_mov_b32_dpp row_newbcast:K (dpp_ctrl 0x150 + K): lane K of each 16-lane row to the whole row
+inline int emu_update_dpp(int v, int ctrl) {
+    const int lane = ::emu::lane_id();
+    return ::emu::from_bits<int>(::emu::wave_op(::emu::kShfl, ::emu::to_bits(v), (lane & ~15) | (ctrl & 15), 64));
+}
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, rmask, bmask, bctl) emu_update_dpp((v), (ctrl))
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)     // instruction scheduling only
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 

@@ -122,6 +122,25 @@ def test_secondary_spectrum(emu):
     assert np.abs(lin - lref).max() <= 1e-10 * lref.max()
 
 
+@pytest.mark.parametrize("nf,nt", [(130, 200), (257, 131), (200, 300)])
+@pytest.mark.parametrize("kw", [{}, {"prewhite": True}, {"window": None}])
+def test_secondary_spectrum_two_trip_path(emu, nf, nt, kw):
+    """Shapes the strided-axis-first path of sspec.hip takes (next_pow2 of both axes >= 256): odd and even
+    nt (16-byte and 8-byte input loads), nf just above a power of two, all three source variants."""
+    import torch
+    from oracle import sspec_oracle
+    from scintools_amd.dynspec import sspec_device
+    rng = np.random.default_rng(nf * 1000 + nt)
+    dyn = rng.standard_normal((nf, nt)) + 3.0 + 0.5 * np.sin(0.07 * np.arange(nt))[None, :] * np.cos(0.11 * np.arange(nf))[:, None]
+    sec = sspec_device(emu.to_device(dyn, torch.float64), **kw).cpu().numpy()
+    ref = sspec_oracle.calc_sspec(dyn, 30.0, 1.0, **kw)[2]
+    assert sec.shape == ref.shape
+    lin, lref = 10 ** (sec / 10), 10 ** (ref / 10)
+    assert np.abs(lin - lref).max() <= 1e-10 * lref.max()
+    strong = lref > 1e-6 * lref.max()
+    assert np.abs(sec - ref)[strong].max() <= 1e-8
+
+
 def test_eigenvalue_sweep_vs_arpack(emu, to, case):
     """The batched two-vector Lanczos sweep incl. its two-stream scheduler (run here in enqueue
     order) against the oracle's ARPACK eigsh, and independent of the batch size."""

@@ -1,5 +1,4 @@
 export TMPDIR=/tmp; O=gpurun_out; mkdir -p $O
-for L in 4 8; do
-SCINT_STRIP_LEN=$L SCINT_SWEEP_GROUPS=1 bash tools/gpu_run.sh quick s3g1_len$L
-done
-SCINT_STRIP_LEN=8 bash tools/gpu_run.sh quick s3_len8
+timeout 900 python -m pytest tests/test_gpu_edges.py tests/test_gpu_parity.py tests/test_gpu_stopping_rule.py -m gpu -q -x 2>&1 | tail -3
+bash tools/gpu_run.sh quick s6
+SCINT_SWEEP_GROUPS=1 bash tools/gpu_run.sh quick s6g1

@@ -9,6 +9,10 @@
 //   bit 3  prefetch of the next tile unconditional (else under `if (t + 1 < ntile)`)
 //   bit 4  LDS-only barrier instead of __syncthreads() in the flush
 //   bit 5  plain instead of non-temporal tile loads
+//   bit 6  flush without its global stores (barriers + LDS traffic only)
+//   bit 7  no LDS / barriers: every wave stores its own 16-row column partial each tile (4x the bytes)
+//   bit 8  no LDS / barriers: wave 0 alone stores its partial each tile (the product's bytes, wrong sums)
+//   bit 9  flush every 8 tiles instead of 4 (64 KiB of partials; X_J then comes from global memory)
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/pk2_probe.hip -o /tmp/pk2_probe && /tmp/pk2_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -35,21 +39,23 @@ __device__ inline double wave_sum(double v) {
 }
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int kTB = 64, kTileElems = 4096, kFlushF = 4, kStrip = 16;
+constexpr int kTB = 64, kTileElems = 4096, kStrip = 16;
 
 template <int F>
 __global__ void __launch_bounds__(256, 2)
 probe_kernel(const cplx* __restrict__ tiles, const cplx* __restrict__ vec, cplx* __restrict__ colpart, cplx* __restrict__ rowpart, int ntile) {
     constexpr bool ROW = F & 1, COL = F & 2, FLUSH = F & 4, UNCOND = F & 8, LDSB = F & 16, NT = !(F & 32);
+    constexpr bool NOST = F & 64, ALLW = F & 128, W0 = F & 256, F8 = F & 512;
+    constexpr int kFlushF = F8 ? 8 : 4;
     __shared__ cplx cred[4][kFlushF][kTB][2];
-    __shared__ cplx xs[kStrip][kTB][2];
+    __shared__ cplx xs[F8 ? 1 : kStrip][kTB][2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const cplx* __restrict__ tp = tiles + (size_t)blockIdx.x * ntile * kTileElems + (16 * w) * kTB + lane;
     cplx a0[8], a1[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) a0[r] = gl<NT>(tp + r * kTB);
     const cplx xI1 = gl<false>(vec + 2 * lane), xI2 = gl<false>(vec + 2 * lane + 1);
-    for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
+    if (!F8) for (int idx = threadIdx.x; idx < ntile * kTB; idx += 256) {
         xs[idx >> 6][idx & 63][0] = gl<false>(vec + 2 * idx);
         xs[idx >> 6][idx & 63][1] = gl<false>(vec + 2 * idx + 1);
     }
@@ -63,7 +69,7 @@ probe_kernel(const cplx* __restrict__ tiles, const cplx* __restrict__ vec, cplx*
         const cplx* __restrict__ tc = tp + (size_t)t * kTileElems;
 #pragma unroll
         for (int r = 0; r < 8; ++r) a1[r] = gl<NT>(tc + (8 + r) * kTB);
-        const cplx xJ1 = xs[t][lane][0], xJ2 = xs[t][lane][1];
+        const cplx xJ1 = F8 ? gl<false>(vec + 2 * (t * kTB + lane)) : xs[t][lane][0], xJ2 = F8 ? gl<false>(vec + 2 * (t * kTB + lane) + 1) : xs[t][lane][1];
         cplx c1 = mk(0.0, 0.0), c2 = mk(0.0, 0.0);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -95,7 +101,12 @@ probe_kernel(const cplx* __restrict__ tiles, const cplx* __restrict__ vec, cplx*
             }
             if (!ROW && !COL) sink = sink + a1[r];
         }
-        if (FLUSH) {
+        if (ALLW || W0) {
+            if (ALLW || w == 0) {
+                gs(colpart + 2 * ((((size_t)blockIdx.x * ntile + t) * (ALLW ? 4 : 1) + (ALLW ? w : 0)) * kTB + lane), c1);
+                gs(colpart + 2 * ((((size_t)blockIdx.x * ntile + t) * (ALLW ? 4 : 1) + (ALLW ? w : 0)) * kTB + lane) + 1, c2);
+            } else sink = sink + c1 + c2;
+        } else if (FLUSH) {
             cred[w][t & (kFlushF - 1)][lane][0] = c1;
             cred[w][t & (kFlushF - 1)][lane][1] = c2;
             if ((t & (kFlushF - 1)) == kFlushF - 1 || t + 1 == ntile) {
@@ -106,7 +117,7 @@ probe_kernel(const cplx* __restrict__ tiles, const cplx* __restrict__ vec, cplx*
                     const int k = c >> 1, v = c & 1, tt = tb + k;
                     if (tt <= t) {
                         const cplx sum = ((cred[0][k][lane][v] + cred[1][k][lane][v]) + cred[2][k][lane][v]) + cred[3][k][lane][v];
-                        gs(colpart + 2 * (((size_t)blockIdx.x * ntile + tt) * kTB + lane) + v, sum);
+                        if (NOST) sink = sink + sum; else gs(colpart + 2 * (((size_t)blockIdx.x * ntile + tt) * kTB + lane) + v, sum);
                     }
                 }
                 if (LDSB) lds_barrier(); else __syncthreads();
@@ -133,6 +144,7 @@ __global__ void fill_kernel(double* p, size_t n) {
     }
 }
 
+static int g_reps = 5;
 template <int F>
 static void run(const cplx* buf, size_t bytes, const cplx* vec, cplx* colpart, cplx* rowpart, const char* what) {
     const int ntile = kStrip;
@@ -141,7 +153,7 @@ static void run(const cplx* buf, size_t bytes, const cplx* vec, cplx* colpart, c
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(probe_kernel<F>, dim3(nwg), dim3(256), 0, 0, buf, vec, colpart, rowpart, ntile);
     hipEventRecord(e0, 0);
-    const int reps = 5;
+    const int reps = g_reps;
     for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(probe_kernel<F>, dim3(nwg), dim3(256), 0, 0, buf, vec, colpart, rowpart, ntile);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
@@ -150,12 +162,14 @@ static void run(const cplx* buf, size_t bytes, const cplx* vec, cplx* colpart, c
     printf("flags %2d  %-58s %7.1f GB/s\n", F, what, (double)nwg * ntile * 65536.0 * reps / (ms * 1e-3) / 1e9);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_reps = atoi(argv[1]);   // sustained runs: 200 repetitions = 0.1 s per variant
+    printf("repetitions per variant: %d\n", g_reps);
     const size_t bytes = (size_t)3 << 30;
     cplx *buf, *vec, *colpart, *rowpart;
     const size_t nwg = bytes / ((size_t)kStrip * 65536);
     if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc(&vec, 1 << 20) != hipSuccess ||
-        hipMalloc(&colpart, nwg * kStrip * kTB * 2 * 16) != hipSuccess || hipMalloc(&rowpart, nwg * kTB * 2 * 16 + 64) != hipSuccess) {
+        hipMalloc(&colpart, nwg * kStrip * kTB * 2 * 16 * 4) != hipSuccess || hipMalloc(&rowpart, nwg * kTB * 2 * 16 + 64) != hipSuccess) {
         printf("alloc failed\n"); return 1;
     }
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (double*)buf, bytes / 8);
@@ -173,5 +187,9 @@ int main() {
     run<7 + 8 + 16>(buf, bytes, vec, colpart, rowpart, "SCINT_PK2_PREFETCH=1 form: uncond + LDS-only barrier");
     run<7 + 32>(buf, bytes, vec, colpart, rowpart, "product kernel with plain (not nt) tile loads");
     run<3 + 8>(buf, bytes, vec, colpart, rowpart, "row + column, no flush, uncond");
+    run<7 + 64>(buf, bytes, vec, colpart, rowpart, "product kernel, flush without its global stores");
+    run<3 + 128>(buf, bytes, vec, colpart, rowpart, "no LDS/barriers: every wave stores its partial (4x bytes)");
+    run<3 + 256>(buf, bytes, vec, colpart, rowpart, "no LDS/barriers: wave 0 stores its partial each tile");
+    run<7 + 512>(buf, bytes, vec, colpart, rowpart, "product kernel, flush every 8 tiles, X_J from global");
     return 0;
 }
