@@ -245,8 +245,10 @@ __global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __
 // with two barriers every 4 tiles, and on synthetic strips that flush took the loop from 6.56 to 5.51 TB/s
 // (barriers + LDS 12 %, its stores under a branch another 4.5 %: a memory operation under a branch makes
 // the compiler's wait counts pessimistic for everything behind it; profiles/r03_pk2_probe.txt).  Hence
-// the loop below is branch-free: the last tile is peeled (no conditional prefetch) and every lane stores
-// its column partial unconditionally (the diagonal tile's goes to a scratch row nobody reads).
+// the loop below is branch-free (the last tile is peeled: no conditional prefetch) and STORE-free: a global
+// store per tile costs 15 % on its own (6.83 -> 5.79 TB/s, profiles/r03_pk2e_probe.txt), so a tile's column
+// partial replaces the block X_J it has just consumed in LDS -- same 2 KiB, and a wave reads and writes
+// only its own 16-column slice of it -- and the strip's partials leave in one coalesced burst at the end.
 // x_I: eight distinct rows per instruction, read from LDS.
 __device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (*__restrict__ xir)[2],
                                         const cplx (&xJ1)[2], const cplx (&xJ2)[2], cplx (&acc1)[8], cplx (&acc2)[8],
@@ -265,8 +267,8 @@ __device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (
         }
     }
 }
-// the eight row groups of a column (lanes l ^ 8, ^ 16, ^ 32; fixed order), then one 16-byte store per lane:
-// row groups 0..3 hold (chunk, vector) = (rg >> 1, rg & 1), groups 4..7 store the same values again
+// the eight row groups of a column (lanes l ^ 8, ^ 16, ^ 32; fixed order), then one 16-byte LDS store per
+// lane: row groups 0..3 hold (chunk, vector) = (rg >> 1, rg & 1), groups 4..7 store the same values again
 __device__ __forceinline__ void pk2_colstore(cplx (&c1)[2], cplx (&c2)[2], int rg, cplx* __restrict__ dst) {
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
@@ -276,8 +278,10 @@ __device__ __forceinline__ void pk2_colstore(cplx (&c1)[2], cplx (&c2)[2], int r
             c2[cc] = mk(c2[cc].x + __shfl_xor(c2[cc].x, o, 64), c2[cc].y + __shfl_xor(c2[cc].y, o, 64));
         }
     }
-    const cplx lo = (rg & 1) ? c2[0] : c1[0], hi = (rg & 1) ? c2[1] : c1[1];
-    gstore(dst, (rg & 2) ? hi : lo);
+    const bool v1 = rg & 1, ch1 = rg & 2;        // (component-wise selects: v_cndmask, not an indexed array)
+    const double lx = v1 ? c2[0].x : c1[0].x, ly = v1 ? c2[0].y : c1[0].y;
+    const double hx = v1 ? c2[1].x : c1[1].x, hy = v1 ? c2[1].y : c1[1].y;
+    *dst = mk(ch1 ? hx : lx, ch1 ? hy : ly);
 }
 
 __global__ void __launch_bounds__(256, 2)
@@ -308,12 +312,7 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
     for (int j = 0; j < 8; ++j) { acc1[j] = mk(0.0, 0.0); acc2[j] = mk(0.0, 0.0); }
     const cplx (*__restrict__ xir)[2] = xi + rg;
     // this lane's slot in a tile's [64][2] column partial: column col + 8 (rg >> 1 & 1), vector rg & 1
-    const int cslot = 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
-    cplx* __restrict__ colpart = sp->colpart + cslot;
-    // the diagonal tile (block I of this strip, if any) has no column partial: its store goes to the strip's
-    // row-partial block, which this workgroup overwrites at the end
-    cplx* __restrict__ dummy = sp->rowpart + cslot;
-    const int tdiag = I - J0;
+    cplx* __restrict__ cslot = lds + 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
 #pragma unroll 1
     for (int t = 0; t + 1 < ntile; ++t) {
         const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
@@ -333,7 +332,7 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
         for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tc + kTileElems + (8 * (k >> 1)) * kTB + 8 * (k & 1));   // rows 0 .. 31 of the next tile
         __builtin_amdgcn_sched_barrier(0);
         pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
-        pk2_colstore(c1, c2, rg, t == tdiag ? dummy : colpart + 2 * (t * kTB));
+        pk2_colstore(c1, c2, rg, cslot + 2 * (t * kTB));
     }
     {   // the last tile: nothing left to prefetch
         const int t = ntile - 1;
@@ -348,28 +347,34 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
         }
         pk2_half(a0, 0, xir, xJ1, xJ2, acc1, acc2, c1, c2);
         pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
-        pk2_colstore(c1, c2, rg, t == tdiag ? dummy : colpart + 2 * (t * kTB));
+        pk2_colstore(c1, c2, rg, cslot + 2 * (t * kTB));
     }
-    // Row partials.  (1) inside the wave, over the 8 lanes of a row group: the wave stores 8 j x 64 lanes,
-    // lane L adds the eight consecutive values L*8 .. L*8+7 = row step L / 8, row group L % 8: row L of the
-    // block; (2) across the four waves (column slices) through LDS, fixed order.  xs / xi are dead once
-    // every wave has left the loop, and so are the scratch stores into rowpart.
-    __syncthreads();
-    cplx* __restrict__ red = lds + w * 576;      // 8 x 64 values + one pad element per 8
-    cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 2560);   // [4 waves][64 rows][2]
+    // Row partials.  (1) inside the wave, over the 8 lanes of a row group: the wave stores 4 j x 64 lanes into
+    // its own scratch, lane L adds the four consecutive values 4L .. 4L+3 (row step L / 16 of the four,
+    // row group (L % 16) / 2, half of its lanes), one shuffle step joins the halves; (2) across the four
+    // waves (column slices) through LDS, fixed order.  Then the strip's column partials (where the X_J
+    // blocks were; the diagonal tile's slot is written too, nobody reads it) leave in one burst.
+    cplx* __restrict__ red = lds + 2176 + w * 288;   // 4 x 64 values + one pad element per 8
+    cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 3328);   // [4 waves][64 rows][2]
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int e = j * 64 + lane;
-            red[e + (e >> 3)] = v ? acc2[j] : acc1[j];
-        }
-        wave_lds_sync();
-        cplx s = red[lane * 9];
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) s = s + red[lane * 9 + k];
-        wave_lds_sync();
-        rsum[w][lane][v] = s;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int e = jj * 64 + lane;
+                red[e + (e >> 3)] = v ? acc2[4 * h + jj] : acc1[4 * h + jj];
+            }
+            wave_lds_sync();
+            const int e0 = 4 * lane;
+            cplx s = red[e0 + (e0 >> 3)];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) s = s + red[e0 + k + (e0 >> 3)];
+            wave_lds_sync();
+            s = mk(s.x + __shfl_xor(s.x, 1, 64), s.y + __shfl_xor(s.y, 1, 64));
+            // lane L: row step 4h + L / 16, row group (L % 16) / 2
+            if ((lane & 1) == 0) rsum[w][8 * (4 * h + (lane >> 4)) + ((lane & 15) >> 1)][v] = s;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 2 * kTB) {
@@ -377,6 +382,8 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
         const cplx tot = ((rsum[0][row][v] + rsum[1][row][v]) + rsum[2][row][v]) + rsum[3][row][v];
         gstore(sp->rowpart + threadIdx.x, tot);
     }
+    cplx* __restrict__ colpart = sp->colpart;
+    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore(colpart + idx, lds[idx]);
 }
 
 __global__ void __launch_bounds__(64 * kRedGroups)
