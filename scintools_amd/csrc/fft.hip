@@ -1003,7 +1003,9 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
     if (workspace_bytes < need) { set_error("scint: sspec workspace too small"); return SCINT_E_WORKSPACE; }
     const int64_t R = 2 * next_pow2(nf), C = 2 * next_pow2(nt);  // dynspec.py:3677-3678
     SCINT_REQUIRE(C >= 16, "sspec: nt must be at least 5");
-    const size_t fft_bytes = std::max(fft2_general_ws(R, C, nf), sspec_fast_workspace(nf, nt));
+    if (sspec_fast_supported(nf, nt, halve))      // two HBM round trips instead of four (sspec.hip)
+        return sspec_fast(dyn, nf, nt, win_t, win_f, prewhite, pd_fd, pd_td, sec_out, workspace, stream);
+    const size_t fft_bytes = fft2_general_ws(R, C, nf);
     Carver cv((char*)workspace + align_up(fft_bytes, 256), workspace_bytes - align_up(fft_bytes, 256));
     double* partial = cv.take<double>(3 * kRedBlocks);
     double* scal = cv.take<double>(8);  // [0] = mean1, [1] = mean2
@@ -1014,8 +1016,6 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
         hipLaunchKernelGGL(sspec_means_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, (double)(nf * nt), scal);
         SCINT_LAUNCH_CHECK();
     }
-    if (sspec_fast_supported(nf, nt, halve))      // two HBM round trips instead of four (sspec.hip)
-        return sspec_fast(dyn, nf, nt, win_t, win_f, scal, prewhite, pd_fd, pd_td, sec_out, workspace, stream);
     WindowedValue wv{dyn, win_t, win_f, scal, (int)nt};
     int32_t rc = SCINT_OK;
 

@@ -12,19 +12,23 @@
 //   -- so a transform never needs more than n complex values in LDS, and a workgroup can do the two
 //   halves one after the other (rows) or two workgroups can share the input (columns).
 //
+//   sspec_prep_kernel   pass 0: the sums behind both means AND a pair-major copy of the input, transposed
+//                       through LDS (the column kernel then streams its two real columns contiguously).
 //   sspec_cols_kernel   axis 0 (frequency -> delay).  Two adjacent REAL columns c, c+1 ride as one complex
-//                       sequence z[r] = d'[r, c] + i d'[r, c+1]; a slot (n/16 threads) transforms one such
-//                       pair, a 1024-thread workgroup holds 16384 points: 4 adjacent pairs at n = 4096 (64
-//                       contiguous bytes per input row, 128 contiguous bytes per output row).  The real
-//                       spectra are separated from Z[k], Z[2n - k] (both inside the same half) and stored
-//                       as Y[k1][c], k1 = 2m + half < R/2: exactly the non-redundant half, [R/2, nt] complex.
-//                       Window, both means and the prewhitening stencil are fused into the loads.
-//   sspec_rows_kernel   axis 1 (time -> Doppler) of the kept rows only: one row per slot, both halves in
-//                       sequence, |.|^2, post-darkening, 10 log10 and the fftshift fused into 16-byte
-//                       stores (the even / odd Doppler bins of one thread are neighbours in memory).
+//                       sequence z[r] = d'[r, c] + i d'[r, c+1]; a workgroup (n/16 threads) transforms one
+//                       such pair and one half.  The real spectra are separated from Z[k], Z[2n - k] (both
+//                       inside the same half) and stored as Y[k1][c], k1 = 2m + half < R/2: exactly the
+//                       non-redundant half, [R/2, nt] complex, in tiles of (4 rows of one parity) x (pair) =
+//                       128 bytes, so that four consecutive threads store one whole line.  Window, both
+//                       means and the prewhitening stencil are fused into the loads.
+//   sspec_rows_kernel   axis 1 (time -> Doppler) of the kept rows only: one (row, half) per workgroup, |.|^2,
+//                       post-darkening, 10 log10 (own 35-instruction form) and the fftshift fused into the stores.
 //
-// HBM traffic at 4096^2: 134 MB (means) + 134..268 (input, twice through the L2 / Infinity Cache) + 268
-// (Y out) + 268 (Y in) + 268 (dB out) = 1.07..1.2 GB for 0.40 GB algorithmic, against 2.18 GB before.
+// HBM traffic at 4096^2: 134 MB in + 134 (pair-major copy out) + 134 (in) + 268 (Y out) + 268..536 (Y in:
+// twice, the second time through the L2) + 268 (dB out) = 1.2..1.5 GB for 0.40 GB algorithmic, against
+// 2.18 GB before; 0.56 ms against 0.71 (profiles/r03_sspec_ablation.txt has the kernel-by-kernel story:
+// 32-byte stores cost the column kernel 146 of 283 us, 16-byte-per-row loads 106; what is left is the
+// fragment traffic of the row kernel -- 32-byte loads, 8-byte stores -- on top of its 136-us instruction floor).
 // Shapes outside 256 <= R/2, C/2 <= 8192 and `halve = 0` keep the generic path (fft.hip).
 #include "sspec.hpp"
 
@@ -34,9 +38,64 @@ namespace scint {
 
 // d'(r, c) of dynspec.py:3667-3674 with NumPy's operation order (as WindowedValue / RowSource in fft.hip)
 struct SspecIn {
-    const double* dyn; const double* wt; const double* wf; const double* scal;   // scal[0] = mean 1, scal[1] = mean 2
+    const double* dynp;           // pair-major copy of the dynamic spectrum: [ceil(nt/2)][nf][2] (sspec_prep_kernel)
+    const double* wt; const double* wf; const double* scal;   // scal[0] = mean 1, scal[1] = mean 2
     int nf, nt, nf_eff, nt_eff, prewhite;
 };
+
+// Pass 0: one read of the dynamic spectrum gives (a) the three sums behind both means of dynspec.py:3667-3674
+// (m1 = mean(dyn), m2 = mean(w_f w_t (dyn - m1)) = (S_wd - m1 S_w) / n, fixed-order partials per 64 x 64 tile) and
+// (b) a PAIR-MAJOR copy dynp[c / 2][r][c % 2]: the column kernel then reads its two real columns as one
+// contiguous stream of 16-byte elements instead of 16 bytes out of every row (one 128-byte line each; that
+// cost it 106 of 283 us at 4096^2, profiles/r03_sspec_ablation.txt).  Tiles transpose through LDS: reads are
+// 512-byte row segments, writes 1-KiB runs of one pair.
+__global__ void __launch_bounds__(256) sspec_prep_kernel(const double* __restrict__ dyn, const double* __restrict__ wt,
+                                                         const double* __restrict__ wf, int nf, int nt,
+                                                         double* __restrict__ dynp, double* __restrict__ partial) {
+    __shared__ double tile[64][65];
+    __shared__ double red[4];
+    const int c0 = (int)blockIdx.x * 64, r0 = (int)blockIdx.y * 64;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = c0 + lane;
+    const double wc = (wt && c < nt) ? wt[c] : 1.0;
+    double sd = 0.0, swd = 0.0, sw = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int rr = w + 4 * i, r = r0 + rr;
+        double d = 0.0;
+        if (r < nf && c < nt) {
+            d = dyn[(int64_t)r * nt + c];
+            const double ww = wf ? wf[r] * wc : 1.0;
+            sd += d; swd += ww * d; sw += ww;
+        }
+        tile[rr][lane] = d;
+    }
+    __syncthreads();
+    // pair pp of the tile, row `lane`: 16 bytes per lane, 1 KiB per wave instruction
+    const int npair = (nt + 1) / 2;
+#pragma unroll 4
+    for (int i = 0; i < 8; ++i) {
+        const int pp = w + 4 * i, p = (c0 >> 1) + pp, r = r0 + lane;
+        if (p < npair && r < nf) {
+            v2d o; o.x = tile[lane][2 * pp]; o.y = tile[lane][2 * pp + 1];
+            *(SCINT_GLOBAL v2d*)(dynp + ((int64_t)p * nf + r) * 2) = o;
+        }
+    }
+    const int b = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, nb = (int)(gridDim.x * gridDim.y);
+    sd = block_sum(sd, red); swd = block_sum(swd, red); sw = block_sum(sw, red);
+    if (threadIdx.x == 0) { partial[b] = sd; partial[nb + b] = swd; partial[2 * nb + b] = sw; }
+}
+__global__ void __launch_bounds__(256) sspec_prep_means_kernel(const double* partial, int np, double n, double* scal) {
+    __shared__ double red[4];
+    double sd = 0.0, swd = 0.0, sw = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) { sd += partial[i]; swd += partial[np + i]; sw += partial[2 * np + i]; }
+    sd = block_sum(sd, red); swd = block_sum(swd, red); sw = block_sum(sw, red);
+    if (threadIdx.x == 0) {
+        const double m1 = sd / n;
+        scal[0] = m1;
+        scal[1] = (swd - m1 * sw) / n;
+    }
+}
 __device__ inline double sspec_d(double x, double wt, double wf, double m1, double m2, bool windowed) {
     double v = x - m1;
     if (windowed) { v = wt * v; v = wf * v; }
@@ -77,36 +136,19 @@ __device__ inline void split_exchange(cplx (&v)[kEPT], double* ldsd, int t, int 
 #pragma unroll
         for (int m = 0; m < RN; ++m) v[q * RN + m] = mk(re[q * RN + m], ldsd[lds_pad(t + q * Tr + m * (n / RN))]);
 }
-template <int RP, int RN>
-__device__ inline void full_exchange(cplx (&v)[kEPT], cplx* lds, int t, int Tr, int n, int Ns) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kEPT / RP; ++q)
-#pragma unroll
-        for (int m = 0; m < RP; ++m) lds[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m];
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kEPT / RN; ++q)
-#pragma unroll
-        for (int m = 0; m < RN; ++m) v[q * RN + m] = lds[lds_pad(t + q * Tr + m * (n / RN))];
-}
-
 // the n-point transform of the 16 values a thread holds (stage-0 order in, last-stage order out)
-template <int R0, int R1, int R2, int R3, bool SPLIT>
-__device__ inline void slot_fft(cplx (&v)[kEPT], void* lds, int t, const cplx* __restrict__ tw) {
+template <int R0, int R1, int R2, int R3>
+__device__ inline void slot_fft(cplx (&v)[kEPT], double* lds, int t, const cplx* __restrict__ tw) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
     stockham_compute<R0>(v, t, Tr, n, 1, tw);
     if constexpr (R1 > 1) {
-        if constexpr (SPLIT) split_exchange<R0, R1>(v, (double*)lds, t, Tr, n, 1);
-        else full_exchange<R0, R1>(v, (cplx*)lds, t, Tr, n, 1);
+        split_exchange<R0, R1>(v, lds, t, Tr, n, 1);
         stockham_compute<R1>(v, t, Tr, n, R0, tw);
         if constexpr (R2 > 1) {
-            if constexpr (SPLIT) split_exchange<R1, R2>(v, (double*)lds, t, Tr, n, R0);
-            else full_exchange<R1, R2>(v, (cplx*)lds, t, Tr, n, R0);
+            split_exchange<R1, R2>(v, lds, t, Tr, n, R0);
             stockham_compute<R2>(v, t, Tr, n, R0 * R1, tw);
             if constexpr (R3 > 1) {
-                if constexpr (SPLIT) split_exchange<R2, R3>(v, (double*)lds, t, Tr, n, R0 * R1);
-                else full_exchange<R2, R3>(v, (cplx*)lds, t, Tr, n, R0 * R1);
+                split_exchange<R2, R3>(v, lds, t, Tr, n, R0 * R1);
                 stockham_compute<R3>(v, t, Tr, n, R0 * R1 * R2, tw);
             }
         }
@@ -118,12 +160,16 @@ struct LastStage {
     static constexpr int Ns = (R3 > 1) ? R0 * R1 * R2 : (R2 > 1) ? R0 * R1 : (R1 > 1) ? R0 : 1;
 };
 
-constexpr int kColsBlock = 1024;
+// Workgroup of the column kernel: 256 threads (one pair at n = 4096, four workgroups and sixteen independent
+// 4-wave barriers per CU).  Measured against 1024-thread workgroups holding four adjacent pairs (one
+// 16-wave barrier domain per CU): 370 us -> see profiles/r03_fft_kernel_stats.csv.  The neighbours that
+// complete a workgroup's 128-byte lines run beside it on the same XCD (block remap below) and meet in its L2.
+template <int N> struct ColsBlock { static constexpr int value = (N / kEPT) >= 256 ? (N / kEPT) : 256; };
 
 template <int R0, int R1, int R2, int R3>
-__global__ void __launch_bounds__(kColsBlock) sspec_cols_kernel(SspecCols a) {
+__global__ void __launch_bounds__(ColsBlock<R0 * R1 * R2 * R3>::value, 4) sspec_cols_kernel(SspecCols a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, SPB = kColsBlock / Tr;
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
     using LS = LastStage<R0, R1, R2, R3>;
     const int i = (int)threadIdx.x / Tr, t = (int)threadIdx.x - i * Tr;
     double* ldsd = reinterpret_cast<double*>(smem_raw) + (size_t)i * lds_pad(n);
@@ -145,7 +191,8 @@ __global__ void __launch_bounds__(kColsBlock) sspec_cols_kernel(SspecCols a) {
         w1 = c0 + 1 < in.nt ? in.wt[c0 + 1] : 0.0;
         w2 = c0 + 2 < in.nt ? in.wt[c0 + 2] : 0.0;
     }
-    const bool aligned = (in.nt & 1) == 0;
+    const double* __restrict__ colp = in.dynp + (int64_t)p * in.nf * 2;        // this pair: [nf][2], contiguous
+    const double* __restrict__ coln = colp + (int64_t)in.nf * 2;                // the next pair (prewhitening stencil)
     cplx v[kEPT];
 #pragma unroll
     for (int q = 0; q < kEPT / R0; ++q) {
@@ -154,29 +201,23 @@ __global__ void __launch_bounds__(kColsBlock) sspec_cols_kernel(SspecCols a) {
             const int s = t + q * Tr + m * (n / R0);          // input row
             cplx z = mk(0.0, 0.0);
             if (active && s < in.nf_eff) {
-                const double* row = in.dyn + (int64_t)s * in.nt + c0;
                 const double f0 = windowed ? in.wf[s] : 1.0;
-                double x0, x1 = 0.0;
-                if (aligned) { const v2d xx = *(const SCINT_GLOBAL v2d*)row; x0 = xx.x; x1 = xx.y; }
-                else { x0 = row[0]; if (c0 + 1 < in.nt) x1 = row[1]; }
-                const double d00 = sspec_d(x0, w0, f0, m1, m2, windowed);
-                const double d01 = sspec_d(x1, w1, f0, m1, m2, windowed);
+                const v2d xx = *(const SCINT_GLOBAL v2d*)(colp + 2 * s);
+                const double d00 = sspec_d(xx.x, w0, f0, m1, m2, windowed);
+                const double d01 = sspec_d(xx.y, w1, f0, m1, m2, windowed);
                 if (!in.prewhite) {
                     z = mk(d00, has1 ? d01 : 0.0);
                 } else {
                     // convolve2d([[1,-1],[-1,1]], d', 'valid')  (dynspec.py:3681): pw[r, c] =
                     // d'[r+1, c+1] - d'[r+1, c] - d'[r, c+1] + d'[r, c], same association as fft.hip
                     const double f1 = windowed ? in.wf[s + 1] : 1.0;
-                    const double* rown = row + in.nt;
-                    double y0, y1 = 0.0;
-                    if (aligned) { const v2d yy = *(const SCINT_GLOBAL v2d*)rown; y0 = yy.x; y1 = yy.y; }
-                    else { y0 = rown[0]; if (c0 + 1 < in.nt) y1 = rown[1]; }
-                    const double d10 = sspec_d(y0, w0, f1, m1, m2, windowed);
-                    const double d11 = sspec_d(y1, w1, f1, m1, m2, windowed);
+                    const v2d yy = *(const SCINT_GLOBAL v2d*)(colp + 2 * (s + 1));
+                    const double d10 = sspec_d(yy.x, w0, f1, m1, m2, windowed);
+                    const double d11 = sspec_d(yy.y, w1, f1, m1, m2, windowed);
                     double zy = 0.0;
                     if (has1) {
-                        const double d02 = sspec_d(row[2], w2, f0, m1, m2, windowed);
-                        const double d12 = sspec_d(rown[2], w2, f1, m1, m2, windowed);
+                        const double d02 = sspec_d(coln[2 * s], w2, f0, m1, m2, windowed);
+                        const double d12 = sspec_d(coln[2 * (s + 1)], w2, f1, m1, m2, windowed);
                         zy = d12 - d11 - d02 + d01;
                     }
                     z = mk(d11 - d10 - d01 + d00, zy);
@@ -186,7 +227,7 @@ __global__ void __launch_bounds__(kColsBlock) sspec_cols_kernel(SspecCols a) {
             v[q * R0 + m] = z;
         }
     }
-    slot_fft<R0, R1, R2, R3, true>(v, ldsd, t, a.tw_n);
+    slot_fft<R0, R1, R2, R3>(v, ldsd, t, a.tw_n);
     // natural order in LDS (real parts, then imaginary parts); thread t separates the two real spectra
     // at m = t + k Tr < n/2 from Z[m] and its partner Z[n - m] (even half) / Z[n - 1 - m] (odd half)
     double are[8], bre[8];
@@ -216,86 +257,119 @@ __global__ void __launch_bounds__(kColsBlock) sspec_cols_kernel(SspecCols a) {
         const int m = t + k * Tr, pm = half ? n - 1 - m : (n - m) & (n - 1);
         const double aim = ldsd[lds_pad(m)], bim = ldsd[lds_pad(pm)];
         // X_c = (Z[k] + conj Z[-k]) / 2,  X_{c+1} = (Z[k] - conj Z[-k]) / (2i)
-        cplx* out = a.Y + (int64_t)(2 * m + half) * a.ldY + c0;
+        // Y in tiles of (4 delay rows of one parity) x (one pair): 128 contiguous bytes from 4 consecutive
+        // threads -- whole lines; row-major Y took 32 bytes per line per workgroup and 146 of the kernel's
+        // 283 us (profiles/r03_sspec_ablation.txt)
+        cplx* out = a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
         gstore(out, mk(0.5 * (are[k] + bre[k]), 0.5 * (aim - bim)));
         gstore(out + 1, mk(0.5 * (aim + bim), -0.5 * (are[k] - bre[k])));
     }
 }
 
 struct SspecRows {
-    const cplx* Y; int ldY; int nt_eff;
+    const cplx* Y; int npairs; int nt_eff;
     int nrows;                    // R/2 kept delay rows
     int C;                        // 2n
     const cplx* tw_n; const cplx* tw_2n;
     double* out;                  // [R/2][C] dB
     int prewhite; const double* pd_fd; const double* pd_td;
+    int xcd_remap;
 };
 
-// KEEP: the 16 inputs of a thread stay in registers for the second half (else they are loaded again).
-template <int R0, int R1, int R2, int R3, bool SPLIT, bool KEEP>
-__global__ void __launch_bounds__((R0 * R1 * R2 * R3 / kEPT) >= 256 ? (R0 * R1 * R2 * R3 / kEPT) : 256)
+// 10 log10(x) for the power of a spectral bin.  The device library's log10 is 135 instructions a value --
+// 4300 of this kernel's 7200 with 32 values per thread, a 115-us floor on 4096^2 by instruction issue alone.
+// Here: x = 2^e m, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s) with s = (m - 1) / (m + 1), |s| <= 0.1716,
+// ten terms of the odd series (truncation 3e-16 absolute); 35 instructions, absolute error a few 1e-15 dB
+// + 2e-16 |result| -- seven orders inside the 1e-8 dB parity tolerance of the path.  Zero, subnormal and
+// non-finite powers are handled by selects (no branch, no library call).
+__device__ inline double ten_log10(double x) {
+    // subnormal powers are scaled into the normal range first; 0 -> -inf, +inf and NaN pass through
+    const bool tiny = x < 2.2250738585072014e-308;
+    const double xn = tiny ? x * 18446744073709551616.0 : x;       // * 2^64
+    const long long bits = __double_as_longlong(xn);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023 - (tiny ? 64 : 0);
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = r * (2.0 - den * r);
+    r = r * (2.0 - den * r);
+    double s = num * r;
+    s = s + r * (num - den * s);                 // s = num / den to the last bit or two
+    const double z = s * s;
+    // 2 (1 + z/3 + z^2/5 + ... + z^9/19) * 10 / ln 10
+    constexpr double k = 8.6858896380650365530225783783321;   // 20 / ln 10
+    double p = k / 19.0;
+    p = p * z + k / 17.0; p = p * z + k / 15.0; p = p * z + k / 13.0; p = p * z + k / 11.0;
+    p = p * z + k / 9.0;  p = p * z + k / 7.0;  p = p * z + k / 5.0;  p = p * z + k / 3.0;
+    p = p * z + k;
+    double res = (double)e * 3.0102999566398119521373889472449 + s * p;   // e * 10 log10 2 + 10 log10 m
+    if (x == 0.0) res = -INFINITY;
+    if (!(x < INFINITY)) res = x;                // +inf, NaN
+    return res;
+}
+
+// One (delay row, half) per slot: the even Doppler bins come from the transform of the row, the odd ones
+// from the transform of the row times W_2n^s.  The two halves of a row are separate slots that run side by
+// side on one XCD (block remap), each stores its bins as 8-byte values 16 bytes apart.  Measured at 4096^2
+// (profiles/r03_sspec_ablation.txt): both halves in one workgroup with the first half's powers held in
+// registers spills at any occupancy worth having (434 us with 68 KiB of LDS and two workgroups per CU);
+// both halves in sequence, each storing as soon as it has its bins, 313 us; side by side 255 us.  The
+// instruction floor of the kernel is 136 us (no loads, no stores).
+template <int R0, int R1, int R2, int R3>
+__global__ void __launch_bounds__((R0 * R1 * R2 * R3 / kEPT) >= 256 ? (R0 * R1 * R2 * R3 / kEPT) : 256, 3)   // three waves per SIMD: 168 registers, no spills (41 spilled at 128)
 sspec_rows_kernel(SspecRows a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
     using LS = LastStage<R0, R1, R2, R3>;
     const int i = (int)threadIdx.x / Tr, t = (int)threadIdx.x - i * Tr;
     const int spb = (int)blockDim.x / Tr;
-    const int k1 = (int)blockIdx.x * spb + i;
+    int lb = (int)blockIdx.x;
+    if (a.xcd_remap) lb = (lb & 7) * ((int)gridDim.x >> 3) + (lb >> 3);
+    const int slot = lb * spb + i;
+    const int k1 = slot >> 1, half = slot & 1;
     const bool active = k1 < a.nrows;
-    void* lds = SPLIT ? (void*)(reinterpret_cast<double*>(smem_raw) + (size_t)i * lds_pad(n))
-                      : (void*)(reinterpret_cast<cplx*>(smem_raw) + (size_t)i * lds_pad(n));
-    const cplx* __restrict__ row = a.Y + (int64_t)(active ? k1 : 0) * a.ldY;
-    cplx x[KEEP ? kEPT : 1];
-    double pe[kEPT];
+    double* lds = reinterpret_cast<double*>(smem_raw) + (size_t)i * lds_pad(n);
+    // row k1 = 2 m + h of the tiled intermediate: element c at tile (m >> 2, c >> 1), slot h, m & 3, c & 1
+    const int kk = active ? k1 : 0;
+    const cplx* __restrict__ row = a.Y + (int64_t)(kk >> 3) * a.npairs * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2;
+    const double td = (a.prewhite && active) ? a.pd_td[k1] : 1.0;
+    double* __restrict__ orow = a.out + (int64_t)kk * a.C;
+    cplx v[kEPT];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        cplx v[kEPT];
+    for (int q = 0; q < kEPT / R0; ++q) {
 #pragma unroll
-        for (int q = 0; q < kEPT / R0; ++q) {
-#pragma unroll
-            for (int m = 0; m < R0; ++m) {
-                const int s = t + q * Tr + m * (n / R0);
-                cplx z;
-                if (KEEP && half == 1) z = x[KEEP ? q * R0 + m : 0];
-                else z = (active && s < a.nt_eff) ? gload(row + s) : mk(0.0, 0.0);
-                if (KEEP && half == 0) x[KEEP ? q * R0 + m : 0] = z;
-                if (half == 1) z = z * a.tw_2n[s];
-                v[q * R0 + m] = z;
-            }
+        for (int m = 0; m < R0; ++m) {
+            const int s = t + q * Tr + m * (n / R0);
+            cplx z = (active && s < a.nt_eff) ? gload(row + (s >> 1) * 16 + (s & 1)) : mk(0.0, 0.0);
+            if (half) z = z * a.tw_2n[s];
+            v[q * R0 + m] = z;
         }
-        slot_fft<R0, R1, R2, R3, SPLIT>(v, lds, t, a.tw_n);
-        if (half == 0) {
+    }
+    slot_fft<R0, R1, R2, R3>(v, lds, t, a.tw_n);
+    if (!active) return;
 #pragma unroll
-            for (int e = 0; e < kEPT; ++e) pe[e] = v[e].x * v[e].x + v[e].y * v[e].y;
-            __syncthreads();      // the first half's last exchange is read before the second half's first one writes
-        } else if (active) {
-            const double td = a.prewhite ? a.pd_td[k1] : 1.0;
-            double* __restrict__ orow = a.out + (int64_t)k1 * a.C;
+    for (int q = 0; q < kEPT / LS::RL; ++q) {
 #pragma unroll
-            for (int q = 0; q < kEPT / LS::RL; ++q) {
-#pragma unroll
-                for (int m = 0; m < LS::RL; ++m) {
-                    const int e = q * LS::RL + m;
-                    const int mm = stockham_out_index<LS::RL>(t, Tr, LS::Ns, q, m);
-                    // Doppler bins 2 mm and 2 mm + 1 at their fftshift-ed place (dynspec.py:3687); C/2 is even
-                    const int col = (2 * mm + n) & (a.C - 1);
-                    double p0 = pe[e], p1 = v[e].x * v[e].x + v[e].y * v[e].y;
-                    if (a.prewhite) {   // post-darkening, column C/2 and row 0 forced to 1 (dynspec.py:3704-3717)
-                        const double d0 = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
-                        const double d1 = (k1 == 0) ? 1.0 : a.pd_fd[col + 1] * td;
-                        p0 = p0 / d0; p1 = p1 / d1;
-                    }
-                    v2d o; o.x = 10.0 * log10(p0); o.y = 10.0 * log10(p1);
-                    __builtin_nontemporal_store(o, (SCINT_GLOBAL v2d*)(orow + col));
-                }
+        for (int m = 0; m < LS::RL; ++m) {
+            const int e = q * LS::RL + m;
+            const int mm = stockham_out_index<LS::RL>(t, Tr, LS::Ns, q, m);
+            // Doppler bin 2 mm + half at its fftshift-ed place (dynspec.py:3687); C/2 = n is even
+            const int col = ((2 * mm + n) & (a.C - 1)) + half;
+            double p = v[e].x * v[e].x + v[e].y * v[e].y;
+            if (a.prewhite) {   // post-darkening, column C/2 and row 0 forced to 1 (dynspec.py:3704-3717)
+                const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
+                p = p / d;
             }
+            __builtin_nontemporal_store(ten_log10(p), (SCINT_GLOBAL double*)(orow + col));
+            __builtin_amdgcn_sched_barrier(0);   // one bin at a time: sixteen interleaved log sequences spill
         }
     }
 }
 
 template <int R0, int R1, int R2, int R3>
 static int32_t launch_cols(const SspecCols& a, hipStream_t stream) {
-    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, SPB = kColsBlock / Tr;
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
     const int tiles = (int)ceil_div(a.npairs, SPB), grid = 2 * tiles;
     SspecCols b = a;
     b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
@@ -311,23 +385,15 @@ template <int R0, int R1, int R2, int R3>
 static int32_t launch_rows(const SspecRows& a, hipStream_t stream) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
     const int block = Tr >= 256 ? Tr : 256, spb = block / Tr;
-    const int grid = (int)ceil_div(a.nrows, spb);
-    // n <= 4096: the whole transform in LDS as complex values (68 KiB at 4096: two workgroups per CU, 256
-    // registers each -- the inputs stay in registers for the second half); 8192: real / imaginary parts
-    // in turn (68 KiB), inputs loaded again
-    if constexpr (n <= 4096) {
-        const size_t lds = (size_t)spb * (size_t)(n + n / 16) * sizeof(cplx);
-        auto k = sspec_rows_kernel<R0, R1, R2, R3, false, true>;
-        if (lds > 64 * 1024)
-            SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
-    } else {
-        const size_t lds = (size_t)spb * (size_t)(n + n / 16) * sizeof(double);
-        auto k = sspec_rows_kernel<R0, R1, R2, R3, true, false>;
-        if (lds > 64 * 1024)
-            SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, a);
-    }
+    SspecRows b = a;
+    const int grid = (int)ceil_div((int64_t)a.nrows * 2, spb);
+    b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+    // real / imaginary parts take turns in LDS (34 KiB per slot at n = 4096: three workgroups per CU)
+    const size_t lds = (size_t)spb * (size_t)(n + n / 16) * sizeof(double);
+    auto k = sspec_rows_kernel<R0, R1, R2, R3>;
+    if (lds > 64 * 1024)
+        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, b);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
@@ -359,13 +425,24 @@ bool sspec_fast_supported(int64_t nf, int64_t nt, int32_t halve) {
     return nr >= 256 && nr <= 8192 && nc >= 256 && nc <= 8192;
 }
 
-size_t sspec_fast_workspace(int64_t nf, int64_t nt) {
-    const int64_t nr = next_pow2(nf);
-    return align_up(sizeof(cplx) * (size_t)nr * (size_t)(2 * ceil_div(nt, 2)), 256);
+struct SspecWs { size_t Y, dynp, partial, scal, total; int tiles_x, tiles_y; };
+static SspecWs sspec_ws(int64_t nf, int64_t nt) {
+    SspecWs w;
+    const int64_t nr = next_pow2(nf), ntp = 2 * ceil_div(nt, 2);
+    w.tiles_x = (int)ceil_div(nt, 64); w.tiles_y = (int)ceil_div(nf, 64);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); const size_t o = off; off += bytes; return o; };
+    w.Y = take(sizeof(cplx) * (size_t)nr * (size_t)ntp);
+    w.dynp = take(sizeof(double) * (size_t)ntp * (size_t)nf);
+    w.partial = take(sizeof(double) * 3 * (size_t)w.tiles_x * (size_t)w.tiles_y);
+    w.scal = take(sizeof(double) * 8);
+    w.total = align_up(off, 256);
+    return w;
 }
+size_t sspec_fast_workspace(int64_t nf, int64_t nt) { return sspec_ws(nf, nt).total; }
 
 int32_t sspec_fast(const double* dyn, int64_t nf, int64_t nt, const double* win_t, const double* win_f,
-                   const double* scal, int32_t prewhite, const double* pd_fd, const double* pd_td,
+                   int32_t prewhite, const double* pd_fd, const double* pd_td,
                    double* sec_out, void* workspace, hipStream_t stream) {
     const int64_t nr = next_pow2(nf), nc = next_pow2(nt);
     const int64_t nf_eff = prewhite ? nf - 1 : nf, nt_eff = prewhite ? nt - 1 : nt;
@@ -374,15 +451,25 @@ int32_t sspec_fast(const double* dyn, int64_t nf, int64_t nt, const double* win_
     const cplx* tw_c = twiddle_table(nc);
     const cplx* tw_2c = twiddle_table(2 * nc);
     if (!tw_r || !tw_2r || !tw_c || !tw_2c) return SCINT_E_HIP;
+    const SspecWs ws = sspec_ws(nf, nt);
+    char* base = (char*)workspace;
+    double* dynp = (double*)(base + ws.dynp);
+    double* partial = (double*)(base + ws.partial);
+    double* scal = (double*)(base + ws.scal);
+    hipLaunchKernelGGL(sspec_prep_kernel, dim3((unsigned)ws.tiles_x, (unsigned)ws.tiles_y), dim3(256), 0, stream, dyn, win_t,
+                       win_f, (int)nf, (int)nt, dynp, partial);
+    hipLaunchKernelGGL(sspec_prep_means_kernel, dim3(1), dim3(256), 0, stream, partial, ws.tiles_x * ws.tiles_y,
+                       (double)(nf * nt), scal);
+    SCINT_LAUNCH_CHECK();
     SspecCols ca{};
-    ca.in = SspecIn{dyn, win_t, win_f, scal, (int)nf, (int)nt, (int)nf_eff, (int)nt_eff, prewhite};
+    ca.in = SspecIn{dynp, win_t, win_f, scal, (int)nf, (int)nt, (int)nf_eff, (int)nt_eff, prewhite};
     ca.npairs = (int)ceil_div(nt_eff, 2);
-    ca.Y = (cplx*)workspace; ca.ldY = 2 * ca.npairs;
+    ca.Y = (cplx*)(base + ws.Y); ca.ldY = 2 * ca.npairs;
     ca.tw_n = tw_r; ca.tw_2n = tw_2r;
     int32_t rc = dispatch_cols(nr, ca, stream);
     if (rc != SCINT_OK) return rc;
     SspecRows ra{};
-    ra.Y = ca.Y; ra.ldY = ca.ldY; ra.nt_eff = (int)nt_eff; ra.nrows = (int)nr; ra.C = (int)(2 * nc);
+    ra.Y = ca.Y; ra.npairs = ca.npairs; ra.nt_eff = (int)nt_eff; ra.nrows = (int)nr; ra.C = (int)(2 * nc);
     ra.tw_n = tw_c; ra.tw_2n = tw_2c; ra.out = sec_out;
     ra.prewhite = prewhite; ra.pd_fd = pd_fd; ra.pd_td = pd_td;
     return dispatch_rows(nc, ra, stream);

@@ -60,6 +60,8 @@ def _stage_sources():
         text = re.sub(r"\bextern\s+__shared__", "extern", text)
         # the LDS-only barrier (inline assembly, common.hpp) is a plain barrier on the interpreter
         text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)\\n\\ts_barrier" ::: "memory"\);', "__syncthreads();", text)
+        # optimisation fences on a register (no instruction): nothing to interpret
+        text = re.sub(r'asm volatile\("" : "\+v"\((\w+)\)\);', "", text)
         # the in-wave LDS hand-off: every lane of the wave must have stored before any lane loads
         text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', "(void)__shfl(0, 0, 64);", text)
         dst = os.path.join(src_out, name.replace(".hip", ".hip.cpp"))

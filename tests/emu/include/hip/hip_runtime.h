@@ -171,6 +171,7 @@ inline int emu_update_dpp(int v, int ctrl) {
 }
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rmask, bmask, bctl) emu_update_dpp((v), (ctrl))
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)     // instruction scheduling only
+#define __builtin_amdgcn_rcp(x) (1.0 / (x))                 // v_rcp_f64: an approximation on the GPU, refined by its callers
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
 

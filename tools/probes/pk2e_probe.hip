@@ -4,6 +4,8 @@
 // 3 GiB buffer).  Variants:
 //   bit 0  column partial store each tile (else accumulated into a sink)
 //   bit 3  column partials into the consumed X_J slots in LDS, one coalesced burst at the end of the strip
+//   bit 4  (with bit 3) the burst as non-temporal stores;  bit 5  (with bit 3) the burst into one 32-KiB region
+//          shared by all workgroups (stays in L2: the cost of issuing the stores without their HBM traffic)
 //   bit 1  three workgroups per CU (launch bound 3, 48 KiB LDS) instead of two
 //   bit 2  x_J from registers re-read per half (shorter live ranges)
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/pk2e_probe.hip -o /tmp/pk2e_probe && /tmp/pk2e_probe [reps]
@@ -20,6 +22,7 @@ __device__ inline cplx operator*(cplx a, cplx b) { return mk(a.x * b.x - a.y * b
 __device__ inline cplx gl(const cplx* p) { const v2d v = *(const GLOBAL v2d*)p; return mk(v.x, v.y); }
 __device__ inline cplx glnt(const cplx* p) { const v2d v = __builtin_nontemporal_load((const GLOBAL v2d*)p); return mk(v.x, v.y); }
 __device__ inline void gs(cplx* p, cplx v) { v2d t; t.x = v.x; t.y = v.y; *(GLOBAL v2d*)p = t; }
+__device__ inline void gsnt(cplx* p, cplx v) { v2d t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, (GLOBAL v2d*)p); }
 __device__ inline void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int kTB = 64, kTileElems = 4096, kStrip = 16;
@@ -113,7 +116,10 @@ probe_kernel(const cplx* __restrict__ tiles, const cplx* __restrict__ vec, cplx*
         tile_end(c1, c2, t);
     }
     __syncthreads();
-    if (F & 8) for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gs(colpart + (size_t)blockIdx.x * ntile * 2 * kTB + idx, lds[idx]);
+    if (F & 8) for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) {
+        cplx* dst = colpart + ((F & 32) ? 0 : (size_t)((F & 64) ? blockIdx.x % 512 : (F & 128) ? blockIdx.x % 2048 : blockIdx.x) * ntile * 2 * kTB) + idx;
+        if (F & 16) gsnt(dst, lds[idx]); else gs(dst, lds[idx]);
+    }
     __syncthreads();
     cplx* __restrict__ red = lds + w * 576;
     cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 2560);
@@ -177,8 +183,10 @@ int main(int argc, char** argv) {
     run<8>(buf, bytes, vec, colpart, rowpart, 16, "column partials through LDS, one burst per strip");
     run<8>(buf, bytes, vec, colpart, rowpart, 8, "column partials through LDS, one burst per strip");
     run<8>(buf, bytes, vec, colpart, rowpart, 4, "column partials through LDS, one burst per strip");
-    run<5>(buf, bytes, vec, colpart, rowpart, 16, "x_J re-read per half");
+    run<8 + 16>(buf, bytes, vec, colpart, rowpart, 16, "... as non-temporal stores");
+    run<8 + 32>(buf, bytes, vec, colpart, rowpart, 16, "... into one L2-resident region");
+    run<8 + 64>(buf, bytes, vec, colpart, rowpart, 16, "... into a 16 MB ring (512 regions)");
+    run<8 + 128>(buf, bytes, vec, colpart, rowpart, 16, "... into a 64 MB ring (2048 regions)");
     run<3>(buf, bytes, vec, colpart, rowpart, 16, "three workgroups per CU");
-    run<7>(buf, bytes, vec, colpart, rowpart, 16, "three workgroups per CU, x_J re-read");
     return 0;
 }
