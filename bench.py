@@ -11,11 +11,18 @@ BASELINE.json configs[2], the configuration the metric is quoted on.
 
 Multi-GPU: one rank per GPU over RCCL.  The driver launches the ranks with
 torch.distributed.run; `python bench.py --gpus N` with no WORLD_SIZE in the environment
-launches them itself (same command line).  The path shards by observation -- every rank
-sweeps its own observation(s) and the eigenvalue curves are all-gathered at the end of each
-step (the only collective).  Default: per-GPU work fixed (weak scaling); `--obs-total T`
-(BASELINE config 4: `--size 2048 --obs-total 64`) deals T observations round-robin to the
-ranks instead (strong scaling).  `value` is the whole-job eta-points/s.
+launches them itself (same command line).  Three partitionings, none with a data-path collective
+(the eigenvalue curves are all-gathered at the end of each step, the only collective):
+  default           one observation per GPU (per-GPU work fixed: weak scaling);
+  --shard eta       ONE observation, its eta range in contiguous blocks over the ranks
+                    (sweep.sharded_eval_sweep; the reference's pool.map pattern, dynspec.py:1706-1723;
+                    total work fixed: strong scaling) -- every rank FFTs the same dynspec locally;
+  --obs-total T     T observations dealt round-robin (BASELINE config 4: `--size 2048 --obs-total 64`;
+                    strong scaling).
+`value` is the whole-job eta-points/s.  For N > 1 the line proves itself: `config.ranks_seen` is
+dist.get_world_size(), `config.backend` the transport, `config.per_rank_eta_per_s` the slowest / fastest
+rank's own rate, and with --shard eta `config.gathered_equals_one_gpu` says whether the gathered curve is
+bit-identical to rank 0 sweeping all curvatures alone (checked after the timed region).
 
 Besides the contract fields the JSON line carries
   roofline      the dominant kernel (eigen mat-vec on the Hermitian tile-packed matrix):
@@ -28,7 +35,9 @@ Besides the contract fields the JSON line carries
                 chisq_calc sweep over the same 256 curvatures, timed after the headline region,
                 with one curvature checked against the oracle's chisq_calc;
   cpu_baseline  (N=1) the NumPy/SciPy oracle (a restatement of the reference) timed on this
-                host: a 3-eta sample as shipped, and eta-parallel over a process pool.
+                host by SURVEY.md 8d's protocol: the conjugate-spectrum FFT plus a 16-eta subset spanning
+                the sweep, median of 3 repetitions, scaled to the 256-eta sweep; and eta-parallel over a
+                process pool.  A floor for context, not the target.
 """
 import argparse
 import ctypes
@@ -76,6 +85,9 @@ def parse():
     ap.add_argument("--obs-total", type=int, default=0,
                     help="total observations per step, dealt round-robin to the ranks (strong scaling; "
                          "BASELINE config 4: --size 2048 --obs-total 64)")
+    ap.add_argument("--shard", choices=["obs", "eta"], default="obs",
+                    help="multi-GPU partitioning: obs = whole observations per rank (default); eta = ONE observation, "
+                         "contiguous eta blocks per rank (sweep.sharded_eval_sweep, strong scaling)")
     ap.add_argument("--objective", choices=["eig", "chisq"], default="eig",
                     help="objective of the headline timed region: eig = Eval_calc sweep of single_search; "
                          "chisq = modeler/chisq_calc sweep")
@@ -87,7 +99,8 @@ def parse():
                          "of the analytic arc -- e.g. a reference-Simulation screen written by "
                          "tests/tools/make_sim_input.py; --size must match")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=3, help="etas timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="etas timed on the CPU oracle (spread over the sweep)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU sample (the median is reported)")
     ap.add_argument("--cpu-pool", type=int, default=-1,
                     help="workers of the eta-parallel oracle baseline (multiprocessing.Pool, one BLAS thread "
                          "each: how a user parallelises the reference, dynspec.py:1715-1719); -1 = every "
@@ -144,19 +157,32 @@ def blas_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(dyn, tau, fd, edges, etas, nsample, npad=0):
-    """Oracle (port of the reference) on a bounded sample: `nsample` curvatures spread over
-    the sweep; the FFT is done once and not counted (it is amortised over 256 etas)."""
+def cpu_baseline(dyn, tau, fd, edges, etas, nsample, npad=0, reps=3):
+    """Oracle (port of the reference) by SURVEY.md 8d's protocol: one repetition = the conjugate-spectrum
+    FFT (ththmod.py:777-787) + Eval_calc on `nsample` curvatures spread over the sweep; `reps` repetitions,
+    the median is kept; the sweep rate is neta / (t_fft + neta * t_eta) with the per-eta time of the sample."""
     from oracle import thth_oracle
-    CS = thth_oracle.conjugate_spectrum(dyn, npad)
     idx = np.unique(np.linspace(0, len(etas) - 1, nsample + 2).astype(int)[1:-1])
-    t0 = time.perf_counter()
-    vals = [thth_oracle.Eval_calc(CS, tau, fd, etas[i], edges) for i in idx]
-    dt = time.perf_counter() - t0
-    return {"value": len(idx) / dt, "unit": "eta-points/s", "cores": int(blas_threads()), "kind": "port",
-            "sample": f"oracle Eval_calc (NumPy gather + ARPACK eigsh) on {len(idx)} of {len(etas)} etas "
-                      f"(indices {idx.tolist()}) of the same {dyn.shape[0]}x{dyn.shape[1]} workload, "
-                      f"{dt:.1f} s; one process, BLAS threads as shipped; CS FFT excluded"}, dict(zip(idx.tolist(), vals))
+    runs, vals = [], None
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        CS = thth_oracle.conjugate_spectrum(dyn, npad)
+        t1 = time.perf_counter()
+        vals = [thth_oracle.Eval_calc(CS, tau, fd, etas[i], edges) for i in idx]
+        t2 = time.perf_counter()
+        runs.append((t1 - t0, t2 - t1))
+    runs.sort(key=lambda r: r[0] + r[1])
+    t_fft, t_eta = runs[len(runs) // 2]
+    per_eta = t_eta / len(idx)
+    sweep_s = t_fft + len(etas) * per_eta
+    return {"value": len(etas) / sweep_s, "unit": "eta-points/s", "cores": int(blas_threads()), "kind": "port",
+            "host_cores": os.cpu_count(),
+            "sample": f"oracle CS FFT + Eval_calc (NumPy gather + ARPACK eigsh) on {len(idx)} of {len(etas)} etas "
+                      f"(indices {idx.tolist()}) of the same {dyn.shape[0]}x{dyn.shape[1]} workload; median of "
+                      f"{len(runs)} repetitions: FFT {t_fft:.2f} s + {per_eta:.2f} s per eta, scaled to the "
+                      f"{len(etas)}-eta sweep ({sweep_s:.0f} s); one process, {int(blas_threads())} BLAS threads "
+                      f"(as shipped) on a {os.cpu_count()}-core host",
+            "repetitions_s": [round(a + b, 2) for a, b in runs]}, dict(zip(idx.tolist(), vals))
 
 
 def _pool_worker(job):
@@ -302,13 +328,18 @@ def main():
 
     size, neta = args.size, args.neta
     nedge = args.nedge or size
-    if args.obs_total > 0:
+    shard_eta = args.shard == "eta"
+    if shard_eta and (args.obs_total > 0 or args.obs != 1 or args.objective != "eig"):
+        raise SystemExit("--shard eta splits the eigenvalue sweep of ONE observation: not with --obs / --obs-total / chisq")
+    if shard_eta:
+        obs_ids, n_obs_job, scaling = [0], 1, "strong"        # every rank holds the same observation
+    elif args.obs_total > 0:
         obs_ids = list(range(rank, args.obs_total, world))       # round-robin (dynspec.py:1706-1723 is the pattern)
         n_obs_job, scaling = args.obs_total, "strong"
     else:
         obs_ids = [rank * args.obs + k for k in range(args.obs)]
         n_obs_job, scaling = world * args.obs, "weak"
-    per_rank_max = -(-n_obs_job // world)
+    per_rank_max = 1 if shard_eta else -(-n_obs_job // world)
     dyn, freqs, times, fd, tau, edges, etas, eta_true = make_workload(size, neta, nedge, seed=3, npad=args.npad,
                                                                       npz=args.dyn_npz)
     dyns = []
@@ -329,6 +360,13 @@ def main():
                 cs_t = ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True)
                 curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
                 fit = (etas[np.nanargmin(curves[k])], np.nan, None)
+        elif shard_eta:
+            # ONE observation, this rank's contiguous block of curvatures; the all-gather is inside
+            from scintools_amd import sweep
+            cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
+            curves[0], info = sweep.sharded_eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
+            fit = ththmod.fit_eig_peak(etas, curves[0], 0.1)
+            return curves, info, fit
         elif len(dyns) == 1:
             cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
             curves[0], info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
@@ -356,9 +394,11 @@ def main():
         lib.scint_profile_begin()
         t0 = time.perf_counter()
         mv_bytes = 0.0
+        local_etas = 0
         for _ in range(steps):
             curves, info, fit = step(objective)
             if info is not None:
+                local_etas += int(info["N"].shape[0])
                 n_ = info["N"].astype(float)
                 mv_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"]))   # Hermitian: upper triangle once
         torch.cuda.synchronize()
@@ -369,14 +409,26 @@ def main():
         ms_sum = (ctypes.c_double * 2)()    # plain sum of the individual launch spans
         launches = (ctypes.c_int64 * 2)()
         lib.scint_profile_end(ms, ms_sum, launches)
+        rank_rates = [local_etas / elapsed]
         if world > 1:
+            # every rank's own rate (its curvatures / its wall time between the two barriers), then the MAX time
+            rr = [torch.zeros(1, dtype=torch.float64, device=comm_dev) for _ in range(world)]
+            dist.all_gather(rr, torch.tensor([local_etas / elapsed], dtype=torch.float64, device=comm_dev))
+            rank_rates = [float(x.item()) for x in rr]
             tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return dict(elapsed=elapsed, curves=curves, info=info, fit=fit, mv_bytes=mv_bytes,
+        return dict(elapsed=elapsed, curves=curves, info=info, fit=fit, mv_bytes=mv_bytes, rank_rates=rank_rates,
                     busy_ms=list(ms), sum_ms=list(ms_sum), launches=list(launches))
 
     head = timed(args.objective, args.steps, args.warmup)
+
+    gathered_equal = None
+    if shard_eta and world > 1 and rank == 0:
+        # outside the timed region: rank 0 sweeps ALL curvatures alone; the gathered curve must be the same bits
+        cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
+        alone = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch)
+        gathered_equal = bool(np.array_equal(alone, head["curves"][0], equal_nan=True))
 
     if rank == 0:
         elapsed, info, fit = head["elapsed"], head["info"], head["fit"]
@@ -394,7 +446,7 @@ def main():
                 else "modeler/chisq_calc sweep")
         out = {
             "metric": "eta_curvature_sweep_points_per_sec",
-            "value": n_obs_job * neta * args.steps / elapsed,
+            "value": n_obs_job * neta * args.steps / elapsed,     # --shard eta: one observation's 256 eta, whoever computed them
             "unit": "eta-points/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -406,10 +458,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not args.dyn_npz else f"synthetic ({os.path.basename(args.dyn_npz)})",
             "config": {"workload": f"{size}x{size} dynspec, {neta}-eta {what}, nedge={nedge}, npad={args.npad}, "
-                                   + (f"{args.obs_total} observations dealt round-robin to the GPUs"
+                                   + ("ONE observation, contiguous eta blocks per GPU (sweep.sharded_eval_sweep)" if shard_eta
+                                      else f"{args.obs_total} observations dealt round-robin to the GPUs"
                                       if args.obs_total > 0 else f"{args.obs} observation(s) per GPU"),
                        "observations_per_step": n_obs_job, "ranks_per_gpu": ranks_per_gpu,
-                       "collective": f"all_gather of float64 [{per_rank_max}, {neta}] per rank per step ({backend})"
+                       "shard": args.shard, "ranks_seen": int(dist.get_world_size()) if world > 1 else 1,
+                       "backend": backend if world > 1 else None,
+                       "per_rank_eta_per_s": {"min": min(head["rank_rates"]), "max": max(head["rank_rates"])},
+                       "gathered_equals_one_gpu": gathered_equal,
+                       "collective": (f"all_gather of float64 [{-(-neta // world)}] per rank per step ({backend})" if shard_eta else
+                                      f"all_gather of float64 [{per_rank_max}, {neta}] per rank per step ({backend})")
                        if world > 1 else None,
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
@@ -457,7 +515,7 @@ def main():
         if world == 1 and args.objective == "eig" and msteps > 0:
             out["sspec"] = sspec_timing(torch, size)
         if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
-            cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad)
+            cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad, args.cpu_reps)
             out["cpu_baseline"] = cb
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(
                 max(abs(eigs[i] - v) / abs(v) for i, v in ref_vals.items()))

@@ -899,8 +899,42 @@ struct RealPairStore {
 };
 
 // out[r * ld + c] = real(ifft2(ifftshift(recov)))[r, c] for r < crop_r, c < crop_c; recov is [R][C].
+// The same last pass with chi^2 as its sink (ththmod.py:330-368, chi^2 sweep): sum over the cropped corner of
+// (model - dspec)^2 where the pixel counts (mask, or finite dspec as ChisqValue below), the model never stored --
+// saves its 8 crop_r crop_c bytes out and back in, and a kernel, per curvature.
+struct RealPairChisq {
+    static constexpr bool kPair = false;
+    static constexpr bool kReduce = true;
+    const double* dspec; const uint8_t* mask; int ld, crop_r, crop_c; double scale; double* partial;
+    struct Slot {
+        const double* da; const double* db; const uint8_t* ma; const uint8_t* mb; int crop_c; double scale;
+        __device__ static inline double term(double model, double d, const uint8_t* m) {
+            const bool use = m ? (*m != 0) : isfinite(d);
+            if (!use) return 0.0;
+            const double e = model - d;
+            return e * e;
+        }
+        __device__ inline void operator()(int k, cplx v, double& acc) const {
+            if (k >= crop_c) return;
+            if (da) acc += term(v.x * scale, da[k], ma ? ma + k : nullptr);
+            if (db) acc += term(v.y * scale, db[k], mb ? mb + k : nullptr);
+        }
+    };
+    __device__ inline Slot open(int64_t s) const {
+        const int a = 2 * (int)s;
+        const bool ha = a < crop_r, hb = a + 1 < crop_r;
+        return Slot{ha ? dspec + (int64_t)a * ld : nullptr, hb ? dspec + (int64_t)(a + 1) * ld : nullptr,
+                    (ha && mask) ? mask + (int64_t)a * ld : nullptr, (hb && mask) ? mask + (int64_t)(a + 1) * ld : nullptr,
+                    crop_c, scale};
+    }
+};
+
+// `fuse` (optional): chi^2 against fuse->dspec instead of storing the model; *fuse_blocks = partial sums written
+// to fuse->partial.  Only the power-of-two path fuses (returns with *fuse_blocks = 0 otherwise: model in `out`).
 static int32_t model_from_recov(const cplx* recov, int64_t R, int64_t C, double* out, int64_t ld, int64_t crop_r,
-                                int64_t crop_c, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                int64_t crop_c, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                                const RealPairChisq* fuse = nullptr, int* fuse_blocks = nullptr) {
+    if (fuse_blocks) *fuse_blocks = 0;
     const double scale = 1.0 / ((double)R * (double)C);
     if (!(is_pow2(R) && is_pow2(C) && R >= 2 && C >= 32 && C <= 8192)) {
         // other shapes: the general complex transform (chirp-z where needed), real part at the sink
@@ -929,6 +963,14 @@ static int32_t model_from_recov(const cplx* recov, int64_t R, int64_t C, double*
     int32_t rc = run_cols_fft(R, Ch, 1, ModelSymSource{recov, (int)R, (int)C}, mid_ld, mid_st, last, stream);
     if (rc != SCINT_OK) return rc;
     const int64_t rows_out = std::min<int64_t>(crop_r, R);
+    if (fuse && fuse_blocks) {
+        RealPairChisq st = *fuse;
+        st.ld = (int)ld; st.crop_r = (int)crop_r; st.crop_c = (int)crop_c; st.scale = scale;
+        // one slot per workgroup for C >= 4096 (256 threads per transform), several below: the launcher's rule
+        const int tps = (int)(C / kEPT), min_block = C <= 128 ? 128 : 256, block = tps >= min_block ? tps : min_block;
+        *fuse_blocks = (int)ceil_div((rows_out + 1) / 2, block / tps);
+        return launch_fft_rows<5, 13>(C, (rows_out + 1) / 2, HermPairLoad{half, ChL, (int)C}, st, stream);
+    }
     return launch_fft_rows<5, 13>(C, (rows_out + 1) / 2, HermPairLoad{half, ChL, (int)C},
                            RealPairStore{out, (int)ld, (int)crop_r, (int)crop_c, scale}, stream);
 }
@@ -1261,6 +1303,7 @@ __global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in
 // dspec^T): ifft2 commutes with the transpose, and a back-map workgroup owns one Doppler column
 // of recov, which is one contiguous row of recov^T -- coalesced stores instead of 16-B stores
 // 16 nfd bytes apart.
+constexpr int kChisqPartials = 8192;   // per-workgroup chi^2 sums of the fused model step (one per two output rows, at most)
 struct ChisqTail : SweepTail {
     GeomDev g; const int32_t* keep_n; const double* etas;
     const cplx* vec; int64_t vstride; const double* w; const double* th_red; int64_t M;
@@ -1277,8 +1320,16 @@ struct ChisqTail : SweepTail {
         int32_t rc = launch_rev_map_rank1(vec + e * vstride, w + e, th_red + e * M, n, g, etas[e], recovT, true,
                                           rev_scratch, tail);
         if (rc != SCINT_OK) return rc;
-        rc = model_from_recov(recovT, g.nfd, g.ntau, modelT, nf, nt, nf, fft_ws, fft_ws_bytes, tail);
+        RealPairChisq fuse{}; fuse.dspec = dspecT; fuse.mask = maskT; fuse.partial = partial;
+        int nblk = 0;
+        rc = model_from_recov(recovT, g.nfd, g.ntau, modelT, nf, nt, nf, fft_ws, fft_ws_bytes, tail,
+                              nt <= 2 * (int64_t)kChisqPartials ? &fuse : nullptr, &nblk);
         if (rc != SCINT_OK) return rc;
+        if (nblk > 0) {     // chi^2 came out of the model transform's last pass: add its per-workgroup sums in order
+            hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, tail, partial, nblk, 1.0 / noise_n, chisq_out + e);
+            SCINT_LAUNCH_CHECK();
+            return SCINT_OK;
+        }
         return launch_reduce2d(ChisqValue{modelT, nf, dspecT, nf, maskT}, nt, nf, 1.0 / noise_n, partial, chisq_out + e, tail);
     }
 };
@@ -1297,7 +1348,7 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
         L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
         L->model[l] = take(sizeof(double) * (size_t)nf * (size_t)nt);
         L->fft[l] = take(L->fft_bytes);
-        L->partial[l] = take(sizeof(double) * (kRedBlocks + 8));
+        L->partial[l] = take(sizeof(double) * (kChisqPartials + 8));
         L->rev[l] = take(256);
     }
     int32_t rc = sweep_workspace_bytes(M, neta, batch, max_iter, true, 1, &L->sweep_bytes);

@@ -171,6 +171,12 @@ __device__ inline int stockham_out_index(int t, int Tr, int Ns, int q, int m) {
     return (j / Ns) * Ns * R + (j & (Ns - 1)) + m * Ns;
 }
 
+// A storer may REDUCE instead of (or besides) storing: it declares `static constexpr bool kReduce = true`, its
+// slot accessor takes a running sum -- sx(index, value, acc) -- and the kernel leaves the workgroup's total
+// (fixed order: lanes, then waves) in st.partial[blockIdx.x]; the caller adds the partials in order.
+template <class S, class = void> struct IsReducing : std::false_type {};
+template <class S> struct IsReducing<S, std::void_t<decltype(S::kReduce)>> : std::true_type {};
+
 // Stage sequence R0,R1,R2,R3 (1 = unused); product = n.
 // SPLIT: the stage exchanges move the real parts, then the imaginary parts, through an LDS buffer of
 // n doubles per slot instead of n complex values.  These kernels' occupancy is set by LDS (a slot
@@ -290,6 +296,18 @@ fft_rows_kernel(RowShape sh, Loader ld, Storer st) {
             for (int k = t; k <= n / 2; k += Tr)
                 sx.pair(k, lds[lds_pad(k)], lds[lds_pad((n - k) & (n - 1))]);
         }
+    } else if constexpr (IsReducing<Storer>::value) {
+        __shared__ double red_[16];
+        double acc = 0.0;
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < kEPT / RL; ++q)
+#pragma unroll
+                for (int m = 0; m < RL; ++m)
+                    sx(stockham_out_index<RL>(t, Tr, Ns, q, m), v[q * RL + m], acc);
+        }
+        acc = block_sum(acc, red_);
+        if (threadIdx.x == 0) st.partial[blockIdx.x] = acc;
     } else {
         if (active) {
 #pragma unroll

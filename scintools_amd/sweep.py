@@ -59,19 +59,29 @@ def _all_gather_blocks(local, n_total, group=None):
     return full
 
 
-def sharded_eval_sweep(CS, tau, fd, etas, edges, group=None, local_fn=None, **kw):
+def sharded_eval_sweep(CS, tau, fd, etas, edges, group=None, local_fn=None, return_info=False, **kw):
     """Eigenvalue curve of ONE observation, eta range split across the ranks.
     Returns the full curve on every rank (identical to the single-process result: each eta
-    is computed by exactly one rank with the same kernels, so not a bit changes)."""
+    is computed by exactly one rank with the same kernels, so not a bit changes).  With
+    ``return_info`` also this rank's info dict (N, Lanczos steps, status of ITS block; None for an
+    empty block) as ``local_fn(..., return_info=True)`` reports it."""
     if local_fn is None:
         from .ththmod import eval_sweep as local_fn
     etas = np.asarray(etas, dtype=float)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return np.asarray(local_fn(CS, tau, fd, etas, edges, **kw))
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi = block_bounds(etas.shape[0], world, rank)
-    local = np.asarray(local_fn(CS, tau, fd, etas[lo:hi], edges, **kw)) if hi > lo else np.empty(0)
-    return _all_gather_blocks(local, etas.shape[0], group)
+    if return_info:
+        kw = dict(kw, return_info=True)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    lo, hi = block_bounds(etas.shape[0], world, dist.get_rank(group) if world > 1 else 0)
+    info = None
+    if hi > lo:
+        local = local_fn(CS, tau, fd, etas[lo:hi], edges, **kw)
+        if return_info:
+            local, info = local
+        local = np.asarray(local)
+    else:
+        local = np.empty(0)
+    full = local if world == 1 else _all_gather_blocks(local, etas.shape[0], group)
+    return (full, info) if return_info else full
 
 
 def sharded_observations(n_obs, sweep_fn, neta, group=None):

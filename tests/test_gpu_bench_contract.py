@@ -14,7 +14,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_json_contract():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--size", "512", "--neta", "16",
-                          "--steps", "2", "--warmup", "1", "--cpu-sample", "1", "--cpu-pool", "0"],
+                          "--steps", "2", "--warmup", "1", "--cpu-sample", "2", "--cpu-reps", "2", "--cpu-pool", "0"],
                          capture_output=True, text=True, timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

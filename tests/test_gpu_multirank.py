@@ -141,3 +141,29 @@ def test_bench_self_spawns_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["value"] == pytest.approx(2 * 16 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)
     assert d["config"]["ranks_per_gpu"] == 2          # oversubscribed on the 1-GPU test box, and says so
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["backend"] in ("gloo", "nccl")
+    rr = d["config"]["per_rank_eta_per_s"]
+    assert 0 < rr["min"] <= rr["max"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_shard_eta_gathers_the_one_gpu_curve():
+    """`bench.py --gpus 2 --shard eta`: ONE observation, contiguous eta blocks per rank through
+    sweep.sharded_eval_sweep (the reference's pool.map pattern, dynspec.py:1706-1723), strong scaling; the line
+    proves itself -- ranks seen, per-rank rates, and the gathered curve bit-identical to one GPU's."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--shard", "eta", "--size", "512",
+                          "--neta", "17", "--steps", "2", "--warmup", "1", "--modeler-steps", "0"],
+                         capture_output=True, text=True, timeout=800, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["shard"] == "eta"
+    assert c["ranks_seen"] == 2 and c["observations_per_step"] == 1
+    assert c["gathered_equals_one_gpu"] is True and c["failed_etas"] == 0
+    assert d["value"] == pytest.approx(17 * 2 / (d["ms_per_step"] * 2 / 1e3), rel=1e-6)     # 17 eta in all, uneven split
+    assert 0 < c["per_rank_eta_per_s"]["min"] <= c["per_rank_eta_per_s"]["max"]
