@@ -127,7 +127,9 @@ int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
  * keep_idx[neta*M] / keep_n[neta]: per-eta crop (host-computed, device arrays).
  * status_out[i] != 0 -> the wrapper stores NaN (ththmod.py:795-799).
  * iters_out[i]: Lanczos steps used (for the roofline accounting); may be NULL.
- * eigs_out/status_out/iters_out are DEVICE arrays.  Asynchronous. */
+ * eigs_out/status_out/iters_out are DEVICE arrays and need no initialisation (the library presets status to a
+ * failure code and the step counts to 0 on the caller's stream; eigenvector rows of the *_vec entry points are
+ * zero beyond their N_i entries, chi^2 of a curvature whose crop leaves nothing stays NaN).  Asynchronous. */
 int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
                                          int32_t max_iter, size_t* bytes /*HOST*/);
 int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,

@@ -131,11 +131,15 @@ __device__ inline Blk2 step_block_wave(const double* __restrict__ ap, const doub
     const double n12 = s[2] * s[2] + s[3] * s[3], tr = s[0] + s[1];
     const double h11 = s[4] - (s[0] * s[0] + n12), h22 = s[5] - (n12 + s[1] * s[1]);
     const cplx h12 = mk(s[6] - s[2] * tr, s[7] - s[3] * tr);
-    b.b11 = h11 > 0.0 ? sqrt(h11) : 0.0;
+    // Both pivots are differences of nearly equal numbers once a direction is exhausted (W^H W - A^H A of a
+    // vector that lies in the span already built): rounding noise of size 1e-16 |W|^2, which 1 / b would blow
+    // up into a garbage basis vector.  A pivot below 1e-14 of its own Gram entry counts as zero.
+    constexpr double kPivotFloor = 1e-14;
+    b.b11 = h11 > kPivotFloor * s[4] ? sqrt(h11) : 0.0;
     b.i11 = b.b11 > 0.0 ? 1.0 / b.b11 : 0.0;
     b.b12 = mk(h12.x * b.i11, h12.y * b.i11);
     const double d = h22 - norm2(b.b12);
-    b.b22 = d > 0.0 ? sqrt(d) : 0.0;
+    b.b22 = d > kPivotFloor * s[5] ? sqrt(d) : 0.0;
     b.i22 = b.b22 > 0.0 ? 1.0 / b.b22 : 0.0;
     return b;
 }
@@ -1145,6 +1149,12 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     if (rc == SCINT_OK) {
         he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
         if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream);
+        // the caller's output buffers need no preparation: a status that is never written reads as a failure
+        // (0x7f7f7f7f), step counts as 0, eigenvector rows are zero beyond their N_i entries
+        if (he == hipSuccess) he = hipMemsetAsync(status_out, 0x7f, sizeof(int32_t) * (size_t)neta, stream);
+        if (he == hipSuccess && iters_out) he = hipMemsetAsync(iters_out, 0, sizeof(int32_t) * (size_t)neta, stream);
+        if (he == hipSuccess && want_vec)
+            he = hipMemsetAsync(vec_out, 0, sizeof(cplx) * (size_t)neta * (size_t)vstride, stream);
         if (he == hipSuccess) he = hipEventRecord(start_ev, stream);
         for (int l = 0; l < kTailLanes && he == hipSuccess; ++l) he = hipStreamWaitEvent(side->tail[l], start_ev, 0);
         if (he == hipSuccess) he = hipStreamWaitEvent(side->aux, start_ev, 0);

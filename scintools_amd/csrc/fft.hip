@@ -1397,6 +1397,8 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
         hipLaunchKernelGGL((transpose_kernel<double>), grid, dim3(256), 0, st, dspec, nf, nt, dspecT);
         if (mask) hipLaunchKernelGGL((transpose_kernel<uint8_t>), grid, dim3(256), 0, st, mask, nf, nt, maskT);
         SCINT_LAUNCH_CHECK();
+        // a curvature whose crop leaves nothing keeps NaN (all-ones bit pattern), as chisq_calc's nan_to_num-free path does
+        SCINT_HIP(hipMemsetAsync(chisq_out, 0xff, sizeof(double) * (size_t)neta, st));
     }
     ChisqTail t;
     t.g = to_dev(*geom); t.keep_n = keep_n; t.etas = etas;

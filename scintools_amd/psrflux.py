@@ -12,7 +12,7 @@ This is host-side I/O in front of the GPU path, written for latency on small obs
   ``np.loadtxt``);
 * :func:`observation` turns the table into the attribute set the reference's ``Dynspec``
   carries (same definitions and roundings, so a file loads to identical attributes);
-* :func:`save_sidecar` / :func:`load_sidecar` keep a binary ``.npz`` image of a parsed file
+* :func:`save_sidecar` / :func:`load_sidecar` keep a binary ``.npz`` image of a parsed file (valid for exactly the text file it was written for: size + mtime_ns)
   next to it; ``Dynspec.load_file`` uses it when it is at least as new as the text file;
 * :func:`write` emits the text format, one ``str.join`` per sub-integration.
 """
@@ -125,18 +125,27 @@ def sidecar_path(path):
     return path + SIDECAR_SUFFIX
 
 
+def _stamp(path):
+    """Identity of the text file a side-car belongs to: size and modification time to the nanosecond."""
+    st = os.stat(path)
+    return np.array([st.st_size, st.st_mtime_ns], dtype=np.int64)
+
+
 def save_sidecar(path, header, table):
-    """Binary image of a parsed text file (loaded instead of re-parsing while it is current)."""
-    np.savez(sidecar_path(path), header=np.array(header, dtype=str), table=table)
+    """Binary image of a parsed text file (loaded instead of re-parsing while it is current).  The text
+    file's size and mtime_ns are stored with it: a replaced text file -- even one with an OLDER timestamp
+    (cp -p, rsync, untar) -- never matches."""
+    np.savez(sidecar_path(path), header=np.array(header, dtype=str), table=table, stamp=_stamp(path))
 
 
 def load_sidecar(path):
-    """(header, table) from the side-car if it exists and is not older than the text file."""
+    """(header, table) from the side-car if it exists and was written for exactly this text file (same size,
+    same mtime_ns); None otherwise."""
     side = sidecar_path(path)
     try:
-        if os.path.getmtime(side) < os.path.getmtime(path):
-            return None
         with np.load(side) as z:
+            if not np.array_equal(z["stamp"], _stamp(path)):
+                return None
             return [str(s) for s in z["header"]], z["table"]
     except (OSError, KeyError, ValueError):
         return None

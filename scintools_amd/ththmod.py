@@ -359,7 +359,7 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
     ws = workspace.get(need.value)
     keep_t = to_device(keep_idx, torch.int32)
     eigs_t = empty((neta,), torch.float64)
-    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    st_t = empty((2, neta), torch.int32)              # status / step counts: initialised inside the library
     etas_c = np.ascontiguousarray(etas_v)
     rc = lib.scint_eval_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
                               keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
@@ -412,8 +412,8 @@ def eigvec_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX
     ws = workspace.get(need.value)
     keep_t = _dv.to_device(keep_idx, torch.int32)
     w_t = empty((neta,), torch.float64)
-    V_t = torch.zeros((neta, M), dtype=torch.complex128, device=cs_t.device)
-    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    V_t = empty((neta, M), torch.complex128)          # zeroed (rows are N_i entries long) and filled inside the library
+    st_t = empty((2, neta), torch.int32)              # status / step counts: initialised inside the library
     etas_c = np.ascontiguousarray(etas_v)
     rc = lib.scint_eigvec_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
                                 keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
@@ -460,10 +460,10 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     _lib.check(lib.scint_chisq_sweep_workspace_bytes(M, neta, batch, max_iter, grid.geom.ntau, grid.geom.nfd, nf, nt,
                                                      ctypes.byref(need)), "chisq_sweep_workspace_bytes")
     ws = workspace.get(need.value)
-    out = torch.full((neta,), float("nan"), dtype=torch.float64, device=cs_t.device)
+    out = empty((neta,), torch.float64)               # NaN-initialised inside the library
     w_t = empty((neta,), torch.float64)
-    V_t = torch.zeros((neta, M), dtype=torch.complex128, device=cs_t.device)
-    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    V_t = empty((neta, M), torch.complex128)          # zeroed (rows are N_i entries long) and filled inside the library
+    st_t = empty((2, neta), torch.int32)
     rc = lib.scint_chisq_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
                                keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                etas_v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta, tol, max_iter, batch,
@@ -526,7 +526,7 @@ def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAU
     ws = workspace.get(need.value)
     keep_t = _dv.to_device(keep_idx, torch.int32)
     eigs_t = empty((neta,), torch.float64)
-    st_t = torch.zeros((2, neta), dtype=torch.int32, device=cs_t.device)
+    st_t = empty((2, neta), torch.int32)
     rc = lib.scint_eval_sweep_multi(ptr(cs_t), ncs, int(cs_t.shape[1] * cs_t.shape[2]),
                                     cs_idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), geoms,
                                     ptr(th_stack), M, ptr(keep_t),

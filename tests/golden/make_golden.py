@@ -372,6 +372,31 @@ def gen_sim_sweep():
     save("sim_sweep.npz", **out)
 
 
+# ---------------------------------------------------------------------------
+# 10. The headline size: a reference Simulation screen at 4096^2 (seed 3), five curvatures across
+#     geomspace(0.25, 4, 256) * sim.eta -- both flat ends (lambda_2 / lambda_1 -> 0.99), the peak and the
+#     two slopes -- through the reference's own Eval_calc.  ~15 min on 8 cores (3 min of it the simulator).
+# ---------------------------------------------------------------------------
+def gen_sim_sweep_4096():
+    import hashlib
+    size, seed = 4096, 3
+    sim = Simulation(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.25, freq=1400, dt=30,
+                     nx=size, ny=128, nf=size, seed=seed, lamsteps=False)
+    dyn = np.array(sim.dyn, dtype=np.float64)
+    d2 = dyn - dyn.mean()
+    fd = thth.fft_axis(sim.times * u.s, u.mHz, 0)
+    tau = thth.fft_axis(sim.freqs * u.MHz, u.us, 0)
+    CS = cs_of(d2, 0)
+    edges = np.linspace(-V(fd).max() / 2, V(fd).max() / 2, size)
+    idx = np.array([0, 64, 128, 192, 255])
+    etas = (np.geomspace(0.25, 4.0, 256) * sim.eta)[idx]
+    eigs = np.array([thth.Eval_calc(CS, tau, fd, e * u.s**3, edges * u.mHz) for e in etas])
+    save("sim_sweep_4096.npz", seed=seed, idx=idx, etas=etas, eigs=eigs, sim_eta=sim.eta,
+         sha256=hashlib.sha256(np.ascontiguousarray(sim.dyn).tobytes()).hexdigest(),
+         freqs01=np.array(sim.freqs[:2]), dt=sim.dt)
+    print("s4096 eta", sim.eta, "eigs", eigs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["small", "sample", "sim", "medium", "fit", "retrieval", "psrflux", "arcfit"]
     if "small" in which:
@@ -392,3 +417,5 @@ if __name__ == "__main__":
         gen_arcfit()
     if "simsweep" in which:        # ~5 min: not in the default list
         gen_sim_sweep()
+    if "simsweep4096" in which:    # ~15 min: not in the default list
+        gen_sim_sweep_4096()

@@ -145,6 +145,11 @@ def test_psrflux_io_matches_reference(golden, tmp_path):
     assert head == head_t and np.array_equal(table, table_t)
     d3 = Dynspec(filename=out2, verbose=False)
     assert np.array_equal(d3.dyn, d2.dyn) and np.array_equal(d3.times, d2.times) and d3.mjd == d2.mjd
+    st0 = _os.stat(out2)
+    _os.utime(out2, ns=(st0.st_atime_ns, st0.st_mtime_ns - 5_000_000_000))      # an OLDER text file (cp -p, untar): ignored too
+    assert psrflux.load_sidecar(out2) is None
+    _os.utime(out2, ns=(st0.st_atime_ns, st0.st_mtime_ns))
+    assert psrflux.load_sidecar(out2) is not None                                # the very same file again
     _os.utime(out2, (_os.path.getmtime(out2) + 10,) * 2)      # text newer than the side-car: ignored
     assert psrflux.load_sidecar(out2) is None
     with pytest.raises(ValueError):

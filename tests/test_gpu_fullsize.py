@@ -62,6 +62,29 @@ def test_sspec_4096_vs_oracle(env):
         assert np.abs(sec - ref)[strong].max() <= 1e-8
 
 
+@pytest.mark.timeout(900)
+def test_config3_with_npad3_eigenvalue_vs_oracle(env):
+    """BASELINE config 3 with the reference's default padding npad = 3: conjugate spectrum 16384^2 (4 GiB on
+    the GPU), the gather reading the 4x finer grid.  One curvature against the oracle (NumPy fft2 of the
+    padded 16384^2 plane + gather + ARPACK: about a minute of host time), rtol 1e-9."""
+    thth, to, arc = env
+    size = 4096
+    dyn, freqs, times, eta_true = arc(size, size, seed=3, nimg=64)
+    dyn -= dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 3), to.fft_axis(freqs, 1.0, 3)
+    assert fd.shape[0] == 4 * size and tau.shape[0] == 4 * size
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    eta = 0.84 * eta_true
+    cs = thth.conjugate_spectrum(dyn, 3)
+    assert tuple(cs.shape) == (4 * size, 4 * size)
+    got, info = thth.eval_sweep(cs, tau, fd, np.array([eta]), edges, return_info=True)
+    assert info["status"][0] == 0
+    del cs
+    CS = to.conjugate_spectrum(dyn, 3)
+    ref = to.Eval_calc(CS, tau, fd, eta, edges)
+    assert got[0] == pytest.approx(ref, rel=1e-9)
+
+
 @pytest.mark.parametrize("size,seed", [(2048, 2), (4096, 3)])
 def test_thth_hermitian_and_eigpair_residual(env, size, seed):
     thth, to, _ = env
