@@ -170,6 +170,21 @@ int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOS
                            int32_t* status_out, int32_t* iters_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same for MANY conjugate spectra of one shape in one batched sweep (arguments as
+ * scint_eval_sweep_multi): the eigenpairs of all chunks of Dynspec.thetatheta_chunks -- one
+ * modeler() call per chunk in the reference, dynspec.py:1765-1826 / ththmod.py:1455 -- in ONE call. */
+int32_t scint_eigvec_sweep_multi_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                                 int32_t max_iter, int64_t ncs, size_t* bytes /*HOST*/);
+int32_t scint_eigvec_sweep_multi(const scint_c128* cs_stack, int64_t ncs, int64_t cs_stride,
+                                 const int32_t* cs_index /*HOST*/, const scint_cs_geom* geoms /*HOST*/,
+                                 const double* th_stack, int64_t M,
+                                 const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
+                                 const double* etas /*HOST*/, int64_t neta,
+                                 double tol, int32_t max_iter, int64_t batch,
+                                 double* w_out, scint_c128* vec_out, int64_t vec_stride,
+                                 int32_t* status_out, int32_t* iters_out,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- dominant eigenpair of a given Hermitian matrix (eigsh k=1 'LA') ----- */
 /* a[n,n] row-major.  v0[n] start vector or NULL (then a fixed pseudo-random
  * start, as modeler's eigsh call has no v0, ththmod.py:308).  w_out[1],

@@ -1241,3 +1241,21 @@ extern "C" int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom*
                      w_out, status_out, iters_out, true, (cplx*)vec_out, vec_stride, nullptr, workspace, workspace_bytes,
                      stream);
 }
+extern "C" int32_t scint_eigvec_sweep_multi_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
+                                                            int32_t max_iter, int64_t ncs, size_t* bytes) {
+    return sweep_workspace_bytes(M, neta, batch, max_iter, true, ncs, bytes);
+}
+
+extern "C" int32_t scint_eigvec_sweep_multi(const scint_c128* cs_stack, int64_t ncs, int64_t cs_stride,
+                                            const int32_t* cs_index, const scint_cs_geom* geoms,
+                                            const double* th_stack, int64_t M, const int32_t* keep_idx,
+                                            const int32_t* keep_n, const double* etas, int64_t neta,
+                                            double tol, int32_t max_iter, int64_t batch, double* w_out,
+                                            scint_c128* vec_out, int64_t vec_stride, int32_t* status_out,
+                                            int32_t* iters_out, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    SCINT_REQUIRE(cs_index != nullptr || ncs == 1, "eigvec_sweep_multi: cs_index required");
+    return run_sweep(cs_stack, ncs, cs_stride, cs_index, geoms, th_stack, M, keep_idx, keep_n, etas, neta, tol,
+                     max_iter, batch, w_out, status_out, iters_out, true, (cplx*)vec_out, vec_stride, nullptr,
+                     workspace, workspace_bytes, stream);
+}

@@ -507,11 +507,17 @@ class Dynspec:
     # ------------------------------------------------------------------ phase retrieval
     def thetatheta_chunks(self, verbose=False, pool=None, memmap=False):
         """theta-theta phase retrieval on all half-overlapping chunks (dynspec.py:1765-1826):
-        fills ``self.chunks[ncf_ret, nct_ret, cwf, cwt]``.  `pool` / `memmap` are accepted for
-        signature compatibility; chunks run one after another on the GPU."""
+        fills ``self.chunks[ncf_ret, nct_ret, cwf, cwt]``.
+
+        ``pool=None`` (default): every chunk's conjugate spectrum goes into one device stack, the dominant
+        eigenpairs of all chunks come from ONE batched sweep and the back-maps / inverse FFTs are queued
+        without a host round trip in between (``ththmod.chunk_retrieval_batch``).  With a ``pool`` it is the
+        reference's ``pool.map(thth.single_chunk_retrieval, pars)`` (dynspec.py:1806-1812); `memmap` is
+        accepted for signature compatibility."""
         if not hasattr(self, "ththeta"):
             self.fit_thetatheta(verbose=verbose, pool=pool)
         self.chunks = np.zeros((self.ncf_ret, self.nct_ret, self.cwf, self.cwt), dtype=complex)
+        pars, where = [], []
         for cf in range(self.ncf_ret):
             fs = slice(cf * (self.cwf // 2), cf * (self.cwf // 2) + self.cwf)
             freq2 = np.copy(self.freqs[fs])
@@ -523,10 +529,17 @@ class Dynspec:
                 dspec2 = np.copy(self.dyn[fs, ts])
                 dspec2 -= np.nanmean(dspec2)
                 dspec2 = np.nan_to_num(dspec2)
-                params = (dspec2, self.edges * (freq / self.fref), time2, freq2, eta, ct, cf, self.npad,
-                          self.thth_tau_mask, verbose)
-                res = thth.single_chunk_retrieval(params)
-                self.chunks[cf, ct, :, :] = res[0]
+                pars.append((dspec2, self.edges * (freq / self.fref), time2, freq2, eta, ct, cf, self.npad,
+                             self.thth_tau_mask, verbose))
+                where.append((cf, ct))
+        if pool is not None:
+            for res in pool.map(thth.single_chunk_retrieval, pars):
+                self.chunks[res[1], res[2], :, :] = res[0]
+            return
+        batch = thth.chunk_retrieval_batch([(p[0], p[1], p[2], p[3], p[4]) for p in pars], self.npad,
+                                           self.thth_tau_mask, verbose=verbose)
+        for (cf, ct), field in zip(where, batch):
+            self.chunks[cf, ct, :, :] = field
 
     def calc_wavefield(self, verbose=False, pool=None, gs=False, memmap=False, niter=1):
         """Mosaic the chunks into the final wavefield (dynspec.py:1828-1856)."""

@@ -545,6 +545,62 @@ def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAU
     return out
 
 
+def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None):
+    """Dominant eigenPAIRS of MANY chunks in one batched device call: modeler's
+    ``eigsh(thth_red, 1, which="LA")`` (ththmod.py:308) for every (chunk, eta) -- what
+    Dynspec.thetatheta_chunks needs from its per-chunk modeler calls (dynspec.py:1765-1826).
+
+    Arguments as :func:`eval_sweep_multi`.  Returns (w list of float64 arrays, V device tensor
+    [n_total, M] complex128 in chunk order, keep list of index arrays per (chunk, eta), info)."""
+    lib = _lib.load()
+    G = [g if isinstance(g, _Grid) else _Grid(*g) for g in grids]
+    ncs = len(G)
+    cs_t = _dv.to_device(cs_stack, torch.complex128)
+    if cs_t.dim() != 3 or cs_t.shape[0] != ncs:
+        raise ValueError("cs_stack must be [nchunk, ntau, nfd] with one spectrum per grid")
+    M = G[0].M
+    if any(g.M != M or (g.geom.ntau, g.geom.nfd) != tuple(cs_t.shape[1:]) for g in G):
+        raise ValueError("all chunks must share the CS shape and the number of edges")
+    etas_all, cs_index, keep_rows, keep_n = [], [], [], []
+    for c, (g, et) in enumerate(zip(G, etas_list)):
+        et = np.atleast_1d(units.strip(et, "etas", "s3", warn=False)).astype(float)
+        ki, kn = _sweep_inputs(g, et)
+        etas_all.append(et); keep_rows.append(ki); keep_n.append(kn)
+        cs_index.append(np.full(et.shape[0], c, dtype=np.int32))
+    etas_v = np.ascontiguousarray(np.concatenate(etas_all))
+    cs_idx = np.ascontiguousarray(np.concatenate(cs_index))
+    keep_idx = np.ascontiguousarray(np.concatenate(keep_rows, axis=0))
+    keep_cnt = np.ascontiguousarray(np.concatenate(keep_n))
+    neta = etas_v.shape[0]
+    if batch is None:
+        batch = default_batch(max(int(keep_cnt.max()), 1), neta)
+    geoms = (_lib.CsGeom * ncs)(*[g.geom for g in G])
+    th_stack = _dv.to_device(np.stack([g.th_cents for g in G]), torch.float64)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_eigvec_sweep_multi_workspace_bytes(M, neta, batch, max_iter, ncs, ctypes.byref(need)),
+               "eigvec_sweep_multi_workspace_bytes")
+    ws = workspace.get(need.value)
+    keep_t = _dv.to_device(keep_idx, torch.int32)
+    w_t = empty((neta,), torch.float64)
+    V_t = empty((neta, M), torch.complex128)
+    st_t = empty((2, neta), torch.int32)
+    rc = lib.scint_eigvec_sweep_multi(ptr(cs_t), ncs, int(cs_t.shape[1] * cs_t.shape[2]),
+                                      cs_idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), geoms,
+                                      ptr(th_stack), M, ptr(keep_t),
+                                      keep_cnt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                      etas_v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta,
+                                      tol, max_iter, batch, ptr(w_t), ptr(V_t), M, ptr(st_t[0]), ptr(st_t[1]),
+                                      ptr(ws), ws.numel(), stream_ptr())
+    _lib.check(rc, "scint_eigvec_sweep_multi")
+    w = w_t.cpu().numpy()
+    st = st_t.cpu().numpy()
+    w[st[0] != 0] = np.nan
+    bounds = np.cumsum([0] + [e.shape[0] for e in etas_all])
+    keeps = [keep_idx[i, : keep_cnt[i]] for i in range(neta)]
+    return ([w[bounds[i]:bounds[i + 1]] for i in range(ncs)], V_t, keeps,
+            {"N": keep_cnt, "iters": st[1], "status": st[0], "batch": batch, "bounds": bounds})
+
+
 def conjugate_spectrum(dspec, npad, tau=None, tau_mask=0.0, coher=True, pad_value=None, out=None):
     """Device conjugate spectrum of a chunk (ththmod.py:777-787): returns a CUDA
     complex128 tensor [(npad+1)*nf, (npad+1)*nt] (written into `out` when given)."""
@@ -647,6 +703,54 @@ def _ifft2_shifted_dev(x_t, scale=1.0, crop=None):
     return out
 
 
+def _wavefield_from_eigpair(grid, e, keep, V, w, shape):
+    """Chunk wavefield from the dominant eigenpair (ththmod.py:1457-1470): theta-theta of the E field with only
+    its theta_2 = 0 row filled with conj(V) sqrt(w), non-Hermitian back-map, shifted inverse FFT cropped to the
+    chunk.  Returns a device tensor [nf, nt] complex128."""
+    n = int(keep.shape[0])
+    dev = require_gpu()
+    E_t = torch.zeros((n, n), dtype=torch.complex128, device=dev)                # allocation + memset
+    row = np.conjugate(np.asarray(V)[:n]) * np.sqrt(w)                            # n numbers: host
+    E_t[n // 2].copy_(torch.from_numpy(row))                                      # memcpy
+    th_red = _theta_centres(grid.edges_red(keep))
+    recov_E = _rev_map_dev(grid.geom, _dv.to_device(th_red, torch.float64), n, e, False, thth_t=E_t)
+    nf, nt = shape
+    return _ifft2_shifted_dev(recov_E, scale=nf * nt / 4, crop=(nf, nt))
+
+
+def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False):
+    """Phase retrieval of MANY chunks of one shape (Dynspec.thetatheta_chunks, dynspec.py:1765-1826): every
+    chunk's conjugate spectrum in one device stack, all dominant eigenpairs in ONE batched sweep
+    (:func:`eigvec_sweep_multi`), then per chunk the back-map and the inverse FFT queued without a host
+    synchronisation in between; one copy back at the end.
+
+    chunks: list of (dspec2[nf, nt], edges, time, freq, eta).  Returns complex [nchunk, nf, nt]; a chunk
+    whose eigen-solve fails is zero, as single_chunk_retrieval leaves it."""
+    nf, nt = np.asarray(chunks[0][0]).shape
+    grids, etas = [], []
+    for dspec2, edges, time, freq, eta in chunks:
+        fd = fft_axis(units.strip(time, "time2", "s", warn=False), 1000.0, npad)
+        tau = fft_axis(units.strip(freq, "freq2", "MHz", warn=False), 1.0, npad)
+        grids.append(_Grid(tau, fd, units.strip(edges, "edges", "mHz", warn=False)))
+        etas.append(np.array([_eta_float(eta)]))
+    dev = require_gpu()
+    stack = torch.empty((len(chunks), (npad + 1) * nf, (npad + 1) * nt), dtype=torch.complex128, device=dev)
+    for k, (dspec2, *_r) in enumerate(chunks):
+        g = grids[k]
+        conjugate_spectrum(np.asarray(dspec2, dtype=float), npad, g.tau, tauMask, True, out=stack[k])
+    w_list, V_t, keeps, info = eigvec_sweep_multi(stack, grids, etas)
+    V = V_t.cpu().numpy()
+    out_t = torch.zeros((len(chunks), nf, nt), dtype=torch.complex128, device=dev)
+    for k in range(len(chunks)):
+        if info["status"][k] != 0 or keeps[k].shape[0] < 2:
+            print("Chunk %d: eigen-decomposition failed" % k, flush=True)
+            continue
+        out_t[k].copy_(_wavefield_from_eigpair(grids[k], float(etas[k][0]), keeps[k], V[k], float(w_list[k][0]), (nf, nt)))
+        if verbose:
+            print("Chunk %d success" % k, flush=True)
+    return out_t.cpu().numpy()
+
+
 def single_chunk_retrieval(params):
     """Phase retrieval on one time/frequency chunk (ththmod.py:1390-1476).
 
@@ -664,16 +768,10 @@ def single_chunk_retrieval(params):
     try:
         cs_t = conjugate_spectrum(dspec2, npad, tau, tauMask, True)
         grid = _Grid(tau, fd, edges_v)
-        red_t, V_t, w, _, _, keep = _modeler_dev(cs_t, grid, e)
-        n = int(keep.shape[0])
-        # ththE_red: only the theta_2 = 0 row is filled, with conj(V) sqrt(w)   (ththmod.py:1459-1461)
-        E_t = torch.zeros((n, n), dtype=torch.complex128, device=cs_t.device)      # allocation + memset
-        row = np.conjugate(V_t.cpu().numpy()) * np.sqrt(w)                          # n numbers: host
-        E_t[n // 2].copy_(torch.from_numpy(row))                                    # memcpy
-        th_red = _theta_centres(grid.edges_red(keep))
-        recov_E = _rev_map_dev(grid.geom, _dv.to_device(th_red, torch.float64), n, e, False, thth_t=E_t)
-        nf, nt = dspec2.shape
-        model_E = _ifft2_shifted_dev(recov_E, scale=nf * nt / 4, crop=(nf, nt)).cpu().numpy()
+        # of modeler's outputs (ththmod.py:1455) only the eigenpair is used here: no rank-1 back-map, no model
+        keep = grid.keep(e)
+        w, V_t, _ = _eigh_top_dev(_thth_dev(cs_t, grid, e, keep, True), None, want_vec=True)
+        model_E = _wavefield_from_eigpair(grid, e, keep, V_t.cpu().numpy(), w, dspec2.shape).cpu().numpy()
         if verbose:
             print("Chunk %s-%s success" % (idx_f, idx_t), flush=True)
     except Exception as exc:   # the reference keeps going with a zero chunk

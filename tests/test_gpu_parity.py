@@ -373,8 +373,9 @@ def _align(a, ref):
 
 
 def test_phase_retrieval_vs_reference_golden(thth, golden):
-    """thetatheta_chunks -> mosaic -> Gerchberg-Saxton on the GPU against the reference's run
-    (tests/golden/make_golden.py::gen_retrieval); wavefields compared up to a global phase."""
+    """thetatheta_chunks (all chunks' eigenpairs in one batched sweep) -> mosaic -> Gerchberg-Saxton on the GPU
+    against the reference's run (tests/golden/make_golden.py::gen_retrieval); wavefields compared up to a
+    global phase; the pool form (chunk by chunk through single_chunk_retrieval) gives the same chunks."""
     from scintools_amd.dynspec import Dynspec
     g = golden("retrieval.npz")
     f = golden("fit_thetatheta.npz")
@@ -386,18 +387,29 @@ def test_phase_retrieval_vs_reference_golden(thth, golden):
     d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50, nedge=128)
     assert np.array_equal(d.edges, g["edges"]) and d.neta == int(g["neta"])
     d.calc_wavefield()
-    assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-6)
-    np.testing.assert_allclose(d.eta_evo, g["eta_evo"], rtol=1e-6)
+    # SURVEY 8c's 1e-9 for V / rev_map / model holds for the whole retrieval chain: measured on an MI355X
+    # (tools/_retr_dev.py, round 3) ththeta 1.8e-10, eta_evo 5.0e-10 (a curve_fit on the eigenvalue curves sits
+    # in between), chunks 4.5e-11, mosaicked wavefield 4.7e-11, after two Gerchberg-Saxton rounds 1.3e-10
+    assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-8)
+    np.testing.assert_allclose(d.eta_evo, g["eta_evo"], rtol=1e-8)
     assert d.chunks.shape == (7, 1, 64, 150)
     for cf, key in ((0, "chunk0"), (3, "chunk3")):
         ref = g[key]
-        assert np.abs(_align(d.chunks[cf, 0], ref) - ref).max() <= 1e-6 * np.abs(ref).max()
+        assert np.abs(_align(d.chunks[cf, 0], ref) - ref).max() <= 1e-9 * np.abs(ref).max()
     ref = g["wavefield"]
     assert d.wavefield.shape == ref.shape
-    assert np.abs(_align(d.wavefield, ref) - ref).max() <= 1e-6 * np.abs(ref).max()
+    assert np.abs(_align(d.wavefield, ref) - ref).max() <= 1e-9 * np.abs(ref).max()
     d.gerchberg_saxton(niter=2)
     ref = g["wavefield_gs"]
-    assert np.abs(_align(d.wavefield, ref) - ref).max() <= 1e-6 * np.abs(ref).max()
+    assert np.abs(_align(d.wavefield, ref) - ref).max() <= 1e-9 * np.abs(ref).max()
+    # the reference's idiom, pool.map(single_chunk_retrieval, pars): same chunks up to each chunk's own phase
+    class SerialPool:
+        def map(self, fn, it):
+            return [fn(x) for x in it]
+    batched = d.chunks.copy()
+    d.thetatheta_chunks(pool=SerialPool())
+    for a, b in zip(batched[:, 0], d.chunks[:, 0]):
+        assert np.abs(_align(a, b) - b).max() <= 1e-9 * np.abs(b).max()
     # the constraints GS enforces: measured amplitudes, and causality after the last projection
     pos = B.dyn[: ref.shape[0]] > 0
     np.testing.assert_allclose(np.abs(d.wavefield[pos]) ** 2, B.dyn[: ref.shape[0]][pos], rtol=1e-9)
