@@ -388,7 +388,7 @@ def test_phase_retrieval_vs_reference_golden(thth, golden):
     assert np.array_equal(d.edges, g["edges"]) and d.neta == int(g["neta"])
     d.calc_wavefield()
     # SURVEY 8c's 1e-9 for V / rev_map / model holds for the whole retrieval chain: measured on an MI355X
-    # (tools/_retr_dev.py, round 3) ththeta 1.8e-10, eta_evo 5.0e-10 (a curve_fit on the eigenvalue curves sits
+    # (tools/retrieval_deviation.py, round 3) ththeta 1.8e-10, eta_evo 5.0e-10 (a curve_fit on the eigenvalue curves sits
     # in between), chunks 4.5e-11, mosaicked wavefield 4.7e-11, after two Gerchberg-Saxton rounds 1.3e-10
     assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-8)
     np.testing.assert_allclose(d.eta_evo, g["eta_evo"], rtol=1e-8)

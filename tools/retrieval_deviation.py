@@ -1,4 +1,5 @@
-"""Deviation of the phase-retrieval chain from the reference run in tests/golden/retrieval.npz (numbers quoted in\ntests/test_gpu_parity.py::test_phase_retrieval_vs_reference_golden).  python tools/retrieval_deviation.py on a GPU box."""
+"""Deviation of the phase-retrieval chain from the reference run in tests/golden/retrieval.npz (numbers quoted in
+tests/test_gpu_parity.py::test_phase_retrieval_vs_reference_golden).  python tools/retrieval_deviation.py on a GPU box."""
 import os, sys, numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO)
 from scintools_amd.dynspec import Dynspec
