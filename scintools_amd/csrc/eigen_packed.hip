@@ -237,23 +237,30 @@ __global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __
     gstore(Qn + 2 * r, x1); gstore(Qn + 2 * r + 1, x2);
 }
 
-// One workgroup = one strip of <= 16 tiles; wave w owns the 16-column slice 16w .. 16w+15 of every tile,
-// ALL 64 rows.  A wave load is eight 128-byte row segments: lane l = 8 rg + cg reads row 8j + rg,
-// columns 16w + 8cc + cg for the sixteen (j, cc), j = 0..7 row steps, cc = 0..1 column chunks.  So
+// One workgroup = one strip: <= 16 column tiles of block row I and (nrows = 2) of block row I+1.  Wave w owns
+// the 16-column slice 16w .. 16w+15 of every tile, ALL 64 rows.  A wave load is eight 128-byte row segments:
+// lane l = 8 rg + cg reads row 8j + rg, columns 16w + 8cc + cg for the sixteen (j, cc), j = 0..7 row steps,
+// cc = 0..1 column chunks.  So
 //   * the COLUMN part  c_J[col] = sum_rows conj(a[row][col]) x_I[row]  is lane-local over 8 rows and
-//     finishes inside the wave (three shuffle steps over the eight row groups): no LDS, no barrier;
+//     finishes inside the wave (three shuffle steps over the eight row groups): no barrier.  It goes to LDS
+//     -- a wave reads and writes only its own 16-column slice -- where the second row of the pair adds its
+//     share, and the strip's partials leave in ONE coalesced burst at the end;
 //   * the ROW part  y_I[row] = sum_J sum_col a[row][col] x_J[col]  keeps 8 rows x 2 vectors of per-lane
-//     accumulators for the whole strip and is reduced once at its end (8 lanes through LDS, then the four
-//     waves through LDS): two barriers per STRIP.
-// Until round 3 a wave owned 16 rows x 64 columns: the column partials then needed a 4-wave LDS reduction
-// with two barriers every 4 tiles, and on synthetic strips that flush took the loop from 6.56 to 5.51 TB/s
-// (barriers + LDS 12 %, its stores under a branch another 4.5 %: a memory operation under a branch makes
-// the compiler's wait counts pessimistic for everything behind it; profiles/r03_pk2_probe.txt).  Hence
-// the loop below is branch-free (the last tile is peeled: no conditional prefetch) and STORE-free: a global
-// store per tile costs 15 % on its own (6.83 -> 5.79 TB/s, profiles/r03_pk2e_probe.txt), so a tile's column
-// partial replaces the block X_J it has just consumed in LDS -- same 2 KiB, and a wave reads and writes
-// only its own 16-column slice of it -- and the strip's partials leave in one coalesced burst at the end.
-// x_I: eight distinct rows per instruction, read from LDS.
+//     accumulators for a row of the strip and is reduced at its end (8 lanes by shuffles, the four waves
+//     through LDS): one barrier per row.
+// What round 3 measured on synthetic strips (profiles/r03_pk2_probe.txt, r03_pk2e_probe.txt), each the reason
+// for a line above: a 4-wave LDS flush of the column partials with two barriers every 4 tiles (the round-2
+// shape: a wave owned 16 rows x 64 columns) took the loop from 6.56 to 5.51 TB/s; a memory operation under a
+// branch makes the compiler's wait counts pessimistic for everything behind it, so the loop is branch-free
+// (last tile peeled: no conditional prefetch) and carries scheduling fences (left alone, the compiler sinks
+// the prefetch below the second half of the tile); and the partial vectors' 3 % of WRITE traffic costs 13 %
+// of the rate wherever in the kernel it is issued (6.78 TB/s without it, the same into an L2-resident
+// region) -- hence two rows per workgroup: half of it.
+// x_I: eight distinct rows per instruction, read from LDS.  256 threads, 76 KiB of LDS, 196 registers: two
+// workgroups per CU.
+constexpr int kLdsXs = 0, kLdsCol = 2048, kLdsXi = 4096, kLdsRsum = 4352, kLdsElems = 4864;   // complex elements
+constexpr size_t kMatvecLdsBytes = sizeof(cplx) * kLdsElems;
+
 __device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (*__restrict__ xir)[2],
                                         const cplx (&xJ1)[2], const cplx (&xJ2)[2], cplx (&acc1)[8], cplx (&acc2)[8],
                                         cplx (&c1)[2], cplx (&c2)[2]) {
@@ -271,9 +278,9 @@ __device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (
         }
     }
 }
-// the eight row groups of a column (lanes l ^ 8, ^ 16, ^ 32; fixed order), then one 16-byte LDS store per
-// lane: row groups 0..3 hold (chunk, vector) = (rg >> 1, rg & 1), groups 4..7 store the same values again
-__device__ __forceinline__ void pk2_colstore(cplx (&c1)[2], cplx (&c2)[2], int rg, cplx* __restrict__ dst) {
+// the eight row groups of a column (lanes l ^ 8, ^ 16, ^ 32; fixed order), then this lane's value of the tile's
+// [64][2] column partial: row groups 0..3 hold (chunk, vector) = (rg >> 1, rg & 1), groups 4..7 the same again
+__device__ __forceinline__ cplx pk2_colsum(cplx (&c1)[2], cplx (&c2)[2], int rg) {
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
 #pragma unroll
@@ -285,41 +292,23 @@ __device__ __forceinline__ void pk2_colstore(cplx (&c1)[2], cplx (&c2)[2], int r
     const bool v1 = rg & 1, ch1 = rg & 2;        // (component-wise selects: v_cndmask, not an indexed array)
     const double lx = v1 ? c2[0].x : c1[0].x, ly = v1 ? c2[0].y : c1[0].y;
     const double hx = v1 ? c2[1].x : c1[1].x, hy = v1 ? c2[1].y : c1[1].y;
-    *dst = mk(ch1 ? hx : lx, ch1 ? hy : ly);
+    return mk(ch1 ? hx : lx, ch1 ? hy : ly);
 }
 
-__global__ void __launch_bounds__(256, 2)
-pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
-    __shared__ cplx lds[4096];                   // 64 KiB: two workgroups per CU
-    cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds);          // [kMaxStrip]: the blocks X_J = rows of Q_j (32 KiB)
-    cplx (*xi)[2] = reinterpret_cast<cplx (*)[2]>(lds + 2048);             // [64]: the block X_I (2 KiB)
-    const Strip* __restrict__ sp = strips + blockIdx.x;
-    const int step = launch - sp->start;
-    if (step < 0 || step >= sp->max_steps) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int cg = lane & 7, rg = lane >> 3, col = 16 * w + cg;
-    const int ntile = sp->ntile;
-    const cplx* __restrict__ tp = sp->tiles + rg * kTB + col;               // row rg, first column of the lane
-    cplx a0[8], a1[8];                                                      // element 2 jj + cc: row 8 (4h + jj) + rg, column col + 8 cc
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tp + (8 * (k >> 1)) * kTB + 8 * (k & 1));
-    const int32_t done = gload(sp->state);
-    const cplx* __restrict__ X = sp->Q + (int64_t)(step % sp->qslots) * sp->qstride * 2;   // Q_j
-    const int I = sp->I, J0 = sp->J0;
-    // X_I and the strip's X_J blocks: contiguous copies of rows of Q_j (the first tile's loads stay in flight)
-    if (threadIdx.x < 2 * kTB) lds[2048 + threadIdx.x] = gload(X + 2 * I * kTB + threadIdx.x);
-    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) lds[idx] = gload(X + 2 * J0 * kTB + idx);
-    if (done >= sp->gen) return;                 // finished job (workgroup-uniform): its loads were harmless
-    __syncthreads();
-    cplx acc1[8], acc2[8];
+// One block row of the strip: tiles t = t0 .. ntile-1 at tp + (t - t0) tiles; a0 holds the first half of tile t0.
+// ADD: the column partials are added to what the first row left (the tile tskip -- the second row's diagonal
+// tile -- adds nothing); else they are stored.  Then the row partials: 8 lanes by shuffles, 4 waves through LDS.
+template <bool ADD>
+__device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, cplx (&a0)[8], int t0, int ntile, int tskip,
+                                       const cplx (*__restrict__ xs)[kTB][2], const cplx (*__restrict__ xir)[2],
+                                       cplx* __restrict__ cslot, cplx* __restrict__ scratch, cplx (*__restrict__ rsum)[kTB][2],
+                                       cplx* __restrict__ rowpart, int lane, int w, int col, int cg, int rg) {
+    cplx a1[8], acc1[8], acc2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { acc1[j] = mk(0.0, 0.0); acc2[j] = mk(0.0, 0.0); }
-    const cplx (*__restrict__ xir)[2] = xi + rg;
-    // this lane's slot in a tile's [64][2] column partial: column col + 8 (rg >> 1 & 1), vector rg & 1
-    cplx* __restrict__ cslot = lds + 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
 #pragma unroll 1
-    for (int t = 0; t + 1 < ntile; ++t) {
-        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
+    for (int t = t0; t + 1 < ntile; ++t) {
+        const cplx* __restrict__ tc = tp + (int64_t)(t - t0) * kTileElems;
 #pragma unroll
         for (int k = 0; k < 8; ++k) a1[k] = gload_nt(tc + (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1));   // rows 32 .. 63
         cplx xJ1[2], xJ2[2], c1[2], c2[2];
@@ -329,18 +318,25 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
             c1[cc] = mk(0.0, 0.0); c2[cc] = mk(0.0, 0.0);
         }
         pk2_half(a0, 0, xir, xJ1, xJ2, acc1, acc2, c1, c2);
-        // (scheduling fences: left alone, the compiler sinks these loads below the second half to save
-        // registers, and the next tile then starts with nothing in flight)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tc + kTileElems + (8 * (k >> 1)) * kTB + 8 * (k & 1));   // rows 0 .. 31 of the next tile
         __builtin_amdgcn_sched_barrier(0);
         pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
-        pk2_colstore(c1, c2, rg, cslot + 2 * (t * kTB));
+        cplx c = pk2_colsum(c1, c2, rg);
+        if (!ADD) cslot[2 * (t * kTB)] = c;
+        else {
+            // one read-modify-write per slot: row groups 4..7 (same values as 0..3) go to a scratch element each.
+            // An address select, not a branch: `if (rg < 4)` here cost 23 % of the kernel's rate (5.6 -> 4.3 TB/s)
+            cplx* __restrict__ dst = rg < 4 ? cslot + 2 * (t * kTB) : scratch;
+            const cplx o = *dst;
+            const double keep = t == tskip ? 0.0 : 1.0;
+            *dst = mk(o.x + keep * c.x, o.y + keep * c.y);
+        }
     }
     {   // the last tile: nothing left to prefetch
         const int t = ntile - 1;
-        const cplx* __restrict__ tc = tp + (int64_t)t * kTileElems;
+        const cplx* __restrict__ tc = tp + (int64_t)(t - t0) * kTileElems;
 #pragma unroll
         for (int k = 0; k < 8; ++k) a1[k] = gload_nt(tc + (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1));
         cplx xJ1[2], xJ2[2], c1[2], c2[2];
@@ -351,43 +347,85 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
         }
         pk2_half(a0, 0, xir, xJ1, xJ2, acc1, acc2, c1, c2);
         pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
-        pk2_colstore(c1, c2, rg, cslot + 2 * (t * kTB));
+        cplx c = pk2_colsum(c1, c2, rg);
+        if (!ADD) cslot[2 * (t * kTB)] = c;
+        else {
+            // one read-modify-write per slot: row groups 4..7 (same values as 0..3) go to a scratch element each.
+            // An address select, not a branch: `if (rg < 4)` here cost 23 % of the kernel's rate (5.6 -> 4.3 TB/s)
+            cplx* __restrict__ dst = rg < 4 ? cslot + 2 * (t * kTB) : scratch;
+            const cplx o = *dst;
+            const double keep = t == tskip ? 0.0 : 1.0;
+            *dst = mk(o.x + keep * c.x, o.y + keep * c.y);
+        }
     }
-    // Row partials.  (1) inside the wave, over the 8 lanes of a row group: the wave stores 4 j x 64 lanes into
-    // its own scratch, lane L adds the four consecutive values 4L .. 4L+3 (row step L / 16 of the four,
-    // row group (L % 16) / 2, half of its lanes), one shuffle step joins the halves; (2) across the four
-    // waves (column slices) through LDS, fixed order.  Then the strip's column partials (where the X_J
-    // blocks were; the diagonal tile's slot is written too, nobody reads it) leave in one burst.
-    cplx* __restrict__ red = lds + 2176 + w * 288;   // 4 x 64 values + one pad element per 8
-    cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + 3328);   // [4 waves][64 rows][2]
+    // row partials: the 8 lanes of a row group (xor 1, 2, 4; fixed order), then the four waves (column slices)
+    if (ADD) __syncthreads();                    // the first row's totals have been read by everybody
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int j = 0; j < 8; ++j) {
+            cplx s = v ? acc2[j] : acc1[j];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int e = jj * 64 + lane;
-                red[e + (e >> 3)] = v ? acc2[4 * h + jj] : acc1[4 * h + jj];
-            }
-            wave_lds_sync();
-            const int e0 = 4 * lane;
-            cplx s = red[e0 + (e0 >> 3)];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) s = s + red[e0 + k + (e0 >> 3)];
-            wave_lds_sync();
-            s = mk(s.x + __shfl_xor(s.x, 1, 64), s.y + __shfl_xor(s.y, 1, 64));
-            // lane L: row step 4h + L / 16, row group (L % 16) / 2
-            if ((lane & 1) == 0) rsum[w][8 * (4 * h + (lane >> 4)) + ((lane & 15) >> 1)][v] = s;
+            for (int o = 1; o < 8; o <<= 1) s = mk(s.x + __shfl_xor(s.x, o, 64), s.y + __shfl_xor(s.y, o, 64));
+            if (cg == 0) rsum[w][8 * j + rg][v] = s;
         }
     }
     __syncthreads();
     if (threadIdx.x < 2 * kTB) {
         const int row = threadIdx.x >> 1, v = threadIdx.x & 1;
         const cplx tot = ((rsum[0][row][v] + rsum[1][row][v]) + rsum[2][row][v]) + rsum[3][row][v];
-        gstore(sp->rowpart + threadIdx.x, tot);
+        gstore(rowpart + threadIdx.x, tot);
     }
+}
+
+__global__ void __launch_bounds__(256, 2)
+pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];             // kMatvecLdsBytes = 76 KiB: two workgroups per CU
+    cplx* lds = reinterpret_cast<cplx*>(smem_raw);
+    cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kLdsXs);     // [kMaxStrip]: the blocks X_J = rows of Q_j (32 KiB)
+    cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kLdsRsum); // [4 waves][64 rows][2] (8 KiB)
+    const Strip* __restrict__ sp = strips + blockIdx.x;
+    const int step = launch - sp->start;
+    if (step < 0 || step >= sp->max_steps) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int cg = lane & 7, rg = lane >> 3, col = 16 * w + cg;
+    const int ntile = sp->ntile;
+    const int lane_off = rg * kTB + col;                                        // row rg, first column of the lane
+    const cplx* __restrict__ tp = sp->tiles + lane_off;
+    cplx a0[8];                                                                 // element 2 jj + cc: row 8 (4h + jj) + rg, column col + 8 cc
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tp + (8 * (k >> 1)) * kTB + 8 * (k & 1));
+    const int32_t done = gload(sp->state);
+    const cplx* __restrict__ X = sp->Q + (int64_t)(step % sp->qslots) * sp->qstride * 2;   // Q_j
+    const int I = sp->I, J0 = sp->J0, nrows = sp->nrows;
+    // X_I of both rows and the strip's X_J blocks: contiguous copies of rows of Q_j (the first tile's loads stay in flight)
+    if (threadIdx.x < nrows * 2 * kTB) lds[kLdsXi + threadIdx.x] = gload(X + 2 * I * kTB + threadIdx.x);
+    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) lds[kLdsXs + idx] = gload(X + 2 * J0 * kTB + idx);
+    if (done >= sp->gen) return;                 // finished job (workgroup-uniform): its loads were harmless
+    __syncthreads();
+    const cplx (*__restrict__ xi)[2] = reinterpret_cast<const cplx (*)[2]>(lds + kLdsXi);
+    // this lane's slot in a tile's [64][2] column partial: column col + 8 (rg >> 1 & 1), vector rg & 1
+    cplx* __restrict__ cslot = lds + kLdsCol + 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
+    pk2_row<false>(tp, a0, 0, ntile, -1, xs, xi + rg, cslot, nullptr, rsum, sp->rowpart, lane, w, col, cg, rg);
+    if (nrows == 2) {
+        // block row I+1 over the same columns: its tiles start at column max(J0, I+1); its diagonal tile (I+1, I+1)
+        // adds no column partial
+        const int t0 = J0 == I ? 1 : 0;
+        if (t0 < ntile) {
+            const cplx* __restrict__ tpB = sp->tilesB + lane_off;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tpB + (8 * (k >> 1)) * kTB + 8 * (k & 1));
+            // (scratch elements of the upper row groups: the first row's X_I block, dead since that row's barrier)
+            pk2_row<true>(tpB, a0, t0, ntile, I + 1 - J0, xs, xi + kTB + rg, cslot, lds + kLdsXi + 32 * w + (lane & 31), rsum,
+                          sp->rowpartB, lane, w, col, cg, rg);
+        } else if (threadIdx.x < 2 * kTB) {
+            gstore(sp->rowpartB + threadIdx.x, mk(0.0, 0.0));   // one-tile strips (tests): row I+1 has nothing in this column range
+        }
+    }
+    // the strip's column partials in one burst (the slot of a diagonal tile is written too; nobody reads it)
+    __syncthreads();
     cplx* __restrict__ colpart = sp->colpart;
-    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore(colpart + idx, lds[idx]);
+    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore(colpart + idx, lds[kLdsCol + idx]);
 }
 
 __global__ void __launch_bounds__(64 * kRedGroups)
@@ -399,12 +437,13 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     if (K >= jb.nb || jb.n < 2 || step < 0 || step >= jb.max_steps || gload(jb.state) >= jb.gen) return;
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
-    // fixed summation order: the row partials of block row K strip by strip, then the column
-    // partials of the tiles above the diagonal in column K; sixteen wavefronts take every 16th
+    // fixed summation order: the row partials of block row K strip by strip, then the column partials of
+    // the row PAIRS above the diagonal in column K; sixteen wavefronts take every 16th
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc1 = mk(0.0, 0.0), acc2 = mk(0.0, 0.0);
-    for (int idx = g; idx < nrow + K; idx += kRedGroups) {
-        const int cI = idx - nrow;                                  // column partial of tile (cI, K)
+    const int npair = (K + 1) >> 1;                                 // pairs of block rows (2p, 2p+1) with a tile above (K, K)
+    for (int idx = g; idx < nrow + npair; idx += kRedGroups) {
+        const int cI = 2 * (idx - nrow);                            // column partial of rows cI and cI+1, in tile (cI, K)'s slot
         const cplx* src = idx < nrow ? jb.rowpart + 2 * ((int64_t)(s0 + idx) * kTB + e)
                                      : jb.colpart + 2 * ((tile_offset(jb.nb, cI) + (K - cI)) * kTB + e);
         acc1 = acc1 + gload(src);
@@ -663,7 +702,7 @@ struct SlabLayout {
 static int max_strips(int nb) {
     const int S = strip_len_for(nb);
     int n = 0;
-    for (int I = 0; I < nb; ++I) n += strips_in_row(nb, I, S);
+    for (int I = 0; I < nb; ++I) n += row_strip_count(nb, I, S);
     return n;
 }
 
@@ -898,26 +937,33 @@ struct SweepGroup {
                 nb_run = std::max(nb_run, J.nb);
                 int32_t* rs0 = hrs + (size_t)s * (size_t)(S.nbmax + 1);
                 int idx = 0;
-                for (int I = 0; I < J.nb; ++I) {
-                    rs0[I] = idx;
-                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len) {
-                        if (J.n < 2) { ++idx; continue; }          // nothing to multiply (the check kernel reports it)
+                for (int I = 0; I < J.nb; ++I) { rs0[I] = idx; idx += row_strip_count(J.nb, I, J.strip_len); }
+                rs0[J.nb] = idx;
+                if (J.n < 2) continue;                             // nothing to multiply (the check kernel reports it)
+                for (int I = 0; I < J.nb; I += 2) {                // rows I and I+1 together, cut on row I's column grid
+                    const int nrows = I + 1 < J.nb ? 2 : 1;
+                    int k = 0;
+                    for (int J0 = I; J0 < J.nb; J0 += J.strip_len, ++k) {
                         Strip& st = hs[nstrips++];
                         const int64_t t0 = tile_offset(J.nb, I) + (J0 - I);
                         st.tiles = J.tiles + t0 * kTileElems;
                         st.Q = J.Q; st.qstride = J.qstride; st.qslots = J.qslots;
-                        st.rowpart = J.rowpart + 2 * (int64_t)idx * kTB;
+                        st.rowpart = J.rowpart + 2 * (int64_t)(rs0[I] + k) * kTB;
                         st.colpart = J.colpart + 2 * t0 * kTB;
                         st.state = J.state;
                         st.I = I; st.J0 = J0; st.ntile = std::min(J.nb, J0 + J.strip_len) - J0;
-                        st.start = J.start; st.gen = J.gen; st.max_steps = J.max_steps; st.job = s;
-                        ++idx;
+                        st.start = J.start; st.gen = J.gen; st.max_steps = J.max_steps; st.nrows = nrows;
+                        st.tilesB = st.tiles; st.rowpartB = st.rowpart;
+                        if (nrows == 2) {
+                            const int JB = std::max(J0, I + 1);
+                            st.tilesB = J.tiles + (tile_offset(J.nb, I + 1) + (JB - (I + 1))) * kTileElems;
+                            st.rowpartB = J.rowpart + 2 * (int64_t)(rs0[I + 1] + k) * kTB;
+                        }
                     }
                 }
-                rs0[J.nb] = idx;
             }
             std::stable_sort(hs, hs + nstrips, [](const Strip& a, const Strip& b) {
-                return a.ntile > b.ntile;
+                return a.ntile * a.nrows > b.ntile * b.nrows;
             });
             std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
             std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
@@ -990,7 +1036,7 @@ struct SweepGroup {
                 hipLaunchKernelGGL(pk2_coef_kernel, dim3((unsigned)ceil_div(nb_run * kTB, kCoefRows), (unsigned)nslots),
                                    dim3(kCoefRows), 0, stream, d_jobs(tab), launch);
                 const int slot = profiler().begin(kProfMatvec, stream);
-                hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), 0, stream, d_strips(tab), launch);
+                hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), kMatvecLdsBytes, stream, d_strips(tab), launch);
                 profiler().end(kProfMatvec, slot, stream);
                 hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
                                    stream, d_jobs(tab), launch);
@@ -1056,6 +1102,8 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     if (workspace_bytes < need) { set_error("scint: sweep workspace too small"); return SCINT_E_WORKSPACE; }
     SideStreams* side = side_streams();
     if (!side) { set_error("scint: could not create the internal sweep streams"); return SCINT_E_HIP; }
+    SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kMatvecLdsBytes));
 
     SweepProblem S;
     S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;

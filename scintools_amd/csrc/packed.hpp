@@ -36,7 +36,6 @@ inline int strip_len_for(int nb) {
     if (forced > 0) return forced > 16 ? 16 : forced;   // tests of schedule independence (16 = kMaxStrip of the mat-vec kernel)
     return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
 }
-inline int strips_in_row(int nb, int I, int S) { return (nb - I + S - 1) / S; }
 
 struct PackedJob {
     // ---- gather ----------------------------------------------------------------
@@ -70,19 +69,33 @@ struct PackedJob {
     double tol;             // target relative accuracy of the eigenvalue
 };
 
-// One mat-vec workgroup's work: tiles (I, J0 .. J0+ntile-1) of one job.  The record carries every
-// pointer the workgroup needs, so that its tile loads are issued after ONE dependent load (this
-// record) instead of three (strip -> job table -> state word); measured in round 3.
+// One mat-vec workgroup's work: the tiles (I, J0 .. J0+ntile-1) of block row I and -- when nrows = 2 -- the
+// tiles of block row I+1 over the same columns (its first one is skipped when J0 = I: below the diagonal).
+// The two rows share the blocks X_J in LDS and ONE column partial per column tile (stored in the slots of
+// row I's tiles): half the partial-vector traffic of a row at a time, and that traffic is what a byte of
+// it costs four times a byte read (profiles/r03_pk2e_probe.txt).  The record carries every pointer the
+// workgroup needs, so that its tile loads are issued after ONE dependent load (this record) instead of
+// three (strip -> job table -> state word).
 struct __attribute__((aligned(16))) Strip {
-    const cplx* tiles;        // first tile of the strip
+    const cplx* tiles;        // first tile of the strip, row I
+    const cplx* tilesB;       // first tile of row I+1 in the strip (column max(J0, I+1)); unused when nrows = 1
     const cplx* Q;            // the job's Q ring (slot j % qslots holds Q_j, slots qstride*2 elements apart)
-    cplx* rowpart;            // this strip's [64][2] row partials
-    cplx* colpart;            // [ntile][64][2] column partials, first tile of the strip first
+    cplx* rowpart;            // row I's [64][2] row partials of this strip
+    cplx* rowpartB;           // row I+1's
+    cplx* colpart;            // [ntile][64][2] column partials, first column tile of the strip first
     const int32_t* state;     // the slot's state word (job done <=> state[0] >= gen)
     int64_t qstride;
     int32_t I, J0, ntile, qslots;
-    int32_t start, gen, max_steps, job;
+    int32_t start, gen, max_steps, nrows;
 };
+
+// Rows are paired (0,1), (2,3), ...; an unpaired last row (odd nb) runs alone.  The second row of a pair is
+// cut on the FIRST row's column grid, so both have the same number of strips.
+inline bool row_is_second(int nb, int I) { return (I & 1) && I < nb; }
+inline int row_strip_count(int nb, int I, int S) {
+    const int lead = (I & 1) ? I - 1 : I;              // the row whose grid this row is cut on
+    return (nb - lead + S - 1) / S;
+}
 
 // Gather for the jobs in slots[0..njobs) (device array of indices into jobs_dev); every job
 // names its own CS, theta grid and geometry (geoms_dev[job.geom]).

@@ -141,6 +141,27 @@ def test_secondary_spectrum_two_trip_path(emu, nf, nt, kw):
     assert np.abs(sec - ref)[strong].max() <= 1e-8
 
 
+@pytest.mark.parametrize("size", [192, 300])
+def test_eigenvalue_sweep_several_block_rows(emu, to, size):
+    """Matrices of 3 and 5 block rows: pairs of rows per mat-vec workgroup with strips beyond the first column
+    range, a second row that starts one tile late, an unpaired last row (the `case` fixture stays below 128)."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=9, nimg=6, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    CS = to.conjugate_spectrum(dyn, 0)
+    etas = np.array([0.8, 1.0, 1.3]) * eta_true
+    ref = np.array([to.Eval_calc(CS, tau, fd, e, edges) for e in etas])
+    eigs, info = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
+    assert np.all(info["status"] == 0) and info["N"].max() == size - 1
+    np.testing.assert_allclose(eigs, ref, rtol=1e-9)
+    w, V, _ = emu.eigvec_sweep(CS, tau, fd, etas[:1], edges)
+    red, _ = to.thth_redmap(CS, tau, fd, etas[0], edges)
+    v = V[0, : red.shape[0]].cpu().numpy()
+    assert np.linalg.norm(red @ v - w[0] * v) <= 1e-8 * abs(w[0])
+
+
 def test_eigenvalue_sweep_vs_arpack(emu, to, case):
     """The batched two-vector Lanczos sweep incl. its two-stream scheduler (run here in enqueue
     order) against the oracle's ARPACK eigsh, and independent of the batch size."""

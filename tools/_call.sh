@@ -1,4 +1,4 @@
 export TMPDIR=/tmp; O=$PWD/gpurun_out; mkdir -p $O
-bash tools/gpu_run.sh suite s19
-python tools/time_wavefield.py 2>&1 | tail -2
-python tools/_retr_dev.py 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_gpu_edges.py tests/test_gpu_parity.py tests/test_gpu_stopping_rule.py -m gpu -q -x -k "not headline" 2>&1 | tail -3
+bash tools/gpu_run.sh quick s20
+SCINT_SWEEP_GROUPS=1 bash tools/gpu_run.sh quick s20g1
