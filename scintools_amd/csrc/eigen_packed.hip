@@ -846,6 +846,7 @@ struct SweepProblem {
     int nbmax, steps_cap, depth, check_every;
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
+    hipEvent_t stagger_ev = nullptr;      // recorded after the first group's first pass
 };
 
 struct SweepGroup {
@@ -1040,6 +1041,9 @@ struct SweepGroup {
                 profiler().end(kProfMatvec, slot, stream);
                 hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
                                    stream, d_jobs(tab), launch);
+                // the other group starts one pass behind this one (see run_sweep): its checks, refills and
+                // reductions then fall beside this group's mat-vecs instead of beside its own twins
+                if (chunk == 0 && i == 0 && S.stagger_ev && slot0 == 0) (void)hipEventRecord(S.stagger_ev, stream);
             }
         }
         hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
@@ -1208,11 +1212,27 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         if (he == hipSuccess) he = hipStreamWaitEvent(side->aux, start_ev, 0);
         if (he != hipSuccess) rc = hip_fail(he, "sweep setup", __FILE__, __LINE__);
     }
+    // Two groups that start together stay in step: equal chunks of equal work, so their convergence checks (one
+    // wavefront per curvature, 160 us), refill gathers and reductions coincide and the GPU has no mat-vec to run
+    // beside them (7 + 6 ms of a 190 ms sweep in the round-3 trace, profiles/r03_timeline.txt).  The second group
+    // therefore waits for the first one's first pass.  Nothing per-job depends on it.
+    if (rc == SCINT_OK && ngroups == 2) {
+        he = hipEventCreateWithFlags(&S.stagger_ev, hipEventDisableTiming);
+        if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
+    }
+    bool staggered = false;
     while (rc == SCINT_OK) {
         bool any = false;
         for (int g = 0; g < ngroups && rc == SCINT_OK; ++g) {
             if (G[g].finished) continue;
             any = true;
+            if (g == 1 && !staggered) {
+                staggered = true;
+                if (G[0].chunk > 0 && G[0].nstrips > 0) {
+                    he = hipStreamWaitEvent(G[1].stream, S.stagger_ev, 0);
+                    if (he != hipSuccess) { rc = hip_fail(he, "sweep stagger", __FILE__, __LINE__); break; }
+                }
+            }
             rc = G[g].advance();
         }
         if (!any) break;
@@ -1233,6 +1253,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             if (G[g].export_done[t]) (void)hipEventDestroy(G[g].export_done[t]);
         }
     if (start_ev) (void)hipEventDestroy(start_ev);
+    if (S.stagger_ev) (void)hipEventDestroy(S.stagger_ev);
     return rc;
 }
 
