@@ -340,9 +340,7 @@ int32_t launch_fft_rows(int64_t n, int64_t nslots, Loader ld, Storer st, hipStre
     sh.nslots = nslots;
     sh.tw = tw;
     const int64_t grid = ceil_div(nslots, sh.slots_per_block);
-    // SCINT_FFT_SPLIT=0 turns the split exchange of the short transforms off (experiments)
-    static const int split_on = [] { const char* e = getenv("SCINT_FFT_SPLIT"); return e ? atoi(e) : 1; }();
-    const bool split = split_on && n >= 32 && n <= 128 && !Storer::kPair;
+    const bool split = n >= 32 && n <= 128 && !Storer::kPair;
     const size_t lds = (size_t)sh.slots_per_block * (size_t)(n + n / 16) * (split ? sizeof(double) : sizeof(cplx));
 #define SCINT_ROWS_K(R0, R1, R2, R3, SP)                                                        \
     do {                                                                                        \
@@ -505,7 +503,7 @@ struct TileSlot {
 //       64 adjacent columns (1 KiB per row) and the workgroups in flight together cover a few
 //       contiguous multi-MiB row bands (DRAM pages and TLB entries get reused);
 //   inner-fast           slot = (((batch * ntiles + tile) << lbits | inner) * 16 + c
-//       a workgroup is one 256-byte tile of 4x as many rows (kept for comparison, SCINT_FFT_TILE_ORDER=0).
+//       a workgroup is one 256-byte tile of 4x as many rows (measured 1-2 % slower; the decode stays for the record).
 __device__ inline TileSlot tile_slot(int64_t slot, int lbits, int ntiles, int ncols, int tile_fast) {
     TileSlot s;
     const uint32_t rest = (uint32_t)(slot >> 4), mask = (1u << lbits) - 1u;
@@ -590,13 +588,12 @@ int32_t run_cols_fft(int64_t len, int64_t ncols, int64_t batches, FirstLoader fi
     // Measured on MI355X: while the working array fits the 256 MiB Infinity Cache the in-place radix
     // passes re-read what they just wrote from the cache and win (4096^2 complex: 0.23 vs 0.28 ms);
     // beyond it every radix pass is an HBM round trip and the two tiled passes win (16384^2: 5.6
-    // vs 7.3 ms).  SCINT_FFT_TWO_PASS = 0 / 2 forces never / always (experiments).
-    static const int two_pass = [] { const char* e = getenv("SCINT_FFT_TWO_PASS"); return e ? atoi(e) : 1; }();
+    // vs 7.3 ms).
     const bool beyond_cache = (double)len * (double)ncols * (double)batches * 16.0 > 300.0 * 1048576.0;
-    if ((two_pass == 2 || (two_pass == 1 && beyond_cache)) && len >= 256 && len <= 16384) {
+    if (beyond_cache && len >= 256 && len <= 16384) {
         const int l = ilog2(len), l2 = l / 2, l1 = l - l2;          // L1 >= L2, both in [16, 128]
         const int64_t ntiles = ceil_div(ncols, 16);
-        static const int tile_fast = [] { const char* e = getenv("SCINT_FFT_TILE_ORDER"); return e ? atoi(e) : 1; }();
+        constexpr int tile_fast = 1;     // workgroups walk along the rows of the array (measured: 1-2 % over tile columns)
         SCINT_REQUIRE(batches * ntiles * 128 < ((int64_t)1 << 32), "fft cols: too many tile slots");
         int32_t rc = launch_fft_rows<4, 7>((int64_t)1 << l1, batches * ntiles * ((int64_t)1 << l2) * 16,
                                      ColsALoad<FirstLoader>{first, (int)ncols, (int)ntiles, tile_fast, l2},
