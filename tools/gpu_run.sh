@@ -11,7 +11,7 @@
 #   modeler  [tag]          the same trace of the chi^2 (modeler) objective
 #   pmc      [tag] [args]   FETCH_SIZE / WRITE_SIZE in separate --pmc passes of a 1-step bench (256 eta)
 #   fft      [tag]          kernel trace + PMC passes of tools/time_fft.py (calc_sspec and CS, 2048^2 .. 8192^2)
-#   probes   [tag]          tools/probes/*.hip (stream ceiling, pk2 body, f64 MFMA layout)
+#   probes   [tag]          tools/probes/*.hip (stream ceiling, the round-2 and round-3 mat-vec loops with their parts switchable, f64 MFMA layout)
 #   all      [tag]          suite, bench, configs, trace, modeler, pmc, fft  (the closing call of a round)
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
@@ -45,6 +45,7 @@ trace_of() {  # name, bench arguments
   db=$(find $O/${TAG}_prof_$1 -name "*.db" | head -1)
   python tools/rocpd_summary.py $db $O/${TAG}_$1_kernel_stats.csv $O/${TAG}_$1_kernel_overlap.json > /dev/null
   head -12 $O/${TAG}_$1_kernel_stats.csv | cut -c1-220
+  python tools/timeline.py $db --top 8 > $O/${TAG}_$1_timeline.txt 2>&1; head -9 $O/${TAG}_$1_timeline.txt
 }
 trace()   { trace_of bench "--steps 3 --warmup 1 $QUICK $EXTRA"; }
 modeler() { trace_of modeler "--objective chisq --steps 2 --warmup 1 --no-cpu-baseline"; }
@@ -69,7 +70,7 @@ fft() {
   pmc_of fft "tools/time_fft.py" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/time_fft.py"
 }
 probes() {
-  for p in stream_probe pk2_probe mfma_f64_probe; do
+  for p in stream_probe pk2_probe pk2e_probe mfma_f64_probe; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/$p.hip -o /tmp/$p 2> /dev/null && timeout 120 /tmp/$p | tee $O/${TAG}_$p.txt
   done
 }
