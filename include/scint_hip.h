@@ -170,6 +170,13 @@ int32_t scint_eigvec_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOS
                            int32_t* status_out, int32_t* iters_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The crop of thth_redmap (ththmod.py:153-155) for every curvature of a sweep, on the device:
+ * keep_idx[e*M ..] = ascending indices i with th_cents[i]^2 * etas[e] < tau_max and |th_cents[i]| < fd_half
+ * (NumPy's expression, same roundings), keep_n[e] their count -- the tables the sweeps take.  th_cents,
+ * keep_idx, keep_n: DEVICE; etas: HOST.  Asynchronous. */
+int32_t scint_sweep_keep(const double* th_cents, int64_t M, const double* etas /*HOST*/, int64_t neta,
+                         double tau_max, double fd_half, int32_t* keep_idx, int32_t* keep_n, void* stream);
+
 /* The same for MANY conjugate spectra of one shape in one batched sweep (arguments as
  * scint_eval_sweep_multi): the eigenpairs of all chunks of Dynspec.thetatheta_chunks -- one
  * modeler() call per chunk in the reference, dynspec.py:1765-1826 / ththmod.py:1455 -- in ONE call. */

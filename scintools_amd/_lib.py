@@ -57,6 +57,7 @@ _SIGNATURES = {
     "scint_eigvec_sweep_workspace_bytes": ([c_int64, c_int64, c_int64, c_int32, POINTER(c_size_t)], c_int32),
     "scint_eigvec_sweep": ([_P, POINTER(CsGeom), _P, c_int64, _P, POINTER(c_int32), POINTER(c_double), c_int64,
                             c_double, c_int32, c_int64, _P, _P, c_int64, _P, _P, _P, c_size_t, _P], c_int32),
+    "scint_sweep_keep": ([_P, c_int64, POINTER(c_double), c_int64, c_double, c_double, _P, _P, _P], c_int32),
     "scint_eigvec_sweep_multi_workspace_bytes": ([c_int64, c_int64, c_int64, c_int32, c_int64, POINTER(c_size_t)],
                                                  c_int32),
     "scint_eigvec_sweep_multi": ([_P, c_int64, c_int64, POINTER(c_int32), POINTER(CsGeom), _P, c_int64, _P,

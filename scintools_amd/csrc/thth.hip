@@ -649,3 +649,63 @@ extern "C" int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, 
                                           hermitian, (cplx*)recov_out),
                           g, (unsigned long long*)workspace, stream);
 }
+
+
+// ------------------------------------------------------------------------------
+// scint_sweep_keep: the crop of thth_redmap (ththmod.py:153-155) for a whole sweep, on the device
+// ------------------------------------------------------------------------------
+// keep[e] = ascending indices i with  th[i]^2 * eta_e < tau_max  and  |th[i]| < fd_half  -- NumPy's expression
+// with its roundings (two multiplications, no contraction: this unit is built with -ffp-contract=off).
+// One 256-thread workgroup per curvature; left-packed by a fixed-order block scan.  On the host this is a
+// Python loop over the curvatures plus a 4 MB upload per sweep (3 % of a 4096^2 / 256-eta step).
+struct KeepEtas { double eta[256]; };
+__global__ void __launch_bounds__(256) sweep_keep_kernel(const double* __restrict__ th, int M, KeepEtas etas, int e0,
+                                                         int neta, double tau_max, double fd_half,
+                                                         int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_n) {
+    __shared__ int wave_tot[4];
+    __shared__ int base_s;
+    const int e = e0 + (int)blockIdx.x;
+    if (e >= neta) return;
+    const double eta = etas.eta[blockIdx.x];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int32_t* __restrict__ out = keep_idx + (int64_t)e * M;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < M; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        bool k = false;
+        if (i < M) {
+            const double t = th[i];
+            const double t2 = t * t;
+            k = (t2 * eta < tau_max) && (fabs(t) < fd_half);
+        }
+        const unsigned long long m = __ballot(k);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int ww = 0; ww < w; ++ww) off += wave_tot[ww];
+        if (k) out[off + before] = i;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) keep_n[e] = base_s;
+}
+
+extern "C" int32_t scint_sweep_keep(const double* th_cents, int64_t M, const double* etas, int64_t neta,
+                                    double tau_max, double fd_half, int32_t* keep_idx, int32_t* keep_n,
+                                    void* stream_) {
+    SCINT_REQUIRE(th_cents && etas && keep_idx && keep_n, "sweep_keep: null pointer");
+    SCINT_REQUIRE(M >= 1 && M < (1 << 30) && neta >= 1, "sweep_keep: bad shape");
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int64_t e0 = 0; e0 < neta; e0 += 256) {
+        KeepEtas ke;
+        const int nb = (int)std::min<int64_t>(256, neta - e0);
+        for (int i = 0; i < 256; ++i) ke.eta[i] = i < nb ? etas[e0 + i] : 0.0;
+        hipLaunchKernelGGL(sweep_keep_kernel, dim3((unsigned)nb), dim3(256), 0, stream, th_cents, (int)M, ke, (int)e0,
+                           (int)neta, tau_max, fd_half, keep_idx, keep_n);
+    }
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}

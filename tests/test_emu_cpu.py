@@ -141,6 +141,19 @@ def test_secondary_spectrum_two_trip_path(emu, nf, nt, kw):
     assert np.abs(sec - ref)[strong].max() <= 1e-8
 
 
+def test_device_crop_tables_equal_the_host_ones(emu, case):
+    """scint_sweep_keep against the NumPy expression of thth_redmap's crop (ththmod.py:153-155): same indices,
+    same counts, for curvatures from 'keeps everything' to 'keeps nothing'."""
+    grid = emu._Grid(case["tau"], case["fd"], np.linspace(-case["fd"].max(), case["fd"].max(), 700))
+    etas = np.concatenate((np.geomspace(1e-3, 1e3, 300) * case["etas"][2], [1e12 * case["etas"][2]]))
+    keep_t, n_dev = emu._sweep_inputs_dev(grid, etas)
+    keep_h, n_h = emu._sweep_inputs(grid, etas)
+    assert np.array_equal(n_dev, n_h) and n_h.max() > 300 and n_h.min() <= 1     # more than one 256-element scan step; the |theta| < fd_max/2 half of the crop binds too
+    kd = keep_t.cpu().numpy()
+    for i, n in enumerate(n_h):
+        assert np.array_equal(kd[i, :n], keep_h[i, :n])
+
+
 @pytest.mark.parametrize("size", [192, 300])
 def test_eigenvalue_sweep_several_block_rows(emu, to, size):
     """Matrices of 3 and 5 block rows: pairs of rows per mat-vec workgroup with strips beyond the first column

@@ -368,6 +368,21 @@ def test_eval_sweep_multi_equals_per_chunk_sweeps(thth, to):
         assert np.array_equal(a, b)
 
 
+def test_device_crop_tables_equal_the_host_ones(thth):
+    """scint_sweep_keep (the eigenvalue sweep's crop tables, built on the device) against the NumPy expression of
+    thth_redmap's crop (ththmod.py:153-155) at the headline shape: same indices, same counts."""
+    import bench
+    dyn, freqs, times, fd, tau, edges, etas, eta_true = bench.make_workload(512, 256, 4096, seed=3)
+    grid = thth._Grid(tau, fd, edges)
+    etas = np.concatenate((etas, np.geomspace(1e-4, 1e6, 99) * eta_true))
+    keep_t, n_dev = thth._sweep_inputs_dev(grid, etas)
+    keep_h, n_h = thth._sweep_inputs(grid, etas)
+    assert np.array_equal(n_dev, n_h) and n_h.max() > 2000 and n_h.min() < 10
+    kd = keep_t.cpu().numpy()
+    for i, n in enumerate(n_h):
+        assert np.array_equal(kd[i, :n], keep_h[i, :n])
+
+
 def _align(a, ref):
     return a * np.exp(-1j * np.angle(np.vdot(ref, a)))
 
