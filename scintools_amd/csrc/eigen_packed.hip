@@ -425,7 +425,7 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
     // the strip's column partials in one burst (the slot of a diagonal tile is written too; nobody reads it)
     __syncthreads();
     cplx* __restrict__ colpart = sp->colpart;
-    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore(colpart + idx, lds[kLdsCol + idx]);
+    for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore_nt(colpart + idx, lds[kLdsCol + idx]);
 }
 
 __global__ void __launch_bounds__(64 * kRedGroups)
