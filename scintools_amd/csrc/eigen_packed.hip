@@ -60,14 +60,7 @@ __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
     return conj(jb.tiles[(tile_offset(jb.nb, bc) + (br - bc)) * kTileElems + (c % kTB) * kTB + (r % kTB)]);
 }
 
-constexpr int kMaxStrip = 16;
-
-// wave-uniform broadcast of lane `src`'s double through the scalar unit (no LDS, no VGPR)
-__device__ inline double readlane_f64(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
+constexpr int kMaxStrip = 16;    // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS)
 
 constexpr int kRedGroups = 16;   // wavefronts per reduce block: each sums every 16th partial vector
 
@@ -260,6 +253,7 @@ __global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __
 // workgroups per CU.
 constexpr int kLdsXs = 0, kLdsCol = 2048, kLdsXi = 4096, kLdsRsum = 4352, kLdsElems = 4864;   // complex elements
 constexpr size_t kMatvecLdsBytes = sizeof(cplx) * kLdsElems;
+static_assert(kLdsCol - kLdsXs == kMaxStrip * kTB * 2 && kLdsXi - kLdsCol == kMaxStrip * kTB * 2, "LDS carve of the mat-vec");
 
 __device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (*__restrict__ xir)[2],
                                         const cplx (&xJ1)[2], const cplx (&xJ2)[2], cplx (&acc1)[8], cplx (&acc2)[8],

@@ -1059,8 +1059,6 @@ extern "C" int32_t scint_sspec(const double* dyn, int64_t nf, int64_t nt, const 
         SCINT_LAUNCH_CHECK();
     }
     WindowedValue wv{dyn, win_t, win_f, scal, (int)nt};
-    int32_t rc = SCINT_OK;
-
     const int64_t nf_eff = prewhite ? nf - 1 : nf, nt_eff = prewhite ? nt - 1 : nt;
     RowSource src{};
     src.mode = SRC_SSPEC; src.wv = wv; src.m2 = scal + 1; src.nt_eff = nt_eff; src.prewhite = prewhite;
