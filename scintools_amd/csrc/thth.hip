@@ -238,8 +238,13 @@ __host__ __device__ inline int64_t hist_bin(double x, double x0, double step, in
     return k;
 }
 
-// The same bin for the gather kernel: the first guess comes from a multiplication by 1/step (the two
-// fix-up loops make the result exact whatever the guess), 32-bit index.
+// The same bin for the back-map kernel, 32-bit index, the first guess from a multiplication by 1/step.  The
+// edges e(k) = (k - 0.5) step + x0 are non-decreasing in k, so the answer is the largest k in [0, n) with
+// e(k) <= x < e(k + 1); a guess that is off by at most one (any sane x: the guess only carries the rounding of
+// one subtraction and one multiplication) is settled with two or three edge evaluations and no loop.  Whatever
+// that does not prove -- a guess further off, the closed last bin, an x outside the axis -- takes the loops of
+// hist_bin.  (The loops alone cost every pair sixty instructions: the compiler unrolls the second one four-fold,
+// `#pragma clang loop unroll(disable)` notwithstanding.)
 __device__ inline int hist_bin_rcp(double x, double x0, double step, double inv_step, int n) {
     if (!(step > 0.0) || x != x) return -1;
     const double guess = floor((x - x0) * inv_step + 0.5);
@@ -248,10 +253,17 @@ __device__ inline int hist_bin_rcp(double x, double x0, double step, double inv_
     int k = (int)guess;
     if (k < 0) k = 0;
     if (k > n) k = n;
-    while (k < n && (((double)(k + 1) - 0.5) * step + x0) <= x) ++k;
-    while (k >= 0 && (((double)k - 0.5) * step + x0) > x) --k;
+    auto edge = [&](int q) { return ((double)q - 0.5) * step + x0; };
+    const double ea = edge(k), eb = edge(k + 1);
+    bool sure;
+    if (k < n && eb <= x) { ++k; sure = k < n && edge(k + 1) > x; }
+    else if (ea > x) { --k; sure = k >= 0 && edge(k) <= x; }
+    else sure = k < n;
+    if (sure) return k;
+    while (k < n && edge(k + 1) <= x) ++k;
+    while (k >= 0 && edge(k) > x) --k;
     if (k < 0) return -1;
-    if (k == n) return (x == (((double)n - 0.5) * step + x0)) ? n - 1 : -1;
+    if (k == n) return (x == edge(n)) ? n - 1 : -1;
     return k;
 }
 
@@ -397,8 +409,10 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // point), so pixel (i, j) contributes  w_ij + conj(w_ji)  with count 2.  For the rank-1
 // Hermitian model w_ji == conj(w_ij) exactly, and sum and count are both halved.
 constexpr int kRevWin = 8;   // widest candidate window (theta centres per fd bin, + 2)
+constexpr int kRevBlock = 16;       // lanes per block of the chunk pre-pass
+constexpr int kRevLiveWords = 64;   // 32 chunks per word: N <= 524288 is pruned, beyond that every chunk is walked
 
-template <int kRevThreads>
+template <int kRevThreads, bool RANK1>
 __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
@@ -420,10 +434,10 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
     const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;        // histogram edges of the column
     const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
     const bool last = (col == g.nfd - 1);                              // last bin is closed on the right
-    const double aw = p.rank1 ? fabs(gload(p.w)) : 0.0;
+    const double aw = RANK1 ? fabs(gload(p.w)) : 0.0;
     const double vmax = __longlong_as_double((long long)p.bound[0]);
-    const RevSplit sp = rev_split_for(p.rank1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)p.bound[1]),
-                                      p.two_eta, !p.rank1 && p.hermitian);
+    const RevSplit sp = rev_split_for(RANK1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)p.bound[1]),
+                                      p.two_eta, !RANK1 && p.hermitian);
     const int N = p.N;
     // window start relative to i, and its width, from the mean theta spacing
     const double th_step = N > 1 ? (gload(p.th + N - 1) - gload(p.th)) / (double)(N - 1) : 0.0;
@@ -435,25 +449,23 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
     const double inv_tstep = 1.0 / g.tau1_step;
     const double row_lo = (double)row0 - 2.0, row_hi = (double)(row0 + rows) + 1.0;   // estimate of bin + 0.5
     auto beyond = [&](double x) { return last ? (x > hi) : (x >= hi); };
-    // what pair (i, j) adds to which row of the slab (by < 0: nothing)
-    struct Contrib { int by; uint32_t c; double rh, rl, ih, il; };
-    auto evaluate = [&](int i, int j, double th_i, double th_j) -> Contrib {
-        Contrib t; t.by = -1; t.c = 0u; t.rh = t.rl = t.ih = t.il = 0.0;
-        if (i == j) return t;                                          // lands in the poisoned centre bin
+    // What pair (i, j) adds to the slab: ONE guarded region per test (slab estimate, exact bin) -- results that
+    // leave a chain of early returns as a struct cost a move or a select per field and per exit
+    // (profiles/r03_revmap_counters.txt: 58 % of the kernel's vector instructions were neither arithmetic nor index work).
+    auto pair = [&](int i, int j, double th_i, double th_j) {
         const double y = p.eta * (th_j * th_j - th_i * th_i);          // tau_map[i, j] (ththmod.py:208-210)
         // cheap slab test first (two rows of slack cover the rounding of this estimate): the exact
         // bin, the weight and the loads are only paid for by the slab that owns the pixel
         const double est = (y - g.tau0) * inv_tstep;
-        if (est < row_lo || est > row_hi) return t;
+        if (i == j || est < row_lo || est > row_hi) return;            // i == j lands in the poisoned centre bin
         const int bin = hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, (int)g.ntau);
-        if (bin < 0) return t;
         const int by = bin - (int)row0;
-        if (by < 0 || by >= rows) return t;
+        if (bin < 0 || by < 0 || by >= rows) return;
         // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
-        const double scl = 1.0 / sqrt(fabs(p.two_eta * (th_i - th_j)));
+        const double scl = rsqrt(fabs(p.two_eta * (th_i - th_j)));   // (1 / sqrt costs a division on top: 25 instructions against 10)
         double wr, wi;
-        t.c = 1u;
-        if (p.rank1) {
+        uint32_t c = 1u;
+        if (RANK1) {
             const cplx o = mulc(gload(p.vec + i), gload(p.vec + j));   // outer(V, conj(V)) * |w|  (:312-313)
             wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
         } else {
@@ -462,59 +474,96 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
             if (p.hermitian) {
                 const cplx u = gload(p.thth + (int64_t)j * p.ld + i);
                 wr += u.x * scl; wi += -(u.y * scl);
-                t.c = 2u;
+                c = 2u;
             }
         }
-        t.by = by;
         if (sp.exact) {
-            t.rh = (wr + sp.s1) - sp.s1; t.ih = (wi + sp.s1) - sp.s1;
-            t.rl = ((wr - t.rh) + sp.s2) - sp.s2; t.il = ((wi - t.ih) + sp.s2) - sp.s2;
+            const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
+            atomicAdd(&rev_lds[by], rh);
+            atomicAdd(&rev_lds[2 * slab + by], ih);
+            atomicAdd(&rev_lds[slab + by], ((wr - rh) + sp.s2) - sp.s2);
+            atomicAdd(&rev_lds[3 * slab + by], ((wi - ih) + sp.s2) - sp.s2);
         } else {
-            t.rh = wr; t.ih = wi;
+            atomicAdd(&rev_lds[by], wr);
+            atomicAdd(&rev_lds[2 * slab + by], wi);
         }
-        return t;
-    };
-    auto deposit = [&](const Contrib& t) {
-        atomicAdd(&rev_lds[t.by], t.rh);
-        atomicAdd(&rev_lds[2 * slab + t.by], t.ih);
-        if (sp.exact) {
-            atomicAdd(&rev_lds[slab + t.by], t.rl);
-            atomicAdd(&rev_lds[3 * slab + t.by], t.il);
-        }
-        atomicAdd((uint32_t*)(rev_lds + 4 * slab) + t.by, t.c);
+        atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
     };
     // (Summing the runs of lanes that hit one accumulator in registers first -- a segmented scan over the
     // wave, legal because the grid-split addends sum exactly in any association -- was measured in round 3:
     // 0.58 ms against 0.38 ms per 4096^2 image.  The kernel is bound by its fp64 arithmetic per pair
     // (exact bin, 1/sqrt, split), not by the LDS atomics.)
     const double lo_hi_min = fmin(lo, hi), lo_hi_max = fmax(lo, hi);
+    // Every pair of theta_i in this column has x = th_j - th_i in [lo, hi] and y = eta x (2 th_i + x): a parabola
+    // in x, extremal at the interval ends or at its vertex x = -th_i.  If that range of y misses the slab by more
+    // than a row on either side of the slack `pair` already allows, no pair of theta_i lands here.  (NaNs compare
+    // false: such a lane goes on.)
+    auto delay_range = [&](double th_i, double& ymin, double& ymax) {
+        const double ya = p.eta * (lo * (2.0 * th_i + lo)), yb = p.eta * (hi * (2.0 * th_i + hi));
+        ymin = fmin(ya, yb); ymax = fmax(ya, yb);
+        if (-th_i >= lo_hi_min && -th_i <= lo_hi_max) {
+            const double yv = -(p.eta * (th_i * th_i));
+            ymin = fmin(ymin, yv); ymax = fmax(ymax, yv);
+        }
+    };
+    auto misses_slab = [&](double ymin, double ymax) {
+        return (ymax - g.tau0) * inv_tstep < row_lo - 1.0 || (ymin - g.tau0) * inv_tstep > row_hi + 1.0;
+    };
+    // Which 256-lane chunks of theta_i can reach the slab at all?  A slab is reached by a contiguous run of i, and
+    // four slabs of a column used to walk all N lanes each -- a quarter of the kernel's vector instructions
+    // (profiles/r03_revmap_counters.txt).  One pass over BLOCKS of 16 lanes instead: for a fixed x the delay is
+    // monotone in theta_i (also as computed: every operation of `delay_range` is monotone in its rounded operand),
+    // so the range of any lane of a block lies in the hull of the ranges of the block's two end lanes -- plus the
+    // vertex values a lane in between may add (theta^2 is monotone on either side of 0).  That needs theta
+    // increasing, which the bound pre-pass has checked (its minimum spacing is 0 otherwise).
+    __shared__ uint32_t live[kRevLiveWords];
+    static_assert(kRevThreads % kRevBlock == 0, "a block of the pre-pass lies inside one chunk");
+    const int nchunk = (N + kRevThreads - 1) / kRevThreads;
+    const bool prune = usable && nchunk <= 32 * kRevLiveWords && __longlong_as_double((long long)p.bound[1]) > 0.0;
+    if (threadIdx.x < kRevLiveWords) live[threadIdx.x] = prune ? 0u : ~0u;
+    __syncthreads();
+    if (prune) {
+        for (int ia = (int)threadIdx.x * kRevBlock; ia < N; ia += kRevThreads * kRevBlock) {
+            const double ta = gload(p.th + ia), tb = gload(p.th + min(N - 1, ia + kRevBlock - 1));
+            double ymin, ymax, ymin_b, ymax_b;
+            delay_range(ta, ymin, ymax);
+            delay_range(tb, ymin_b, ymax_b);
+            ymin = fmin(ymin, ymin_b); ymax = fmax(ymax, ymax_b);
+            if (-tb <= lo_hi_max && -ta >= lo_hi_min) {            // some theta of the block may have its vertex in the column
+                const double va = -(p.eta * (ta * ta)), vb = -(p.eta * (tb * tb));
+                ymin = fmin(ymin, fmin(va, vb)); ymax = fmax(ymax, fmax(va, vb));
+                if (ta <= 0.0 && tb >= 0.0) { const double v0 = -(p.eta * 0.0); ymin = fmin(ymin, v0); ymax = fmax(ymax, v0); }
+            }
+            if (!misses_slab(ymin, ymax)) {
+                const int c = ia / kRevThreads;
+                atomicOr(&live[c >> 5], 1u << (c & 31));
+            }
+        }
+    }
+    __syncthreads();
     for (int base = 0; usable && base < N; base += kRevThreads) {      // trip count uniform over the workgroup
+        const int chunk = base / kRevThreads;
+        if (nchunk <= 32 * kRevLiveWords && !((live[chunk >> 5] >> (chunk & 31)) & 1u)) continue;
         const int i = base + (int)threadIdx.x;
         bool active = i < N;
         const double th_i = active ? gload(p.th + i) : 0.0;
         if (active) {
-            // every pair of this lane has x = th_j - th_i in [lo, hi] and y = eta x (2 th_i + x): a parabola
-            // in x, extremal at the interval ends or at its vertex x = -th_i.  If that range of y misses the
-            // slab by more than a row on either side of the slack `evaluate` already allows, no pair of
-            // this lane lands here.  (NaNs compare false: the lane goes on.)
-            const double ya = p.eta * (lo * (2.0 * th_i + lo)), yb = p.eta * (hi * (2.0 * th_i + hi));
-            double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
-            if (-th_i >= lo_hi_min && -th_i <= lo_hi_max) {
-                const double yv = -(p.eta * (th_i * th_i));
-                ymin = fmin(ymin, yv); ymax = fmax(ymax, yv);
-            }
-            if ((ymax - g.tau0) * inv_tstep < row_lo - 1.0 || (ymin - g.tau0) * inv_tstep > row_hi + 1.0) active = false;
+            double ymin, ymax;
+            delay_range(th_i, ymin, ymax);
+            if (misses_slab(ymin, ymax)) active = false;
         }
         if (__ballot(active) == 0ull) continue;                        // wave-uniform
         const int g0 = i + s0;                                         // first candidate
-        double tj[kRevWin + 2];                                        // th[g0 - 1 .. g0 + W]
+        // th[g0 - 1 .. g0 + W], every index clamped into the array and every lane loading (no predicate per position:
+        // ten predicated loads were a fifth of the kernel's instructions).  A clamped GUARD is the array's end element:
+        // if that is still outside the column it speaks for everything beyond it, and a guard position outside the
+        // array passes by its index alone; a clamped CANDIDATE is discarded by its index below.
+        double tj[kRevWin + 2];
 #pragma unroll
         for (int k = 0; k < kRevWin + 2; ++k) {
-            const int idx = g0 - 1 + k;
-            // the two guards are clamped into the array: a guard at the array's end that is still
-            // outside the column speaks for everything beyond it
-            const int cl = k == 0 ? min(idx, N - 1) : (k == W + 1 ? max(idx, 0) : idx);
-            tj[k] = (active && k <= W + 1 && cl >= 0 && cl < N) ? gload(p.th + cl) : nan("");
+            tj[k] = 0.0;
+            if (k > W + 1) continue;                                   // uniform: nothing beyond the upper guard is loaded
+            tj[k] = gload(p.th + min(max(g0 - 1 + k, 0), N - 1));
         }
         double t_hi = tj[1];                                           // tj[W + 1] without dynamic indexing
 #pragma unroll
@@ -522,24 +571,40 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
         const bool below_ok = (g0 - 1 < 0) || !(tj[0] - th_i >= lo);
         const bool above_ok = (g0 + W >= N) || beyond(t_hi - th_i);
         const bool windowed = active && W > 0 && below_ok && above_ok;
-        if (active && !windowed) {                                     // irregular grid: search, deposit pair by pair
-            for (int j = rev_first_ge(p.th, N, th_i, lo, g0); j < N; ++j) {
-                const double th_j = gload(p.th + j);
-                if (beyond(th_j - th_i)) break;
-                const Contrib t = evaluate(i, j, th_i, th_j);
-                if (t.by >= 0) deposit(t);
-            }
-        }
+        // This lane's pairs are the j of ONE run ja .. ja + nj - 1 (fl(th[j] - th_i) is non-decreasing in j): from the
+        // window when its guards bracket the column, else from a search.  One loop then serves every lane -- its trip
+        // count is the wave's longest run (two or three on the grids of the path) -- with ONE copy of `evaluate`
+        // instead of one per window position; the run's theta values are re-read (they were just loaded).
+        int ja = 0, nj = 0;
+        if (windowed) {
+            int kf = 0, kl = -1;
 #pragma unroll
-        for (int k = 1; k <= kRevWin; ++k) {
-            if (k > W) break;                                          // W is uniform over the workgroup
-            const int j = g0 - 1 + k;
-            Contrib t; t.by = -1; t.c = 0u; t.rh = t.rl = t.ih = t.il = 0.0;
-            if (windowed && j >= 0 && j < N) {
+            for (int k = 1; k <= kRevWin; ++k) {
+                if (k > W) break;                                      // W is uniform over the workgroup
+                const int j = g0 - 1 + k;
                 const double x = tj[k] - th_i;                         // fd_map[i, j]  (ththmod.py:207)
-                if (x >= lo && !beyond(x)) t = evaluate(i, j, th_i, tj[k]);
+                if ((unsigned)j < (unsigned)N && x >= lo && !beyond(x)) {
+                    if (kl < 0) kf = k;
+                    kl = k;
+                }
             }
-            if (t.by >= 0) deposit(t);
+            ja = g0 - 1 + kf;
+            nj = kl < 0 ? 0 : kl - kf + 1;
+        } else if (active) {                                           // irregular grid
+            ja = rev_first_ge(p.th, N, th_i, lo, g0);
+            int jb = ja;
+            while (jb < N && !beyond(gload(p.th + jb) - th_i)) ++jb;
+            nj = jb - ja;
+        }
+        for (int r = 0; __ballot(r < nj) != 0ull; ++r) {
+            if (r < nj) {
+                const int j = ja + r;
+                const double th_j = gload(p.th + j);
+                const double x = th_j - th_i;
+                // (inside a window every position is tested on its own, as a position outside the column may sit
+                // between two inside it when theta is not monotone to the last bit)
+                if (!windowed || (x >= lo && !beyond(x))) pair(i, j, th_i, th_j);
+            }
         }
     }
     __syncthreads();
@@ -592,7 +657,10 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    hipLaunchKernelGGL(rev_gather_kernel<kRevThreadsK>, grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
+    if (p.rank1)
+        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, true>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
+    else
+        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, false>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

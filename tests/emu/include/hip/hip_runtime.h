@@ -183,6 +183,7 @@ inline double __hiloint2double(int hi, int lo) {
 }
 inline long long __double_as_longlong(double v) { return ::emu::from_bits<long long>(::emu::to_bits(v)); }
 inline double __longlong_as_double(long long v) { return ::emu::from_bits<double>(::emu::to_bits(v)); }
+inline double rsqrt(double v) { return 1.0 / sqrt(v); }   // the device library's reciprocal square root
 inline int __double2int_rz(double v) { return (int)v; }
 inline int __double2int_rn(double v) { return (int)nearbyint(v); }
 inline long long __double2ll_rz(double v) { return (long long)v; }

@@ -216,6 +216,19 @@ def test_rev_map_explicit_matrix(emu, to, case):
         assert np.abs(np.nan_to_num(got) - np.nan_to_num(ref)).max() <= 1e-9 * np.abs(np.nan_to_num(ref)).max()
 
 
+def test_back_map_bits_are_pinned(emu):
+    """rev_map images of the interpreted kernel on 22 grids (rank-1 and explicit, Hermitian or not, irregular theta,
+    several delay slabs and 256-lane chunks, pairs pushed off the delay axis) have the SHA-256 they had before the
+    round-3 rewrite of rev_gather_kernel (one copy of the pair arithmetic, chunk pre-pass, loop-free bin): the sums
+    are order-independent by construction, so a rewrite may not change a bit."""
+    import json
+    import revmap_probe
+    got = revmap_probe.digests(revmap_probe.images(emu))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "revmap_bits.json")) as fh:
+        want = json.load(fh)
+    assert got == want, [k for k in want if got.get(k) != want[k]]
+
+
 def test_results_do_not_depend_on_the_schedule(tmp_path):
     """Waves, lanes and blocks interpreted in the opposite order (SCINT_EMU_ORDER=rev) must give the
     same bits for every product of the path (FFT, gather, the two-vector Lanczos sweep, eigenvectors,
