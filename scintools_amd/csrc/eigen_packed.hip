@@ -47,9 +47,11 @@
 
 namespace scint {
 
-constexpr int kCheckEveryBlock = 3;   // passes per chunk (between convergence checks); SCINT_CHECK_EVERY overrides (tests).
-                                      // Measured at 4096^2 / 256 eta: every 2 / 3 / 4 / 5 passes ->
-                                      // 31.2 / 31.6 / 32.1 / 32.7 passes per eta, 1203 / 1211 / 1196 / 1198 eta/s (3 interleaved runs each)
+constexpr int kCheckEveryBlock = 2;   // passes per chunk (between convergence checks); SCINT_CHECK_EVERY overrides (tests).
+                                      // Measured at 4096^2 / 256 eta with the check on the group's own stream (round 3,
+                                      // interleaved, two rounds, profiles/r03_check_stream_ab.txt): every 1 / 2 / 3 passes ->
+                                      // 30.6 / 31.2 / 31.6 passes per eta, 1331 / 1412 / 1400 eta/s (check on the sweep's
+                                      // stream, every 3: 1387).  Round 2, check in line: every 2 / 3 / 4 / 5 -> 1203 / 1211 / 1196 / 1198.
 constexpr int kFirstCheck = 8;
 constexpr int kMaxK = 512;   // upper bound on the Lanczos steps a caller may ask for
 
@@ -801,7 +803,7 @@ static char* pinned_staging(size_t bytes) {
 // (Measured in round 3, profiles/r03_tail_schedule_ab.json: highest stream priority for the tail streams costs
 // 6 %, 1 / 2 / 4 lanes and 36-KiB / 144-KiB back-map workgroups are within 3 % of each other -- the chi^2 sweep
 // is bound by the SUM of the mat-vec's and the tail kernels' GPU time, not by how they interleave.)
-struct SideStreams { hipStream_t aux = nullptr, tail[kTailLanes] = {}; };
+struct SideStreams { hipStream_t aux = nullptr, chk[2] = {}, tail[kTailLanes] = {}; };
 static SideStreams* side_streams() {
     thread_local std::map<int, SideStreams> streams;
     int dev = 0;
@@ -810,6 +812,8 @@ static SideStreams* side_streams() {
     if (it != streams.end()) return &it->second;
     SideStreams s;
     if (hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (auto& c : s.chk)
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (auto& t : s.tail)
         if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return &(streams[dev] = s);
@@ -847,7 +851,8 @@ struct SweepGroup {
     SweepProblem* P;
     int slot0, nslots;                    // global index of the group's first slot, its slot count
     hipStream_t stream;
-    hipEvent_t chunk_done[kTabs], export_done[kTabs];
+    hipStream_t check_stream;             // the group's convergence checks run here, beside the next chunk's first pass
+    hipEvent_t chunk_done[kTabs], export_done[kTabs], steps_done[kTabs];
     // host staging (pinned), one set per table copy; slot indices in all tables are group-local
     PackedJob* h_jobs[kTabs]; Strip* h_strips[kTabs]; int32_t* h_fresh[kTabs]; int32_t* h_fin[kTabs];
     int64_t* h_fin_eta[kTabs]; int32_t* h_rs[kTabs]; int32_t* h_flags[kTabs];
@@ -1028,6 +1033,10 @@ struct SweepGroup {
         if (nstrips > 0) {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
+                // the previous chunk's check (on check_stream) reads the partial sums the SECOND reduce from here
+                // overwrites: it has had a whole pass to finish, this wait only makes that a guarantee
+                if (chunk > 0 && i == (S.check_every > 1 ? 1 : 0))
+                    (void)hipStreamWaitEvent(stream, chunk_done[(chunk - 1) % kTabs], 0);
                 hipLaunchKernelGGL(pk2_coef_kernel, dim3((unsigned)ceil_div(nb_run * kTB, kCoefRows), (unsigned)nslots),
                                    dim3(kCoefRows), 0, stream, d_jobs(tab), launch);
                 const int slot = profiler().begin(kProfMatvec, stream);
@@ -1040,12 +1049,15 @@ struct SweepGroup {
                 if (chunk == 0 && i == 0 && S.stagger_ev && slot0 == 0) (void)hipEventRecord(S.stagger_ev, stream);
             }
         }
-        hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, stream, d_jobs(tab), launch0 + S.check_every);
+        he = hipEventRecord(steps_done[chunk % kTabs], stream);
+        if (he == hipSuccess) he = hipStreamWaitEvent(check_stream, steps_done[chunk % kTabs], 0);
+        if (he != hipSuccess) return hip_fail(he, "sweep check hand-off", __FILE__, __LINE__);
+        hipLaunchKernelGGL(pk2_check_kernel, dim3((unsigned)nslots), dim3(64), 0, check_stream, d_jobs(tab), launch0 + S.check_every);
         he = hipGetLastError();
         if (he == hipSuccess)
             he = hipMemcpyAsync(h_flags[chunk % kTabs], S.states_dev + 4 * slot0, sizeof(int32_t) * 4 * (size_t)nslots,
-                                hipMemcpyDeviceToHost, stream);
-        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], stream);
+                                hipMemcpyDeviceToHost, check_stream);
+        if (he == hipSuccess) he = hipEventRecord(chunk_done[chunk % kTabs], check_stream);
         if (he != hipSuccess) return hip_fail(he, "sweep chunk", __FILE__, __LINE__);
         ++chunk;
         return SCINT_OK;
@@ -1150,9 +1162,10 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         grp.slot0 = g == 0 ? 0 : nslots / 2;
         grp.nslots = (ngroups == 1 ? nslots : (g == 0 ? nslots / 2 : nslots - nslots / 2));
         grp.stream = g == 0 ? stream : side->aux;
+        grp.check_stream = side->chk[g];
         const size_t nsl = (size_t)grp.nslots;
         for (int t = 0; t < kTabs; ++t) {
-            grp.chunk_done[t] = grp.export_done[t] = nullptr;
+            grp.chunk_done[t] = grp.export_done[t] = grp.steps_done[t] = nullptr;
             grp.h_jobs[t] = (PackedJob*)take(sizeof(PackedJob) * nsl);
             grp.h_strips[t] = (Strip*)take(sizeof(Strip) * nsl * (size_t)S.BL.smax);
             grp.h_fresh[t] = (int32_t*)take(sizeof(int32_t) * nsl);
@@ -1163,6 +1176,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             if (rc == SCINT_OK) {
                 he = hipEventCreateWithFlags(&grp.chunk_done[t], hipEventDisableTiming);
                 if (he == hipSuccess) he = hipEventCreateWithFlags(&grp.export_done[t], hipEventDisableTiming);
+                if (he == hipSuccess) he = hipEventCreateWithFlags(&grp.steps_done[t], hipEventDisableTiming);
                 if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
             }
         }
@@ -1235,6 +1249,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     // asynchronous fault in the last queued chunk or in a tail step surfaces here and nowhere else
     hipError_t sync_err = hipStreamSynchronize(stream);
     { const hipError_t e2 = hipStreamSynchronize(side->aux); if (sync_err == hipSuccess) sync_err = e2; }
+    for (auto& c : side->chk) { const hipError_t e2 = hipStreamSynchronize(c); if (sync_err == hipSuccess) sync_err = e2; }
     for (int l = 0; l < kTailLanes; ++l) {
         const hipError_t e2 = hipStreamSynchronize(side->tail[l]);
         if (sync_err == hipSuccess) sync_err = e2;
@@ -1245,6 +1260,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         for (int t = 0; t < kTabs; ++t) {
             if (G[g].chunk_done[t]) (void)hipEventDestroy(G[g].chunk_done[t]);
             if (G[g].export_done[t]) (void)hipEventDestroy(G[g].export_done[t]);
+            if (G[g].steps_done[t]) (void)hipEventDestroy(G[g].steps_done[t]);
         }
     if (start_ev) (void)hipEventDestroy(start_ev);
     if (S.stagger_ev) (void)hipEventDestroy(S.stagger_ev);

@@ -156,8 +156,29 @@ __device__ inline void stockham_compute(cplx (&v)[kEPT], int t, int Tr, int n, i
         if (Ns > 1) {
             const int k = j & (Ns - 1);
             const int step = k * (n / (Ns * R));  // index into W_n of W_{Ns R}^k
+            // x[m] *= W^(step m), m = 1 .. R-1.  ONE table read (W^step: consecutive lanes read consecutive or
+            // 16-fold repeated entries) and the powers by multiplication, two interleaved chains of depth R/2
+            // (relative error of the last power ~ R/2 roundings: 1e-15, five orders inside the tightest
+            // tolerance of any transform here).  Reading each power from the table costs R-1 loads whose lanes are
+            // step*m entries apart -- in the last stage of a 4096-point row up to 64 cache lines per wave
+            // instruction, ~600 line accesses per wave and stage against 128 for the row's own data; the row
+            // kernels then sit at 39 % VALU-busy waiting for the texture path (profiles/r03_sspec_counters.txt).
+            if constexpr (R >= 4) {
+                const cplx w1 = tw[step];                      // step < n / R
+                const cplx w2 = mk(w1.x * w1.x - w1.y * w1.y, 2.0 * (w1.x * w1.y));
+                cplx wo = w1, we = w2;
+                x[1] = x[1] * wo;
+                x[2] = x[2] * we;
 #pragma unroll
-            for (int m = 1; m < R; ++m) x[m] = x[m] * tw[(step * m) & (n - 1)];
+                for (int m = 3; m < R; m += 2) {
+                    wo = wo * w2;
+                    x[m] = x[m] * wo;
+                    if (m + 1 < R) { we = we * w2; x[m + 1] = x[m + 1] * we; }
+                }
+            } else {
+#pragma unroll
+                for (int m = 1; m < R; ++m) x[m] = x[m] * tw[(step * m) & (n - 1)];
+            }
         }
         SmallFFT<R>::run(x);
 #pragma unroll

@@ -361,7 +361,7 @@ sspec_rows_kernel(SspecRows a) {
                 const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
                 p = p / d;
             }
-            __builtin_nontemporal_store(ten_log10(p), (SCINT_GLOBAL double*)(orow + col));
+            *(SCINT_GLOBAL double*)(orow + col) = ten_log10(p);    // (non-temporal: same at 4096^2, 2.5 % slower at 8192^2)
             __builtin_amdgcn_sched_barrier(0);   // one bin at a time: sixteen interleaved log sequences spill
         }
     }
