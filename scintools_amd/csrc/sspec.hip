@@ -276,13 +276,14 @@ struct SspecRows {
     int xcd_remap;
 };
 
-// 10 log10(x) for the power of a spectral bin.  The device library's log10 is 135 instructions a value --
+// 10 log10(x), series form (round 3, first version; now the path of zero, subnormal and non-finite powers and the
+// check of the table form below).  The device library's log10 is 135 instructions a value --
 // 4300 of this kernel's 7200 with 32 values per thread, a 115-us floor on 4096^2 by instruction issue alone.
 // Here: x = 2^e m, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s) with s = (m - 1) / (m + 1), |s| <= 0.1716,
 // ten terms of the odd series (truncation 3e-16 absolute); 35 instructions, absolute error a few 1e-15 dB
 // + 2e-16 |result| -- seven orders inside the 1e-8 dB parity tolerance of the path.  Zero, subnormal and
 // non-finite powers are handled by selects (no branch, no library call).
-__device__ inline double ten_log10(double x) {
+__device__ __attribute__((noinline)) double ten_log10_series(double x) {
     // subnormal powers are scaled into the normal range first; 0 -> -inf, +inf and NaN pass through
     const bool tiny = x < 2.2250738585072014e-308;
     const double xn = tiny ? x * 18446744073709551616.0 : x;       // * 2^64
@@ -309,6 +310,156 @@ __device__ inline double ten_log10(double x) {
     return res;
 }
 
+// 10 log10(x) for the power of a spectral bin, table form: x = 2^e m, m in [1, 2); the top seven mantissa bits pick
+// c = 1 + (i + 1/2) / 128 and the table holds (1/c rounded, -(10 / ln 10) ln of THAT rounded value), so
+// 10 log10 m = klc + (10 / ln 10) log1p(r), r = m / c - 1 (one fma, |r| <= 2^-8), five terms of the series (the sixth is
+// 6e-16).  21 instructions and no division against 38 and a reciprocal (a quarter-rate instruction) for the series
+// form above -- the sixteen logarithms of a thread were 28 % of the row kernel's vector instructions
+// (profiles/r03_sspec_counters.txt).  Absolute error a few 1e-15 dB + 2e-16 |result|, as before.
+// tools/gen_log_table.py writes the table (60-digit arithmetic, one rounding per entry).
+__device__ const double kTenLogTab[128][2] = {
+    {0x1.fe01fe01fe020p-1, 0x1.156831cd1ad54p-6},
+    {0x1.fa11caa01fa12p-1, 0x1.9e7fabcc74a1ep-5},
+    {0x1.f6310aca0dbb5p-1, 0x1.5816114b8d2b7p-4},
+    {0x1.f25f644230ab5p-1, 0x1.dfe0e3ff6205ep-4},
+    {0x1.ee9c7f8458e02p-1, 0x1.33522d9f46dd4p-3},
+    {0x1.eae807aba01ebp-1, 0x1.7632367028c46p-3},
+    {0x1.e741aa59750e4p-1, 0x1.b8927c0493a33p-3},
+    {0x1.e3a9179dc1a73p-1, 0x1.fa74e2eb771a8p-3},
+    {0x1.e01e01e01e01ep-1, 0x1.1deda281b0d86p-2},
+    {0x1.dca01dca01dcap-1, 0x1.3e63b8e5331afp-2},
+    {0x1.d92f2231e7f8ap-1, 0x1.5e9d97558e092p-2},
+    {0x1.d5cac807572b2p-1, 0x1.7e9c1ba36d410p-2},
+    {0x1.d272ca3fc5b1ap-1, 0x1.9e601edea68a7p-2},
+    {0x1.cf26e5c44bfc6p-1, 0x1.bdea7578bf30ap-2},
+    {0x1.cbe6d9601cbe7p-1, 0x1.dd3bef663a2d1p-2},
+    {0x1.c8b265afb8a42p-1, 0x1.fc55583ebc30bp-2},
+    {0x1.c5894d10d4986p-1, 0x1.0d9bbbae08fc9p-1},
+    {0x1.c26b5392ea01cp-1, 0x1.1cf187fc1263cp-1},
+    {0x1.bf583ee868d8bp-1, 0x1.2c2c70a4f4198p-1},
+    {0x1.bc4fd65883e7bp-1, 0x1.3b4cd350a60c5p-1},
+    {0x1.b951e2b18ff23p-1, 0x1.4a530bc11e6a2p-1},
+    {0x1.b65e2e3beee05p-1, 0x1.593f73df5dc4bp-1},
+    {0x1.b37484ad806cep-1, 0x1.681263c80bdcep-1},
+    {0x1.b094b31d922a4p-1, 0x1.76cc31d7a984dp-1},
+    {0x1.adbe87f94905ep-1, 0x1.856d32b65bce6p-1},
+    {0x1.aaf1d2f87ebfdp-1, 0x1.93f5b963548fdp-1},
+    {0x1.a82e65130e159p-1, 0x1.a266173fdc15bp-1},
+    {0x1.a574107688a4ap-1, 0x1.b0be9c19ffac3p-1},
+    {0x1.a2c2a87c51ca0p-1, 0x1.beff9636e8839p-1},
+    {0x1.a01a01a01a01ap-1, 0x1.cd29525cde489p-1},
+    {0x1.9d79f176b682dp-1, 0x1.db3c1bdcf8a45p-1},
+    {0x1.9ae24ea5510dap-1, 0x1.e9383c9c82b17p-1},
+    {0x1.9852f0d8ec0ffp-1, 0x1.f71dfd1e13575p-1},
+    {0x1.95cbb0be377aep-1, 0x1.0276d2452eaa0p+0},
+    {0x1.934c67f9b2ce6p-1, 0x1.0953bc5c5cd32p+0},
+    {0x1.90d4f120190d5p-1, 0x1.1025df1bb7716p+0},
+    {0x1.8e6527af1373fp-1, 0x1.16ed5c29dbf7ap+0},
+    {0x1.8bfce8062ff3ap-1, 0x1.1daa5490c63bfp+0},
+    {0x1.899c0f601899cp-1, 0x1.245ce8c196b07p+0},
+    {0x1.87427bcc092b9p-1, 0x1.2b0538983bae3p+0},
+    {0x1.84f00c2780614p-1, 0x1.31a3635efedb0p+0},
+    {0x1.82a4a0182a4a0p-1, 0x1.383787d1f7a74p+0},
+    {0x1.8060180601806p-1, 0x1.3ec1c42263d64p+0},
+    {0x1.7e225515a4f1dp-1, 0x1.454235f9e6fc9p+0},
+    {0x1.7beb3922e017cp-1, 0x1.4bb8fa7db1d08p+0},
+    {0x1.79baa6bb6398bp-1, 0x1.52262e5192271p+0},
+    {0x1.77908119ac60dp-1, 0x1.5889ed9aec67fp+0},
+    {0x1.756cac201756dp-1, 0x1.5ee454039f416p+0},
+    {0x1.734f0c541fe8dp-1, 0x1.65357cbcd2575p+0},
+    {0x1.713786d9c7c09p-1, 0x1.6b7d8281b0a57p+0},
+    {0x1.6f26016f26017p-1, 0x1.71bc7f9a0f431p+0},
+    {0x1.6d1a62681c861p-1, 0x1.77f28ddd01318p+0},
+    {0x1.6b1490aa31a3dp-1, 0x1.7e1fc6b358d5ep+0},
+    {0x1.691473a88d0c0p-1, 0x1.8444431a17bb0p+0},
+    {0x1.6719f3601671ap-1, 0x1.8a601ba4cd300p+0},
+    {0x1.6524f853b4aa3p-1, 0x1.9073687fe453bp+0},
+    {0x1.63356b88ac0dep-1, 0x1.967e4172e2178p+0},
+    {0x1.614b36831ae94p-1, 0x1.9c80bde293bf3p+0},
+    {0x1.5f66434292dfcp-1, 0x1.a27af4d32e5c3p+0},
+    {0x1.5d867c3ece2a5p-1, 0x1.a86cfcea5fc16p+0},
+    {0x1.5babcc647fa91p-1, 0x1.ae56ec7151652p+0},
+    {0x1.59d61f123ccaap-1, 0x1.b438d9569da4ep+0},
+    {0x1.5805601580560p-1, 0x1.ba12d93037d6dp+0},
+    {0x1.56397ba7c52e2p-1, 0x1.bfe5013d47958p+0},
+    {0x1.54725e6bb82fep-1, 0x1.c5af6667f7aa5p+0},
+    {0x1.52aff56a8054bp-1, 0x1.cb721d4738f9cp+0},
+    {0x1.50f22e111c4c5p-1, 0x1.d12d3a2079d13p+0},
+    {0x1.4f38f62dd4c9bp-1, 0x1.d6e0d0e951ef3p+0},
+    {0x1.4d843bedc2c4cp-1, 0x1.dc8cf54923a3cp+0},
+    {0x1.4bd3edda68fe1p-1, 0x1.e231ba9ab2565p+0},
+    {0x1.4a27fad76014ap-1, 0x1.e7cf33edaeca8p+0},
+    {0x1.4880522014880p-1, 0x1.ed657408396efp+0},
+    {0x1.46dce34596066p-1, 0x1.f2f48d685b03cp+0},
+    {0x1.453d9e2c776cap-1, 0x1.f87c924573e2bp+0},
+    {0x1.43a2730abee4dp-1, 0x1.fdfd9491a22fap+0},
+    {0x1.420b5265e5951p-1, 0x1.01bbd2fd8f9b4p+1},
+    {0x1.40782d10e6566p-1, 0x1.04756bf6ca1c9p+1},
+    {0x1.3ee8f42a5af07p-1, 0x1.072b9dc9b376dp+1},
+    {0x1.3d5d991aa75c6p-1, 0x1.09de70eb7ef4dp+1},
+    {0x1.3bd60d9232955p-1, 0x1.0c8dedb1fe9c7p+1},
+    {0x1.3a524387ac822p-1, 0x1.0f3a1c543dab2p+1},
+    {0x1.38d22d366088ep-1, 0x1.11e304eb17606p+1},
+    {0x1.3755bd1c945eep-1, 0x1.1488af71ca31ep+1},
+    {0x1.35dce5f9f2af8p-1, 0x1.172b23c687818p+1},
+    {0x1.34679ace01346p-1, 0x1.19ca69aafff02p+1},
+    {0x1.32f5ced6a1dfap-1, 0x1.1c6688c4ec656p+1},
+    {0x1.3187758e9ebb6p-1, 0x1.1eff889e93e3cp+1},
+    {0x1.301c82ac40260p-1, 0x1.219570a74e3f5p+1},
+    {0x1.2eb4ea1fed14bp-1, 0x1.2428483403ce8p+1},
+    {0x1.2d50a012d50a0p-1, 0x1.26b8167faa29ap+1},
+    {0x1.2bef98e5a3711p-1, 0x1.2944e2abbe0d9p+1},
+    {0x1.2a91c92f3c105p-1, 0x1.2bceb3c0ba762p+1},
+    {0x1.293725bb804a5p-1, 0x1.2e5590ae8d03fp+1},
+    {0x1.27dfa38a1ce4dp-1, 0x1.30d9804d07bf8p+1},
+    {0x1.268b37cd60127p-1, 0x1.335a895c504c9p+1},
+    {0x1.2539d7e9177b2p-1, 0x1.35d8b2854c9fbp+1},
+    {0x1.23eb79717605bp-1, 0x1.3854025a0d45ap+1},
+    {0x1.22a0122a0122ap-1, 0x1.3acc7f56354ecp+1},
+    {0x1.21579804855e6p-1, 0x1.3d422fdf5fee5p+1},
+    {0x1.2012012012012p-1, 0x1.3fb51a4583db6p+1},
+    {0x1.1ecf43c7fb84cp-1, 0x1.422544c354853p+1},
+    {0x1.1d8f5672e4abdp-1, 0x1.4492b57ea1272p+1},
+    {0x1.1c522fc1ce059p-1, 0x1.46fd7288b1ccep+1},
+    {0x1.1b17c67f2bae3p-1, 0x1.496581dea2512p+1},
+    {0x1.19e0119e0119ep-1, 0x1.4bcae969bb687p+1},
+    {0x1.18ab083902bdbp-1, 0x1.4e2daeffc9c16p+1},
+    {0x1.1778a191bd684p-1, 0x1.508dd8637348ep+1},
+    {0x1.1648d50fc3201p-1, 0x1.52eb6b448a9ddp+1},
+    {0x1.151b9a3fdd5c9p-1, 0x1.55466d4060bfep+1},
+    {0x1.13f0e8d344724p-1, 0x1.579ee3e215060p+1},
+    {0x1.12c8b89edc0acp-1, 0x1.59f4d4a2e3654p+1},
+    {0x1.11a3019a74826p-1, 0x1.5c4844ea71169p+1},
+    {0x1.107fbbe011080p-1, 0x1.5e993a0f17a16p+1},
+    {0x1.0f5edfab325a2p-1, 0x1.60e7b9562e5a0p+1},
+    {0x1.0e40655826011p-1, 0x1.6333c7f452594p+1},
+    {0x1.0d24456359e3ap-1, 0x1.657d6b0dacfa3p+1},
+    {0x1.0c0a7868b4171p-1, 0x1.67c4a7b638e5fp+1},
+    {0x1.0af2f722eecb5p-1, 0x1.6a0982f205b67p+1},
+    {0x1.09ddba6af8360p-1, 0x1.6c4c01b57a391p+1},
+    {0x1.08cabb37565e2p-1, 0x1.6e8c28e5955adp+1},
+    {0x1.07b9f29b8eae2p-1, 0x1.70c9fd582dc48p+1},
+    {0x1.06ab59c7912fbp-1, 0x1.730583d430305p+1},
+    {0x1.059eea0727586p-1, 0x1.753ec111dc7ffp+1},
+    {0x1.04949cc1664c5p-1, 0x1.7775b9bb019bdp+1},
+    {0x1.038c6b78247fcp-1, 0x1.79aa726b38218p+1},
+    {0x1.02864fc7729e9p-1, 0x1.7bdcefb01be9fp+1},
+    {0x1.0182436517a37p-1, 0x1.7e0d3609846cdp+1},
+    {0x1.0080402010080p-1, 0x1.803b49e9bc09dp+1},
+};
+__device__ inline double ten_log10(double x, const double (*tab)[2]) {
+    const unsigned hi = (unsigned)__double2hiint(x);
+    const unsigned ef = hi >> 20;                                   // sign and exponent field
+    if (ef - 1u >= 2046u) return ten_log10_series(x);               // zero, subnormal, inf, NaN (a power is never negative)
+    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+    const unsigned i = (hi >> 13) & 127u;
+    const double r = fma(m, tab[i][0], -1.0);
+    constexpr double k = 4.3429448190325182765112891891661;         // 10 / ln 10
+    double p = k / 5.0;
+    p = fma(p, r, -k / 4.0); p = fma(p, r, k / 3.0); p = fma(p, r, -k / 2.0); p = fma(p, r, k);
+    return fma(p, r, fma((double)((int)ef - 1023), 3.0102999566398119521373889472449, tab[i][1]));
+}
+
 // One (delay row, half) per slot: the even Doppler bins come from the transform of the row, the odd ones
 // from the transform of the row times W_2n^s.  The two halves of a row are separate slots that run side by
 // side on one XCD (block remap), each stores its bins as 8-byte values 16 bytes apart.  Measured at 4096^2
@@ -330,6 +481,8 @@ sspec_rows_kernel(SspecRows a) {
     const int k1 = slot >> 1, half = slot & 1;
     const bool active = k1 < a.nrows;
     double* lds = reinterpret_cast<double*>(smem_raw) + (size_t)i * lds_pad(n);
+    __shared__ double tlog[128][2];                                 // ten_log10's table (visible after the transform's barriers)
+    if (threadIdx.x < 128) { tlog[threadIdx.x][0] = kTenLogTab[threadIdx.x][0]; tlog[threadIdx.x][1] = kTenLogTab[threadIdx.x][1]; }
     // row k1 = 2 m + h of the tiled intermediate: element c at tile (m >> 2, c >> 1), slot h, m & 3, c & 1
     const int kk = active ? k1 : 0;
     const cplx* __restrict__ row = a.Y + (int64_t)(kk >> 3) * a.npairs * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2;
@@ -361,7 +514,7 @@ sspec_rows_kernel(SspecRows a) {
                 const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
                 p = p / d;
             }
-            *(SCINT_GLOBAL double*)(orow + col) = ten_log10(p);    // (non-temporal: same at 4096^2, 2.5 % slower at 8192^2)
+            *(SCINT_GLOBAL double*)(orow + col) = ten_log10(p, tlog);    // (non-temporal: same at 4096^2, 2.5 % slower at 8192^2)
             __builtin_amdgcn_sched_barrier(0);   // one bin at a time: sixteen interleaved log sequences spill
         }
     }
