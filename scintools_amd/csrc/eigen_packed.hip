@@ -64,7 +64,10 @@ __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
 
 constexpr int kMaxStrip = 16;    // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS)
 
-constexpr int kRedGroups = 16;   // wavefronts per reduce block: each sums every 16th partial vector
+constexpr int kRedGroups = 4;    // wavefronts per reduce block: each sums every 4th partial vector.  8 KiB of LDS: the block fits
+                                 // beside the two 76-KiB mat-vec workgroups of a CU.  With 16 wavefronts (32 KiB) it had to wait for
+                                 // a mat-vec workgroup of the OTHER slot group to retire: 22 us alone, 170-270 us in the sweep;
+                                 // interleaved A/B (profiles/r03_check_stream_ab.txt): 16 / 8 / 4 wavefronts -> 1433 / 1433-1455 / 1454 eta/s
 
 
 __global__ void __launch_bounds__(64) pk_ritz_scale_kernel(const PackedJob* jobs, const int32_t* slots,
@@ -434,7 +437,7 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
     // fixed summation order: the row partials of block row K strip by strip, then the column partials of
-    // the row PAIRS above the diagonal in column K; sixteen wavefronts take every 16th
+    // the row PAIRS above the diagonal in column K; the block's wavefronts take every kRedGroups-th
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc1 = mk(0.0, 0.0), acc2 = mk(0.0, 0.0);
     const int npair = (K + 1) >> 1;                                 // pairs of block rows (2p, 2p+1) with a tile above (K, K)
