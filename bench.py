@@ -498,6 +498,24 @@ def main():
                                                     "upper-triangle tiles written)",
                        "frac": (gather_bytes / ga_s / 1e9 / HBM_PEAK_GBS) if ga_s > 0 else 0.0},
         }
+        if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta:
+            # the same sweep with ONE slot group (SCINT_SWEEP_GROUPS=1, read per call): every mat-vec launch has the
+            # GPU to itself, so this is the kernel's own rate; in the headline schedule two groups' launches and the
+            # small kernels share the GPU and `achieved` above is bytes / (time any mat-vec launch is in flight)
+            os.environ["SCINT_SWEEP_GROUPS"] = "1"
+            try:
+                one = timed("eig", min(args.steps, 3), 1)
+            finally:
+                del os.environ["SCINT_SWEEP_GROUPS"]
+            one_s = one["busy_ms"][1] / 1e3
+            if one_s > 0:
+                out["roofline"]["one_slot_group"] = {
+                    "achieved": one["mv_bytes"] / one_s / 1e9, "unit": "GB/s",
+                    "frac": one["mv_bytes"] / one_s / 1e9 / HBM_PEAK_GBS,
+                    "avg_launch_ms": one["sum_ms"][1] / max(1, one["launches"][1]),
+                    "eta_per_s": neta * min(args.steps, 3) / one["elapsed"],
+                    "note": "the mat-vec kernel with the GPU to itself: same sweep, one slot group on one stream "
+                            "(launches do not overlap; achieved = algorithmic bytes / sum of the launch durations)"}
         msteps = args.modeler_steps if args.modeler_steps is not None else min(args.steps, 3)
         if world == 1 and args.objective == "eig" and msteps > 0 and len(dyns) == 1:
             mod = timed("chisq", msteps, 1)

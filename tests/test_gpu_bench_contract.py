@@ -32,6 +32,8 @@ def test_bench_json_contract():
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] == pytest.approx(r["achieved"] / r["peak"])
+    one = r["one_slot_group"]            # the mat-vec with the GPU to itself (same sweep, one slot group)
+    assert one["unit"] == "GB/s" and 0 < one["frac"] == pytest.approx(one["achieved"] / r["peak"]) and one["eta_per_s"] > 0
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
