@@ -76,11 +76,12 @@ int32_t scint_device_count(void);
  * by hipEvents on its stream.  end() synchronises the device and returns, per kernel, the length
  * in milliseconds of the UNION of its launch intervals (the sweep drives two streams, so
  * launches may overlap), the plain SUM of the individual launch spans (sum / launches is the
- * average a kernel trace reports) and the launch counts (HOST arrays of 2).  Not thread-safe;
+ * average a kernel trace reports) and the launch counts (HOST arrays of 3; [2] is the complex64
+ * mat-vec of the mixed-precision sweep, see scint_sweep_precision).  Not thread-safe;
  * off by default. */
 int32_t scint_profile_begin(void);
-int32_t scint_profile_end(double* ms_out /*HOST[2]*/, double* ms_sum_out /*HOST[2]*/,
-                          int64_t* launches_out /*HOST[2]*/);
+int32_t scint_profile_end(double* ms_out /*HOST[3]*/, double* ms_sum_out /*HOST[3]*/,
+                          int64_t* launches_out /*HOST[3]*/);
 
 /* ---- secondary spectrum: Dynspec.calc_sspec core (dynspec.py:3665-3721) -- */
 /* dyn[nf,nt] -> sec[(halve? nrfft/2 : nrfft), ncfft] in dB, where
@@ -132,6 +133,16 @@ int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
  * zero beyond their N_i entries, chi^2 of a curvature whose crop leaves nothing stays NaN).  Asynchronous. */
 int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
                                          int32_t max_iter, size_t* bytes /*HOST*/);
+/* Operand precision of the ITERATION of the eigenvalue sweeps (scint_eval_sweep, scint_eval_sweep_multi), per process:
+ *   0  float64 throughout (the default): every Lanczos pass streams the complex128 tiles;
+ *   1  mixed: the passes stream a complex64 copy of theta-theta (float64 vectors and sums), and the eigenvalue that
+ *      is returned is the Ritz value of a certificate pass on the complex128 tiles that satisfies the float64 sweep's
+ *      own a-posteriori bound, evaluated in float64 on that matrix -- same tolerance, same status codes
+ *      (csrc/eigen_packed.hip, "Mixed precision").  Eigenvector sweeps are not affected.
+ *  -1  query.
+ * Returns the previous mode.  Call it BEFORE the *_workspace_bytes of a sweep: the mixed sweep needs a larger
+ * workspace.  The environment variable SCINT_SWEEP_PRECISION=mixed|f64 sets the initial mode. */
+int32_t scint_sweep_precision(int32_t mode);
 int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
                          const double* th_cents, int64_t M,
                          const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,

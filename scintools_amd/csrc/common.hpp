@@ -60,6 +60,21 @@ __device__ inline void gstore_nt(cplx* p, cplx v) {
     __builtin_nontemporal_store(t, (SCINT_GLOBAL v2d*)p);
 }
 
+// complex64 pair stored as two floats (8 bytes), non-temporal; and four floats (two complex64) loaded at once
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ inline void gstore_nt(T* p, double re, double im) {
+    static_assert(sizeof(T) == 8, "complex64 element");
+    v2f t; t.x = (float)re; t.y = (float)im;
+    __builtin_nontemporal_store(t, (SCINT_GLOBAL v2f*)p);
+}
+template <class T>
+__device__ inline v4f gload_nt4(const T* p) {
+    static_assert(sizeof(T) == 8, "complex64 element");
+    return __builtin_nontemporal_load((const SCINT_GLOBAL v4f*)p);
+}
+
 // ---- workgroup barrier for LDS hand-offs ---------------------------------------------------------
 // __syncthreads() is a workgroup-scope fence + barrier: the fence also waits for every GLOBAL access
 // in flight (s_waitcnt vmcnt(0)), i.e. it drains the loads a kernel has prefetched for its next

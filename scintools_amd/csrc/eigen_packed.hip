@@ -427,6 +427,10 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
     for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore_nt(colpart + idx, lds[kLdsCol + idx]);
 }
 
+}  // namespace scint
+#include "matvec32.hpp"
+namespace scint {
+
 __global__ void __launch_bounds__(64 * kRedGroups)
 pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     __shared__ cplx part[kRedGroups][kTB][2];
@@ -437,12 +441,14 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     const int par = step & 1;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
     // fixed summation order: the row partials of block row K strip by strip, then the column partials of
-    // the row PAIRS above the diagonal in column K; the block's wavefronts take every kRedGroups-th
+    // the row GROUPS (pairs; quadruples for complex64 strips) above the diagonal in column K; the block's wavefronts
+    // take every kRedGroups-th
     const int s0 = jb.row_strip0[K], nrow = jb.row_strip0[K + 1] - s0;
     cplx acc1 = mk(0.0, 0.0), acc2 = mk(0.0, 0.0);
-    const int npair = (K + 1) >> 1;                                 // pairs of block rows (2p, 2p+1) with a tile above (K, K)
+    const int lg = jb.rowgroup_lg;
+    const int npair = (K + (1 << lg) - 1) >> lg;                    // groups of block rows (R p .. R p + R-1) with a tile above (K, K)
     for (int idx = g; idx < nrow + npair; idx += kRedGroups) {
-        const int cI = 2 * (idx - nrow);                            // column partial of rows cI and cI+1, in tile (cI, K)'s slot
+        const int cI = (idx - nrow) << lg;                          // column partial of rows cI .. cI+R-1, in tile (cI, K)'s slot
         const cplx* src = idx < nrow ? jb.rowpart + 2 * ((int64_t)(s0 + idx) * kTB + e)
                                      : jb.colpart + 2 * ((tile_offset(jb.nb, cI) + (K - cI)) * kTB + e);
         acc1 = acc1 + gload(src);
@@ -481,6 +487,7 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
 }
 
 constexpr int kMaxKB = 128;    // block steps held in LDS by the block check kernel (T up to 256 x 256)
+constexpr int kSvecStride = 2 * kMaxKB + 4;   // complex elements between the two exported eigenvectors of T_k (jb.svec)
 
 // eigenvalues of the Hermitian pentadiagonal T (diagonal dg, T[i+1][i] = e1[i], T[i+2][i] = e2[i])
 // strictly below x: signs of the pivots of the banded LDL^H factorisation of T - x
@@ -537,6 +544,7 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
     const int k_done = launches_done - jb.start;           // block steps this job has completed
     if (jb.n < 2) {
         if (lane == 0) {
+            jb.state[2] = 0;
             jb.state[0] = jb.gen;
             jb.status_out[0] = SCINT_E_EMPTY;
             jb.eig_out[0] = nan("");
@@ -544,7 +552,7 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         }
         return;
     }
-    if (k_done < kFirstCheck / 2 && k_done < jb.max_steps) return;
+    if (k_done < kFirstCheck / 2 && k_done < jb.max_steps && !(jb.certify && k_done >= 1)) return;
     const int k = min(k_done, jb.max_steps);
     const int n = 2 * k;
     // A_{k-1}, B_{k-1} are still in the partials of the last reduce kernel
@@ -584,58 +592,65 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
     const double bnorm = sqrt(last.b11 * last.b11 + last.b22 * last.b22 + norm2(last.b12));
     const bool finite = isfinite(lo) && isfinite(hi) && isfinite(bnorm);
     double theta = nan(""), theta2 = -INFINITY, resid = nan(""), err = nan("");
+    bool have_vectors = false;      // the factorisation ran: T_k's eigenvectors can be exported
+    double tiny = 0.0;
+    // Ritz vector by inverse iteration on T - sigma (lane 0), sigma just above the Ritz value: factorisation,
+    // two solves from the vector of ones; returns |s|^2 of the (max-scaled) vector left in sv
+    auto inverse_iteration = [&](double value) {
+        const double sigma = value + 8e-16 * fmax(fabs(value), scale * 1e-3);
+        double r1 = 0.0, r2 = 0.0;
+        cplx p = mk(0.0, 0.0), q = mk(0.0, 0.0);
+        for (int i = 0; i < n; ++i) {
+            double d = ((dg[i] - sigma) - norm2(p) * r1) - norm2(q) * r2;
+            if (fabs(d) < tiny) d = -tiny;
+            const cplx below = i >= 1 ? e2[i - 1] : mk(0.0, 0.0);
+            const cplx pn = e1[i] - mulc(below, p) * r1;
+            fd[i] = d; fm[i] = pn;
+            q = below; p = pn; r2 = r1; r1 = 1.0 / d;
+        }
+        for (int i = 0; i < n; ++i) sv[i] = mk(1.0, 0.0);
+        double nrm = 1.0;
+        for (int it = 0; it < 2; ++it) {
+            // L y = rhs:  L_{i,i-1} = M_{i,i-1}/d_{i-1},  L_{i,i-2} = e2[i-2]/d_{i-2}
+            for (int i = 0; i < n; ++i) {
+                cplx y = sv[i];
+                if (i >= 1) y = y - (fm[i - 1] * sv[i - 1]) * (1.0 / fd[i - 1]);
+                if (i >= 2) y = y - (e2[i - 2] * sv[i - 2]) * (1.0 / fd[i - 2]);
+                sv[i] = y;
+            }
+            for (int i = 0; i < n; ++i) sv[i] = sv[i] * (1.0 / fd[i]);
+            // L^H s = z
+            for (int i = n - 1; i >= 0; --i) {
+                cplx z = sv[i];
+                if (i + 1 < n) z = z - mulc(sv[i + 1], fm[i]) * (1.0 / fd[i]);        // conj(L_{i+1,i}) s_{i+1}
+                if (i + 2 < n) z = z - mulc(sv[i + 2], e2[i]) * (1.0 / fd[i]);        // conj(L_{i+2,i}) s_{i+2}
+                sv[i] = z;
+            }
+            double mx = 0.0;
+            for (int i = 0; i < n; ++i) mx = fmax(mx, fmax(fabs(sv[i].x), fabs(sv[i].y)));
+            const double sc = mx > 0.0 && isfinite(mx) ? 1.0 / mx : 0.0;
+            nrm = 0.0;
+            for (int i = 0; i < n; ++i) { sv[i] = sv[i] * sc; nrm += norm2(sv[i]); }
+        }
+        return nrm;
+    };
     if (finite && scale == 0.0 && bnorm == 0.0) {
         theta = 0.0; theta2 = 0.0; resid = 0.0; err = 0.0;     // all-zero theta-theta
     } else if (finite) {
-        const double tiny = scale * 1e-300 + 1e-300;
+        tiny = scale * 1e-300 + 1e-300;
         lo = lo - 1e-15 * fabs(lo) - 1e-300;
         hi = hi + 1e-15 * fabs(hi) + 1e-300;
         theta = band_multisect(dg, e1, e2, n, n, lo, hi, tiny, lane);
         if (n >= 2) theta2 = band_multisect(dg, e1, e2, n, n - 1, lo, theta, tiny, lane);
         if (lane == 0) {
-            // Ritz vector by inverse iteration on T - sigma, sigma just above theta; only its last
-            // block is needed: resid = || B_{k-1} s_last || / ||s||
-            const double sigma = theta + 8e-16 * fmax(fabs(theta), scale * 1e-3);
-            double r1 = 0.0, r2 = 0.0;
-            cplx p = mk(0.0, 0.0), q = mk(0.0, 0.0);
-            for (int i = 0; i < n; ++i) {
-                double d = ((dg[i] - sigma) - norm2(p) * r1) - norm2(q) * r2;
-                if (fabs(d) < tiny) d = -tiny;
-                const cplx below = i >= 1 ? e2[i - 1] : mk(0.0, 0.0);
-                const cplx pn = e1[i] - mulc(below, p) * r1;
-                fd[i] = d; fm[i] = pn;
-                q = below; p = pn; r2 = r1; r1 = 1.0 / d;
-            }
-            for (int i = 0; i < n; ++i) sv[i] = mk(1.0, 0.0);
-            double nrm = 1.0;
-            for (int it = 0; it < 2; ++it) {
-                // L y = rhs:  L_{i,i-1} = M_{i,i-1}/d_{i-1},  L_{i,i-2} = e2[i-2]/d_{i-2}
-                for (int i = 0; i < n; ++i) {
-                    cplx y = sv[i];
-                    if (i >= 1) y = y - (fm[i - 1] * sv[i - 1]) * (1.0 / fd[i - 1]);
-                    if (i >= 2) y = y - (e2[i - 2] * sv[i - 2]) * (1.0 / fd[i - 2]);
-                    sv[i] = y;
-                }
-                for (int i = 0; i < n; ++i) sv[i] = sv[i] * (1.0 / fd[i]);
-                // L^H s = z
-                for (int i = n - 1; i >= 0; --i) {
-                    cplx z = sv[i];
-                    if (i + 1 < n) z = z - mulc(sv[i + 1], fm[i]) * (1.0 / fd[i]);        // conj(L_{i+1,i}) s_{i+1}
-                    if (i + 2 < n) z = z - mulc(sv[i + 2], e2[i]) * (1.0 / fd[i]);        // conj(L_{i+2,i}) s_{i+2}
-                    sv[i] = z;
-                }
-                double mx = 0.0;
-                for (int i = 0; i < n; ++i) mx = fmax(mx, fmax(fabs(sv[i].x), fabs(sv[i].y)));
-                const double sc = mx > 0.0 && isfinite(mx) ? 1.0 / mx : 0.0;
-                nrm = 0.0;
-                for (int i = 0; i < n; ++i) { sv[i] = sv[i] * sc; nrm += norm2(sv[i]); }
-            }
+            // only the last block of the Ritz vector is needed here: resid = || B_{k-1} s_last || / ||s||
+            const double nrm = inverse_iteration(theta);
             const cplx sl0 = sv[n - 2], sl1 = sv[n - 1];
             const cplx rr1 = sl0 * last.b11 + last.b12 * sl1;
             const cplx rr2 = sl1 * last.b22;
             resid = nrm > 0.0 ? sqrt((norm2(rr1) + norm2(rr2)) / nrm) : bnorm;
             if (!isfinite(resid)) resid = bnorm;
-            if (jb.want_vec) {                      // unit-norm eigenvector of T_k for the Ritz vector
+            if (jb.want_vec || jb.use32) {          // unit-norm eigenvector of T_k for the Ritz vector
                 cplx* out = (cplx*)jb.svec;
                 const double inv = nrm > 0.0 ? 1.0 / sqrt(nrm) : 0.0;
                 for (int i = 0; i < n; ++i) out[i] = sv[i] * inv;
@@ -644,11 +659,13 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         resid = __shfl(resid, 0, 64);
         const double gap = theta - theta2;
         err = (gap > resid) ? resid * resid / gap : resid;
+        have_vectors = true;
     }
     if (lane == 0) {
         const double prev = jb.result[3];
         const double at = fmax(fabs(theta), 1e-300);
-        const bool settled = (theta - prev) <= 1e3 * jb.tol * at;
+        // (a certificate pass starts from converged Ritz vectors: its first value has nothing to settle from)
+        const bool settled = (theta - prev) <= 1e3 * jb.tol * at || (jb.certify && k == 1);
         const bool exact = finite && (n >= jb.n || bnorm == 0.0);
         // eigenvector wanted: same gap-aware rule as the single-vector check (pk_check_kernel)
         const double prev2 = jb.result[1], gap2 = theta - theta2;
@@ -659,11 +676,31 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         const bool stop = conv || !finite || k >= jb.max_steps;
         jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
         if (stop) {
+            // Iteration phase of the mixed sweep, converged: nothing is reported yet -- the two top Ritz vectors go
+            // to the certificate pass on the complex128 tiles (the host restarts the slot when it sees state[2]).
+            const bool hand_over = jb.use32 && conv && have_vectors && isfinite(theta);
+            if (hand_over) {
+                cplx* out = (cplx*)jb.svec + kSvecStride;
+                if (n >= 2 && theta2 > -INFINITY) {
+                    const double nrm = inverse_iteration(theta2);
+                    const double inv = nrm > 0.0 && isfinite(nrm) ? 1.0 / sqrt(nrm) : 0.0;
+                    for (int i = 0; i < n; ++i) out[i] = sv[i] * inv;
+                } else {
+                    for (int i = 0; i < n; ++i) out[i] = mk(0.0, 0.0);
+                }
+            }
+            // an iteration phase that ends here (no convergence within the step budget, non-finite input, all-zero
+            // matrix) reports the Ritz value of the scaled complex64 copy, scaled back, with its status
+            const double unscale = jb.use32 ? 1.0 / gload(jb.scale32) : 1.0;
             jb.state[1] = k;
+            jb.state[2] = hand_over ? 1 : 0;
+            __threadfence();
             jb.state[0] = jb.gen;
-            jb.eig_out[0] = jb.want_vec ? theta : fabs(theta);   // modeler keeps the sign of w
-            if (jb.iters_out) jb.iters_out[0] = k;
-            jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
+            if (!hand_over) {
+                jb.eig_out[0] = (jb.want_vec ? theta : fabs(theta)) * unscale;   // modeler keeps the sign of w
+                if (jb.iters_out) jb.iters_out[0] = k + jb.iters_base;
+                jb.status_out[0] = (!finite || !isfinite(theta)) ? SCINT_E_NONFINITE : (conv ? SCINT_OK : SCINT_E_NOCONV);
+            }
         }
     }
 }
@@ -689,39 +726,88 @@ __global__ void __launch_bounds__(64) pk2_ritz_kernel(const PackedJob* jobs, con
     if (e == 0) jb.upart[0][K] = p;   // the job is finished: its partial arrays are free
 }
 
+// Start block of a certificate pass (mixed sweep): the two top Ritz vectors of the iteration phase,
+//   y_c = sum_j (Q_j[:,0] s_c[2j] + Q_j[:,1] s_c[2j+1]),  c = 1, 2,   s_c = the eigenvectors of T_k the check exported,
+// written where pk2_init_kernel writes two rows of theta-theta: into U[0], with the partial sums of their Gram matrix
+// (the coefficient kernel of step 0 orthonormalises the block: Cholesky-QR, as for any start block).  The slot's Q
+// history is read here for the last time; a thread clears its own rows of the two slots step 0 reads after it has read
+// them.  jb is the NEW description of the slot (certify = 1, iters_base = block steps of the iteration phase).
+__global__ void __launch_bounds__(64) pk2_restart_kernel(const PackedJob* jobs, const int32_t* slots) {
+    const PackedJob jb = jobs[slots[blockIdx.y]];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (K == 0 && e == 0) { jb.state[1] = 0; jb.result[1] = -INFINITY; jb.result[3] = -INFINITY; }
+    if (K >= jb.nb) return;
+    const int r = K * kTB + e;
+    const int k = jb.iters_base;
+    const cplx* __restrict__ s1 = (const cplx*)jb.svec;
+    const cplx* __restrict__ s2 = s1 + kSvecStride;
+    cplx y1 = mk(0.0, 0.0), y2 = mk(0.0, 0.0);
+    for (int j = 0; j < k; ++j) {
+        const cplx* __restrict__ q = jb.Q + (int64_t)j * jb.qstride * 2 + 2 * r;
+        const cplx q0 = q[0], q1 = q[1];
+        y1 = (y1 + q0 * s1[2 * j]) + q1 * s1[2 * j + 1];
+        y2 = (y2 + q0 * s2[2 * j]) + q1 * s2[2 * j + 1];
+    }
+    if (r >= jb.n) { y1 = mk(0.0, 0.0); y2 = mk(0.0, 0.0); }
+    jb.U[0][2 * r] = y1; jb.U[0][2 * r + 1] = y2;
+    jb.U[1][2 * r] = mk(0.0, 0.0); jb.U[1][2 * r + 1] = mk(0.0, 0.0);
+    cplx* qm1 = jb.Q + (int64_t)(jb.qslots - 1) * jb.qstride * 2;     // "Q_{-1}" = 0
+    qm1[2 * r] = mk(0.0, 0.0); qm1[2 * r + 1] = mk(0.0, 0.0);
+    jb.Q[2 * r] = mk(0.0, 0.0); jb.Q[2 * r + 1] = mk(0.0, 0.0);
+    const double g11 = wave_sum(norm2(y1)), g22 = wave_sum(norm2(y2));
+    const cplx g12 = wave_sum(mulc(y2, y1));                           // conj(y1) y2
+    if (e == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { jb.apart[0][4 * K + c] = 0.0; jb.apart[1][4 * K + c] = 0.0; jb.upart[1][4 * K + c] = 0.0; }
+        jb.upart[0][4 * K] = g11; jb.upart[0][4 * K + 1] = g22; jb.upart[0][4 * K + 2] = g12.x; jb.upart[0][4 * K + 3] = g12.y;
+    }
+}
+
 // ------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------
 struct SlabLayout {
-    size_t tiles, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
+    size_t tiles, tiles32, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
         coef, alpha, beta, result, total;
     int qslots;
 };
 
+// strip length of the complex64 strips of an nb-block matrix (a function of nb only, like strip_len_for)
+static int strip_len32_for(int nb) { return std::min(strip_len_for(nb), kMaxStrip32); }
+
+// row partial vectors of a matrix (one per block row and strip): complex128 strips (pairs of rows), complex64 strips
 static int max_strips(int nb) {
     const int S = strip_len_for(nb);
     int n = 0;
     for (int I = 0; I < nb; ++I) n += row_strip_count(nb, I, S);
     return n;
 }
+static int max_strips32(int nb) {
+    const int S = strip_len32_for(nb);
+    int n = 0;
+    for (int I = 0; I < nb; ++I) n += row_strip_count(nb, I, S, kRows32);
+    return n;
+}
 
-static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec) {
+static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, bool mixed) {
     SlabLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     // the strip count is not monotone in nb across the strip-length thresholds: take the max
     int smax = 0;
-    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, max_strips(nb));
+    for (int nb = 1; nb <= nbmax; ++nb) smax = std::max(smax, std::max(max_strips(nb), mixed ? max_strips32(nb) : 0));
     L.tiles = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTileElems);
+    L.tiles32 = mixed ? take(sizeof(c32) * (size_t)tile_count(nbmax) * kTileElems) : 0;
     // vectors, partial vectors and scalar histories of the two-vector (block) recurrence: 2 columns,
     // 4 scalars per coefficient (all small next to the tiles)
     const size_t bw = 2, sc = bw * bw;
     L.U0 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     L.U1 = take(sizeof(cplx) * (size_t)nbmax * kTB * bw);
     // (block steps: <= kMaxKB + 1 are used)
-    L.qslots = want_vec ? max_steps + 1 : 2;
+    // (the mixed sweep keeps every Q_j of the iteration phase: its Ritz vectors start the certificate pass)
+    L.qslots = want_vec ? max_steps + 1 : (mixed ? std::min(max_steps, kMaxKB) + 1 : 2);
     L.Q = take(sizeof(cplx) * (size_t)nbmax * kTB * (size_t)L.qslots * bw);
-    L.svec = take(sizeof(cplx) * bw * (size_t)(max_steps + 2));   // eigenvector of T_k (complex, bw per block step)
+    L.svec = take(sizeof(cplx) * (size_t)std::max<int64_t>(bw * (int64_t)(max_steps + 2), 2 * kSvecStride));   // eigenvector(s) of T_k
     L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
     L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
     L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
@@ -742,32 +828,67 @@ constexpr int kTabs = 3;   // rotating copies of the per-chunk tables (job table
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, states, slots, fin_slots, fin_eta, geoms, total;   // table offsets: copy 0; copies are *_stride apart
-    size_t jobs_stride, strips_stride, list_stride, fin_eta_stride;
+    size_t jobs, strips, strips32, states, slots, fin_slots, restart, fin_eta, geoms, scales, scale_bits, total;   // table offsets: copy 0; copies are *_stride apart
+    size_t jobs_stride, strips_stride, strips32_stride, list_stride, fin_eta_stride;
 };
 
-static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs) {
+static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs, bool mixed) {
     BatchLayout B;
-    B.slab = slab_layout(nbmax, max_steps, want_vec);
+    B.slab = slab_layout(nbmax, max_steps, want_vec, mixed);
     B.smax = 0;
-    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, max_strips(nb));
+    // (workgroups per matrix: never more than its row partials, whichever strip shape is in use)
+    for (int nb = 1; nb <= nbmax; ++nb) B.smax = std::max(B.smax, std::max(max_strips(nb), mixed ? max_strips32(nb) : 0));
     size_t off = B.slab.total * (size_t)nbatch;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
     B.jobs_stride = align_up(sizeof(PackedJob) * (size_t)nbatch, 256);
     B.strips_stride = align_up(sizeof(Strip) * (size_t)nbatch * (size_t)B.smax, 256);
+    B.strips32_stride = mixed ? align_up(sizeof(Strip32) * (size_t)nbatch * (size_t)B.smax, 256) : 0;
     B.list_stride = align_up(sizeof(int32_t) * (size_t)nbatch, 256);
     B.fin_eta_stride = align_up(sizeof(int64_t) * (size_t)nbatch, 256);
     B.jobs = take(B.jobs_stride * kTabs);
     B.strips = take(B.strips_stride * kTabs);
+    B.strips32 = take(B.strips32_stride * kTabs);
     B.states = take(sizeof(int32_t) * 4 * (size_t)nbatch);
     B.slots = take(B.list_stride * kTabs);
     B.fin_slots = take(B.list_stride * kTabs);
+    B.restart = take(B.list_stride * kTabs);
     B.fin_eta = take(B.fin_eta_stride * kTabs);
     B.geoms = take(sizeof(GeomDev) * (size_t)ncs);
+    B.scales = take(sizeof(double) * (size_t)ncs);
+    B.scale_bits = take(sizeof(unsigned long long) * (size_t)ncs);
     B.total = align_up(off, 256);
     return B;
 }
 
+
+// ---- Mixed precision: "complex64-stored iteration, complex128 certificate" --------------------------------------
+// The eigenvalue sweep is bound by the bytes of theta-theta it streams per Lanczos pass.  In this mode the gather also
+// writes a complex64 copy of the tiles (scaled by a power of two taken from max |CS|), and a curvature runs in two phases:
+//   iteration    block Lanczos exactly as above -- float64 vectors, sums and recurrence -- on the Hermitian matrix
+//                A~ = fl32(scale A) (pk2_matvec32_kernel: half the bytes per pass), until ITS top eigenpair has converged
+//                by the usual rule (at tol / 4).  A~ is 2^-24-close to scale A entry by entry, so its top eigenvector
+//                v~ is within ~1e-8 / gap of A's.  Nothing of this phase is reported.
+//   certificate  the two top Ritz vectors [v~, v~_2] start a NEW block-Lanczos run on the complex128 tiles: after ONE
+//                pass, T_1 = [v~ v~_2]^H A [v~ v~_2] gives the Ritz value theta (a Rayleigh quotient of the float64
+//                matrix: its error is quadratic in the eigenvector error, ~1e-15 relative), theta_2, and the residual
+//                || A v - theta v || computed with A itself; the stopping rule of the float64 sweep is applied to THEM
+//                (err = resid^2 / (theta - theta_2) <= tol |theta|).  If it holds -- it does unless tol is below what
+//                the complex64 perturbation leaves, or the gap is tiny -- theta is returned; if not, the run simply
+//                continues on the complex128 tiles until it does.
+// So every returned eigenvalue is a Ritz value of the float64 matrix that satisfies the float64 sweep's own a-posteriori
+// bound, evaluated in float64 on that matrix; complex64 only chooses the subspace.  Cost per curvature at 4096^2: P passes
+// of 68 MB + 1 of 136 MB (+ 68 MB of gather writes) instead of P passes of 136 MB.  Eigenvector sweeps (modeler, chi^2,
+// phase retrieval) stay on the float64 tiles throughout: the eigenvector itself is only 1e-8 / gap accurate after the
+// iteration phase and would need most of its passes again.
+// Selected per process by scint_sweep_precision() (default: SCINT_SWEEP_PRECISION=mixed|f64 in the environment, else f64).
+static int& sweep_mode_ref() {
+    static int mode = [] {
+        const char* e = getenv("SCINT_SWEEP_PRECISION");
+        return (e && (e[0] == 'm' || e[0] == 'M')) ? 1 : 0;
+    }();
+    return mode;
+}
+bool sweep_mixed() { return sweep_mode_ref() == 1; }
 
 int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
                               int64_t ncs, size_t* bytes) {
@@ -776,7 +897,7 @@ int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t ma
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, !want_vec && sweep_mixed()).total + 4096;
     return SCINT_OK;
 }
 
@@ -845,6 +966,7 @@ struct SweepProblem {
     bool want_vec; cplx* vec_out; int64_t vstride;
     SweepTail* tail_hook; hipStream_t tail[kTailLanes]; int tail_rr = 0;   // retired curvatures go round the tail streams
     int nbmax, steps_cap, depth, check_every;
+    bool mixed = false; double tol = 0.0; const double* scales_dev = nullptr;   // the mixed sweep (see "Mixed precision" above)
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
     hipEvent_t stagger_ev = nullptr;      // recorded after the first group's first pass
@@ -859,12 +981,16 @@ struct SweepGroup {
     // host staging (pinned), one set per table copy; slot indices in all tables are group-local
     PackedJob* h_jobs[kTabs]; Strip* h_strips[kTabs]; int32_t* h_fresh[kTabs]; int32_t* h_fin[kTabs];
     int64_t* h_fin_eta[kTabs]; int32_t* h_rs[kTabs]; int32_t* h_flags[kTabs];
+    Strip32* h_strips32[kTabs]; int32_t* h_restart[kTabs];
     // schedule state
     std::vector<PackedJob> jobs;          // current description of every slot of the group
     std::vector<int64_t> slot_eta;        // running eta or -1
     std::vector<int32_t> slot_gen;
     std::vector<int32_t> fin_slots;
     std::vector<int64_t> fin_eta;
+    std::vector<int8_t> slot_phase;       // mixed sweep: 0 = iteration on the complex64 tiles, 1 = certificate on the complex128 tiles
+    std::vector<std::pair<int32_t, int32_t>> restart;   // (slot, block steps of its iteration phase): certificate passes to start
+    int nstrips32 = 0;
     int active = 0, chunk = 0, seen = 0;  // chunks queued / chunks whose flags have been harvested
     bool finished = false;
     int tab_of_chunk[kTabs];              // table copy used by chunk c, indexed c % kTabs
@@ -876,6 +1002,10 @@ struct SweepGroup {
     }
     int32_t* d_fresh(int t) const { return (int32_t*)(P->base + P->BL.slots + P->BL.list_stride * (size_t)t) + slot0; }
     int32_t* d_fin(int t) const { return (int32_t*)(P->base + P->BL.fin_slots + P->BL.list_stride * (size_t)t) + slot0; }
+    int32_t* d_restart(int t) const { return (int32_t*)(P->base + P->BL.restart + P->BL.list_stride * (size_t)t) + slot0; }
+    Strip32* d_strips32(int t) const {
+        return (Strip32*)(P->base + P->BL.strips32 + P->BL.strips32_stride * (size_t)t) + (size_t)slot0 * (size_t)P->BL.smax;
+    }
     int64_t* d_fin_eta(int t) const { return (int64_t*)(P->base + P->BL.fin_eta + P->BL.fin_eta_stride * (size_t)t) + slot0; }
 
     // retire what chunk `c` finished (its flags are on the host)
@@ -883,8 +1013,16 @@ struct SweepGroup {
         const int32_t* flags = h_flags[c % kTabs];
         fin_slots.clear();
         fin_eta.clear();
+        restart.clear();
         for (int s = 0; s < nslots; ++s) {
             if (slot_eta[(size_t)s] < 0 || flags[4 * s] < slot_gen[(size_t)s]) continue;
+            if (P->mixed && slot_phase[(size_t)s] == 0 && flags[4 * s + 2] == 1) {
+                // the iteration phase has converged: the curvature stays in its slot for the certificate pass
+                slot_phase[(size_t)s] = 1;
+                restart.push_back({s, flags[4 * s + 1]});
+                continue;
+            }
+            slot_phase[(size_t)s] = 0;
             fin_slots.push_back(s);
             fin_eta.push_back(slot_eta[(size_t)s]);
             slot_eta[(size_t)s] = -1;            // results were written by the check kernel
@@ -910,14 +1048,28 @@ struct SweepGroup {
             J.cs = S.cs + c * S.cs_stride; J.th = S.th_cents + c * S.M; J.geom = (int32_t)c;
             J.keep = S.keep_idx + e * S.M; J.n = n; J.nb = (int)ceil_div(std::max(n, 1), kTB);
             J.max_steps = std::min(std::min(S.steps_cap, kMaxKB), std::max((n + 1) / 2, 1));
-            J.strip_len = strip_len_for(J.nb);
+            J.strip_len = S.mixed ? strip_len32_for(J.nb) : strip_len_for(J.nb);
             J.start = launch0;
             J.gen = ++slot_gen[(size_t)s];
             J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
             J.iters_out = S.iters_out ? S.iters_out + e : nullptr;
+            J.use32 = S.mixed ? 1 : 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = S.mixed ? 2 : 1;
+            J.scale32 = S.mixed ? S.scales_dev + c : nullptr;
+            J.tol = S.mixed ? 0.25 * S.tol : S.tol;     // (the certificate then passes at the first attempt)
+            slot_phase[(size_t)s] = 0;
             fresh.push_back(s);
         }
-        const bool changed = chunk == 0 || !fresh.empty() || !fin_slots.empty();
+        // certificate passes: the same curvature in the same slot, a new generation on the complex128 tiles.  It joins at
+        // the LAST pass of this chunk, so that the chunk's check sees its first (and, as a rule, only) step.
+        for (const auto& rs : restart) {
+            PackedJob& J = jobs[(size_t)rs.first];
+            J.use32 = 0; J.certify = 1; J.iters_base = rs.second; J.rowgroup_lg = 1;
+            J.strip_len = strip_len_for(J.nb);
+            J.start = launch0 + S.check_every - 1;
+            J.gen = ++slot_gen[(size_t)rs.first];
+            J.tol = S.tol;
+        }
+        const bool changed = chunk == 0 || !fresh.empty() || !fin_slots.empty() || !restart.empty();
         int tab = chunk == 0 ? 0 : tab_of_chunk[(chunk - 1) % kTabs];
         hipError_t he = hipSuccess;
         if (changed) {
@@ -931,8 +1083,10 @@ struct SweepGroup {
             // strips of every running job, block row by block row; longest strips first: the short
             // ones of the last block rows then fill the tail of the launch (dispatch order only)
             Strip* hs = h_strips[tab];
+            Strip32* hs32 = h_strips32[tab];
             int32_t* hrs = h_rs[tab];
             nstrips = 0;
+            nstrips32 = 0;
             nb_run = 1;
             for (int s = 0; s < nslots; ++s) {
                 PackedJob& J = jobs[(size_t)s];
@@ -940,9 +1094,30 @@ struct SweepGroup {
                 nb_run = std::max(nb_run, J.nb);
                 int32_t* rs0 = hrs + (size_t)s * (size_t)(S.nbmax + 1);
                 int idx = 0;
-                for (int I = 0; I < J.nb; ++I) { rs0[I] = idx; idx += row_strip_count(J.nb, I, J.strip_len); }
+                const int R = 1 << J.rowgroup_lg;
+                for (int I = 0; I < J.nb; ++I) { rs0[I] = idx; idx += row_strip_count(J.nb, I, J.strip_len, R); }
                 rs0[J.nb] = idx;
                 if (J.n < 2) continue;                             // nothing to multiply (the check kernel reports it)
+                if (J.use32) {                                     // rows I .. I+3 together, cut on row I's column grid
+                    for (int I = 0; I < J.nb; I += kRows32) {
+                        const int nrows = std::min(kRows32, J.nb - I);
+                        int k = 0;
+                        for (int J0 = I; J0 < J.nb; J0 += J.strip_len, ++k) {
+                            Strip32& st = hs32[nstrips32++];
+                            st.Q = J.Q; st.qstride = J.qstride; st.qslots = J.qslots;
+                            st.colpart = J.colpart + 2 * (tile_offset(J.nb, I) + (J0 - I)) * kTB;
+                            st.state = J.state;
+                            st.I = I; st.J0 = J0; st.ntile = std::min(J.nb, J0 + J.strip_len) - J0;
+                            st.start = J.start; st.gen = J.gen; st.max_steps = J.max_steps; st.nrows = nrows;
+                            for (int r = 0; r < kRows32; ++r) {
+                                const int Ir = std::min(I + r, J.nb - 1), JB = std::max(J0, Ir);
+                                st.tiles[r] = J.tiles32 + (tile_offset(J.nb, Ir) + (JB - Ir)) * kTileElems;
+                                st.rowpart[r] = J.rowpart + 2 * (int64_t)(rs0[Ir] + k) * kTB;
+                            }
+                        }
+                    }
+                    continue;
+                }
                 for (int I = 0; I < J.nb; I += 2) {                // rows I and I+1 together, cut on row I's column grid
                     const int nrows = I + 1 < J.nb ? 2 : 1;
                     int k = 0;
@@ -968,12 +1143,18 @@ struct SweepGroup {
             std::stable_sort(hs, hs + nstrips, [](const Strip& a, const Strip& b) {
                 return a.ntile * a.nrows > b.ntile * b.nrows;
             });
+            std::stable_sort(hs32, hs32 + nstrips32, [](const Strip32& a, const Strip32& b) {
+                return a.ntile * a.nrows > b.ntile * b.nrows;
+            });
+            std::vector<int32_t> redo;                            // slots whose strip grid is new: fresh ones and restarts
+            redo.assign(fresh.begin(), fresh.end());
+            for (const auto& rs : restart) { redo.push_back(rs.first); h_restart[tab][&rs - restart.data()] = rs.first; }
             std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
             std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
             int nb_fresh = 0;
-            for (int s : fresh) {
+            for (int s : fresh) nb_fresh = std::max(nb_fresh, jobs[(size_t)s].nb);
+            for (int s : redo) {
                 const PackedJob& J = jobs[(size_t)s];
-                nb_fresh = std::max(nb_fresh, J.nb);
                 he = hipMemcpyAsync(S.base + L.total * (size_t)(slot0 + s) + L.row_strip0,
                                     hrs + (size_t)s * (size_t)(S.nbmax + 1), sizeof(int32_t) * (size_t)(J.nb + 1),
                                     hipMemcpyHostToDevice, stream);
@@ -983,6 +1164,10 @@ struct SweepGroup {
                 he = hipMemcpyAsync(d_jobs(tab), h_jobs[tab], sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream);
             if (he == hipSuccess && nstrips > 0)
                 he = hipMemcpyAsync(d_strips(tab), hs, sizeof(Strip) * (size_t)nstrips, hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess && nstrips32 > 0)
+                he = hipMemcpyAsync(d_strips32(tab), hs32, sizeof(Strip32) * (size_t)nstrips32, hipMemcpyHostToDevice, stream);
+            if (he == hipSuccess && !restart.empty())
+                he = hipMemcpyAsync(d_restart(tab), h_restart[tab], sizeof(int32_t) * restart.size(), hipMemcpyHostToDevice, stream);
             if (he == hipSuccess && !fresh.empty())
                 he = hipMemcpyAsync(d_fresh(tab), h_fresh[tab], sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, stream);
             if (he != hipSuccess) return hip_fail(he, "sweep table upload", __FILE__, __LINE__);
@@ -1023,8 +1208,15 @@ struct SweepGroup {
                     if (rc != SCINT_OK) return rc;
                 }
             }
+            if (!restart.empty()) {
+                int nb_re = 1;
+                for (const auto& rs : restart) nb_re = std::max(nb_re, jobs[(size_t)rs.first].nb);
+                hipLaunchKernelGGL(pk2_restart_kernel, dim3((unsigned)nb_re, (unsigned)restart.size()), dim3(64), 0, stream,
+                                   d_jobs(tab), d_restart(tab));
+            }
             if (!fresh.empty()) {
-                int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream);
+                int32_t rc = launch_gather_packed(S.geoms_dev, S.M, d_jobs(tab), d_fresh(tab), (int)fresh.size(), nb_fresh, stream,
+                                                  S.mixed);
                 if (rc != SCINT_OK) return rc;
                 hipLaunchKernelGGL(pk2_init_kernel, dim3((unsigned)nb_fresh, (unsigned)fresh.size()), dim3(64), 0, stream,
                                    d_jobs(tab), d_fresh(tab));
@@ -1033,7 +1225,7 @@ struct SweepGroup {
             if (he != hipSuccess) return hip_fail(he, "sweep refill", __FILE__, __LINE__);
         }
         tab_of_chunk[chunk % kTabs] = tab;
-        if (nstrips > 0) {
+        if (nstrips + nstrips32 > 0) {
             for (int i = 0; i < S.check_every; ++i) {
                 const int launch = launch0 + i;
                 // the previous chunk's check (on check_stream) reads the partial sums the SECOND reduce from here
@@ -1042,9 +1234,17 @@ struct SweepGroup {
                     (void)hipStreamWaitEvent(stream, chunk_done[(chunk - 1) % kTabs], 0);
                 hipLaunchKernelGGL(pk2_coef_kernel, dim3((unsigned)ceil_div(nb_run * kTB, kCoefRows), (unsigned)nslots),
                                    dim3(kCoefRows), 0, stream, d_jobs(tab), launch);
-                const int slot = profiler().begin(kProfMatvec, stream);
-                hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), kMatvecLdsBytes, stream, d_strips(tab), launch);
-                profiler().end(kProfMatvec, slot, stream);
+                if (nstrips32 > 0) {
+                    const int slot = profiler().begin(kProfMatvec32, stream);
+                    hipLaunchKernelGGL(pk2_matvec32_kernel, dim3((unsigned)nstrips32), dim3(256), kMatvec32LdsBytes, stream,
+                                       d_strips32(tab), launch);
+                    profiler().end(kProfMatvec32, slot, stream);
+                }
+                if (nstrips > 0) {
+                    const int slot = profiler().begin(kProfMatvec, stream);
+                    hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), kMatvecLdsBytes, stream, d_strips(tab), launch);
+                    profiler().end(kProfMatvec, slot, stream);
+                }
                 hipLaunchKernelGGL(pk2_reduce_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64 * kRedGroups), 0,
                                    stream, d_jobs(tab), launch);
                 // the other group starts one pass behind this one (see run_sweep): its checks, refills and
@@ -1073,6 +1273,7 @@ struct SweepGroup {
         int fin_chunk = -1;
         fin_slots.clear();
         fin_eta.clear();
+        restart.clear();
         const bool more = active > 0 || S.next_eta < S.neta;
         if (chunk - seen >= S.depth || (!more && seen < chunk)) {
             hipError_t he = hipEventSynchronize(chunk_done[seen % kTabs]);
@@ -1081,7 +1282,7 @@ struct SweepGroup {
             harvest(seen);
             fin_chunk = seen++;
         }
-        if (active == 0 && S.next_eta >= S.neta && fin_slots.empty()) {
+        if (active == 0 && S.next_eta >= S.neta && fin_slots.empty() && restart.empty()) {
             if (seen == chunk) finished = true;     // nothing running, nothing queued
             return SCINT_OK;                        // else: keep draining the chunks in flight
         }
@@ -1117,12 +1318,15 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     if (!side) { set_error("scint: could not create the internal sweep streams"); return SCINT_E_HIP; }
     SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kMatvecLdsBytes));
+    SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kMatvec32LdsBytes));
 
     SweepProblem S;
     S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
     S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
     S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
     S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook;
+    S.mixed = !want_vec && !tail_hook && sweep_mixed(); S.tol = tol;
     for (int l = 0; l < kTailLanes; ++l) S.tail[l] = side->tail[l];
     S.nbmax = (int)ceil_div(M, kTB);
     S.steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
@@ -1135,20 +1339,22 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEveryBlock;
     const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
     const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
-    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs);
+    S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs, S.mixed);
     const SlabLayout& L = S.BL.slab;
     S.base = (char*)workspace;
     S.states_dev = (int32_t*)(S.base + S.BL.states);
     S.geoms_dev = (const GeomDev*)(S.base + S.BL.geoms);
+    S.scales_dev = (const double*)(S.base + S.BL.scales);
 
     // pinned staging: geometry table + per group kTabs x {jobs, strips, fresh, fin, fin_eta, row_strip0, flags}
     auto per_tab = [&](size_t nsl) {
         return align_up(sizeof(PackedJob) * nsl, 64) + align_up(sizeof(Strip) * nsl * (size_t)S.BL.smax, 64) +
-               2 * align_up(sizeof(int32_t) * nsl, 64) + align_up(sizeof(int64_t) * nsl, 64) +
+               (S.mixed ? align_up(sizeof(Strip32) * nsl * (size_t)S.BL.smax, 64) : 0) +
+               3 * align_up(sizeof(int32_t) * nsl, 64) + align_up(sizeof(int64_t) * nsl, 64) +
                align_up(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1), 64) + align_up(sizeof(int32_t) * 4 * nsl, 64);
     };
     const size_t geom_bytes = align_up(sizeof(GeomDev) * (size_t)ncs, 64);
-    char* pin = pinned_staging(geom_bytes + per_tab((size_t)nslots) * kTabs + 64 * 7 * kTabs * 2);
+    char* pin = pinned_staging(geom_bytes + per_tab((size_t)nslots) * kTabs + 64 * 9 * kTabs * 2);
     if (!pin) return SCINT_E_HIP;
     GeomDev* h_geoms = (GeomDev*)pin;
     for (int64_t c = 0; c < ncs; ++c) h_geoms[c] = to_dev(geom[c]);
@@ -1176,6 +1382,8 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             grp.h_fin_eta[t] = (int64_t*)take(sizeof(int64_t) * nsl);
             grp.h_rs[t] = (int32_t*)take(sizeof(int32_t) * nsl * (size_t)(S.nbmax + 1));
             grp.h_flags[t] = (int32_t*)take(sizeof(int32_t) * 4 * nsl);
+            grp.h_strips32[t] = (Strip32*)take(S.mixed ? sizeof(Strip32) * nsl * (size_t)S.BL.smax : 0);
+            grp.h_restart[t] = (int32_t*)take(sizeof(int32_t) * nsl);
             if (rc == SCINT_OK) {
                 he = hipEventCreateWithFlags(&grp.chunk_done[t], hipEventDisableTiming);
                 if (he == hipSuccess) he = hipEventCreateWithFlags(&grp.export_done[t], hipEventDisableTiming);
@@ -1186,10 +1394,13 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         grp.jobs.assign(nsl, PackedJob());
         grp.slot_eta.assign(nsl, -1);
         grp.slot_gen.assign(nsl, 0);
+        grp.slot_phase.assign(nsl, 0);
         for (int s = 0; s < grp.nslots; ++s) {                    // static part of every slot
             char* sl = S.base + L.total * (size_t)(grp.slot0 + s);
             PackedJob& J = grp.jobs[(size_t)s];
             J.tiles = (cplx*)(sl + L.tiles);
+            J.tiles32 = S.mixed ? (c32*)(sl + L.tiles32) : nullptr;
+            J.scale32 = nullptr; J.use32 = 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = 1;
             J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
             J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
             J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
@@ -1212,6 +1423,11 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     if (rc == SCINT_OK) {
         he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
         if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream);
+        if (he == hipSuccess && S.mixed) {
+            const int32_t src = launch_cs_scale((const cplx*)cs, ncs, cs_stride, (int64_t)geom[0].ntau * geom[0].nfd,
+                                                (unsigned long long*)(S.base + S.BL.scale_bits), (double*)(S.base + S.BL.scales), stream);
+            if (src != SCINT_OK) rc = src;
+        }
         // the caller's output buffers need no preparation: a status that is never written reads as a failure
         // (0x7f7f7f7f), step counts as 0, eigenvector rows are zero beyond their N_i entries
         if (he == hipSuccess) he = hipMemsetAsync(status_out, 0x7f, sizeof(int32_t) * (size_t)neta, stream);
@@ -1239,7 +1455,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             any = true;
             if (g == 1 && !staggered) {
                 staggered = true;
-                if (G[0].chunk > 0 && G[0].nstrips > 0) {
+                if (G[0].chunk > 0 && G[0].nstrips + G[0].nstrips32 > 0) {
                     he = hipStreamWaitEvent(G[1].stream, S.stagger_ev, 0);
                     if (he != hipSuccess) { rc = hip_fail(he, "sweep stagger", __FILE__, __LINE__); break; }
                 }
@@ -1273,6 +1489,14 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
 }  // namespace scint
 
 using namespace scint;
+
+extern "C" int32_t scint_sweep_precision(int32_t mode) {
+    int& m = sweep_mode_ref();
+    const int32_t before = m;
+    if (mode == 0 || mode == 1) m = mode;
+    else if (mode != -1) { set_error("scint: sweep_precision: mode must be 0 (f64), 1 (mixed) or -1 (query)"); return SCINT_E_ARG; }
+    return before;
+}
 
 extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
                                                     int32_t max_iter, size_t* bytes) {

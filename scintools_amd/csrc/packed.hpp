@@ -23,6 +23,13 @@ namespace scint {
 constexpr int kTB = 64;                       // tile edge
 constexpr int kTileElems = kTB * kTB;         // 4096 complex = 64 KiB
 
+// complex64 copy of a tile (32 KiB): what the ITERATION of the mixed-precision sweep streams (eigen_packed.hip,
+// "f32-stored iteration, f64 certificate"); the eigenvalue that is returned never comes from it
+struct __attribute__((aligned(8))) c32 { float x, y; };
+static_assert(sizeof(c32) == 8, "c32 must be two floats");
+constexpr int kRows32 = 4;        // block rows per workgroup of the complex64 mat-vec (same tile bytes per workgroup as two complex128 rows)
+constexpr int kMaxStrip32 = 14;   // its column tiles per strip: 28 + 28 KiB of X_J blocks and column partials, 72 KiB of LDS in all
+
 __host__ __device__ inline int64_t tile_offset(int nb, int I) {
     return (int64_t)I * nb - (int64_t)I * (I - 1) / 2;
 }
@@ -46,6 +53,12 @@ struct PackedJob {
     const int32_t* keep;    // [n] indices into th
     int32_t n, nb;
     cplx* tiles;            // [tile_count(nb)][64][64]
+    c32* tiles32;           // the same tiles as complex64, scaled by *scale32 (nullptr: not wanted)
+    const double* scale32;  // power of two that brings max |CS| of this job's spectrum into [0.5, 1)
+    int32_t use32;          // 1: the mat-vec of this job streams tiles32 (iteration phase of the mixed sweep)
+    int32_t certify;        // 1: restarted on the complex128 tiles from the Ritz vectors of the iteration phase
+    int32_t iters_base;     // passes of the iteration phase (certify: added to the reported count; restart: its T_k has 2 iters_base rows)
+    int32_t rowgroup_lg;    // log2 of the block rows that share one column partial: 1 (complex128 strips), 2 (complex64)
     // ---- Lanczos state -----------------------------------------------------------
     int32_t max_steps, strip_len;
     int32_t start, gen;     // launch index of this job's Lanczos step 0; generation of the slot (>= 1)
@@ -91,16 +104,34 @@ struct __attribute__((aligned(16))) Strip {
 
 // Rows are paired (0,1), (2,3), ...; an unpaired last row (odd nb) runs alone.  The second row of a pair is
 // cut on the FIRST row's column grid, so both have the same number of strips.
-inline bool row_is_second(int nb, int I) { return (I & 1) && I < nb; }
-inline int row_strip_count(int nb, int I, int S) {
-    const int lead = (I & 1) ? I - 1 : I;              // the row whose grid this row is cut on
+// (R = 4 rows per group for the complex64 strips: rows of a group are all cut on the FIRST row's grid.)
+inline int row_strip_count(int nb, int I, int S, int R = 2) {
+    const int lead = I - I % R;                        // the row whose grid this row is cut on
     return (nb - lead + S - 1) / S;
 }
 
+// One workgroup of the complex64 mat-vec: tiles (I + r, J0 .. J0+ntile-1) for r = 0 .. nrows-1 (row I + r starts at
+// column max(J0, I + r): nothing below the diagonal is stored).  One column partial per column tile for the group.
+struct __attribute__((aligned(16))) Strip32 {
+    const c32* tiles[kRows32];  // first tile of row I + r in the strip
+    cplx* rowpart[kRows32];     // row I + r's [64][2] row partials of this strip
+    const cplx* Q;
+    cplx* colpart;              // [ntile][64][2]
+    const int32_t* state;
+    int64_t qstride;
+    int32_t I, J0, ntile, qslots;
+    int32_t start, gen, max_steps, nrows;
+};
+
 // Gather for the jobs in slots[0..njobs) (device array of indices into jobs_dev); every job
 // names its own CS, theta grid and geometry (geoms_dev[job.geom]).
+// with32: every job also gets its complex64 copy (job.tiles32, scaled by *job.scale32).
 int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
-                             const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream);
+                             const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream, bool with32 = false);
+// scale[c] = 2^-e with max(|re|, |im|) over the finite elements of spectrum c in [2^(e-1), 2^e) (1 when that
+// maximum is 0); `bits` is scratch of ncs words.  Queued on `stream`.
+int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t nelem, unsigned long long* bits,
+                        double* scale, hipStream_t stream);
 
 // What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
 // on the host while the sweep runs; enqueues on a tail stream that already waits for the export.
@@ -121,6 +152,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
                   int64_t batch, double* eigs_out, int32_t* status_out, int32_t* iters_out, bool want_vec,
                   cplx* vec_out, int64_t vstride, SweepTail* tail_hook, void* workspace, size_t workspace_bytes,
                   void* stream);
+bool sweep_mixed();   // scint_sweep_precision(): eigenvalue sweeps iterate on a complex64 copy and certify on the complex128 tiles
 int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
                               int64_t ncs, size_t* bytes);
 

@@ -135,6 +135,9 @@ __device__ inline void tile_coords(int nb, int t, int& I, int& J) {
     J = i + (t - (int)tile_offset(nb, i));
 }
 
+// F32: the tile also leaves as complex64, multiplied by the job's power-of-two scale (exact) and rounded once
+// -- the operand of the iteration phase of the mixed-precision sweep (eigen_packed.hip).
+template <bool F32>
 __global__ void __launch_bounds__(256)
 thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
                           const PackedJob* __restrict__ jobs, const int32_t* __restrict__ slots) {
@@ -157,6 +160,8 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
     const double th_j = jin ? gload(th + kj) : 0.0;
     const double sq_j = th_j * th_j;
     cplx* __restrict__ tile = jp->tiles + (int64_t)t * kTileElems + lane;
+    c32* __restrict__ tile32 = F32 ? jp->tiles32 + (int64_t)t * kTileElems + lane : nullptr;
+    const double sc32 = F32 ? gload(jp->scale32) : 1.0;
     const bool diag = (I == J);
     // the wave's 16 rows: lanes 0..15 fetch keep / theta_i once (one dependent load pair), every
     // row then reads them back through the scalar unit
@@ -197,6 +202,7 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
             const double none = e.off == -2 ? nan("") : 0.0;
             const cplx v = mk(e.off >= 0 ? vx : none, e.off >= 0 ? vy : none);
             gstore_nt(tile + (16 * w + 8 * b + k) * kTB, v);   // written once, read much later
+            if (F32) gstore_nt(tile32 + (16 * w + 8 * b + k) * kTB, v.x * sc32, v.y * sc32);
         }
     };
     // batch by batch (8 reads in flight per lane, ~100 VGPRs, 4 waves per SIMD); issuing both
@@ -205,13 +211,60 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
 }
 
 int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
-                             const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream) {
+                             const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream, bool with32) {
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
     SCINT_REQUIRE(nbmax <= 32767 && njobs <= 65535, "gather: grid too large");
     const int slot = profiler().begin(kProfGather, stream);
-    hipLaunchKernelGGL(thth_gather_packed_kernel, dim3((unsigned)tile_count(nbmax), (unsigned)njobs), dim3(256), 0,
-                       stream, geoms_dev, M, jobs_dev, slots_dev);
+    const dim3 grid((unsigned)tile_count(nbmax), (unsigned)njobs);
+    if (with32) hipLaunchKernelGGL(thth_gather_packed_kernel<true>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
+    else hipLaunchKernelGGL(thth_gather_packed_kernel<false>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
+// max(|re|, |im|) over the finite elements of a conjugate spectrum, as the bit pattern of a non-negative double
+// (integer order = numeric order: atomicMax is exact and order-independent), then the power of two that brings
+// it into [0.5, 1).  The complex64 copy of theta-theta is gathered from the spectrum times this scale, so the
+// iteration phase of the mixed sweep does not depend on the units of the dynamic spectrum.
+__global__ void __launch_bounds__(256) cs_absmax_kernel(const cplx* __restrict__ cs, int64_t cs_stride, int64_t nelem,
+                                                        unsigned long long* __restrict__ bits) {
+    __shared__ double red[4];
+    const cplx* __restrict__ src = cs + (int64_t)blockIdx.y * cs_stride;
+    double m = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nelem; k += (int64_t)gridDim.x * 256) {
+        const cplx v = gload(src + k);
+        const double a = fabs(v.x), b = fabs(v.y);
+        if (a <= 1.7976931348623157e308) m = fmax(m, a);       // NaN and inf fail the comparison
+        if (b <= 1.7976931348623157e308) m = fmax(m, b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        atomicMax(bits + blockIdx.y, (unsigned long long)__double_as_longlong(m));
+    }
+}
+__global__ void __launch_bounds__(64) cs_scale_kernel(const unsigned long long* __restrict__ bits, double* __restrict__ scale,
+                                                      int64_t ncs) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= ncs) return;
+    const double m = __longlong_as_double((long long)bits[c]);
+    int e = 0;
+    if (m > 0.0) (void)frexp(m, &e);                           // m = f 2^e, f in [0.5, 1)
+    e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+    scale[c] = m > 0.0 ? ldexp(1.0, -e) : 1.0;
+}
+
+int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t nelem, unsigned long long* bits,
+                        double* scale, hipStream_t stream) {
+    SCINT_REQUIRE(ncs >= 1 && ncs <= 65535 && nelem >= 1, "cs_scale: bad arguments");
+    SCINT_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long) * (size_t)ncs, stream));
+    const unsigned nblk = (unsigned)std::min<int64_t>(ceil_div(nelem, 256 * 8), 2048);
+    hipLaunchKernelGGL(cs_absmax_kernel, dim3(nblk, (unsigned)ncs), dim3(256), 0, stream, cs, cs_stride, nelem, bits);
+    hipLaunchKernelGGL(cs_scale_kernel, dim3((unsigned)ceil_div(ncs, 64)), dim3(64), 0, stream, bits, scale, ncs);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

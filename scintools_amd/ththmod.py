@@ -337,6 +337,20 @@ def default_batch(nmax, neta):
     return int(max(1, min(neta, 256, want, cap)))
 
 
+def sweep_precision(mode=None):
+    """Operand precision of the iteration of the eigenvalue sweeps (``scint_sweep_precision``), per process.
+
+    ``"f64"`` (default): every Lanczos pass streams the complex128 theta-theta.  ``"mixed"``: the passes stream a
+    complex64 copy and the eigenvalue returned is the Ritz value of a certificate pass on the complex128 matrix that
+    meets the same a-posteriori bound (same ``tol``, same status codes).  ``None`` only queries.  Returns the mode
+    that was in force before the call."""
+    lib = _lib.load()
+    codes = {None: -1, "f64": 0, "mixed": 1}
+    if mode not in codes:
+        raise ValueError("sweep_precision: mode must be 'f64', 'mixed' or None")
+    return "mixed" if lib.scint_sweep_precision(codes[mode]) == 1 else "f64"
+
+
 def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,
                return_info=False):
     """Dominant eigenvalue for every curvature in `etas`: the loop of
