@@ -98,6 +98,12 @@ def parse():
                     help="observation 0 from a file (keys dyn[nf, nt], freqs [MHz], times [s], eta [s^3]) instead "
                          "of the analytic arc -- e.g. a reference-Simulation screen written by "
                          "tests/tools/make_sim_input.py; --size must match")
+    ap.add_argument("--precision", choices=["f64", "mixed"], default="f64",
+                    help="operand of the Lanczos passes of the eigenvalue sweep: complex128 throughout (f64), or a "
+                         "complex64 copy with a complex128 certificate pass per curvature (mixed; ththmod.sweep_precision)")
+    ap.add_argument("--mixed-steps", type=int, default=0,
+                    help="N=1, --precision f64: also time this many steps of the mixed sweep on the same workload and "
+                         "compare its curve with the float64 one (object 'mixed_precision' of the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16, help="etas timed on the CPU oracle (spread over the sweep)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU sample (the median is reported)")
@@ -140,6 +146,16 @@ def make_workload(size, neta, nedge, seed, npad=0, npz=None):
     edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge)
     etas = np.geomspace(0.25, 4.0, neta) * eta_true
     return dyn, freqs, times, fd, tau, edges, etas, eta_true
+
+
+def mixed_summary(run, steps, netas):
+    """What a run of the mixed sweep streamed, from the library's count (scint_sweep_stats)."""
+    s = run["stats"]
+    return {"what": "Lanczos passes on a complex64 copy of theta-theta (float64 vectors and sums); the eigenvalue returned is "
+                    "the Ritz value of a certificate pass on the complex128 tiles under the float64 sweep's a-posteriori bound",
+            "complex64_bytes_per_step": s[0] / steps, "complex128_bytes_per_step": s[1] / steps,
+            "certified_per_step": s[2] / steps, "certificate_passes_mean": s[3] / max(1.0, s[2]),
+            "lanczos_steps_mean": float(run["info"]["iters"].mean()), "curvatures_per_step": netas}
 
 
 def lanczos_block():
@@ -395,19 +411,27 @@ def main():
         t0 = time.perf_counter()
         mv_bytes = 0.0
         local_etas = 0
+        stats = np.zeros(4)
+        st = (ctypes.c_double * 4)()
         for _ in range(steps):
             curves, info, fit = step(objective)
             if info is not None:
                 local_etas += int(info["N"].shape[0])
                 n_ = info["N"].astype(float)
-                mv_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"]))   # Hermitian: upper triangle once
+                if objective == "eig" and ththmod.sweep_precision() == "mixed":
+                    # bytes by operand from the library's own count (the per-eta step counts do not split by phase)
+                    lib.scint_sweep_stats(st)
+                    stats += np.array(list(st))
+                    mv_bytes += st[0] + st[1]
+                else:
+                    mv_bytes += float(np.sum(8.0 * n_ * (n_ + 1.0) * info["iters"]))   # Hermitian: upper triangle once
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        ms = (ctypes.c_double * 2)()        # union of each kernel's launch intervals
-        ms_sum = (ctypes.c_double * 2)()    # plain sum of the individual launch spans
-        launches = (ctypes.c_int64 * 2)()
+        ms = (ctypes.c_double * 3)()        # union of each kernel's launch intervals: gather, complex128 mat-vec, complex64 mat-vec
+        ms_sum = (ctypes.c_double * 3)()    # plain sum of the individual launch spans
+        launches = (ctypes.c_int64 * 3)()
         lib.scint_profile_end(ms, ms_sum, launches)
         rank_rates = [local_etas / elapsed]
         if world > 1:
@@ -419,8 +443,11 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return dict(elapsed=elapsed, curves=curves, info=info, fit=fit, mv_bytes=mv_bytes, rank_rates=rank_rates,
-                    busy_ms=list(ms), sum_ms=list(ms_sum), launches=list(launches))
+                    busy_ms=list(ms), sum_ms=list(ms_sum), launches=list(launches), stats=stats)
 
+    mixed = args.precision == "mixed" and args.objective == "eig"
+    if mixed:
+        ththmod.sweep_precision("mixed")
     head = timed(args.objective, args.steps, args.warmup)
 
     gathered_equal = None
@@ -436,12 +463,14 @@ def main():
         n_ = info["N"].astype(float)
         # packed gather: one CS read per strict-upper element + the upper-triangle tiles written
         gather_bytes = float(np.sum(8.0 * n_ * (n_ - 1.0) + 8.0 * n_ * (n_ + 1.0))) * args.steps
-        mv_s, ga_s = head["busy_ms"][1] / 1e3, head["busy_ms"][0] / 1e3
-        alg_bytes = head["mv_bytes"]
+        # the dominant kernel: the complex128 mat-vec, or -- mixed sweep -- the complex64 one
+        mvk = 2 if mixed else 1
+        mv_s, ga_s = head["busy_ms"][mvk] / 1e3, head["busy_ms"][0] / 1e3
+        alg_bytes = head["stats"][0] if mixed else head["mv_bytes"]
         achieved = alg_bytes / mv_s / 1e9 if mv_s > 0 else 0.0
-        ratio, ratio_src = pmc_traffic_ratio()
+        ratio, ratio_src = pmc_traffic_ratio() if not mixed else (None, None)
         launches = head["launches"]
-        alg_per_launch = alg_bytes / max(1, launches[1])
+        alg_per_launch = alg_bytes / max(1, launches[mvk])
         what = ("theta-theta eigenvalue sweep (Eval_calc loop of single_search)" if args.objective == "eig"
                 else "modeler/chisq_calc sweep")
         out = {
@@ -469,21 +498,22 @@ def main():
                        "collective": (f"all_gather of float64 [{-(-neta // world)}] per rank per step ({backend})" if shard_eta else
                                       f"all_gather of float64 [{per_rank_max}, {neta}] per rank per step ({backend})")
                        if world > 1 else None,
+                       "sweep_precision": args.precision if args.objective == "eig" else "f64",
                        "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
                        "lanczos_vectors_per_step": lanczos_block()[0],
                        "batch": int(info["batch"]), "failed_etas": int(np.sum(info["status"] != 0)),
                        "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
-            "roofline": {"kernel": lanczos_block()[1], "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "pk2_matvec32_kernel" if mixed else lanczos_block()[1], "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg_per_launch,
                          "traffic": (ratio * alg_per_launch) if ratio else None,
                          "traffic_note": (f"HBM bytes per launch = {ratio:.3f} x algorithmic bytes; ratio measured "
                                           f"with rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
                                           f"separate passes), {ratio_src}") if ratio else None,
-                         "avg_launch_ms": head["sum_ms"][1] / max(1, launches[1]), "launches": int(launches[1]),
-                         "busy_ms": head["busy_ms"][1],
+                         "avg_launch_ms": head["sum_ms"][mvk] / max(1, launches[mvk]), "launches": int(launches[mvk]),
+                         "busy_ms": head["busy_ms"][mvk],
                          "timing_note": "achieved = algorithmic bytes / busy_ms; busy_ms = union of this kernel's "
                                         "hipEvent launch intervals on its launch streams (equal to launches x "
                                         "avg_launch_ms when the sweep runs on one stream); tools/rocpd_summary.py "
@@ -498,7 +528,30 @@ def main():
                                                     "upper-triangle tiles written)",
                        "frac": (gather_bytes / ga_s / 1e9 / HBM_PEAK_GBS) if ga_s > 0 else 0.0},
         }
-        if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta:
+        if mixed:
+            out["roofline"]["mixed"] = mixed_summary(head, args.steps, neta * n_obs_job)
+            ththmod.sweep_precision("f64")        # every other leg of the line is the float64 library
+        if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta and not mixed and args.mixed_steps > 0:
+            ththmod.sweep_precision("mixed")
+            try:
+                mx = timed("eig", args.mixed_steps, 1)
+            finally:
+                ththmod.sweep_precision("f64")
+            ref_curve, got = eigs, mx["curves"][0]
+            out["mixed_precision"] = dict(
+                mixed_summary(mx, args.mixed_steps, neta),
+                value=neta * args.mixed_steps / mx["elapsed"], unit="eta-points/s", steps=args.mixed_steps,
+                ms_per_step=1e3 * mx["elapsed"] / args.mixed_steps,
+                speedup_vs_f64=(neta * args.mixed_steps / mx["elapsed"]) / out["value"],
+                failed_etas=int(np.sum(mx["info"]["status"] != 0)),
+                max_rel_diff_vs_f64_curve=float(np.nanmax(np.abs(got - ref_curve) / np.abs(ref_curve))),
+                matvec32={"achieved": mx["stats"][0] / (mx["busy_ms"][2] / 1e3) / 1e9 if mx["busy_ms"][2] > 0 else 0.0,
+                          "unit": "GB/s", "avg_launch_ms": mx["sum_ms"][2] / max(1, mx["launches"][2]),
+                          "launches": int(mx["launches"][2]), "busy_ms": mx["busy_ms"][2],
+                          "share_of_step_time": mx["busy_ms"][2] / 1e3 / mx["elapsed"]},
+                matvec64={"achieved": mx["stats"][1] / (mx["busy_ms"][1] / 1e3) / 1e9 if mx["busy_ms"][1] > 0 else 0.0,
+                          "unit": "GB/s", "launches": int(mx["launches"][1]), "busy_ms": mx["busy_ms"][1]})
+        if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta and not mixed:
             # the same sweep with ONE slot group (SCINT_SWEEP_GROUPS=1, read per call): every mat-vec launch has the
             # GPU to itself, so this is the kernel's own rate; in the headline schedule two groups' launches and the
             # small kernels share the GPU and `achieved` above is bytes / (time any mat-vec launch is in flight)

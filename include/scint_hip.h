@@ -143,6 +143,10 @@ int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
  * Returns the previous mode.  Call it BEFORE the *_workspace_bytes of a sweep: the mixed sweep needs a larger
  * workspace.  The environment variable SCINT_SWEEP_PRECISION=mixed|f64 sets the initial mode. */
 int32_t scint_sweep_precision(int32_t mode);
+/* Diagnostics of the calling thread's last sweep (any of the sweep entry points), for the roofline accounting:
+ * out[0] algorithmic bytes of its complex64 passes (4 n (n + 1) each), out[1] of its complex128 passes (8 n (n + 1)),
+ * out[2] curvatures that went through a certificate, out[3] complex128 passes those certificates took. */
+int32_t scint_sweep_stats(double* out /*HOST[4]*/);
 int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
                          const double* th_cents, int64_t M,
                          const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "scint_mean": ([_P, c_int64, POINTER(c_double), _P], c_int32),
     "scint_thth_map": ([_P, POINTER(CsGeom), _P, c_int64, _P, c_int64, c_double, c_int32, _P, _P], c_int32),
     "scint_sweep_precision": ([c_int32], c_int32),
+    "scint_sweep_stats": ([POINTER(c_double)], c_int32),
     "scint_eval_sweep_workspace_bytes": ([c_int64, c_int64, c_int64, c_int32, POINTER(c_size_t)], c_int32),
     "scint_eval_sweep": ([_P, POINTER(CsGeom), _P, c_int64, _P, POINTER(c_int32), POINTER(c_double), c_int64,
                           c_double, c_int32, c_int64, _P, _P, _P, _P, c_size_t, _P], c_int32),

@@ -959,6 +959,11 @@ static SideStreams* side_streams() {
 // copies, on the host and on the device.  Per-job arithmetic does not depend on any of this
 // (fixed-order sums inside a job), so results are bit-identical for every depth, batch size,
 // grouping and arrival order.
+// What the calling thread's last sweep streamed (scint_sweep_stats): algorithmic bytes 4 n (n + 1) per complex64 pass and
+// 8 n (n + 1) per complex128 pass of an n x n matrix, certificates started, complex128 passes they took.
+struct SweepStats { double bytes32 = 0, bytes64 = 0, certified = 0, cert_passes = 0; };
+static SweepStats& sweep_stats() { thread_local SweepStats st; return st; }
+
 struct SweepProblem {
     const cplx* cs; int64_t cs_stride; const int32_t* cs_index; const double* th_cents; int64_t M;
     const int32_t* keep_idx; const int32_t* keep_n; const double* etas; int64_t neta;
@@ -1016,8 +1021,13 @@ struct SweepGroup {
         restart.clear();
         for (int s = 0; s < nslots; ++s) {
             if (slot_eta[(size_t)s] < 0 || flags[4 * s] < slot_gen[(size_t)s]) continue;
+            const double nn = (double)jobs[(size_t)s].n * ((double)jobs[(size_t)s].n + 1.0), steps = (double)flags[4 * s + 1];
+            SweepStats& st = sweep_stats();
+            if (jobs[(size_t)s].use32) st.bytes32 += 4.0 * nn * steps; else st.bytes64 += 8.0 * nn * steps;
+            if (slot_phase[(size_t)s] == 1) st.cert_passes += steps;
             if (P->mixed && slot_phase[(size_t)s] == 0 && flags[4 * s + 2] == 1) {
                 // the iteration phase has converged: the curvature stays in its slot for the certificate pass
+                st.certified += 1;
                 slot_phase[(size_t)s] = 1;
                 restart.push_back({s, flags[4 * s + 1]});
                 continue;
@@ -1321,6 +1331,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kMatvec32LdsBytes));
 
+    sweep_stats() = SweepStats();
     SweepProblem S;
     S.cs = (const cplx*)cs; S.cs_stride = cs_stride; S.cs_index = cs_index; S.th_cents = th_cents; S.M = M;
     S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
@@ -1496,6 +1507,13 @@ extern "C" int32_t scint_sweep_precision(int32_t mode) {
     if (mode == 0 || mode == 1) m = mode;
     else if (mode != -1) { set_error("scint: sweep_precision: mode must be 0 (f64), 1 (mixed) or -1 (query)"); return SCINT_E_ARG; }
     return before;
+}
+
+extern "C" int32_t scint_sweep_stats(double* out) {
+    SCINT_REQUIRE(out, "sweep_stats: null pointer");
+    const SweepStats& st = sweep_stats();
+    out[0] = st.bytes32; out[1] = st.bytes64; out[2] = st.certified; out[3] = st.cert_passes;
+    return SCINT_OK;
 }
 
 extern "C" int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,

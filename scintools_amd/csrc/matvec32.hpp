@@ -83,7 +83,11 @@ __device__ __forceinline__ void pk32_row(const c32* __restrict__ tp, v4f (&a0)[8
 #pragma unroll 1
     for (; t + 2 < ntile; t += 2) {                                       // tiles t and t+1; tile t+2 exists
         const c32* __restrict__ tc = tp + (int64_t)(t - t0) * kTileElems;
+        // (fences on both sides of both prefetches: left alone, the compiler hoists the first conversions of a0 above
+        // these loads and then waits for ALL of a0 before the first product -- vmcnt(1), loads, vmcnt(8) in the ISA)
+        __builtin_amdgcn_sched_barrier(0);
         pk32_load_tile(a1, tc + kTileElems);
+        __builtin_amdgcn_sched_barrier(0);
         tile_step(a0, t);
         __builtin_amdgcn_sched_barrier(0);
         pk32_load_tile(a0, tc + 2 * kTileElems);

@@ -39,6 +39,18 @@ def main(out_path):
     res["red_nh"] = ththmod.thth_redmap(CS, tau, fd, etas[2], edges, False)[0]
     eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, return_info=True)
     res["eigs_b2"], res["iters_b2"] = eigs, info["iters"]
+    ththmod.sweep_precision("mixed")        # complex64 iteration + complex128 certificate (a 300^2 case: four-row strips)
+    try:
+        eigs, info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, return_info=True)
+        res["eigs_mx"], res["iters_mx"] = eigs, info["iters"]
+        d3, f3, t3, e3 = arc_dynspec(300, 300, seed=9, nimg=6, noise=0.05)
+        fd3, tau3 = thth_oracle.fft_axis(t3, 1000.0, 0), thth_oracle.fft_axis(f3, 1.0, 0)
+        cs3 = ththmod.conjugate_spectrum(d3 - d3.mean(), 0, pad_value=0.0)
+        eigs, info = ththmod.eval_sweep(cs3, tau3, fd3, np.array([0.8, 1.3]) * e3, np.linspace(-fd3.max() / 2, fd3.max() / 2, 300),
+                                        return_info=True)
+        res["eigs_mx300"], res["iters_mx300"] = eigs, info["iters"]
+    finally:
+        ththmod.sweep_precision("f64")
     w, V, _ = ththmod.eigvec_sweep(cs_t, tau, fd, etas[1:4], edges)
     res["w_b2"], res["V_b2"] = w, V.cpu().numpy()
     m = ththmod.modeler(CS, tau, fd, etas[2], edges)

@@ -187,6 +187,119 @@ def test_eigenvalue_sweep_vs_arpack(emu, to, case):
     assert np.array_equal(eigs, eigs2)
 
 
+@pytest.fixture()
+def mixed(emu):
+    """The eigenvalue sweeps of this test iterate on the complex64 copy and certify on the complex128 tiles."""
+    emu.sweep_precision("mixed")
+    yield emu
+    emu.sweep_precision("f64")
+
+
+def _sweep_stats(thth):
+    import ctypes
+    from scintools_amd import _lib
+    st = (ctypes.c_double * 4)()
+    _lib.check(_lib.load().scint_sweep_stats(st), "scint_sweep_stats")
+    return dict(bytes32=st[0], bytes64=st[1], certified=st[2], cert_passes=st[3])
+
+
+@pytest.mark.parametrize("size", [96, 192, 300, 520])
+def test_mixed_sweep_against_float64_sweep_and_arpack(emu, to, size):
+    """Mixed precision (eigen_packed.hip): the passes stream complex64 tiles -- four block rows per workgroup, rows that
+    start one to three tiles late, a last group of one to three rows, strips of two and four tiles --, the returned
+    value is the Ritz value of the certificate pass on the complex128 tiles.  It has to agree with the float64 sweep far
+    inside its tolerance (both are Ritz values of the SAME float64 matrix under the same bound) and with ARPACK to the
+    parity bar; every curvature goes through exactly one certificate, which here passes at its first step."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=9, nimg=6, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    CS = to.conjugate_spectrum(dyn, 0)
+    etas = np.array([0.8, 1.0, 1.3]) * eta_true if size < 500 else np.array([1.0]) * eta_true
+    e64, i64 = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
+    assert _sweep_stats(emu)["bytes32"] == 0
+    assert emu.sweep_precision("mixed") == "f64"
+    try:
+        emx, imx = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
+        st = _sweep_stats(emu)
+        emx2 = emu.eval_sweep(CS, tau, fd, etas, edges, batch=2)
+    finally:
+        assert emu.sweep_precision("f64") == "mixed"
+    assert np.all(imx["status"] == 0) and np.all(i64["status"] == 0)
+    np.testing.assert_allclose(emx, e64, rtol=1e-13)
+    if size < 500:
+        ref = np.array([to.Eval_calc(CS, tau, fd, e, edges) for e in etas])
+        np.testing.assert_allclose(emx, ref, rtol=1e-9)
+    assert np.array_equal(emx, emx2)                                  # batch size / slot grouping: same bits
+    assert st["certified"] == len(etas) and st["cert_passes"] == len(etas)
+    n_ = imx["N"].astype(float)
+    assert st["bytes64"] == np.sum(8 * n_ * (n_ + 1))                 # ONE complex128 pass per curvature
+    assert st["bytes32"] == np.sum(4 * n_ * (n_ + 1) * (imx["iters"] - 1))
+    assert np.all(imx["iters"] <= i64["iters"] + 3)                   # the iteration phase costs what the float64 sweep costs (tol / 4: a check or so more)
+
+
+def test_mixed_sweep_does_not_depend_on_the_units_of_the_data(mixed, to, case):
+    """The complex64 copy is taken from the spectrum times a power of two derived from max |CS|: data scaled by 2^-200
+    (every element far below the float32 range) or 2^+150 (far above it) give the same bits, scaled."""
+    c = case
+    base = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"])
+    for k in (-200, 150):
+        got, info = mixed.eval_sweep(c["CS"] * 2.0 ** k, c["tau"], c["fd"], c["etas"], c["edges"], return_info=True)
+        assert np.all(info["status"] == 0)
+        assert np.array_equal(got, np.ldexp(base, k))
+
+
+def test_mixed_sweep_edge_cases(mixed, to, case):
+    """What the float64 sweep does at the edges of the domain, the mixed one does too: an all-zero spectrum gives 0,
+    a crop to nothing NaN (status EMPTY), non-finite input NaN, an iteration cap a NOCONV status (NaN, like the
+    reference's exception path), tiny matrices -- whose Krylov space is complete before anything converges -- LAPACK's
+    value."""
+    c = case
+    assert mixed.eval_sweep(np.zeros_like(c["CS"]), c["tau"], c["fd"], c["etas"][:1], c["edges"])[0] == 0.0
+    etas = np.array([c["etas"][2], 1e9 * c["etas"][2]])
+    eigs, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], etas, c["edges"], return_info=True)
+    assert np.isfinite(eigs[0]) and np.isnan(eigs[1]) and info["status"][1] == 5
+    bad = c["CS"].copy()
+    bad[bad.shape[0] // 2 + 3, bad.shape[1] // 2 + 5] = np.nan
+    ref64 = None
+    mixed.sweep_precision("f64")
+    ref64, i64 = mixed.eval_sweep(bad, c["tau"], c["fd"], c["etas"][2:3], c["edges"], return_info=True)
+    mixed.sweep_precision("mixed")
+    got, info = mixed.eval_sweep(bad, c["tau"], c["fd"], c["etas"][2:3], c["edges"], return_info=True)
+    assert info["status"][0] == i64["status"][0] and np.array_equal(np.isnan(got), np.isnan(ref64))
+    eigs, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"][2:3], c["edges"], max_iter=3, return_info=True)
+    assert info["status"][0] == 4 and np.isnan(eigs[0])
+    for nedge in (4, 6, 10, 34):
+        edges = np.linspace(-c["fd"].max() / 2, c["fd"].max() / 2, nedge)
+        red, _ = to.thth_redmap(c["CS"], c["tau"], c["fd"], c["etas"][2], edges)
+        eig, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"][2:3], edges, return_info=True)
+        assert info["N"][0] == red.shape[0] and info["status"][0] == 0
+        assert eig[0] == pytest.approx(abs(np.linalg.eigvalsh(red)[-1]), rel=1e-10, abs=1e-9)
+
+
+def test_mixed_sweep_small_gaps_and_several_spectra(mixed, to):
+    """Noise-like spectra (small spectral gaps; the certificate's gap comes from the SECOND Ritz vector of the iteration
+    phase) against LAPACK, and the many-spectra entry point (scint_eval_sweep_multi: one power-of-two scale per
+    spectrum -- the second spectrum is 2^40 times the first) against the single-spectrum one."""
+    rng = np.random.default_rng(5)
+    nf, nt = 150, 130
+    dyn = rng.standard_normal((nf, nt)) + 5 * np.outer(np.cos(np.arange(nf) * 0.3), np.cos(np.arange(nt) * 0.2))
+    fd = to.fft_axis(np.arange(nt) * 30.0, 1000.0, 0)
+    tau = to.fft_axis(1400 + np.arange(nf) * 0.1, 1.0, 0)
+    CS = to.conjugate_spectrum(dyn - dyn.mean(), 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 120)
+    etas = tau.max() / (fd.max() / 2) ** 2 * np.array([0.3, 1.0, 3.0])
+    ref = np.array([np.linalg.eigvalsh(to.thth_redmap(CS, tau, fd, e, edges)[0])[-1] for e in etas])
+    eigs, info = mixed.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
+    assert np.all(info["status"] == 0)
+    np.testing.assert_allclose(eigs, np.abs(ref), rtol=1e-11)
+    import torch
+    stack = torch.from_numpy(np.stack([CS, CS * 2.0 ** 40]))
+    out = mixed.eval_sweep_multi(stack, [(tau, fd, edges)] * 2, [etas, etas[::-1]])
+    assert np.array_equal(out[0], eigs) and np.array_equal(out[1], np.ldexp(eigs[::-1], 40))
+
+
 def test_modeler_and_chisq_sweep(emu, to, case):
     c = case
     eta = c["etas"][2]
