@@ -42,7 +42,7 @@ from .device import empty, ptr, require_gpu, stream_ptr, workspace
 
 DEFAULT_TOL = 1e-12       # Ritz-residual tolerance of the Lanczos eigen-solver
 DEFAULT_MAX_ITER = 300    # Lanczos steps (ARPACK needs 30-50 restarts-equivalent mat-vecs)
-DEFAULT_BATCH_BYTES = 16 << 30  # HBM budget for concurrently resident theta-theta matrices (of 288 GB)
+DEFAULT_BATCH_BYTES = 32 << 30  # HBM budget for concurrently resident theta-theta matrices (of 288 GB)
 
 
 # ----------------------------------------------------------------------------
@@ -333,7 +333,14 @@ def default_batch(nmax, neta):
     strip = 16 if nb >= 32 else (8 if nb >= 16 else (4 if nb >= 8 else (2 if nb >= 4 else 1)))
     strips = sum(-(-(nb - i) // strip) for i in range(nb))
     want = -(-11000 // max(strips, 1))     # measured on MI355X at N = 4095: 48 / 56 / 70 slots -> 1079 / 1084 / 1094 eta/s
-    cap = max(1, DEFAULT_BATCH_BYTES // (8 * (nb * 64) ** 2 + 1))
+    per_slot = 8 * (nb * 64) ** 2 + 1
+    if _lib.load().scint_sweep_precision(-1) == 1:
+        # mixed sweep: a workgroup of the complex64 mat-vec covers four block rows (half as many workgroups per matrix),
+        # and a slot idles for two of its ~19 chunks around the certificate pass: twice the slots for the same fill;
+        # a slot also holds the complex64 copy and the Q history (ththmod.DEFAULT_BATCH_BYTES is a budget, not a limit)
+        want *= 2
+        per_slot = per_slot * 3 // 2 + 130 * 32 * nb * 64
+    cap = max(1, DEFAULT_BATCH_BYTES // per_slot)
     return int(max(1, min(neta, 256, want, cap)))
 
 

@@ -12,6 +12,8 @@
 #   pmc      [tag] [args]   FETCH_SIZE / WRITE_SIZE in separate --pmc passes of a 1-step bench (256 eta)
 #   fft      [tag]          kernel trace + PMC passes of tools/time_fft.py (calc_sspec and CS, 2048^2 .. 8192^2)
 #   probes   [tag]          tools/probes/*.hip (stream ceiling, the round-2 and round-3 mat-vec loops with their parts switchable, f64 MFMA layout)
+#   mixed    [tag] [args]   the mixed-precision sweep: a 3-step bench with its --mixed-steps leg (rate, bytes by operand, curve against
+#                           the float64 one), then tests/test_gpu_zz_mixed.py
 #   all      [tag]          suite, bench, configs, trace, modeler, pmc, fft  (the closing call of a round)
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
@@ -69,13 +71,23 @@ fft() {
   grep -E "sspec|cs " $O/${TAG}_prof_fft.log | head -12
   pmc_of fft "tools/time_fft.py" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/time_fft.py"
 }
+mixed() {
+  timeout 200 python bench.py --steps 3 --warmup 1 $QUICK --mixed-steps 3 $EXTRA > $O/${TAG}_mixed.json 2> $O/${TAG}_mixed.err; echo "bench rc=$?"
+  python tools/bench_line.py $O/${TAG}_mixed.json; python -c "
+import json,sys
+d=json.loads([l for l in open('$O/${TAG}_mixed.json') if l.startswith('{')][-1]); m=d.get('mixed_precision',{})
+print({k:m.get(k) for k in ('value','speedup_vs_f64','failed_etas','max_rel_diff_vs_f64_curve','lanczos_steps_mean','certificate_passes_mean')}); print(m.get('matvec32')); print(m.get('matvec64'))"
+  tail -3 $O/${TAG}_mixed.err
+  timeout 170 python -m pytest tests/test_gpu_zz_mixed.py -m gpu -q -x --durations=5 > $O/${TAG}_mixed_pytest.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_mixed_pytest.log
+  grep -E "passed|failed|^FAILED|^ERROR|rc=|Error|assert" $O/${TAG}_mixed_pytest.log | tail -12
+}
 probes() {
   for p in stream_probe pk2_probe pk2e_probe mfma_f64_probe; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/$p.hip -o /tmp/$p 2> /dev/null && timeout 120 /tmp/$p | tee $O/${TAG}_$p.txt
   done
 }
 case $CMD in
-  suite|bench|quick|configs|trace|modeler|pmc|fft|probes) $CMD ;;
+  suite|bench|quick|configs|trace|modeler|pmc|fft|probes|mixed) $CMD ;;
   all) suite; bench; configs; trace; modeler; pmc; fft ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
