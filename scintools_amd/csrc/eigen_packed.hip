@@ -377,13 +377,13 @@ __device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, cplx (&a0)[
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
-pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
+// (the workgroup's whole work, so that the mixed sweep can put complex128 and complex64 strips into ONE launch:
+// pk2_matvec_mixed_kernel in matvec32.hpp)
+__device__ __forceinline__ void pk2_matvec_body(const Strip* __restrict__ sp, int launch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];             // kMatvecLdsBytes = 76 KiB: two workgroups per CU
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
     cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kLdsXs);     // [kMaxStrip]: the blocks X_J = rows of Q_j (32 KiB)
     cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kLdsRsum); // [4 waves][64 rows][2] (8 KiB)
-    const Strip* __restrict__ sp = strips + blockIdx.x;
     const int step = launch - sp->start;
     if (step < 0 || step >= sp->max_steps) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -425,6 +425,11 @@ pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
     __syncthreads();
     cplx* __restrict__ colpart = sp->colpart;
     for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore_nt(colpart + idx, lds[kLdsCol + idx]);
+}
+
+__global__ void __launch_bounds__(256, 2)
+pk2_matvec_kernel(const Strip* __restrict__ strips, int launch) {
+    pk2_matvec_body(strips + blockIdx.x, launch);
 }
 
 }  // namespace scint
@@ -1244,13 +1249,19 @@ struct SweepGroup {
                     (void)hipStreamWaitEvent(stream, chunk_done[(chunk - 1) % kTabs], 0);
                 hipLaunchKernelGGL(pk2_coef_kernel, dim3((unsigned)ceil_div(nb_run * kTB, kCoefRows), (unsigned)nslots),
                                    dim3(kCoefRows), 0, stream, d_jobs(tab), launch);
-                if (nstrips32 > 0) {
+                if (nstrips32 > 0 && nstrips > 0) {
+                    // certificate passes ride in the launch of the complex64 strips (a launch of their own -- a few
+                    // curvatures' strips -- ran at 1.4 TB/s and took 17 % of the mixed sweep's mat-vec time)
+                    const int slot = profiler().begin(kProfMatvec32, stream);
+                    hipLaunchKernelGGL(pk2_matvec_mixed_kernel, dim3((unsigned)(nstrips32 + nstrips)), dim3(256), kMatvecLdsBytes, stream,
+                                       d_strips32(tab), nstrips32, d_strips(tab), launch);
+                    profiler().end(kProfMatvec32, slot, stream);
+                } else if (nstrips32 > 0) {
                     const int slot = profiler().begin(kProfMatvec32, stream);
                     hipLaunchKernelGGL(pk2_matvec32_kernel, dim3((unsigned)nstrips32), dim3(256), kMatvec32LdsBytes, stream,
                                        d_strips32(tab), launch);
                     profiler().end(kProfMatvec32, slot, stream);
-                }
-                if (nstrips > 0) {
+                } else if (nstrips > 0) {
                     const int slot = profiler().begin(kProfMatvec, stream);
                     hipLaunchKernelGGL(pk2_matvec_kernel, dim3((unsigned)nstrips), dim3(256), kMatvecLdsBytes, stream, d_strips(tab), launch);
                     profiler().end(kProfMatvec, slot, stream);
@@ -1330,6 +1341,8 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
                                   (int)kMatvecLdsBytes));
     SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kMatvec32LdsBytes));
+    SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kMatvecLdsBytes));
 
     sweep_stats() = SweepStats();
     SweepProblem S;

@@ -121,13 +121,11 @@ __device__ __forceinline__ void pk32_row(const c32* __restrict__ tp, v4f (&a0)[8
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
-pk2_matvec32_kernel(const Strip32* __restrict__ strips, int launch) {
+__device__ __forceinline__ void pk32_matvec_body(const Strip32* __restrict__ sp, int launch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];             // kMatvec32LdsBytes = 72 KiB
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
     cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kL32Xs);     // [kMaxStrip32]: the blocks X_J = rows of Q_j
     cplx (*rsum)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kL32Rsum); // [4 waves][64 rows][2]
-    const Strip32* __restrict__ sp = strips + blockIdx.x;
     const int step = launch - sp->start;
     if (step < 0 || step >= sp->max_steps) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -167,6 +165,20 @@ pk2_matvec32_kernel(const Strip32* __restrict__ strips, int launch) {
     __syncthreads();
     cplx* __restrict__ colpart = sp->colpart;
     for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore_nt(colpart + idx, lds[kL32Col + idx]);
+}
+
+__global__ void __launch_bounds__(256, 2)
+pk2_matvec32_kernel(const Strip32* __restrict__ strips, int launch) {
+    pk32_matvec_body(strips + blockIdx.x, launch);
+}
+
+// Complex64 strips (workgroups 0 .. n32-1) and the complex128 strips of the certificate passes in one launch: the
+// few certificates of a pass fill the tail of the launch instead of running as a small launch of their own.
+// 76 KiB of dynamic LDS (the larger of the two carves).
+__global__ void __launch_bounds__(256, 2)
+pk2_matvec_mixed_kernel(const Strip32* __restrict__ strips32, int n32, const Strip* __restrict__ strips64, int launch) {
+    if ((int)blockIdx.x < n32) pk32_matvec_body(strips32 + blockIdx.x, launch);
+    else pk2_matvec_body(strips64 + ((int)blockIdx.x - n32), launch);
 }
 
 }  // namespace scint
