@@ -28,6 +28,8 @@ constexpr int kTileElems = kTB * kTB;         // 4096 complex = 64 KiB
 struct __attribute__((aligned(8))) c32 { float x, y; };
 static_assert(sizeof(c32) == 8, "c32 must be two floats");
 constexpr int kRows32 = 4;        // block rows per workgroup of the complex64 mat-vec (same tile bytes per workgroup as two complex128 rows)
+constexpr int kRows32Lg = kRows32 == 4 ? 2 : (kRows32 == 2 ? 1 : 0);
+static_assert((1 << kRows32Lg) == kRows32, "kRows32 must be 1, 2 or 4");
 constexpr int kMaxStrip32 = 14;   // its column tiles per strip: 28 + 28 KiB of X_J blocks and column partials, 72 KiB of LDS in all
 
 __host__ __device__ inline int64_t tile_offset(int nb, int I) {
