@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--precision", choices=["f64", "mixed"], default="f64",
                     help="operand of the Lanczos passes of the eigenvalue sweep: complex128 throughout (f64), or a "
                          "complex64 copy with a complex128 certificate pass per curvature (mixed; ththmod.sweep_precision)")
-    ap.add_argument("--mixed-steps", type=int, default=0,
+    ap.add_argument("--mixed-steps", type=int, default=3,
                     help="N=1, --precision f64: also time this many steps of the mixed sweep on the same workload and "
                          "compare its curve with the float64 one (object 'mixed_precision' of the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1253,7 +1253,7 @@ struct SweepGroup {
                     // certificate passes ride in the launch of the complex64 strips (a launch of their own -- a few
                     // curvatures' strips -- ran at 1.4 TB/s and took 17 % of the mixed sweep's mat-vec time)
                     const int slot = profiler().begin(kProfMatvec32, stream);
-                    hipLaunchKernelGGL(pk2_matvec_mixed_kernel, dim3((unsigned)(nstrips32 + nstrips)), dim3(256), kMatvecLdsBytes, stream,
+                    hipLaunchKernelGGL(pk2_matvec_mixed_kernel, dim3((unsigned)(nstrips32 + nstrips)), dim3(256), kMatvecMixedLdsBytes, stream,
                                        d_strips32(tab), nstrips32, d_strips(tab), launch);
                     profiler().end(kProfMatvec32, slot, stream);
                 } else if (nstrips32 > 0) {
@@ -1342,7 +1342,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)kMatvec32LdsBytes));
     SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kMatvecLdsBytes));
+                                  (int)kMatvecMixedLdsBytes));
 
     sweep_stats() = SweepStats();
     SweepProblem S;

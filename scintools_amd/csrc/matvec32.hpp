@@ -174,7 +174,8 @@ pk2_matvec32_kernel(const Strip32* __restrict__ strips, int launch) {
 
 // Complex64 strips (workgroups 0 .. n32-1) and the complex128 strips of the certificate passes in one launch: the
 // few certificates of a pass fill the tail of the launch instead of running as a small launch of their own.
-// 76 KiB of dynamic LDS (the larger of the two carves).
+// Dynamic LDS: the larger of the two carves (76 KiB).
+constexpr size_t kMatvecMixedLdsBytes = kMatvecLdsBytes > kMatvec32LdsBytes ? kMatvecLdsBytes : kMatvec32LdsBytes;
 __global__ void __launch_bounds__(256, 2)
 pk2_matvec_mixed_kernel(const Strip32* __restrict__ strips32, int n32, const Strip* __restrict__ strips64, int launch) {
     if ((int)blockIdx.x < n32) pk32_matvec_body(strips32 + blockIdx.x, launch);
