@@ -34,6 +34,11 @@ def test_bench_json_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     one = r["one_slot_group"]            # the mat-vec with the GPU to itself (same sweep, one slot group)
     assert one["unit"] == "GB/s" and 0 < one["frac"] == pytest.approx(one["achieved"] / r["peak"]) and one["eta_per_s"] > 0
+    mp = d["mixed_precision"]            # the mixed-precision sweep on the same workload: a reported leg, never `value`
+    assert d["config"]["sweep_precision"] == "f64"
+    assert mp["failed_etas"] == 0 and mp["max_rel_diff_vs_f64_curve"] < 1e-11 and mp["value"] > 0
+    assert mp["certified_per_step"] == 16 and mp["certificate_passes_mean"] >= 1.0
+    assert mp["complex64_bytes_per_step"] > 0 and mp["complex128_bytes_per_step"] > 0
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
