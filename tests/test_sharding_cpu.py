@@ -113,6 +113,7 @@ def _worker_emu(rank, world, port, q):
     from scintools_amd import sweep, ththmod
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     to, CS, tau, fd, etas, edges = _problem()
+    assert ththmod.sweep_precision() == os.environ.get("SCINT_SWEEP_PRECISION", "f64")   # a rank takes the mode from its environment
     full = sweep.sharded_eval_sweep(CS, tau, fd, etas, edges)
 
     def one_obs(i):
@@ -125,8 +126,12 @@ def _worker_emu(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_world2_gloo_with_the_interpreted_kernels(monkeypatch):
+@pytest.mark.parametrize("precision", ["f64", "mixed"])
+def test_world2_gloo_with_the_interpreted_kernels(monkeypatch, precision):
+    """(`mixed`: every rank's sweep iterates on the complex64 copy and certifies on the complex128 tiles -- the mode is
+    per process, the ranks read it from SCINT_SWEEP_PRECISION; gathered bits equal the single-process bits as before.)"""
     import subprocess
+    monkeypatch.setenv("SCINT_SWEEP_PRECISION", precision)
     sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
     import emulated
     try:
@@ -135,8 +140,12 @@ def test_world2_gloo_with_the_interpreted_kernels(monkeypatch):
         pytest.skip(f"host interpreter could not be built: {exc}")
     from scintools_amd import ththmod
     to, CS, tau, fd, etas, edges = _problem()
-    single = ththmod.eval_sweep(CS, tau, fd, etas, edges)
-    single_obs = np.stack([ththmod.eval_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges) for i in range(3)])
+    before = ththmod.sweep_precision(precision)
+    try:
+        single = ththmod.eval_sweep(CS, tau, fd, etas, edges)
+        single_obs = np.stack([ththmod.eval_sweep(CS * (1.0 + i), tau, fd, etas[:3], edges) for i in range(3)])
+    finally:
+        ththmod.sweep_precision(before)
     np.testing.assert_allclose(single, _oracle_sweep(CS, tau, fd, etas, edges), rtol=1e-9)
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
