@@ -13,8 +13,12 @@
 // 16-column slice 16w .. 16w+15 of every tile, all 64 rows; lane l = 8 rg + cg reads row 8j + rg, columns
 // 16w + 2cg and 16w + 2cg + 1 (ONE 16-byte load: a wave load is eight full 128-byte row segments) for j = 0..7 --
 // eight loads hold a whole tile, and two tiles are in flight per wave (16 KiB, as in the complex128 kernel, where
-// the sixteen loads are the two halves of one tile).  Column partials finish inside the wave (shuffles over the
-// eight row groups), row partials by shuffles over the eight column pairs and one LDS step over the four waves.
+// the sixteen loads are the two halves of one tile).  Column partials finish inside the wave (a reduce-scatter over
+// the eight row groups), row partials by shuffles over the eight column pairs and one LDS step over the four waves.
+// With twice the elements per byte the float64 arithmetic is no longer free (the complex128 kernel is ~30 % VALU-busy
+// at its rate, this one would be ~60 %), so the loop is written for instruction count: products as fused
+// multiply-add chains and the reduce-scatter bring a pair of tiles from 1052 to 814 instructions per wave (528 float64
+// operations for the 512 the products need, 32 cross-lane exchanges instead of 96).
 // The tile loop is branch-free: tiles go two at a time, the odd one out is peeled behind the loop.
 // 256 threads, 72 KiB of LDS: two workgroups per CU, with room for the 8-KiB reduce blocks beside them.
 #pragma once
@@ -40,12 +44,35 @@ __device__ __forceinline__ void pk32_tile(const v4f (&a)[8], const cplx (*__rest
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const cplx e = mk((double)(cc ? a[j].z : a[j].x), (double)(cc ? a[j].w : a[j].y));
-            acc1[j] = acc1[j] + e * xJ1[cc];
-            acc2[j] = acc2[j] + e * xJ2[cc];
+            // (four fused multiply-adds per product: as `acc + e * x` the compiler forms the product first -- mul, fma,
+            // add per component, 128 more float64 instructions per pair of tiles)
+            acc1[j].x = fma(-e.y, xJ1[cc].y, fma(e.x, xJ1[cc].x, acc1[j].x));
+            acc1[j].y = fma(e.y, xJ1[cc].x, fma(e.x, xJ1[cc].y, acc1[j].y));
+            acc2[j].x = fma(-e.y, xJ2[cc].y, fma(e.x, xJ2[cc].x, acc2[j].x));
+            acc2[j].y = fma(e.y, xJ2[cc].x, fma(e.x, xJ2[cc].y, acc2[j].y));
             c1[cc] = mk(c1[cc].x + e.x * x1.x + e.y * x1.y, c1[cc].y + e.x * x1.y - e.y * x1.x);   // conj(a) x_I
             c2[cc] = mk(c2[cc].x + e.x * x2.x + e.y * x2.y, c2[cc].y + e.x * x2.y - e.y * x2.x);
         }
     }
+}
+
+// Column partial of a tile over the eight row groups as a reduce-scatter: at every exchange a lane keeps the half it
+// will own -- vector rg & 1 after the exchange with row group rg ^ 1 (lanes l ^ 8), chunk (rg >> 1) & 1 after rg ^ 2
+// (l ^ 16) -- and the last exchange (l ^ 32) completes the sum: 8 double exchanges instead of the 24 of an all-reduce
+// followed by a select (pk2_colsum).  Fixed order; the lane ends with the value of its slot (row groups 4..7 with the
+// same values as 0..3), as pk2_colsum returns it.
+__device__ __forceinline__ cplx pk32_colsum(const cplx (&c1)[2], const cplx (&c2)[2], int rg) {
+    const bool v1 = rg & 1, ch1 = rg & 2;
+    auto sel = [](bool p, cplx a, cplx b) { return mk(p ? a.x : b.x, p ? a.y : b.y); };
+    auto xchg = [](cplx v, int o) { return mk(__shfl_xor(v.x, o, 64), __shfl_xor(v.y, o, 64)); };
+    cplx m0 = sel(v1, c2[0], c1[0]), m1 = sel(v1, c2[1], c1[1]);          // the vector this lane keeps, both chunks
+    const cplx s0 = sel(v1, c1[0], c2[0]), s1 = sel(v1, c1[1], c2[1]);    // the other vector goes to the partner
+    m0 = m0 + xchg(s0, 8);
+    m1 = m1 + xchg(s1, 8);
+    cplx m = sel(ch1, m1, m0);
+    const cplx s = sel(ch1, m0, m1);
+    m = m + xchg(s, 16);
+    return m + xchg(m, 32);
 }
 
 // One block row of the strip: tiles t = t0 .. ntile-1 (t0 < ntile) at tp + (t - t0) tiles; a0 holds tile t0.
@@ -68,7 +95,7 @@ __device__ __forceinline__ void pk32_row(const c32* __restrict__ tp, v4f (&a0)[8
             c1[cc] = mk(0.0, 0.0); c2[cc] = mk(0.0, 0.0);
         }
         pk32_tile(a, xir, xJ1, xJ2, acc1, acc2, c1, c2);
-        const cplx c = pk2_colsum(c1, c2, rg);
+        const cplx c = pk32_colsum(c1, c2, rg);
         if (!ADD) cslot[2 * (t * kTB)] = c;
         else {
             // one read-modify-write per slot: row groups 4..7 (same values as 0..3) go to a scratch element each
