@@ -1,5 +1,4 @@
 #!/bin/bash
-set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-timeout 45 python -m pytest tests/test_gpu_bench_contract.py -m gpu -q -x > $O/r03mx_contract.log 2>&1; echo "pytest rc=$?" >> $O/r03mx_contract.log
-tail -6 $O/r03mx_contract.log
+timeout 20 python bench.py --precision mixed --steps 5 --warmup 1 --no-cpu-baseline --modeler-steps 0 > $O/r03mx_slim.json 2> $O/r03mx_slim.err
+python tools/bench_line.py $O/r03mx_slim.json
