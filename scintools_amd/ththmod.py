@@ -326,7 +326,7 @@ def chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask=None):
     return float(out.cpu()[0])
 
 
-def default_batch(nmax, neta):
+def default_batch(nmax, neta, eigenvalues_only=True):
     """Curvatures resident per launch: enough tile strips (one workgroup each) to fill the
     256 CUs several times over, within the HBM budget for the packed matrices (8 N^2 bytes)."""
     nb = -(-nmax // 64)
@@ -334,7 +334,7 @@ def default_batch(nmax, neta):
     strips = sum(-(-(nb - i) // strip) for i in range(nb))
     want = -(-11000 // max(strips, 1))     # measured on MI355X at N = 4095: 48 / 56 / 70 slots -> 1079 / 1084 / 1094 eta/s
     per_slot = 8 * (nb * 64) ** 2 + 1
-    if _lib.load().scint_sweep_precision(-1) == 1:
+    if eigenvalues_only and _lib.load().scint_sweep_precision(-1) == 1:
         # mixed sweep: a workgroup of the complex64 mat-vec covers four block rows (half as many workgroups per matrix),
         # and a slot idles for two of its ~19 chunks around the certificate pass: twice the slots for the same fill;
         # a slot also holds the complex64 copy and the Q history (ththmod.DEFAULT_BATCH_BYTES is a budget, not a limit)
@@ -441,7 +441,7 @@ def eigvec_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX
     keep_idx, keep_n = _sweep_inputs(grid, etas_v)
     nmax = max(int(keep_n.max()), 1)
     if batch is None:
-        batch = default_batch(nmax, neta)
+        batch = default_batch(nmax, neta, eigenvalues_only=False)
     need = ctypes.c_size_t()
     _lib.check(lib.scint_eigvec_sweep_workspace_bytes(M, neta, batch, max_iter, ctypes.byref(need)),
                "eigvec_sweep_workspace_bytes")
@@ -480,7 +480,7 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     neta, M = etas_v.shape[0], grid.M
     keep_idx, keep_n = _sweep_inputs(grid, etas_v)
     if batch is None:
-        batch = default_batch(max(int(keep_n.max()), 1), neta)
+        batch = default_batch(max(int(keep_n.max()), 1), neta, eigenvalues_only=False)
     d_t = _dv.to_device(dspec, torch.float64)
     nf, nt = (int(v) for v in d_t.shape)
     m_t = None if mask is None else _dv.to_device(np.asarray(mask, dtype=np.uint8), torch.uint8)
@@ -609,7 +609,7 @@ def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEF
     keep_cnt = np.ascontiguousarray(np.concatenate(keep_n))
     neta = etas_v.shape[0]
     if batch is None:
-        batch = default_batch(max(int(keep_cnt.max()), 1), neta)
+        batch = default_batch(max(int(keep_cnt.max()), 1), neta, eigenvalues_only=False)
     geoms = (_lib.CsGeom * ncs)(*[g.geom for g in G])
     th_stack = _dv.to_device(np.stack([g.th_cents for g in G]), torch.float64)
     need = ctypes.c_size_t()
