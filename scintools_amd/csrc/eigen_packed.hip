@@ -114,7 +114,9 @@ struct Blk2 {
     double i11, i22;                // 1/b11, 1/b22; 0 when that direction is exhausted
 };
 
-__device__ inline Blk2 step_block_wave(const double* __restrict__ ap, const double* __restrict__ up, int nb, int lane) {
+// direct: `up` holds the Gram matrix of W - Q A itself (pk2_cert_resid_kernel: step 0 of a certificate), not of W
+__device__ inline Blk2 step_block_wave(const double* __restrict__ ap, const double* __restrict__ up, int nb, int lane,
+                                       bool direct = false) {
     double s[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) s[c] = 0.0;
@@ -127,12 +129,13 @@ __device__ inline Blk2 step_block_wave(const double* __restrict__ ap, const doub
     Blk2 b;
     b.a11 = s[0]; b.a22 = s[1]; b.a12 = mk(s[2], s[3]);
     const double n12 = s[2] * s[2] + s[3] * s[3], tr = s[0] + s[1];
-    const double h11 = s[4] - (s[0] * s[0] + n12), h22 = s[5] - (n12 + s[1] * s[1]);
-    const cplx h12 = mk(s[6] - s[2] * tr, s[7] - s[3] * tr);
+    const double h11 = direct ? s[4] : s[4] - (s[0] * s[0] + n12), h22 = direct ? s[5] : s[5] - (n12 + s[1] * s[1]);
+    const cplx h12 = direct ? mk(s[6], s[7]) : mk(s[6] - s[2] * tr, s[7] - s[3] * tr);
     // Both pivots are differences of nearly equal numbers once a direction is exhausted (W^H W - A^H A of a
     // vector that lies in the span already built): rounding noise of size 1e-16 |W|^2, which 1 / b would blow
     // up into a garbage basis vector.  A pivot below 1e-14 of its own Gram entry counts as zero.
-    constexpr double kPivotFloor = 1e-14;
+    // (direct: the entries ARE the squared norms -- no cancellation to guard against, only a true zero)
+    const double kPivotFloor = direct ? 0.0 : 1e-14;
     b.b11 = h11 > kPivotFloor * s[4] ? sqrt(h11) : 0.0;
     b.i11 = b.b11 > 0.0 ? 1.0 / b.b11 : 0.0;
     b.b12 = mk(h12.x * b.i11, h12.y * b.i11);
@@ -201,7 +204,8 @@ __global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __
     if ((int)blockIdx.x * kCoefRows >= jb.nb * kTB) return;
     const int par = step & 1;
     if (threadIdx.x < 64) {
-        const Blk2 sc = step_block_wave(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, threadIdx.x);
+        const Blk2 sc = step_block_wave(par ? jb.apart[1] : jb.apart[0], par ? jb.upart[1] : jb.upart[0], jb.nb, threadIdx.x,
+                                        jb.certify && step == 1);
         if (threadIdx.x == 0) {
             sh[0] = sc.a11; sh[1] = sc.a22; sh[2] = sc.a12.x; sh[3] = sc.a12.y;
             sh[4] = sc.b11; sh[5] = sc.b22; sh[6] = sc.b12.x; sh[7] = sc.b12.y;
@@ -491,6 +495,30 @@ pk2_reduce_kernel(const PackedJob* __restrict__ jobs, int launch) {
     }
 }
 
+// Step 0 of a certificate pass starts from vectors that are eigenvectors to ~1e-8: R = W_0 - Q_0 A_0 is 1e-8 of W_0, and the
+// Gram form  R^H R = W^H W - A^H A  that every other step uses would lose it entirely (relative 1e-16: below rounding, and
+// below the pivot floor, which would then declare the direction exhausted and report a zero residual).  Here R is formed row
+// by row -- each element w - (q A) carries a relative error of 1e-8, not 1 -- and the partial sums of ITS Gram matrix replace
+// those of W for this one step (step_block_wave(direct)): the certificate's residual || A v - theta v || and the block Q_1 of a
+// certificate that continues are computed from the float64 matrix to eight digits.  One wavefront per 64-row block.
+__global__ void __launch_bounds__(64) pk2_cert_resid_kernel(const PackedJob* __restrict__ jobs, int launch) {
+    const PackedJob jb = jobs[blockIdx.y];
+    const int K = blockIdx.x, e = threadIdx.x;
+    if (!jb.certify || launch - jb.start != 0 || K >= jb.nb || jb.n < 2 || gload(jb.state) >= jb.gen) return;
+    // (step 0: parity 0 -- the reduce kernel wrote W_0 to U[1] and the partial sums to apart[1] / upart[1])
+    const Blk2 sc = step_block_wave(jb.apart[1], jb.upart[1], jb.nb, e);
+    const int r = K * kTB + e;
+    const cplx* __restrict__ Q0 = jb.Q;                                 // slot 0
+    const cplx u1 = gload(jb.U[1] + 2 * r), u2 = gload(jb.U[1] + 2 * r + 1);
+    const cplx q1 = gload(Q0 + 2 * r), q2 = gload(Q0 + 2 * r + 1);
+    const cplx y1 = u1 - (q1 * sc.a11 + mulc(q2, sc.a12));             // as blk_q_row
+    const cplx y2 = u2 - (q1 * sc.a12 + q2 * sc.a22);
+    const double g11 = wave_sum(norm2(y1)), g22 = wave_sum(norm2(y2));
+    const cplx g12 = wave_sum(mulc(y2, y1));                            // conj(y1) y2
+    // (other blocks may already have replaced their W-Gram sums when this one reads them above: only A_0 -- apart -- is used here)
+    if (e == 0) { double* un = jb.upart[1]; un[4 * K] = g11; un[4 * K + 1] = g22; un[4 * K + 2] = g12.x; un[4 * K + 3] = g12.y; }
+}
+
 constexpr int kMaxKB = 128;    // block steps held in LDS by the block check kernel (T up to 256 x 256)
 constexpr int kSvecStride = 2 * kMaxKB + 4;   // complex elements between the two exported eigenvectors of T_k (jb.svec)
 
@@ -561,7 +589,8 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
     const int k = min(k_done, jb.max_steps);
     const int n = 2 * k;
     // A_{k-1}, B_{k-1} are still in the partials of the last reduce kernel
-    const Blk2 last = step_block_wave((k & 1) ? jb.apart[1] : jb.apart[0], (k & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane);
+    const Blk2 last = step_block_wave((k & 1) ? jb.apart[1] : jb.apart[0], (k & 1) ? jb.upart[1] : jb.upart[0], jb.nb, lane,
+                                      jb.certify && k == 1);
     for (int j = lane; j < k; j += 64) {
         double a11, a22; cplx a12;
         if (j < k - 1) { const double* A = jb.alpha + 4 * j; a11 = A[0]; a22 = A[1]; a12 = mk(A[2], A[3]); }
@@ -1270,6 +1299,9 @@ struct SweepGroup {
                                    stream, d_jobs(tab), launch);
                 // the other group starts one pass behind this one (see run_sweep): its checks, refills and
                 // reductions then fall beside this group's mat-vecs instead of beside its own twins
+                if (!restart.empty() && i == S.check_every - 1)      // step 0 of the certificates that joined at this pass
+                    hipLaunchKernelGGL(pk2_cert_resid_kernel, dim3((unsigned)nb_run, (unsigned)nslots), dim3(64), 0, stream,
+                                       d_jobs(tab), launch);
                 if (chunk == 0 && i == 0 && S.stagger_ev && slot0 == 0) (void)hipEventRecord(S.stagger_ev, stream);
             }
         }

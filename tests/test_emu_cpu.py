@@ -278,6 +278,27 @@ def test_mixed_sweep_edge_cases(mixed, to, case):
         assert eig[0] == pytest.approx(abs(np.linalg.eigvalsh(red)[-1]), rel=1e-10, abs=1e-9)
 
 
+def test_mixed_sweep_certificate_measures_the_float64_residual(mixed, to, case):
+    """The certificate must SEE the residual the complex64 copy leaves (|| A v - theta v || ~ 1e-8 |theta|), although it is
+    1e-8 of the vectors it is computed from: formed as W^H W - A^H A it would vanish in rounding (and under the pivot
+    floor) and every certificate would pass.  With a tolerance below what that residual allows (tol = 1e-16 asks for
+    resid < 1e-9 |theta| at these gaps) the certificates must therefore NOT pass at their first step: the runs continue on
+    the complex128 tiles, and still end with the float64 sweep's values."""
+    c = case
+    mixed.sweep_precision("f64")
+    ref, iref = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], tol=1e-16, return_info=True)
+    mixed.sweep_precision("mixed")
+    got, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], tol=1e-16, return_info=True)
+    st = _sweep_stats(mixed)
+    assert np.all(info["status"] == 0) and np.all(iref["status"] == 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-13)
+    assert st["certified"] == len(c["etas"]) and st["cert_passes"] >= 2 * len(c["etas"])
+    # at the default tolerance the same certificates pass at once (the residual is small enough, and is seen to be)
+    got, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], return_info=True)
+    st = _sweep_stats(mixed)
+    assert st["cert_passes"] == len(c["etas"])
+
+
 def test_mixed_sweep_small_gaps_and_several_spectra(mixed, to):
     """Noise-like spectra (small spectral gaps; the certificate's gap comes from the SECOND Ritz vector of the iteration
     phase) against LAPACK, and the many-spectra entry point (scint_eval_sweep_multi: one power-of-two scale per
