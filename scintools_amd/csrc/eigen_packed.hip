@@ -6,18 +6,22 @@
 //
 //   pk2_coef_kernel    the step's 2x2 coefficients A_{j-1}, B_{j-1} from the previous step's fixed-order partial
 //                      sums and the block Q_j they define, once per job (1024 rows per workgroup).
-//   pk2_matvec_kernel  one workgroup per strip of <= 16 tiles (I, J0..J1), described by ONE 80-byte record:
+//   pk2_matvec_kernel  one workgroup per strip of <= 16 column tiles of TWO block rows, described by ONE record:
 //                      streams the tiles once (16 independent 1-KiB wave loads in flight per wave) and
-//                      multiplies BOTH vectors of the block Q_j: row partials sum_J A_IJ X_J (64 lanes stride
-//                      the columns; reduced over the lanes through LDS at the end of the strip) and, per
-//                      off-diagonal tile, the column partials A_IJ^H X_I (lane-local over rows, 4-wave LDS
-//                      reduction every 4 tiles; X_I broadcast with v_readlane).  HBM bound: 8 N (N + 1)
-//                      bytes per pass.
+//                      multiplies BOTH vectors of the block Q_j: a wave owns a 16-column slice of every tile, so
+//                      the column partials A_IJ^H X_I finish inside the wave (shuffles) and leave in one burst
+//                      per strip; row partials sum_J A_IJ X_J by shuffles + one LDS step.  HBM bound:
+//                      8 N (N + 1) bytes per pass.
 //   pk2_reduce_kernel  per 64-row block: fixed-order sum of its row/column partials -> W_j and the
 //                      partial sums of A_j = Q_j^H W_j and of the Gram matrix W_j^H W_j.
-//   pk2_check_kernel   (every 3 passes) top two eigenvalues of the pentadiagonal T_k by 64-lane
+//   pk2_check_kernel   (every 2 passes, on the group's check stream) top two eigenvalues of the pentadiagonal T_k by 64-lane
 //                      multisection on a banded LDL^H Sturm count, Ritz residual by inverse iteration,
 //                      a-posteriori bound  err <= min(resid, resid^2 / (theta_1 - theta_2)).
+//
+// Mixed-precision eigenvalue sweep (opt-in, scint_sweep_precision; "Mixed precision" further down): the passes above run on a
+// complex64 copy of the tiles (matvec32.hpp: pk2_matvec32_kernel, pk2_matvec_mixed_kernel), the check hands the two top Ritz
+// vectors over (pk2_restart_kernel) to a certificate run on the complex128 tiles whose first residual is formed row by row
+// (pk2_cert_resid_kernel); the value returned is that run's Ritz value under the same stopping rule.
 //
 // Scheduling (SweepGroup below): the `batch` slots are kept full -- when a curvature converges its
 // slot is re-filled with the next eta of the sweep (continuous batching; every job carries the
