@@ -281,14 +281,14 @@ def test_mixed_sweep_edge_cases(mixed, to, case):
 def test_mixed_sweep_certificate_measures_the_float64_residual(mixed, to, case):
     """The certificate must SEE the residual the complex64 copy leaves (|| A v - theta v || ~ 1e-8 |theta|), although it is
     1e-8 of the vectors it is computed from: formed as W^H W - A^H A it would vanish in rounding (and under the pivot
-    floor) and every certificate would pass.  With a tolerance below what that residual allows (tol = 1e-16 asks for
-    resid < 1e-9 |theta| at these gaps) the certificates must therefore NOT pass at their first step: the runs continue on
+    floor) and every certificate would pass.  With a tolerance below what that residual allows (tol = 1e-17 asks for
+    resid < 3e-10 |theta| at these gaps) the certificates must therefore NOT pass at their first step: the runs continue on
     the complex128 tiles, and still end with the float64 sweep's values."""
     c = case
     mixed.sweep_precision("f64")
-    ref, iref = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], tol=1e-16, return_info=True)
+    ref, iref = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], tol=1e-17, return_info=True)
     mixed.sweep_precision("mixed")
-    got, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], tol=1e-16, return_info=True)
+    got, info = mixed.eval_sweep(c["CS"], c["tau"], c["fd"], c["etas"], c["edges"], tol=1e-17, return_info=True)
     st = _sweep_stats(mixed)
     assert np.all(info["status"] == 0) and np.all(iref["status"] == 0)
     np.testing.assert_allclose(got, ref, rtol=1e-13)

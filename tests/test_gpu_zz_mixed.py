@@ -157,16 +157,16 @@ def test_units_of_the_data_and_edge_cases(mixed, env):
 def test_certificate_measures_the_float64_residual(mixed, env):
     """The certificate has to see the residual the complex64 copy leaves (~1e-8 |theta|, eight digits below the vectors it
     is formed from: pk2_cert_resid_kernel computes it row by row, the Gram form would lose it).  Asked for more than that
-    residual allows (tol = 1e-16), no certificate may pass at its first step; the runs continue on the complex128 tiles and
+    residual allows (tol = 1e-17), no certificate may pass at its first step; the runs continue on the complex128 tiles and
     end with the float64 sweep's values."""
     thth, to, _ = env
     dyn, fd, tau, edges, eta_true = _arc(to, 512, seed=5, nimg=24)
     etas = np.geomspace(0.5, 2.0, 12) * eta_true
     cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
     mixed.sweep_precision("f64")
-    ref, iref = mixed.eval_sweep(cs, tau, fd, etas, edges, tol=1e-16, return_info=True)
+    ref, iref = mixed.eval_sweep(cs, tau, fd, etas, edges, tol=1e-17, return_info=True)
     mixed.sweep_precision("mixed")
-    got, info = mixed.eval_sweep(cs, tau, fd, etas, edges, tol=1e-16, return_info=True)
+    got, info = mixed.eval_sweep(cs, tau, fd, etas, edges, tol=1e-17, return_info=True)
     st = _stats()
     assert np.all(info["status"] == 0) and np.all(iref["status"] == 0)
     np.testing.assert_allclose(got, ref, rtol=1e-13)
