@@ -69,7 +69,7 @@ struct PackedJob {
     int64_t qstride;        // elements between slots (>= nb*64)
     int32_t qslots;         // 2 = ring (eigenvalue only); max_steps+1 = keep all (Ritz vector wanted)
     int32_t want_vec;       // 1: stop on the Ritz residual and export the eigenvector of T_k
-    double* svec;           // [max_steps + 1] eigenvector of T_k (want_vec)
+    double* svec;           // eigenvector of T_k for theta_1 (want_vec / mixed hand-over) and, kSvecStride complex elements on, for theta_2 (hand-over)
     cplx* rowpart;          // [nstrips][64]   row-block partial sums per strip
     cplx* colpart;          // [ntiles][64]    column-block partial sums per off-diagonal tile
     const int32_t* row_strip0;  // [nb+1] first strip index of each block row
@@ -79,7 +79,8 @@ struct PackedJob {
     double* alpha;          // [max_steps + 1]
     double* beta;           // [max_steps + 2]   beta[i] couples i-1 and i
     double* result;         // [4] theta, err estimate, resid, theta2
-    int32_t* state;         // [4] last FINISHED generation of the slot (job done <=> state[0] >= gen), steps, -, -
+    int32_t* state;         // [4] last FINISHED generation of the slot (job done <=> state[0] >= gen), steps, 1 = the iteration
+                            //     phase of a mixed sweep has converged and hands over to a certificate run (the host restarts the slot), -
     double* eig_out; int32_t* status_out; int32_t* iters_out;
     double tol;             // target relative accuracy of the eigenvalue
 };
