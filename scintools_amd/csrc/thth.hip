@@ -260,10 +260,13 @@ __global__ void __launch_bounds__(64) cs_scale_kernel(const unsigned long long* 
 
 int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t nelem, unsigned long long* bits,
                         double* scale, hipStream_t stream) {
-    SCINT_REQUIRE(ncs >= 1 && ncs <= 65535 && nelem >= 1, "cs_scale: bad arguments");
+    SCINT_REQUIRE(ncs >= 1 && nelem >= 1, "cs_scale: bad arguments");
     SCINT_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long) * (size_t)ncs, stream));
     const unsigned nblk = (unsigned)std::min<int64_t>(ceil_div(nelem, 256 * 8), 2048);
-    hipLaunchKernelGGL(cs_absmax_kernel, dim3(nblk, (unsigned)ncs), dim3(256), 0, stream, cs, cs_stride, nelem, bits);
+    for (int64_t c0 = 0; c0 < ncs; c0 += 65535) {               // (grid.y is limited to 65535)
+        const unsigned nc = (unsigned)std::min<int64_t>(ncs - c0, 65535);
+        hipLaunchKernelGGL(cs_absmax_kernel, dim3(nblk, nc), dim3(256), 0, stream, cs + c0 * cs_stride, cs_stride, nelem, bits + c0);
+    }
     hipLaunchKernelGGL(cs_scale_kernel, dim3((unsigned)ceil_div(ncs, 64)), dim3(64), 0, stream, bits, scale, ncs);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
