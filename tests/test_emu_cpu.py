@@ -299,6 +299,36 @@ def test_mixed_sweep_certificate_measures_the_float64_residual(mixed, to, case):
     assert st["cert_passes"] == len(c["etas"])
 
 
+def test_mixed_sweep_fuzz_against_the_float64_sweep(emu, to):
+    """Random small problems (shapes, padding, edge counts either side of the 64-row blocks, 1 to 19 images, noise from
+    none to five times the signal, curvatures a factor five either side of the arc, batch sizes): the mixed sweep returns
+    the float64 sweep's status for every curvature and its value to 1e-11 (100 such trials ran clean when this was written;
+    the test keeps twelve)."""
+    from scintools_amd.synth import arc_dynspec
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        nf, nt = int(rng.integers(40, 260)), int(rng.integers(40, 260))
+        nedge = int(rng.choice([34, 64, 66, 100, 128, 130, 192, 194, 200, 256, 258, 260]))
+        npad = int(rng.integers(0, 2))
+        dyn, freqs, times, eta_true = arc_dynspec(nf, nt, seed=int(rng.integers(1 << 30)), nimg=int(rng.integers(1, 20)),
+                                                  noise=float(rng.choice([0.0, 0.05, 1.0, 5.0])))
+        dyn = dyn - dyn.mean()
+        fd, tau = to.fft_axis(times, 1000.0, npad), to.fft_axis(freqs, 1.0, npad)
+        edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge)
+        CS = to.conjugate_spectrum(dyn, npad)
+        etas = eta_true * np.exp(rng.uniform(np.log(0.2), np.log(5.0), size=int(rng.integers(1, 7))))
+        batch = int(rng.integers(1, 8))
+        e64, i64 = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True, batch=batch)
+        emu.sweep_precision("mixed")
+        try:
+            emx, imx = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True, batch=batch)
+        finally:
+            emu.sweep_precision("f64")
+        assert np.array_equal(i64["status"], imx["status"]), (trial, i64["status"], imx["status"])
+        good = i64["status"] == 0
+        np.testing.assert_allclose(emx[good], e64[good], rtol=1e-11, err_msg=f"trial {trial}")
+
+
 def test_mixed_sweep_small_gaps_and_several_spectra(mixed, to):
     """Noise-like spectra (small spectral gaps; the certificate's gap comes from the SECOND Ritz vector of the iteration
     phase) against LAPACK, and the many-spectra entry point (scint_eval_sweep_multi: one power-of-two scale per
