@@ -138,7 +138,8 @@ int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
  *   1  mixed: the passes stream a complex64 copy of theta-theta (float64 vectors and sums), and the eigenvalue that
  *      is returned is the Ritz value of a certificate pass on the complex128 tiles that satisfies the float64 sweep's
  *      own a-posteriori bound, evaluated in float64 on that matrix -- same tolerance, same status codes
- *      (csrc/eigen_packed.hip, "Mixed precision").  Eigenvector sweeps are not affected.
+ *      (csrc/eigen_packed.hip, "Mixed precision").  iters_out[i] then counts the passes of both phases (complex64 and
+ *      complex128; scint_sweep_stats splits the bytes).  Eigenvector sweeps are not affected.
  *  -1  query.
  * Returns the previous mode.  Call it BEFORE the *_workspace_bytes of a sweep: the mixed sweep needs a larger
  * workspace.  The environment variable SCINT_SWEEP_PRECISION=mixed|f64 sets the initial mode. */
