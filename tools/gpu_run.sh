@@ -14,7 +14,7 @@
 #   probes   [tag]          tools/probes/*.hip (stream ceiling, the round-2 and round-3 mat-vec loops with their parts switchable, f64 MFMA layout)
 #   mixed    [tag] [args]   the mixed-precision sweep: a 3-step bench with its --mixed-steps leg (rate, bytes by operand, curve against
 #                           the float64 one), then tests/test_gpu_zz_mixed.py
-#   all      [tag]          suite, bench, configs, trace, modeler, pmc, fft  (the closing call of a round)
+#   all      [tag]          suite, bench, configs, trace, modeler, pmc, fft, mixed  (the closing call of a round)
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -88,7 +88,7 @@ probes() {
 }
 case $CMD in
   suite|bench|quick|configs|trace|modeler|pmc|fft|probes|mixed) $CMD ;;
-  all) suite; bench; configs; trace; modeler; pmc; fft ;;
+  all) suite; bench; configs; trace; modeler; pmc; fft; mixed ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
 find $O -name "*.db" -size +20M -delete
