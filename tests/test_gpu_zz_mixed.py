@@ -173,3 +173,30 @@ def test_certificate_measures_the_float64_residual(mixed, env):
     assert st["certified"] == len(etas) and st["cert_passes"] >= 2 * len(etas)
     got, info = mixed.eval_sweep(cs, tau, fd, etas, edges, return_info=True)
     assert _stats()["cert_passes"] <= 1.5 * len(etas)
+
+
+def test_single_search_and_fit_thetatheta_vs_the_reference(mixed, golden):
+    """The callers of the sweep in mixed mode against the reference's OWN runs (tests/golden, unmodified reference): the
+    chunk search on the tutorial data -- eigenvalue curve rtol 1e-9, fitted curvature 1e-6 -- and Dynspec.fit_thetatheta
+    (every chunk's sweep in one batched call) with the tolerances of tests/test_gpu_parity.py."""
+    g = golden("thth_sample.npz")
+    params = [g["chunk"], g["freq"], g["time"], g["etas"], g["edges"], None, False, 0.1,
+              int(g["npad"]), True, 0.0, False]
+    eta_fit, eta_sig, fm, tm, eigs = mixed.single_search(params)
+    np.testing.assert_allclose(eigs, g["eigs"], rtol=1e-9)
+    assert float(eta_fit) == pytest.approx(float(g["eta_fit"]), rel=1e-6)
+    assert float(eta_sig) == pytest.approx(float(g["eta_sig"]), rel=1e-4)
+    assert _stats()["certified"] == len(g["etas"])
+    from scintools_amd.dynspec import Dynspec
+    f = golden("fit_thetatheta.npz")
+
+    class B:
+        dyn, freqs, times, dt, df = f["dspec"], f["freq"], f["time"], float(f["dt"]), float(f["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50)
+    etas, eigs, popt = d.thetatheta_single(cf=0, ct=0, plot=False, arrays=True)
+    np.testing.assert_allclose(eigs, f["single_eigs"], rtol=1e-9)
+    d.fit_thetatheta()
+    np.testing.assert_allclose(d.eta_evo, f["eta_evo"], rtol=1e-6)
+    np.testing.assert_allclose(d.eta_evo_err, f["eta_evo_err"], rtol=1e-4)
+    assert d.ththeta == pytest.approx(float(f["ththeta"]), rel=1e-6)
