@@ -42,3 +42,19 @@ def test_bench_workload_is_the_baseline_config():
     assert edges.shape == (256,) and np.allclose(edges, -edges[::-1])
     assert etas.shape == (32,) and np.isclose(etas[0], 0.25 * eta_true) and np.isclose(etas[-1], 4.0 * eta_true)
     assert np.all(np.diff(fd) > 0) and np.all(np.diff(tau) > 0)
+
+
+def test_experiment_patches_still_apply():
+    """tools/experiments/*.patch are variants queued for the next GPU call (tools/build_variant.sh): each must still apply to
+    the tree it is meant to be measured against."""
+    import glob
+    import shutil
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("git") or not os.path.isdir(os.path.join(repo, ".git")):
+        pytest.skip("not a git checkout")
+    patches = sorted(glob.glob(os.path.join(repo, "tools", "experiments", "*.patch")))
+    assert patches
+    for p in patches:
+        out = subprocess.run(["git", "apply", "--check", p], cwd=repo, capture_output=True, text=True)
+        assert out.returncode == 0, (os.path.basename(p), out.stderr[-500:])
