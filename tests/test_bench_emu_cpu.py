@@ -51,3 +51,43 @@ def test_precision_mixed_line():
     assert r["kernel"] == "pk2_matvec32_kernel" and r["achieved"] > 0 and r["traffic"] is None
     assert r["mixed"]["certified_per_step"] == 6 and r["algorithmic_bytes_per_step"] == r["mixed"]["complex64_bytes_per_step"]
     assert "mixed_precision" not in d and "one_slot_group" not in r
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra", [[], ["--shard", "eta", "--precision", "mixed"]])
+def test_two_ranks(extra):
+    """bench.py as the driver launches it for N = 2 (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment;
+    gloo here, the ranks' "GPUs" are the interpreter): the weak-scaling default, and ONE observation's curvatures in blocks
+    over the ranks with the mixed sweep -- whose gathered curve must equal rank 0's own sweep of all curvatures, bit for bit."""
+    import socket
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
+        import emulated
+        emulated.load()
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:
+        pytest.skip(f"host interpreter could not be built: {exc}")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    args = ["--gpus", "2", "--size", "128", "--neta", "7", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+            "--modeler-steps", "0"] + extra
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, PROBE] + args, env=env, cwd=REPO, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 0 prints the line
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["failed_etas"] == 0
+    assert c["per_rank_eta_per_s"]["min"] > 0
+    if extra:
+        assert d["scaling"] == "strong" and c["sweep_precision"] == "mixed" and c["gathered_equals_one_gpu"] is True
+        assert d["roofline"]["kernel"] == "pk2_matvec32_kernel"
+    else:
+        assert d["scaling"] == "weak" and c["sweep_precision"] == "f64" and "mixed_precision" not in d
