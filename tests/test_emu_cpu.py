@@ -329,6 +329,30 @@ def test_mixed_sweep_fuzz_against_the_float64_sweep(emu, to):
         np.testing.assert_allclose(emx[good], e64[good], rtol=1e-11, err_msg=f"trial {trial}")
 
 
+@pytest.mark.parametrize("strip_len", [5, 14])
+def test_mixed_sweep_long_strips(strip_len):
+    """Strips of 5 and of 14 column tiles (what 4096^2 runs with) x four block rows on a 700^2 problem (11 block rows:
+    groups of 4, 4 and 3 rows; strips of full length, remainders of one and two tiles; the two-tiles-at-a-time loop of the
+    complex64 mat-vec with even and odd counts and rows that start one to three tiles late): the mixed sweep against the
+    float64 sweep with the same forced strip length (SCINT_STRIP_LEN is read once per process: a process of its own)."""
+    import json
+    import subprocess
+    try:
+        import emulated
+        emulated.load()
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:
+        pytest.skip(f"host interpreter could not be built: {exc}")
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "strip_probe.py")
+    env = dict(os.environ, SCINT_STRIP_LEN=str(strip_len), OPENBLAS_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, probe, "700"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["f64"]["status"] == [0, 0] and d["mixed"]["status"] == [0, 0] and max(d["f64"]["N"]) == 699
+    np.testing.assert_allclose(d["mixed"]["eigs"], d["f64"]["eigs"], rtol=1e-12)
+    assert d["mixed"]["stats"][2] == 2 and d["mixed"]["stats"][3] == 2          # two certificates, one pass each
+    assert d["mixed"]["stats"][0] > 0 and d["f64"]["stats"][0] == 0
+
+
 def test_mixed_sweep_small_gaps_and_several_spectra(mixed, to):
     """Noise-like spectra (small spectral gaps; the certificate's gap comes from the SECOND Ritz vector of the iteration
     phase) against LAPACK, and the many-spectra entry point (scint_eval_sweep_multi: one power-of-two scale per
