@@ -87,7 +87,7 @@ def parse():
                          "BASELINE config 4: --size 2048 --obs-total 64)")
     ap.add_argument("--shard", choices=["obs", "eta"], default="obs",
                     help="multi-GPU partitioning: obs = whole observations per rank (default); eta = ONE observation, "
-                         "contiguous eta blocks per rank (sweep.sharded_eval_sweep, strong scaling)")
+                         "curvatures dealt interleaved, etas[rank::world] (sweep.sharded_eval_sweep, strong scaling)")
     ap.add_argument("--objective", choices=["eig", "chisq"], default="eig",
                     help="objective of the headline timed region: eig = Eval_calc sweep of single_search; "
                          "chisq = modeler/chisq_calc sweep")
@@ -397,7 +397,7 @@ def main():
                 curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
                 fit = (etas[np.nanargmin(curves[k])], np.nan, None)
         elif shard_eta:
-            # ONE observation, this rank's contiguous block of curvatures; the all-gather is inside
+            # ONE observation, this rank's interleaved share of the curvatures; the all-gather is inside
             from scintools_amd import sweep
             cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
             curves[0], info = sweep.sharded_eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
@@ -470,6 +470,32 @@ def main():
         ththmod.sweep_precision("mixed")
     head = timed(args.objective, args.steps, args.warmup)
 
+    share_balance = None
+    if shard_eta and world > 1:
+        # outside the timed region: N, pass counts and status of EVERY curvature (a rank's info covers its own share),
+        # so that the line's N_min / N_max / lanczos_steps_mean / failed_etas describe the whole sweep
+        from scintools_amd import sweep
+        width = -(-neta // world)
+        mine = torch.full((3, width), -1, dtype=torch.int64, device=comm_dev)
+        li = head["info"]
+        if li is not None:
+            k = int(li["N"].shape[0])
+            mine[0, :k] = torch.from_numpy(li["N"].astype(np.int64)).to(comm_dev)
+            mine[1, :k] = torch.from_numpy(li["iters"].astype(np.int64)).to(comm_dev)
+            mine[2, :k] = torch.from_numpy(li["status"].astype(np.int64)).to(comm_dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        whole = {k: np.zeros(neta, dtype=np.int64) for k in ("N", "iters", "status")}
+        for r in range(world):
+            idx = sweep.eta_share(neta, world, r)
+            pr = parts[r].cpu().numpy()
+            for j, k in enumerate(("N", "iters", "status")):
+                whole[k][idx] = pr[j, : idx.shape[0]]
+        cost = 8.0 * whole["N"] * (whole["N"] + 1.0) * whole["iters"]
+        share_balance = {"max_over_mean_matvec_bytes_per_rank": sweep.share_imbalance(cost, world),
+                         "rank0_share_of_matvec_bytes": float(cost[sweep.eta_share(neta, world, 0)].sum() / cost.sum())}
+        head["info"] = dict(whole, batch=(li or {}).get("batch", 0))
+
     gathered_equal = None
     if shard_eta and world > 1 and rank == 0:
         # outside the timed region: rank 0 sweeps ALL curvatures alone; the gathered curve must be the same bits
@@ -507,14 +533,14 @@ def main():
             "dtype": "f64",
             "data": "synthetic" if not args.dyn_npz else f"synthetic ({os.path.basename(args.dyn_npz)})",
             "config": {"workload": f"{size}x{size} dynspec, {neta}-eta {what}, nedge={nedge}, npad={args.npad}, "
-                                   + ("ONE observation, contiguous eta blocks per GPU (sweep.sharded_eval_sweep)" if shard_eta
+                                   + ("ONE observation, curvatures dealt interleaved to the GPUs (sweep.sharded_eval_sweep)" if shard_eta
                                       else f"{args.obs_total} observations dealt round-robin to the GPUs"
                                       if args.obs_total > 0 else f"{args.obs} observation(s) per GPU"),
                        "observations_per_step": n_obs_job, "ranks_per_gpu": ranks_per_gpu,
                        "shard": args.shard, "ranks_seen": int(dist.get_world_size()) if world > 1 else 1,
                        "backend": backend if world > 1 else None,
                        "per_rank_eta_per_s": {"min": min(head["rank_rates"]), "max": max(head["rank_rates"])},
-                       "gathered_equals_one_gpu": gathered_equal,
+                       "gathered_equals_one_gpu": gathered_equal, "eta_share_balance": share_balance,
                        "collective": (f"all_gather of float64 [{-(-neta // world)}] per rank per step ({backend})" if shard_eta else
                                       f"all_gather of float64 [{per_rank_max}, {neta}] per rank per step ({backend})")
                        if world > 1 else None,
@@ -525,7 +551,9 @@ def main():
                        "lanczos_vectors_per_step": lanczos_block()[0],
                        "batch": int(info["batch"]), "failed_etas": int(np.sum(info["status"] != 0)),
                        "eta_fit_over_true": float(fit[0] / eta_true) if np.isfinite(fit[0]) else None},
-            "roofline": {"kernel": "pk2_matvec32_kernel" if mixed else lanczos_block()[1], "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "pk2_matvec32_kernel" if mixed else lanczos_block()[1],
+                         "scope": "rank 0's own launches and bytes" if world > 1 else "the one GPU's launches",
+                         "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg_per_launch,
                          "traffic": (ratio * alg_per_launch) if ratio else None,

@@ -7,7 +7,14 @@ collective: each rank computes its share and the only communication is one all-g
 float64 eigenvalues at the end (256 eta -> 2 KiB in total).
 
 Two partitionings:
-  * :func:`sharded_eval_sweep` -- one observation, contiguous eta blocks per rank.  Every
+  * :func:`sharded_eval_sweep` -- one observation, its curvatures dealt to the ranks INTERLEAVED
+    (rank r takes etas[r::world], :func:`eta_share`).  The cost of a curvature is bytes x passes
+    = 8 N (N + 1) x Lanczos passes, and both vary smoothly along a sweep (the crop takes N from
+    4095 down to 2447 across the headline sweep): contiguous blocks -- what this module dealt
+    until round 4 -- differ by up to 2.5x in bytes per rank and cap the strong-scaling efficiency
+    at 0.86 for 2, 4 and 8 ranks; interleaved shares are within 1 % of each other
+    (:func:`share_imbalance`, tests/test_sharding_cpu.py).  The reference never had the
+    problem: its ``pool.map`` deals whole chunks of equal shape (dynspec.py:1706-1723).  Every
     rank holds the conjugate spectrum (each rank FFTs the same dynspec locally: cheaper than
     broadcasting a 0.25-4 GiB complex plane).
   * :func:`sharded_observations` -- a batch of observations dealt round-robin to the ranks,
@@ -36,6 +43,21 @@ def block_bounds(n, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def eta_share(n, world, rank):
+    """Indices of the `n` curvatures of one sweep that `rank` computes: every world-th one, starting at `rank`.
+    Neighbouring curvatures cost nearly the same (N and the pass count vary smoothly with eta), so interleaved
+    shares carry equal work whatever the cost profile is; sizes differ by at most one."""
+    return np.arange(rank, n, world)
+
+
+def share_imbalance(cost, world, shares=eta_share):
+    """max over ranks / mean over ranks of the summed `cost` (one number per curvature, e.g. 8 N (N + 1) x passes)
+    under the partition `shares(n, world, rank)`: 1.0 is perfect, and 1 / it bounds the strong-scaling efficiency."""
+    cost = np.asarray(cost, dtype=float)
+    per_rank = np.array([cost[shares(cost.shape[0], world, r)].sum() for r in range(world)])
+    return float(per_rank.max() / per_rank.mean())
+
+
 def _device_for_backend(group=None):
     backend = dist.get_backend(group)
     if str(backend) == "nccl":
@@ -43,8 +65,8 @@ def _device_for_backend(group=None):
     return torch.device("cpu")
 
 
-def _all_gather_blocks(local, n_total, group=None):
-    """All-gather variable-length float64 blocks laid out by block_bounds -> full array."""
+def _all_gather_shares(local, n_total, group=None):
+    """All-gather the ranks' float64 shares (laid out by eta_share) -> full array, every value where its curvature is."""
     world = dist.get_world_size(group)
     dev = _device_for_backend(group)
     width = -(-n_total // world)
@@ -54,33 +76,35 @@ def _all_gather_blocks(local, n_total, group=None):
     dist.all_gather(out, buf, group=group)
     full = np.empty(n_total, dtype=np.float64)
     for r in range(world):
-        lo, hi = block_bounds(n_total, world, r)
-        full[lo:hi] = out[r][: hi - lo].cpu().numpy()
+        idx = eta_share(n_total, world, r)
+        full[idx] = out[r][: idx.shape[0]].cpu().numpy()
     return full
 
 
 def sharded_eval_sweep(CS, tau, fd, etas, edges, group=None, local_fn=None, return_info=False, **kw):
-    """Eigenvalue curve of ONE observation, eta range split across the ranks.
+    """Eigenvalue curve of ONE observation, its curvatures dealt interleaved to the ranks (:func:`eta_share`).
     Returns the full curve on every rank (identical to the single-process result: each eta
-    is computed by exactly one rank with the same kernels, so not a bit changes).  With
-    ``return_info`` also this rank's info dict (N, Lanczos steps, status of ITS block; None for an
-    empty block) as ``local_fn(..., return_info=True)`` reports it."""
+    is computed by exactly one rank with the same kernels, and a curvature's arithmetic does not depend on
+    which others share its launch, so not a bit changes).  With ``return_info`` also this rank's info dict
+    (N, Lanczos steps, status of ITS share, plus ``"eta_index"``: which curvatures those are; None for an
+    empty share) as ``local_fn(..., return_info=True)`` reports it."""
     if local_fn is None:
         from .ththmod import eval_sweep as local_fn
     etas = np.asarray(etas, dtype=float)
     if return_info:
         kw = dict(kw, return_info=True)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    lo, hi = block_bounds(etas.shape[0], world, dist.get_rank(group) if world > 1 else 0)
+    mine = eta_share(etas.shape[0], world, dist.get_rank(group) if world > 1 else 0)
     info = None
-    if hi > lo:
-        local = local_fn(CS, tau, fd, etas[lo:hi], edges, **kw)
+    if mine.shape[0] > 0:
+        local = local_fn(CS, tau, fd, etas[mine], edges, **kw)
         if return_info:
             local, info = local
+            info = dict(info, eta_index=mine)
         local = np.asarray(local)
     else:
         local = np.empty(0)
-    full = local if world == 1 else _all_gather_blocks(local, etas.shape[0], group)
+    full = local if world == 1 else _all_gather_shares(local, etas.shape[0], group)
     return (full, info) if return_info else full
 
 

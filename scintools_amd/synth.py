@@ -13,6 +13,19 @@ tests to make inputs of any size without the reference's simulator.
 import numpy as np
 
 
+def arc_axes(nf, nt, eta_true=0.02, df=None, dt=30.0, f0=1400.0, theta_max=None):
+    """(freqs[nf] MHz, times[nt] s, theta_max mHz, df MHz) of :func:`arc_dynspec` -- the axes alone, for callers that
+    need the grids of a workload (crop sizes N per curvature, sharding models) without synthesising its pixels."""
+    fd_max = 1e3 / (2 * dt)
+    if theta_max is None:
+        theta_max = fd_max / 2
+    if df is None:
+        df = 0.7 / (2 * eta_true * theta_max**2)
+    freqs = f0 + (np.arange(nf) - nf // 2) * df
+    times = dt * np.arange(nt)
+    return freqs, times, theta_max, df
+
+
 def arc_dynspec(nf, nt, seed=0, eta_true=0.02, nimg=64, df=None, dt=30.0,
                 f0=1400.0, theta_max=None, noise=1.0):
     """Return (dyn[nf, nt] float64, freqs[nf] MHz, times[nt] s, eta_true s**3).
@@ -22,13 +35,7 @@ def arc_dynspec(nf, nt, seed=0, eta_true=0.02, nimg=64, df=None, dt=30.0,
     eta_true*theta_max**2 is 70 % of tau_max = 1/(2 df) us.
     """
     rng = np.random.default_rng(seed)
-    fd_max = 1e3 / (2 * dt)
-    if theta_max is None:
-        theta_max = fd_max / 2
-    if df is None:
-        df = 0.7 / (2 * eta_true * theta_max**2)
-    freqs = f0 + (np.arange(nf) - nf // 2) * df
-    times = dt * np.arange(nt)
+    freqs, times, theta_max, df = arc_axes(nf, nt, eta_true, df, dt, f0, theta_max)
     theta = rng.uniform(-theta_max, theta_max, nimg)
     amp = (rng.standard_normal(nimg) + 1j * rng.standard_normal(nimg))
     amp *= np.exp(-(theta / (theta_max / 2)) ** 2)
