@@ -114,6 +114,9 @@ def parse():
     return ap.parse_args()
 
 
+NPROF = 5      # kernels scint_profile_end reports on (include/scint_hip.h)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -449,10 +452,11 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        ms = (ctypes.c_double * 3)()        # union of each kernel's launch intervals: gather, complex128 mat-vec, complex64 mat-vec
-        ms_sum = (ctypes.c_double * 3)()    # plain sum of the individual launch spans
-        launches = (ctypes.c_int64 * 3)()
-        lib.scint_profile_end(ms, ms_sum, launches)
+        # union of each kernel's launch intervals: gather, complex128 mat-vec, complex64 mat-vec, rank-1 back-map, model transform
+        ms = (ctypes.c_double * NPROF)()
+        ms_sum = (ctypes.c_double * NPROF)()    # plain sum of the individual launch spans
+        launches = (ctypes.c_int64 * NPROF)()
+        lib.scint_profile_end(ms, ms_sum, launches, NPROF)
         rank_rates = [local_etas / elapsed]
         if world > 1:
             # every rank's own rate (its curvatures / its wall time between the two barriers), then the MAX time
@@ -590,14 +594,14 @@ def main():
             except Exception as exc:
                 out["mixed_precision"] = {"error": repr(exc)}
         if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta and not mixed:
-            # the same sweep with ONE slot group (SCINT_SWEEP_GROUPS=1, read per call): every mat-vec launch has the
+            # the same sweep with ONE slot group (scint_sweep_schedule): every mat-vec launch has the
             # GPU to itself, so this is the kernel's own rate; in the headline schedule two groups' launches and the
             # small kernels share the GPU and `achieved` above is bytes / (time any mat-vec launch is in flight)
-            os.environ["SCINT_SWEEP_GROUPS"] = "1"
+            lib.scint_sweep_schedule(-1, -1, 1)
             try:
                 one = timed("eig", min(args.steps, 3), 1)
             finally:
-                del os.environ["SCINT_SWEEP_GROUPS"]
+                lib.scint_sweep_schedule(-1, -1, 0)
             one_s = one["busy_ms"][1] / 1e3
             if one_s > 0:
                 out["roofline"]["one_slot_group"] = {

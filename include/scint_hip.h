@@ -76,12 +76,14 @@ int32_t scint_device_count(void);
  * by hipEvents on its stream.  end() synchronises the device and returns, per kernel, the length
  * in milliseconds of the UNION of its launch intervals (the sweep drives two streams, so
  * launches may overlap), the plain SUM of the individual launch spans (sum / launches is the
- * average a kernel trace reports) and the launch counts (HOST arrays of 3; [2] is the complex64
- * mat-vec of the mixed-precision sweep, see scint_sweep_precision).  Not thread-safe;
- * off by default. */
+ * average a kernel trace reports) and the launch counts.  HOST arrays of `count` entries; the
+ * library fills min(count, 5) of them and never writes beyond `count` (since version 101: the
+ * entry point wrote a fixed 2, then 3, entries before): [2] is the complex64 mat-vec of the
+ * mixed-precision sweep (scint_sweep_precision), [3] the rank-1 back-map and [4] the model
+ * transform + chi^2 of the model steps of scint_chisq_sweep.  Not thread-safe; off by default. */
 int32_t scint_profile_begin(void);
-int32_t scint_profile_end(double* ms_out /*HOST[3]*/, double* ms_sum_out /*HOST[3]*/,
-                          int64_t* launches_out /*HOST[3]*/);
+int32_t scint_profile_end(double* ms_out /*HOST[count]*/, double* ms_sum_out /*HOST[count]*/,
+                          int64_t* launches_out /*HOST[count]*/, int32_t count);
 
 /* ---- secondary spectrum: Dynspec.calc_sspec core (dynspec.py:3665-3721) -- */
 /* dyn[nf,nt] -> sec[(halve? nrfft/2 : nrfft), ncfft] in dB, where
@@ -130,7 +132,10 @@ int32_t scint_thth_map(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
  * iters_out[i]: Lanczos steps used (for the roofline accounting); may be NULL.
  * eigs_out/status_out/iters_out are DEVICE arrays and need no initialisation (the library presets status to a
  * failure code and the step counts to 0 on the caller's stream; eigenvector rows of the *_vec entry points are
- * zero beyond their N_i entries, chi^2 of a curvature whose crop leaves nothing stays NaN).  Asynchronous. */
+ * zero beyond their N_i entries, chi^2 of a curvature whose crop leaves nothing stays NaN).
+ * NOT asynchronous: like every *_sweep entry point this one drives the caller's stream AND the library's internal
+ * streams from a host-side scheduler that reads convergence flags back, and returns with all of them drained -- results
+ * are complete (in device memory) on return, and an asynchronous fault of any queued kernel is reported by this call. */
 int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
                                          int32_t max_iter, size_t* bytes /*HOST*/);
 /* Operand precision of the ITERATION of the eigenvalue sweeps (scint_eval_sweep, scint_eval_sweep_multi), per process:
@@ -144,6 +149,13 @@ int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
  * Returns the previous mode.  Call it BEFORE the *_workspace_bytes of a sweep: the mixed sweep needs a larger
  * workspace.  The environment variable SCINT_SWEEP_PRECISION=mixed|f64 sets the initial mode. */
 int32_t scint_sweep_precision(int32_t mode);
+/* Scheduling of the sweeps, per process (the host-side scheduler of eigen_packed.hip; the reference has no counterpart --
+ * its loop, ththmod.py:788-799, is sequential): chunks queued ahead of the convergence flags the host has seen (`depth`,
+ * 1 or 2), Lanczos passes between convergence checks (`check_every`, 1..16), slot groups on separate streams (`groups`,
+ * 1 or 2).  0 restores the measured default, -1 leaves a setting as it is.  Initial values: SCINT_SWEEP_DEPTH /
+ * SCINT_CHECK_EVERY / SCINT_SWEEP_GROUPS in the environment, read once.  No setting changes a bit of any result
+ * (tests/test_gpu_edges.py); they exist for that test and for bench.py's one-slot-group leg. */
+int32_t scint_sweep_schedule(int32_t depth, int32_t check_every, int32_t groups);
 /* Diagnostics of the calling thread's last sweep (any of the sweep entry points), for the roofline accounting:
  * out[0] algorithmic bytes of its complex64 passes (4 n (n + 1) each), out[1] of its complex128 passes (8 n (n + 1)),
  * out[2] curvatures that went through a certificate, out[3] complex128 passes those certificates took. */

@@ -39,7 +39,7 @@ _SIGNATURES = {
     "scint_last_error": ([c_char_p, c_size_t], c_int32),
     "scint_device_count": ([], c_int32),
     "scint_profile_begin": ([], c_int32),
-    "scint_profile_end": ([POINTER(c_double), POINTER(c_double), POINTER(c_int64)], c_int32),
+    "scint_profile_end": ([POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_int32], c_int32),
     "scint_sspec_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_sspec": ([_P, c_int64, c_int64, _P, _P, c_int32, c_int32, _P, _P, _P, _P, c_size_t, _P], c_int32),
     "scint_cs_workspace_bytes": ([c_int64, c_int64, c_int64, POINTER(c_size_t)], c_int32),
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "scint_mean": ([_P, c_int64, POINTER(c_double), _P], c_int32),
     "scint_thth_map": ([_P, POINTER(CsGeom), _P, c_int64, _P, c_int64, c_double, c_int32, _P, _P], c_int32),
     "scint_sweep_precision": ([c_int32], c_int32),
+    "scint_sweep_schedule": ([c_int32, c_int32, c_int32], c_int32),
     "scint_sweep_stats": ([POINTER(c_double)], c_int32),
     "scint_eval_sweep_workspace_bytes": ([c_int64, c_int64, c_int64, c_int32, POINTER(c_size_t)], c_int32),
     "scint_eval_sweep": ([_P, POINTER(CsGeom), _P, c_int64, _P, POINTER(c_int32), POINTER(c_double), c_int64,

@@ -32,13 +32,14 @@ extern "C" int32_t scint_profile_begin(void) {
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_profile_end(double* ms_out, double* ms_sum_out, int64_t* launches_out) {
+extern "C" int32_t scint_profile_end(double* ms_out, double* ms_sum_out, int64_t* launches_out, int32_t count) {
     scint::Profiler& p = scint::profiler();
+    if (count < 0) { scint::set_error("scint: profile_end: negative count"); return SCINT_E_ARG; }
     if (hipDeviceSynchronize() != hipSuccess) return SCINT_E_HIP;
     p.collect();
     p.finish();
     p.enabled = false;
-    for (int k = 0; k < scint::kProfCount; ++k) {
+    for (int k = 0; k < scint::kProfCount && k < count; ++k) {       // never more than the caller's arrays hold
         if (ms_out) ms_out[k] = p.ms[k];
         if (ms_sum_out) ms_sum_out[k] = p.ms_sum[k];
         if (launches_out) launches_out[k] = p.launches[k];
@@ -46,7 +47,7 @@ extern "C" int32_t scint_profile_end(double* ms_out, double* ms_sum_out, int64_t
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_version(void) { return 100; }
+extern "C" int32_t scint_version(void) { return 101; }   // 101: scint_profile_end takes the length of the caller's arrays
 
 extern "C" int32_t scint_last_error(char* buf, size_t n) {
     if (!buf || n == 0) return SCINT_E_ARG;

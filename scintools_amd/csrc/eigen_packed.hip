@@ -43,6 +43,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <vector>
 
@@ -919,24 +920,46 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_
 // phase retrieval) stay on the float64 tiles throughout: the eigenvector itself is only 1e-8 / gap accurate after the
 // iteration phase and would need most of its passes again.
 // Selected per process by scint_sweep_precision() (default: SCINT_SWEEP_PRECISION=mixed|f64 in the environment, else f64).
-static int& sweep_mode_ref() {
-    static int mode = [] {
+static std::atomic<int>& sweep_mode_ref() {
+    static std::atomic<int> mode([] {
         const char* e = getenv("SCINT_SWEEP_PRECISION");
         return (e && (e[0] == 'm' || e[0] == 'M')) ? 1 : 0;
-    }();
+    }());
     return mode;
 }
-bool sweep_mixed() { return sweep_mode_ref() == 1; }
+bool sweep_mixed() { return sweep_mode_ref().load() == 1; }
 
-int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
-                              int64_t ncs, size_t* bytes) {
+// (the precision mode is an argument here: run_sweep reads the process-wide switch ONCE and sizes, lays out and runs
+//  with that one value -- a concurrent scint_sweep_precision() cannot make the layout disagree with the size check)
+static int32_t sweep_workspace_bytes_mode(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
+                                          int64_t ncs, bool mixed_mode, size_t* bytes) {
     SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && ncs >= 1,
                   "sweep_workspace_bytes: bad arguments");
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, !want_vec && sweep_mixed()).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, !want_vec && mixed_mode).total + 4096;
     return SCINT_OK;
+}
+int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
+                              int64_t ncs, size_t* bytes) {
+    return sweep_workspace_bytes_mode(M, neta, batch, max_iter, want_vec, ncs, sweep_mixed(), bytes);
+}
+
+// Scheduling switches (scint_sweep_schedule; initial values from SCINT_SWEEP_DEPTH / SCINT_CHECK_EVERY / SCINT_SWEEP_GROUPS,
+// read ONCE per process -- until round 4 run_sweep called getenv three times per sweep).  0 = the measured default.  None
+// selects a different kernel or changes a result bit: they exist for the tests that prove exactly that, and for bench.py's
+// one-slot-group leg.
+struct SweepSchedule { std::atomic<int> depth{0}, check_every{0}, groups{0}; };
+static SweepSchedule& sweep_schedule() {
+    static SweepSchedule sc;
+    static const bool init = [] {
+        auto env_int = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+        sc.depth = env_int("SCINT_SWEEP_DEPTH"); sc.check_every = env_int("SCINT_CHECK_EVERY"); sc.groups = env_int("SCINT_SWEEP_GROUPS");
+        return true;
+    }();
+    (void)init;
+    return sc;
 }
 
 // Pinned host staging, kept per host thread and grown on demand (a hipHostMalloc per sweep call
@@ -965,7 +988,14 @@ static char* pinned_staging(size_t bytes) {
 // (Measured in round 3, profiles/r03_tail_schedule_ab.json: highest stream priority for the tail streams costs
 // 6 %, 1 / 2 / 4 lanes and 36-KiB / 144-KiB back-map workgroups are within 3 % of each other -- the chi^2 sweep
 // is bound by the SUM of the mat-vec's and the tail kernels' GPU time, not by how they interleave.)
-struct SideStreams { hipStream_t aux = nullptr, chk[2] = {}, tail[kTailLanes] = {}; };
+// The sweep's events live here too, created once with the streams (until round 4 run_sweep created and destroyed ~20 of them
+// per call): a sweep drains every stream before it returns, so the next sweep of the thread finds them all idle.
+constexpr int kTabsEv = 3;   // = kTabs (declared below)
+struct SideStreams {
+    hipStream_t aux = nullptr, chk[2] = {}, tail[kTailLanes] = {};
+    hipEvent_t chunk_done[2][kTabsEv] = {}, export_done[2][kTabsEv] = {}, steps_done[2][kTabsEv] = {};
+    hipEvent_t start_ev = nullptr, stagger_ev = nullptr;
+};
 static SideStreams* side_streams() {
     thread_local std::map<int, SideStreams> streams;
     int dev = 0;
@@ -978,6 +1008,11 @@ static SideStreams* side_streams() {
         if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (auto& t : s.tail)
         if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    auto mk_ev = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    for (int g = 0; g < 2; ++g)
+        for (int t = 0; t < kTabsEv; ++t)
+            if (!mk_ev(&s.chunk_done[g][t]) || !mk_ev(&s.export_done[g][t]) || !mk_ev(&s.steps_done[g][t])) return nullptr;
+    if (!mk_ev(&s.start_ev) || !mk_ev(&s.stagger_ev)) return nullptr;
     return &(streams[dev] = s);
 }
 
@@ -999,6 +1034,7 @@ static SideStreams* side_streams() {
 // grouping and arrival order.
 // What the calling thread's last sweep streamed (scint_sweep_stats): algorithmic bytes 4 n (n + 1) per complex64 pass and
 // 8 n (n + 1) per complex128 pass of an n x n matrix, certificates started, complex128 passes they took.
+static_assert(kTabsEv == kTabs, "event sets per group = table copies");
 struct SweepStats { double bytes32 = 0, bytes64 = 0, certified = 0, cert_passes = 0; };
 static SweepStats& sweep_stats() { thread_local SweepStats st; return st; }
 
@@ -1368,17 +1404,26 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     }
     SCINT_REQUIRE(!want_vec || (vec_out && vstride >= M), "sweep: bad eigenvector output");
     hipStream_t stream = (hipStream_t)stream_;
+    const bool mixed_mode = sweep_mixed();      // the ONE read of the process-wide switch for this sweep
     size_t need = 0;
-    sweep_workspace_bytes(M, neta, batch, max_iter, want_vec, ncs, &need);
+    sweep_workspace_bytes_mode(M, neta, batch, max_iter, want_vec, ncs, mixed_mode, &need);
     if (workspace_bytes < need) { set_error("scint: sweep workspace too small"); return SCINT_E_WORKSPACE; }
     SideStreams* side = side_streams();
-    if (!side) { set_error("scint: could not create the internal sweep streams"); return SCINT_E_HIP; }
-    SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kMatvecLdsBytes));
-    SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kMatvec32LdsBytes));
-    SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kMatvecMixedLdsBytes));
+    if (!side) { set_error("scint: could not create the internal sweep streams and events"); return SCINT_E_HIP; }
+    {   // dynamic-LDS limits of the mat-vec kernels: once per (thread, device)
+        thread_local std::map<int, bool> lds_set;
+        int dev = 0;
+        SCINT_HIP(hipGetDevice(&dev));
+        if (!lds_set[dev]) {
+            SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kMatvecLdsBytes));
+            SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kMatvec32LdsBytes));
+            SCINT_HIP(hipFuncSetAttribute((const void*)pk2_matvec_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kMatvecMixedLdsBytes));
+            lds_set[dev] = true;
+        }
+    }
 
     sweep_stats() = SweepStats();
     SweepProblem S;
@@ -1386,19 +1431,16 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
     S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
     S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook;
-    S.mixed = !want_vec && !tail_hook && sweep_mixed(); S.tol = tol;
+    S.mixed = !want_vec && !tail_hook && mixed_mode; S.tol = tol;
     for (int l = 0; l < kTailLanes; ++l) S.tail[l] = side->tail[l];
     S.nbmax = (int)ceil_div(M, kTB);
     S.steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nslots = (int)std::min(batch, neta);
-    const char* depth_env = getenv("SCINT_SWEEP_DEPTH");    // read per call: tests compare schedules in one process
-    const int forced_depth = depth_env ? atoi(depth_env) : 0;
+    const SweepSchedule& sched = sweep_schedule();
+    const int forced_depth = sched.depth.load(), forced_every = sched.check_every.load(), forced_groups = sched.groups.load();
     S.depth = forced_depth >= 1 && forced_depth <= 2 ? forced_depth : 2;
-    const char* every_env = getenv("SCINT_CHECK_EVERY");
-    const int forced_every = every_env ? atoi(every_env) : 0;
     S.check_every = forced_every >= 1 && forced_every <= 16 ? forced_every : kCheckEveryBlock;
-    const char* groups_env = getenv("SCINT_SWEEP_GROUPS");
-    const int ngroups = (nslots >= 4 && !(groups_env && atoi(groups_env) == 1)) ? 2 : 1;
+    const int ngroups = (nslots >= 4 && forced_groups != 1) ? 2 : 1;
     S.BL = batch_layout(S.nbmax, S.steps_cap, nslots, want_vec, ncs, S.mixed);
     const SlabLayout& L = S.BL.slab;
     S.base = (char*)workspace;
@@ -1421,9 +1463,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     char* q = pin + geom_bytes;
     auto take = [&](size_t bytes) { char* r = q; q += align_up(bytes, 64); return r; };
 
-    hipEvent_t start_ev = nullptr;
-    hipError_t he = hipEventCreateWithFlags(&start_ev, hipEventDisableTiming);
-    int32_t rc = he == hipSuccess ? SCINT_OK : hip_fail(he, "sweep events", __FILE__, __LINE__);
+    hipEvent_t start_ev = side->start_ev;
+    hipError_t he = hipSuccess;
+    int32_t rc = SCINT_OK;
     SweepGroup G[2];
     for (int g = 0; g < ngroups; ++g) {
         SweepGroup& grp = G[g];
@@ -1434,7 +1476,8 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         grp.check_stream = side->chk[g];
         const size_t nsl = (size_t)grp.nslots;
         for (int t = 0; t < kTabs; ++t) {
-            grp.chunk_done[t] = grp.export_done[t] = grp.steps_done[t] = nullptr;
+            grp.chunk_done[t] = side->chunk_done[g][t]; grp.export_done[t] = side->export_done[g][t];
+            grp.steps_done[t] = side->steps_done[g][t];
             grp.h_jobs[t] = (PackedJob*)take(sizeof(PackedJob) * nsl);
             grp.h_strips[t] = (Strip*)take(sizeof(Strip) * nsl * (size_t)S.BL.smax);
             grp.h_fresh[t] = (int32_t*)take(sizeof(int32_t) * nsl);
@@ -1444,12 +1487,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             grp.h_flags[t] = (int32_t*)take(sizeof(int32_t) * 4 * nsl);
             grp.h_strips32[t] = (Strip32*)take(S.mixed ? sizeof(Strip32) * nsl * (size_t)S.BL.smax : 0);
             grp.h_restart[t] = (int32_t*)take(sizeof(int32_t) * nsl);
-            if (rc == SCINT_OK) {
-                he = hipEventCreateWithFlags(&grp.chunk_done[t], hipEventDisableTiming);
-                if (he == hipSuccess) he = hipEventCreateWithFlags(&grp.export_done[t], hipEventDisableTiming);
-                if (he == hipSuccess) he = hipEventCreateWithFlags(&grp.steps_done[t], hipEventDisableTiming);
-                if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
-            }
         }
         grp.jobs.assign(nsl, PackedJob());
         grp.slot_eta.assign(nsl, -1);
@@ -1503,10 +1540,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     // wavefront per curvature, 160 us), refill gathers and reductions coincide and the GPU has no mat-vec to run
     // beside them (7 + 6 ms of a 190 ms sweep in the round-3 trace, profiles/r03_timeline.txt).  The second group
     // therefore waits for the first one's first pass.  Nothing per-job depends on it.
-    if (rc == SCINT_OK && ngroups == 2) {
-        he = hipEventCreateWithFlags(&S.stagger_ev, hipEventDisableTiming);
-        if (he != hipSuccess) rc = hip_fail(he, "sweep events", __FILE__, __LINE__);
-    }
+    if (rc == SCINT_OK && ngroups == 2) S.stagger_ev = side->stagger_ev;
     bool staggered = false;
     while (rc == SCINT_OK) {
         bool any = false;
@@ -1535,15 +1569,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     }
     { const hipError_t e2 = hipGetLastError(); if (sync_err == hipSuccess) sync_err = e2; }
     if (rc == SCINT_OK && sync_err != hipSuccess) rc = hip_fail(sync_err, "sweep completion", __FILE__, __LINE__);
-    for (int g = 0; g < ngroups; ++g)
-        for (int t = 0; t < kTabs; ++t) {
-            if (G[g].chunk_done[t]) (void)hipEventDestroy(G[g].chunk_done[t]);
-            if (G[g].export_done[t]) (void)hipEventDestroy(G[g].export_done[t]);
-            if (G[g].steps_done[t]) (void)hipEventDestroy(G[g].steps_done[t]);
-        }
-    if (start_ev) (void)hipEventDestroy(start_ev);
-    if (S.stagger_ev) (void)hipEventDestroy(S.stagger_ev);
-    return rc;
+    return rc;      // (streams and events stay with the thread: side_streams())
 }
 
 }  // namespace scint
@@ -1551,11 +1577,20 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
 using namespace scint;
 
 extern "C" int32_t scint_sweep_precision(int32_t mode) {
-    int& m = sweep_mode_ref();
-    const int32_t before = m;
-    if (mode == 0 || mode == 1) m = mode;
-    else if (mode != -1) { set_error("scint: sweep_precision: mode must be 0 (f64), 1 (mixed) or -1 (query)"); return SCINT_E_ARG; }
-    return before;
+    std::atomic<int>& m = sweep_mode_ref();
+    if (mode == 0 || mode == 1) return m.exchange(mode);
+    if (mode != -1) { set_error("scint: sweep_precision: mode must be 0 (f64), 1 (mixed) or -1 (query)"); return SCINT_E_ARG; }
+    return m.load();
+}
+
+extern "C" int32_t scint_sweep_schedule(int32_t depth, int32_t check_every, int32_t groups) {
+    SCINT_REQUIRE(depth >= -1 && depth <= 2 && check_every >= -1 && check_every <= 16 && groups >= -1 && groups <= 2,
+                  "sweep_schedule: depth in 0..2, check_every in 0..16, groups in 0..2 (0 = default, -1 = leave as is)");
+    SweepSchedule& sc = sweep_schedule();
+    if (depth >= 0) sc.depth = depth;
+    if (check_every >= 0) sc.check_every = check_every;
+    if (groups >= 0) sc.groups = groups;
+    return SCINT_OK;
 }
 
 extern "C" int32_t scint_sweep_stats(double* out) {

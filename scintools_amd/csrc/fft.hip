@@ -31,6 +31,7 @@
 
 #include "fft.hpp"
 #include "packed.hpp"
+#include "prof.hpp"
 #include "sspec.hpp"
 
 namespace scint {
@@ -1315,20 +1316,24 @@ struct ChisqTail : SweepTail {
         if (n < 2) return SCINT_OK;                       // crop-to-nothing: chi^2 stays NaN
         cplx* recovT = recovT_[lane]; double* modelT = modelT_[lane]; void* fft_ws = fft_ws_[lane];
         double* partial = partial_[lane]; void* rev_scratch = rev_scratch_[lane];
+        const int ps = profiler().begin(kProfRevmap, tail);
         int32_t rc = launch_rev_map_rank1(vec + e * vstride, w + e, th_red + e * M, n, g, etas[e], recovT, true,
                                           rev_scratch, tail);
+        profiler().end(kProfRevmap, ps, tail);
         if (rc != SCINT_OK) return rc;
         RealPairChisq fuse{}; fuse.dspec = dspecT; fuse.mask = maskT; fuse.partial = partial;
         int nblk = 0;
+        const int pm = profiler().begin(kProfModel, tail);
         rc = model_from_recov(recovT, g.nfd, g.ntau, modelT, nf, nt, nf, fft_ws, fft_ws_bytes, tail,
                               nt <= 2 * (int64_t)kChisqPartials ? &fuse : nullptr, &nblk);
-        if (rc != SCINT_OK) return rc;
-        if (nblk > 0) {     // chi^2 came out of the model transform's last pass: add its per-workgroup sums in order
+        if (rc == SCINT_OK && nblk > 0) {     // chi^2 came out of the model transform's last pass: add its per-workgroup sums in order
             hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, tail, partial, nblk, 1.0 / noise_n, chisq_out + e);
-            SCINT_LAUNCH_CHECK();
-            return SCINT_OK;
+            if (hipGetLastError() != hipSuccess) rc = SCINT_E_HIP;
+        } else if (rc == SCINT_OK) {
+            rc = launch_reduce2d(ChisqValue{modelT, nf, dspecT, nf, maskT}, nt, nf, 1.0 / noise_n, partial, chisq_out + e, tail);
         }
-        return launch_reduce2d(ChisqValue{modelT, nf, dspecT, nf, maskT}, nt, nf, 1.0 / noise_n, partial, chisq_out + e, tail);
+        profiler().end(kProfModel, pm, tail);
+        return rc;
     }
 };
 

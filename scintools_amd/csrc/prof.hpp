@@ -8,7 +8,9 @@
 
 namespace scint {
 
-enum ProfKernel { kProfGather = 0, kProfMatvec = 1, kProfMatvec32 = 2, kProfCount = 3 };   // (2: the complex64 mat-vec of the mixed sweep)
+// (2: the complex64 mat-vec of the mixed sweep; 3, 4: the model step of the chi^2 sweep -- rank-1 back-map with its bound kernel,
+//  complex-to-real model transform with the chi^2 sink and the final sum)
+enum ProfKernel { kProfGather = 0, kProfMatvec = 1, kProfMatvec32 = 2, kProfRevmap = 3, kProfModel = 4, kProfCount = 5 };
 
 struct Profiler {
     bool enabled = false;
@@ -16,9 +18,9 @@ struct Profiler {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> open[kProfCount];
     // ms[k] is the length of the UNION of kernel k's launch intervals: the sweep drives two
     // streams, so launches of one kernel may overlap in time and must not be counted twice.
-    double ms[kProfCount] = {0, 0, 0};
-    double ms_sum[kProfCount] = {0, 0, 0};    // plain sum of the individual launch spans (what rocprofv3 averages)
-    int64_t launches[kProfCount] = {0, 0, 0};
+    double ms[kProfCount] = {};
+    double ms_sum[kProfCount] = {};    // plain sum of the individual launch spans (what rocprofv3 averages)
+    int64_t launches[kProfCount] = {};
     hipEvent_t base = nullptr;             // time origin of the current begin/end window
     std::vector<std::pair<float, float>> spans[kProfCount];
 

@@ -758,37 +758,67 @@ def _wavefield_from_eigpair(grid, e, keep, V, w, shape):
     return _ifft2_shifted_dev(recov_E, scale=nf * nt / 4, crop=(nf, nt))
 
 
-def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False):
-    """Phase retrieval of MANY chunks of one shape (Dynspec.thetatheta_chunks, dynspec.py:1765-1826): every
-    chunk's conjugate spectrum in one device stack, all dominant eigenpairs in ONE batched sweep
-    (:func:`eigvec_sweep_multi`), then per chunk the back-map and the inverse FFT queued without a host
-    synchronisation in between; one copy back at the end.
+RETRIEVAL_GROUP_BYTES = 8 << 30   # device bytes of conjugate spectra stacked per retrieval group (the rule of Dynspec._fit_chunks)
 
-    chunks: list of (dspec2[nf, nt], edges, time, freq, eta).  Returns complex [nchunk, nf, nt]; a chunk
-    whose eigen-solve fails is zero, as single_chunk_retrieval leaves it."""
+
+def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None):
+    """Phase retrieval of MANY chunks of one shape (Dynspec.thetatheta_chunks, dynspec.py:1765-1826): the chunks'
+    conjugate spectra in one device stack, all their dominant eigenpairs in ONE batched sweep
+    (:func:`eigvec_sweep_multi`), then per chunk the back-map and the inverse FFT queued without a host
+    synchronisation in between; one copy back per group.
+
+    The chunks are processed in GROUPS whose stacked conjugate spectra stay below ``group_bytes`` (default
+    ``RETRIEVAL_GROUP_BYTES`` = 8 GiB, the rule ``Dynspec._fit_chunks`` uses for the fit): an observation with many
+    large chunks needs nchunk x (npad+1)^2 x nf x nt x 16 B for one stack of all of them, which the chunk-by-chunk
+    reference path never did.  Tutorial-sized data is one group, as before.
+
+    chunks: list of (dspec2[nf, nt], edges, time, freq, eta).  Returns complex [nchunk, nf, nt].  A chunk whose
+    preparation, eigen-solve or back-map fails is zero and the error is printed -- what the reference's
+    single_chunk_retrieval does (ththmod.py:1471-1475) -- and the other chunks are unaffected."""
     nf, nt = np.asarray(chunks[0][0]).shape
-    grids, etas = [], []
-    for dspec2, edges, time, freq, eta in chunks:
-        fd = fft_axis(units.strip(time, "time2", "s", warn=False), 1000.0, npad)
-        tau = fft_axis(units.strip(freq, "freq2", "MHz", warn=False), 1.0, npad)
-        grids.append(_Grid(tau, fd, units.strip(edges, "edges", "mHz", warn=False)))
-        etas.append(np.array([_eta_float(eta)]))
+    R, C = (npad + 1) * nf, (npad + 1) * nt
+    per_group = max(1, int((RETRIEVAL_GROUP_BYTES if group_bytes is None else group_bytes) // (16 * R * C)))
     dev = require_gpu()
-    stack = torch.empty((len(chunks), (npad + 1) * nf, (npad + 1) * nt), dtype=torch.complex128, device=dev)
-    for k, (dspec2, *_r) in enumerate(chunks):
-        g = grids[k]
-        conjugate_spectrum(np.asarray(dspec2, dtype=float), npad, g.tau, tauMask, True, out=stack[k])
-    w_list, V_t, keeps, info = eigvec_sweep_multi(stack, grids, etas)
-    V = V_t.cpu().numpy()
-    out_t = torch.zeros((len(chunks), nf, nt), dtype=torch.complex128, device=dev)
-    for k in range(len(chunks)):
-        if info["status"][k] != 0 or keeps[k].shape[0] < 2:
-            print("Chunk %d: eigen-decomposition failed" % k, flush=True)
+    out = np.zeros((len(chunks), nf, nt), dtype=complex)
+    for g0 in range(0, len(chunks), per_group):
+        group = chunks[g0:g0 + per_group]
+        stack = torch.empty((len(group), R, C), dtype=torch.complex128, device=dev)
+        grids, etas, live = [], [], []
+        for k, (dspec2, edges, time, freq, eta) in enumerate(group):
+            try:
+                fd = fft_axis(units.strip(time, "time2", "s", warn=False), 1000.0, npad)
+                tau = fft_axis(units.strip(freq, "freq2", "MHz", warn=False), 1.0, npad)
+                grid = _Grid(tau, fd, units.strip(edges, "edges", "mHz", warn=False))
+                e = np.array([_eta_float(eta)])
+                if (grid.geom.ntau, grid.geom.nfd) != (R, C) or (grids and grid.M != grids[0].M):
+                    raise ValueError("axes or edges of this chunk do not match the chunk shape (%d, %d)" % (nf, nt))
+                conjugate_spectrum(np.asarray(dspec2, dtype=float), npad, grid.tau, tauMask, True, out=stack[len(live)])
+            except Exception as exc:          # this chunk stays zero; the slot of the stack is reused by the next one
+                print("Chunk %d: %s" % (g0 + k, exc), flush=True)
+                continue
+            grids.append(grid)
+            etas.append(e)
+            live.append(k)
+        if not live:
             continue
-        out_t[k].copy_(_wavefield_from_eigpair(grids[k], float(etas[k][0]), keeps[k], V[k], float(w_list[k][0]), (nf, nt)))
-        if verbose:
-            print("Chunk %d success" % k, flush=True)
-    return out_t.cpu().numpy()
+        w_list, V_t, keeps, info = eigvec_sweep_multi(stack[: len(live)], grids, etas)
+        V = V_t.cpu().numpy()
+        out_t = torch.zeros((len(live), nf, nt), dtype=torch.complex128, device=dev)
+        for j, k in enumerate(live):
+            if info["status"][j] != 0 or keeps[j].shape[0] < 2:
+                print("Chunk %d: eigen-decomposition failed" % (g0 + k), flush=True)
+                continue
+            try:
+                out_t[j].copy_(_wavefield_from_eigpair(grids[j], float(etas[j][0]), keeps[j], V[j], float(w_list[j][0]),
+                                                       (nf, nt)))
+            except Exception as exc:
+                print("Chunk %d: %s" % (g0 + k, exc), flush=True)
+                out_t[j].zero_()
+                continue
+            if verbose:
+                print("Chunk %d success" % (g0 + k), flush=True)
+        out[g0 + np.asarray(live)] = out_t.cpu().numpy()
+    return out
 
 
 def single_chunk_retrieval(params):

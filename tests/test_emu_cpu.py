@@ -391,6 +391,31 @@ def test_modeler_and_chisq_sweep(emu, to, case):
     np.testing.assert_allclose(chis, refc, rtol=1e-9)
 
 
+def test_chunk_retrieval_in_byte_bounded_groups(emu, to, capsys):
+    """the batched phase retrieval stacks conjugate spectra only up to a byte budget (groups, as the fit path
+    does), and a chunk that cannot be prepared is left zero with its error printed while the others go on -- the reference's
+    single_chunk_retrieval does the same chunk by chunk (ththmod.py:1471-1475).  Groups of one, of two and one group of
+    all give the same chunks; each equals the oracle's single_chunk_retrieval up to its global phase."""
+    from scintools_amd.synth import arc_dynspec
+    chunks = []
+    for k in range(3):
+        dyn, freqs, times, eta_true = arc_dynspec(48, 40, seed=30 + k, nimg=8)
+        dyn = dyn - dyn.mean()
+        fd = to.fft_axis(times, 1000.0, 1)
+        chunks.append((dyn, np.linspace(-fd.max() / 2, fd.max() / 2, 40), times, freqs, eta_true))
+    bad = (chunks[0][0], chunks[0][1], chunks[0][2][:7], chunks[0][3], chunks[0][4])      # time axis of the wrong length
+    everything = emu.chunk_retrieval_batch(chunks, 1, 0.0)
+    one_by_one = emu.chunk_retrieval_batch(chunks, 1, 0.0, group_bytes=1)
+    assert np.array_equal(everything, one_by_one)
+    with_bad = emu.chunk_retrieval_batch([chunks[0], bad, chunks[1], chunks[2]], 1, 0.0, group_bytes=2 * 16 * 96 * 80)
+    assert "Chunk 1:" in capsys.readouterr().out
+    assert np.array_equal(with_bad[[0, 2, 3]], everything) and not with_bad[1].any()
+    for k, (dyn, edges, times, freqs, eta) in enumerate(chunks):
+        ref = to.single_chunk_retrieval(dyn, edges, times, freqs, eta, 1)
+        got = everything[k] * np.exp(-1j * np.angle(np.vdot(ref, everything[k])))
+        assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
 def test_rev_map_explicit_matrix(emu, to, case):
     c = case
     rng = np.random.default_rng(0)

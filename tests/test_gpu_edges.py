@@ -103,16 +103,18 @@ def test_sweep_is_schedule_invariant(env):
     # by default two groups of slots run on two streams and the host queues two chunks ahead of the
     # convergence flags; one group and/or synchronous scheduling (depth 1) must give the same
     # bits, for eigenvalues and for eigenvectors
-    import os
+    from scintools_amd import _lib
+    lib = _lib.load()
     w2, V2, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
-    for depth, groups in (("1", "2"), ("2", "1"), ("1", "1")):
-        os.environ["SCINT_SWEEP_DEPTH"], os.environ["SCINT_SWEEP_GROUPS"] = depth, groups
+    for depth, every, groups in ((1, 0, 2), (2, 0, 1), (1, 0, 1), (2, 3, 2), (1, 1, 1)):
+        assert lib.scint_sweep_schedule(depth, every, groups) == 0
         try:
             assert np.array_equal(thth.eval_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6), ref)
             w1, V1, _ = thth.eigvec_sweep(p["CS"], p["tau"], p["fd"], etas, p["edges"], batch=6)
         finally:
-            del os.environ["SCINT_SWEEP_DEPTH"], os.environ["SCINT_SWEEP_GROUPS"]
+            assert lib.scint_sweep_schedule(0, 0, 0) == 0
         assert np.array_equal(w1, w2) and np.array_equal(V1.cpu().numpy(), V2.cpu().numpy())
+    assert lib.scint_sweep_schedule(3, 0, 0) != 0 and lib.scint_sweep_schedule(0, 17, 0) != 0      # out of range: refused
 
 
 def test_dynspec_with_nans_goes_through_fit_thetatheta(env):
