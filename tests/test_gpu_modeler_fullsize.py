@@ -137,6 +137,41 @@ def test_chisq_sweep_vs_chisq_calc(env, case):
     assert abs(fine[np.argmin(chi_f)] / eta_true - 1) <= 0.06
 
 
+@pytest.mark.timeout(900)
+def test_cropped_modeler_4096_vs_oracle(env):
+    """A curvature whose crop bites (3.5 eta_true at 4096^2: N = 2617 of M = 4095) against the ORACLE's modeler --
+    until round 4 the oracle model at 4096^2 existed only at 0.93 eta_true, where N = M, and the cropped curvatures of
+    the chi^2 sweep were compared with the product's own per-eta chisq_calc (missing 6).  thth_red and
+    edges_red bit-equal; w, V, thth2, recov (identical empty-bin masks), model to 1e-9; chi^2 from chisq_calc and
+    from the batched sweep to 1e-9 of the oracle's."""
+    thth, to = env
+    from scintools_amd.synth import arc_dynspec
+    size = 4096
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
+    dyn -= dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    eta = 3.5 * eta_true
+    CS = to.conjugate_spectrum(dyn, 0)
+    ref = to.modeler(CS, tau, fd, eta, edges)
+    cs_t = thth.to_device(CS)
+    got = thth.modeler(cs_t, tau, fd, eta, edges)
+    n = ref[0].shape[0]
+    assert n == 2617 and got[0].shape == (n, n)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[4], ref[4])
+    assert got[5] == pytest.approx(ref[5], rel=1e-9)
+    assert 1 - abs(np.vdot(ref[6], got[6])) <= 1e-9
+    assert np.abs(got[1] - ref[1]).max() <= 1e-9 * np.abs(ref[1]).max()
+    _assert_image_close(got[2], ref[2], 1e-9, "recov (cropped)")
+    assert np.abs(got[3] - ref[3]).max() <= 1e-9 * np.abs(ref[3]).max()
+    N = float(dyn.size)
+    chi_ref = np.sum((ref[3] - dyn) ** 2) / N
+    assert thth.chisq_calc(dyn, cs_t, tau, fd, eta, edges, N) == pytest.approx(chi_ref, rel=1e-9)
+    chis, info = thth.chisq_sweep(dyn, cs_t, tau, fd, np.array([0.5, 3.5, 3.9]) * eta_true, edges, N, return_info=True)
+    assert int(info["N"][1]) == n and np.all(info["status"] == 0)
+    assert chis[1] == pytest.approx(chi_ref, rel=1e-9)
+
+
 def test_rev_map_and_modeler_are_bit_reproducible(env, case):
     """np.histogram2d is deterministic, so the back-map must be too: the per-pixel sums are
     accumulated on a fixed binary grid (order-independent), and repeated calls -- explicit and
