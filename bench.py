@@ -71,6 +71,80 @@ def pmc_traffic_ratio():
     return k.get("traffic_over_algorithmic"), os.path.relpath(files[-1], REPO)
 
 
+def pmc_modeler_ratio():
+    """HBM bytes / algorithmic bytes of ONE WHOLE STEP of the modeler / chi^2 objective (every kernel of the step), from the
+    newest committed summary of `tools/gpu_run.sh pmc_modeler` (separate FETCH_SIZE / WRITE_SIZE passes of
+    `bench.py --objective chisq`, tools/pmc_modeler_summary.py).  None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_modeler_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        summ = json.load(fh)
+    return summ.get("traffic_over_algorithmic"), os.path.relpath(files[-1], REPO)
+
+
+def port_vs_reference():
+    """Time of the oracle ("port") over the time of the unmodified reference on the same conjugate spectrum, recorded in the
+    build container by tests/golden/time_port_vs_reference.py (the bench box has no /root/reference)."""
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "port_vs_reference_timing.json")) as fh:
+            t = json.load(fh)
+        return {"port_over_reference_time": t["port_over_reference_time"], "max_rel_diff": t["max_rel_diff"],
+                "size": t["size"], "host_cores": t["host_cores"],
+                "source": "tests/golden/port_vs_reference_timing.json (tests/golden/time_port_vs_reference.py, build container)"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
+    """The `modeler` object of the line from a timed chi^2 run: rate, pass count, and a roofline of its own.
+
+    Algorithmic bytes per curvature: eigenPAIR passes x 8 N (N + 1) (upper triangle of the packed Hermitian
+    theta-theta once per two-vector pass) + 16 N^2 for the gather + 16 ntau nfd written by the rank-1 back-map (recov) +
+    16 ntau nfd read by the model transform + 8 nf nt of the dynamic spectrum read by the chi^2 sink.  `achieved` is those
+    bytes over the WALL time of the step -- the mat-vecs, back-maps and model transforms of different curvatures share the
+    GPU on four streams, so the objective as a whole, not one kernel, is what the fraction describes; `parts` gives each
+    kernel's own bytes over the union of its launch intervals."""
+    chis, minfo = mod["curves"][0], mod["info"]
+    n_ = minfo["N"].astype(float)
+    mv = float(np.sum(8.0 * n_ * (n_ + 1.0) * minfo["iters"]))
+    ga = float(np.sum(16.0 * n_ * n_))
+    rv, mt = neta * geom_bytes, neta * (geom_bytes + dspec_bytes)
+    per_step = mv + ga + rv + mt
+    el = mod["elapsed"] / msteps
+    ratio, src = pmc_modeler_ratio()
+
+    def part(bytes_per_step, k):
+        busy = mod["busy_ms"][k] / 1e3 / msteps
+        return {"algorithmic_bytes_per_step": bytes_per_step, "busy_ms_per_step": 1e3 * busy,
+                "launches_per_step": mod["launches"][k] / msteps,
+                "avg_launch_ms": mod["sum_ms"][k] / max(1, mod["launches"][k]),
+                "achieved": bytes_per_step / busy / 1e9 if busy > 0 else 0.0, "unit": "GB/s",
+                "frac": bytes_per_step / busy / 1e9 / HBM_PEAK_GBS if busy > 0 else 0.0,
+                "share_of_step_time": busy / el}
+    return {
+        "workload": f"ththmod.modeler / chisq_calc over the same {neta} curvatures (ththmod.py:274-368): "
+                    "eigenPAIR (Ritz-residual stop), rank-1 rev_map, inverse FFT, chi^2",
+        "value": neta / el, "unit": "eta-points/s", "steps": msteps, "ms_per_step": 1e3 * el,
+        "lanczos_steps_mean": float(minfo["iters"].mean()),
+        "failed_etas": int(np.sum(minfo["status"] != 0)),
+        "matvec_share_of_step_time": mod["busy_ms"][1] / 1e3 / mod["elapsed"],
+        "matvec_GBs": mod["mv_bytes"] / (mod["busy_ms"][1] / 1e3) / 1e9 if mod["busy_ms"][1] > 0 else 0.0,
+        "eta_at_min_chisq_over_true": float(etas[np.nanargmin(chis)] / eta_true),
+        "roofline": {"bound": "hbm", "scope": "the whole objective: algorithmic bytes of every kernel of a step / wall time of the step",
+                     "achieved": per_step / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": per_step / el / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_eta": per_step / neta,
+                     "algorithmic_bytes_per_eta_by_part": {"eigenpair_passes": mv / neta, "gather": ga / neta,
+                                                           "back_map_write": rv / neta, "model_read_plus_dspec": mt / neta},
+                     "traffic": ratio * per_step / neta if ratio else None,
+                     "traffic_note": (f"HBM bytes per eta = {ratio:.3f} x algorithmic (every kernel of a chi^2 step; rocprofv3 "
+                                      f"PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), {src}") if ratio else None,
+                     "parts": {"pk2_matvec_kernel": part(mv, 1), "thth_gather_packed_kernel": part(ga, 0),
+                               "rev_gather_kernel (rank-1)": part(rv, 3), "model transform + chi^2 sink": part(mt, 4)}}}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,7 +515,7 @@ def main():
             if info is not None:
                 local_etas += int(info["N"].shape[0])
                 n_ = info["N"].astype(float)
-                if objective == "eig" and ththmod.sweep_precision() == "mixed":
+                if objective == "eig" and ththmod.sweep_precision() in ("mixed", "mixed-all"):
                     # bytes by operand from the library's own count (the per-eta step counts do not split by phase)
                     lib.scint_sweep_stats(st)
                     stats += np.array(list(st))
@@ -611,25 +685,43 @@ def main():
                     "eta_per_s": neta * min(args.steps, 3) / one["elapsed"],
                     "note": "the mat-vec kernel with the GPU to itself: same sweep, one slot group on one stream "
                             "(launches do not overlap; achieved = algorithmic bytes / sum of the launch durations)"}
+        if world == 1 and args.objective == "chisq" and len(dyns) == 1:
+            # the chi^2 objective as the headline region (tools/gpu_run.sh modeler / pmc_modeler): the same object
+            out["modeler"] = modeler_objects(head, args.steps, neta, etas, eta_true, 16.0 * R * C, 8.0 * size * size)
         msteps = args.modeler_steps if args.modeler_steps is not None else min(args.steps, 3)
         if world == 1 and args.objective == "eig" and msteps > 0 and len(dyns) == 1:
             mod = timed("chisq", msteps, 1)
-            chis, minfo = mod["curves"][0], mod["info"]
-            out["modeler"] = {
-                "workload": f"ththmod.modeler / chisq_calc over the same {neta} curvatures (ththmod.py:274-368): "
-                            "eigenPAIR (Ritz-residual stop), rank-1 rev_map, inverse FFT, chi^2",
-                "value": neta * msteps / mod["elapsed"], "unit": "eta-points/s", "steps": msteps,
-                "ms_per_step": 1e3 * mod["elapsed"] / msteps,
-                "lanczos_steps_mean": float(minfo["iters"].mean()),
-                "failed_etas": int(np.sum(minfo["status"] != 0)),
-                "matvec_share_of_step_time": mod["busy_ms"][1] / 1e3 / mod["elapsed"],
-                "matvec_GBs": mod["mv_bytes"] / (mod["busy_ms"][1] / 1e3) / 1e9 if mod["busy_ms"][1] > 0 else 0.0,
-                "eta_at_min_chisq_over_true": float(etas[np.nanargmin(chis)] / eta_true)}
+            chis = mod["curves"][0]
+            out["modeler"] = modeler_objects(mod, msteps, neta, etas, eta_true, 16.0 * R * C, 8.0 * size * size)
+            try:                                   # the same objective with the eigenpair iteration on the complex64 copy
+                ththmod.sweep_precision("mixed-all")
+                try:
+                    mxa = timed("chisq", msteps, 1)
+                finally:
+                    ththmod.sweep_precision("f64")
+                got = mxa["curves"][0]
+                out["modeler"]["mixed_all"] = {
+                    "what": "scint_sweep_precision(2): the eigenPAIR iteration streams the complex64 copy to the eigenvalue rule, "
+                            "the vector is finished on the complex128 tiles to the float64 sweep's residual rule; a reported leg, "
+                            "not modeler.value",
+                    "value": neta * msteps / mxa["elapsed"], "unit": "eta-points/s", "ms_per_step": 1e3 * mxa["elapsed"] / msteps,
+                    "speedup_vs_f64": (neta * msteps / mxa["elapsed"]) / out["modeler"]["value"],
+                    "lanczos_steps_mean": float(mxa["info"]["iters"].mean()),
+                    "failed_etas": int(np.sum(mxa["info"]["status"] != 0)),
+                    "max_rel_diff_vs_f64_chisq_curve": float(np.nanmax(np.abs(got - chis) / np.abs(chis)))}
+            except Exception as exc:               # a reported leg must never take the line down
+                out["modeler"]["mixed_all"] = {"error": repr(exc)}
         if world == 1 and args.objective == "eig" and msteps > 0:
             out["sspec"] = sspec_timing(torch, size)
         if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
             cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad, args.cpu_reps)
             out["cpu_baseline"] = cb
+            pr = port_vs_reference()
+            if pr:
+                cb["port_vs_reference"] = pr
+                cb["sample"] += (f"; the port takes {pr['port_over_reference_time']:.2f} x the time of the unmodified reference's "
+                                 f"Eval_calc on the same {pr['size']}^2 conjugate spectrum (values identical, rel. diff "
+                                 f"{pr['max_rel_diff']:.1e}; {pr['source']})")
             out["cpu_baseline"]["max_rel_diff_vs_gpu"] = float(
                 max(abs(eigs[i] - v) / abs(v) for i, v in ref_vals.items()))
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]

@@ -145,9 +145,12 @@ int32_t scint_eval_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch,
  *      own a-posteriori bound, evaluated in float64 on that matrix -- same tolerance, same status codes
  *      (csrc/eigen_packed.hip, "Mixed precision").  iters_out[i] then counts the passes of both phases (complex64 and
  *      complex128; scint_sweep_stats splits the bytes).  Eigenvector sweeps are not affected.
+ *   2  mixed-all: as 1, and the eigenPAIR sweeps (scint_eigvec_sweep*, scint_chisq_sweep) iterate on the complex64 copy too,
+ *      to the eigenvalue rule; the run that starts from the two Ritz vectors on the complex128 tiles then continues to
+ *      the eigenvector rule of the float64 sweep (residual of the float64 matrix, in float64).
  *  -1  query.
  * Returns the previous mode.  Call it BEFORE the *_workspace_bytes of a sweep: the mixed sweep needs a larger
- * workspace.  The environment variable SCINT_SWEEP_PRECISION=mixed|f64 sets the initial mode. */
+ * workspace.  The environment variable SCINT_SWEEP_PRECISION=mixed|mixed-all|f64 sets the initial mode. */
 int32_t scint_sweep_precision(int32_t mode);
 /* Scheduling of the sweeps, per process (the host-side scheduler of eigen_packed.hip; the reference has no counterpart --
  * its loop, ththmod.py:788-799, is sequential): chunks queued ahead of the convergence flags the host has seen (`depth`,

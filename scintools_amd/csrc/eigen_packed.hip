@@ -41,6 +41,7 @@
 // matrix-core strips 960, matrix-core bands 1163 with four vectors and 967 with eight, against 1201
 // for this kernel in the same interleaved A/B on one MI355X).
 #include <math.h>
+#include <string.h>
 
 #include <algorithm>
 #include <atomic>
@@ -710,7 +711,8 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         const double prev2 = jb.result[1], gap2 = theta - theta2;
         const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
         const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= 30.0 * jb.tol * gap2);
-        const bool ok = jb.want_vec ? vec_ok : (err <= jb.tol * at && settled);
+        // (the iteration phase of a mixed eigenPAIR sweep runs to the eigenVALUE rule: its vector is finished on the complex128 tiles)
+        const bool ok = (jb.want_vec && !jb.use32) ? vec_ok : (err <= jb.tol * at && settled);
         const bool conv = finite && (ok || exact);
         const bool stop = conv || !finite || k >= jb.max_steps;
         jb.result[0] = theta; jb.result[1] = theta2; jb.result[2] = resid; jb.result[3] = theta;
@@ -923,27 +925,33 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_
 static std::atomic<int>& sweep_mode_ref() {
     static std::atomic<int> mode([] {
         const char* e = getenv("SCINT_SWEEP_PRECISION");
-        return (e && (e[0] == 'm' || e[0] == 'M')) ? 1 : 0;
+        if (!e || !(e[0] == 'm' || e[0] == 'M')) return 0;
+        return strncmp(e + 1, "ixed-all", 8) == 0 ? 2 : 1;     // "mixed-all": the eigenPAIR sweeps too (mode 2 below)
     }());
     return mode;
 }
-bool sweep_mixed() { return sweep_mode_ref().load() == 1; }
+// Mode 2 ("mixed-all", round 4): the eigenPAIR sweeps (modeler, chi^2, retrieval) also iterate on the complex64 copy -- to the
+// eigenVALUE rule -- and the run that starts from the two Ritz vectors on the complex128 tiles (the certificate run of the
+// eigenvalue sweep) simply continues to the eigenVECTOR rule: the vector returned is a Ritz vector of the float64 matrix that
+// meets the float64 sweep's own residual bound.
+int sweep_mode() { return sweep_mode_ref().load(); }
+static bool mode_is_mixed(int mode, bool want_vec) { return want_vec ? mode == 2 : mode >= 1; }
 
 // (the precision mode is an argument here: run_sweep reads the process-wide switch ONCE and sizes, lays out and runs
 //  with that one value -- a concurrent scint_sweep_precision() cannot make the layout disagree with the size check)
 static int32_t sweep_workspace_bytes_mode(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
-                                          int64_t ncs, bool mixed_mode, size_t* bytes) {
+                                          int64_t ncs, int mode, size_t* bytes) {
     SCINT_REQUIRE(bytes && M >= 1 && neta >= 1 && batch >= 1 && max_iter >= 1 && ncs >= 1,
                   "sweep_workspace_bytes: bad arguments");
     const int nbmax = (int)ceil_div(M, kTB);
     const int steps = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
     const int nbatch = (int)std::min(batch, neta);
-    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, !want_vec && mixed_mode).total + 4096;
+    *bytes = batch_layout(nbmax, steps, nbatch, want_vec, ncs, mode_is_mixed(mode, want_vec)).total + 4096;
     return SCINT_OK;
 }
 int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
                               int64_t ncs, size_t* bytes) {
-    return sweep_workspace_bytes_mode(M, neta, batch, max_iter, want_vec, ncs, sweep_mixed(), bytes);
+    return sweep_workspace_bytes_mode(M, neta, batch, max_iter, want_vec, ncs, sweep_mode(), bytes);
 }
 
 // Scheduling switches (scint_sweep_schedule; initial values from SCINT_SWEEP_DEPTH / SCINT_CHECK_EVERY / SCINT_SWEEP_GROUPS,
@@ -1404,9 +1412,9 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     }
     SCINT_REQUIRE(!want_vec || (vec_out && vstride >= M), "sweep: bad eigenvector output");
     hipStream_t stream = (hipStream_t)stream_;
-    const bool mixed_mode = sweep_mixed();      // the ONE read of the process-wide switch for this sweep
+    const int mode = sweep_mode();              // the ONE read of the process-wide switch for this sweep
     size_t need = 0;
-    sweep_workspace_bytes_mode(M, neta, batch, max_iter, want_vec, ncs, mixed_mode, &need);
+    sweep_workspace_bytes_mode(M, neta, batch, max_iter, want_vec, ncs, mode, &need);
     if (workspace_bytes < need) { set_error("scint: sweep workspace too small"); return SCINT_E_WORKSPACE; }
     SideStreams* side = side_streams();
     if (!side) { set_error("scint: could not create the internal sweep streams and events"); return SCINT_E_HIP; }
@@ -1431,7 +1439,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.keep_idx = keep_idx; S.keep_n = keep_n; S.etas = etas; S.neta = neta;
     S.eigs_out = eigs_out; S.status_out = status_out; S.iters_out = iters_out;
     S.want_vec = want_vec; S.vec_out = vec_out; S.vstride = vstride; S.tail_hook = tail_hook;
-    S.mixed = !want_vec && !tail_hook && mixed_mode; S.tol = tol;
+    S.mixed = mode_is_mixed(mode, want_vec); S.tol = tol;
     for (int l = 0; l < kTailLanes; ++l) S.tail[l] = side->tail[l];
     S.nbmax = (int)ceil_div(M, kTB);
     S.steps_cap = (int)std::min<int64_t>(std::min<int64_t>(max_iter, M), kMaxK);
@@ -1578,8 +1586,8 @@ using namespace scint;
 
 extern "C" int32_t scint_sweep_precision(int32_t mode) {
     std::atomic<int>& m = sweep_mode_ref();
-    if (mode == 0 || mode == 1) return m.exchange(mode);
-    if (mode != -1) { set_error("scint: sweep_precision: mode must be 0 (f64), 1 (mixed) or -1 (query)"); return SCINT_E_ARG; }
+    if (mode >= 0 && mode <= 2) return m.exchange(mode);
+    if (mode != -1) { set_error("scint: sweep_precision: mode must be 0 (f64), 1 (mixed), 2 (mixed-all) or -1 (query)"); return SCINT_E_ARG; }
     return m.load();
 }
 

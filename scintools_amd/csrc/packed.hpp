@@ -155,7 +155,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
                   int64_t batch, double* eigs_out, int32_t* status_out, int32_t* iters_out, bool want_vec,
                   cplx* vec_out, int64_t vstride, SweepTail* tail_hook, void* workspace, size_t workspace_bytes,
                   void* stream);
-bool sweep_mixed();   // scint_sweep_precision(): eigenvalue sweeps iterate on a complex64 copy and certify on the complex128 tiles
+int sweep_mode();     // 0 f64, 1 mixed (eigenvalue sweeps), 2 mixed-all (eigenpair sweeps too); scint_sweep_precision(): eigenvalue sweeps iterate on a complex64 copy and certify on the complex128 tiles
 int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, bool want_vec,
                               int64_t ncs, size_t* bytes);
 

@@ -334,7 +334,8 @@ def default_batch(nmax, neta, eigenvalues_only=True):
     strips = sum(-(-(nb - i) // strip) for i in range(nb))
     want = -(-11000 // max(strips, 1))     # measured on MI355X at N = 4095: 48 / 56 / 70 slots -> 1079 / 1084 / 1094 eta/s
     per_slot = 8 * (nb * 64) ** 2 + 1
-    if eigenvalues_only and _lib.load().scint_sweep_precision(-1) == 1:
+    mode = _lib.load().scint_sweep_precision(-1)
+    if mode == 2 or (eigenvalues_only and mode == 1):
         # mixed sweep: a workgroup of the complex64 mat-vec covers four block rows (half as many workgroups per matrix),
         # and a slot idles for two of its ~19 chunks around the certificate pass: twice the slots for the same fill;
         # a slot also holds the complex64 copy and the Q history (ththmod.DEFAULT_BATCH_BYTES is a budget, not a limit)
@@ -349,17 +350,19 @@ def sweep_precision(mode=None):
 
     ``"f64"`` (default): every Lanczos pass streams the complex128 theta-theta.  ``"mixed"``: the passes stream a
     complex64 copy and the eigenvalue returned is the Ritz value of a certificate pass on the complex128 matrix that
-    meets the same a-posteriori bound (same ``tol``, same status codes).  ``None`` only queries.  Returns the mode
-    that was in force before the call.
+    meets the same a-posteriori bound (same ``tol``, same status codes).  ``"mixed-all"``: the eigenPAIR sweeps
+    (``eigvec_sweep``, ``chisq_sweep``, the batched retrieval) also iterate on the complex64 copy, and finish the vector on
+    the complex128 matrix to the float64 sweep's own residual rule.  ``None`` only queries.  Returns the mode that was in
+    force before the call.
 
     What it buys is HBM bytes: 1.6x the sweep rate at N = 4095 on one MI355X.  Sweeps of small matrices
     (the 64 x 150 chunks of the tutorial data: N ~ 100) are bound by launch latency, not bytes, and a curvature spends
     two to three extra chunks of passes around its certificate: leave those in ``"f64"``."""
     lib = _lib.load()
-    codes = {None: -1, "f64": 0, "mixed": 1}
+    codes = {None: -1, "f64": 0, "mixed": 1, "mixed-all": 2}
     if mode not in codes:
-        raise ValueError("sweep_precision: mode must be 'f64', 'mixed' or None")
-    return "mixed" if lib.scint_sweep_precision(codes[mode]) == 1 else "f64"
+        raise ValueError("sweep_precision: mode must be 'f64', 'mixed', 'mixed-all' or None")
+    return {0: "f64", 1: "mixed", 2: "mixed-all"}[lib.scint_sweep_precision(codes[mode])]
 
 
 def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,

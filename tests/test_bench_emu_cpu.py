@@ -54,6 +54,33 @@ def test_precision_mixed_line():
 
 
 @pytest.mark.timeout(900)
+def test_modeler_leg_has_its_own_roofline():
+    """The `modeler` object of the line: rate, a roofline of its own whose parts add up, and the
+    mixed-all leg against the float64 chi^2 curve."""
+    args = SMALL[:-2] + ["--modeler-steps", "1", "--mixed-steps", "0"]
+    try:
+        sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
+        import emulated
+        emulated.load()
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:
+        pytest.skip(f"host interpreter could not be built: {exc}")
+    out = subprocess.run([sys.executable, PROBE] + args, capture_output=True, text=True, timeout=800, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    m = d["modeler"]
+    r = m["roofline"]
+    assert m["value"] > 0 and m["failed_etas"] == 0 and r["bound"] == "hbm" and 0 < r["frac"] == r["achieved"] / r["peak"]
+    parts = r["algorithmic_bytes_per_eta_by_part"]
+    assert abs(sum(parts.values()) - r["algorithmic_bytes_per_eta"]) <= 1e-9 * r["algorithmic_bytes_per_eta"]
+    assert parts["back_map_write"] == 16.0 * 128 * 128 and parts["model_read_plus_dspec"] == 24.0 * 128 * 128
+    for k in ("pk2_matvec_kernel", "rev_gather_kernel (rank-1)", "model transform + chi^2 sink"):
+        assert r["parts"][k]["launches_per_step"] > 0 and r["parts"][k]["achieved"] > 0, k
+    mx = m["mixed_all"]
+    assert "error" not in mx, mx
+    assert mx["failed_etas"] == 0 and mx["max_rel_diff_vs_f64_chisq_curve"] < 1e-9 and mx["value"] > 0
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("extra", [[], ["--shard", "eta", "--precision", "mixed"]])
 def test_two_ranks(extra):
     """bench.py as the driver launches it for N = 2 (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment;

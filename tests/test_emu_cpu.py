@@ -375,6 +375,41 @@ def test_mixed_sweep_small_gaps_and_several_spectra(mixed, to):
     assert np.array_equal(out[0], eigs) and np.array_equal(out[1], np.ldexp(eigs[::-1], 40))
 
 
+@pytest.mark.parametrize("size", [96, 192, 300])
+def test_mixed_all_eigenpair_sweeps_against_the_float64_ones(emu, to, size):
+    """``sweep_precision("mixed-all")`` (scint_sweep_precision(2)): the eigenPAIR sweeps iterate on the complex64 copy to
+    the eigenvalue rule and finish the vector on the complex128 tiles from the two Ritz vectors, to the float64 sweep's
+    own residual rule.  Eigenvectors (up to the one global phase), eigenvalues
+    and chi^2 equal the float64 sweep's far inside the parity bar; fewer complex128 bytes are streamed."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=9, nimg=6, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    CS = to.conjugate_spectrum(dyn, 0)
+    etas = np.array([0.8, 1.0, 1.3]) * eta_true
+    w64, v64 = emu.eigvec_sweep(CS, tau, fd, etas, edges)[:2]
+    b64 = _sweep_stats(emu)
+    c64 = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 1.0)
+    assert b64["bytes32"] == 0
+    assert emu.sweep_precision("mixed-all") == "f64"
+    try:
+        wmx, vmx = emu.eigvec_sweep(CS, tau, fd, etas, edges)[:2]
+        bmx = _sweep_stats(emu)
+        cmx = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 1.0)
+        emx = emu.eval_sweep(CS, tau, fd, etas, edges)               # mode 2 includes the mixed eigenvalue sweep
+    finally:
+        assert emu.sweep_precision("f64") == "mixed-all"
+    np.testing.assert_allclose(wmx, w64, rtol=1e-12)
+    np.testing.assert_allclose(emx, w64, rtol=1e-12)
+    for a, b in zip(vmx.cpu().numpy(), v64.cpu().numpy()):
+        ph = np.vdot(b, a) / abs(np.vdot(b, a))                      # rows are unit vectors of arbitrary phase
+        assert np.abs(a / ph - b).max() <= 1e-10 * np.abs(b).max()   # (1 - |<a, b>| would only see the SQUARE of this)
+    np.testing.assert_allclose(cmx, c64, rtol=1e-9)
+    assert bmx["bytes32"] > 0 and bmx["certified"] == len(etas)
+    assert bmx["bytes64"] + bmx["bytes32"] < b64["bytes64"]          # what it is for
+
+
 def test_modeler_and_chisq_sweep(emu, to, case):
     c = case
     eta = c["etas"][2]

@@ -200,3 +200,39 @@ def test_single_search_and_fit_thetatheta_vs_the_reference(mixed, golden):
     np.testing.assert_allclose(d.eta_evo, f["eta_evo"], rtol=1e-6)
     np.testing.assert_allclose(d.eta_evo_err, f["eta_evo_err"], rtol=1e-4)
     assert d.ththeta == pytest.approx(float(f["ththeta"]), rel=1e-6)
+
+
+def test_mixed_all_eigenpair_and_chisq_sweeps_against_the_float64_ones(env):
+    """scint_sweep_precision(2), "mixed-all" (round 4): the eigenPAIR sweeps iterate on the complex64 copy to the eigenvalue
+    rule and finish the vector on the complex128 tiles, to the float64 sweep's own residual rule.  2048^2, twelve curvatures
+    over the sweep's range: eigenvalues of the float64 eigenpair sweep to 1e-12, eigenvectors to 1e-9 of their largest entry
+    after removing the one global phase, chi^2 (ththmod.py:330-368) to the parity bar of the float64 path, 1e-9 -- and one
+    curvature of it against the oracle's chisq_calc; fewer bytes streamed than by the float64 eigenpair sweep."""
+    thth, to, _ = env
+    dyn, fd, tau, edges, eta_true = _arc(to, 2048)
+    etas = np.geomspace(0.3, 3.5, 12) * eta_true
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
+    w64, v64, i64 = thth.eigvec_sweep(cs, tau, fd, etas, edges)
+    b64 = _stats()
+    c64 = thth.chisq_sweep(dyn, cs, tau, fd, etas, edges, 1.0)
+    assert thth.sweep_precision("mixed-all") == "f64"
+    try:
+        wmx, vmx, imx = thth.eigvec_sweep(cs, tau, fd, etas, edges)
+        bmx = _stats()
+        cmx = thth.chisq_sweep(dyn, cs, tau, fd, etas, edges, 1.0)
+        cmx2 = thth.chisq_sweep(dyn, cs, tau, fd, etas, edges, 1.0)
+    finally:
+        assert thth.sweep_precision("f64") == "mixed-all"
+    assert np.all(imx["status"] == 0) and np.all(i64["status"] == 0)
+    np.testing.assert_allclose(wmx, w64, rtol=1e-12)
+    a_, b_ = vmx.cpu().numpy(), v64.cpu().numpy()
+    for a, b in zip(a_, b_):
+        ph = np.vdot(b, a) / abs(np.vdot(b, a))
+        assert np.abs(a / ph - b).max() <= 1e-9 * np.abs(b).max()
+    np.testing.assert_allclose(cmx, c64, rtol=1e-9)
+    assert np.array_equal(cmx, cmx2)                              # bit-reproducible from call to call
+    assert bmx["bytes32"] > 0 and bmx["certified"] == len(etas)
+    assert bmx["bytes64"] + bmx["bytes32"] < b64["bytes64"]
+    k = 5
+    ref = to.chisq_calc(dyn, to.conjugate_spectrum(dyn, 0), tau, fd, etas[k], edges, 1.0)
+    assert abs(cmx[k] - ref) <= 1e-9 * abs(ref)

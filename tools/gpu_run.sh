@@ -10,6 +10,9 @@
 #   trace    [tag] [args]   rocprofv3 --kernel-trace --stats of a 3-step bench -> per-kernel stats + interval unions
 #   modeler  [tag]          the same trace of the chi^2 (modeler) objective
 #   pmc      [tag] [args]   FETCH_SIZE / WRITE_SIZE in separate --pmc passes of a 1-step bench (256 eta)
+#   pmc_modeler [tag]       the same two PMC passes of the chi^2 (modeler) objective -> <tag>_pmc_modeler_summary.json (whole-step traffic / algorithmic)
+#   mixedev  [tag]          evidence set of the mixed sweep with THIS library: kernel trace, FETCH/WRITE PMC, six hardware counters
+#   counters [tag] [args]   two --pmc passes (instruction counts + activity; cycles + waits) of a 1-step bench, tools/pmc_any.py
 #   fft      [tag]          kernel trace + PMC passes of tools/time_fft.py (calc_sspec and CS, 2048^2 .. 8192^2)
 #   probes   [tag]          tools/probes/*.hip (stream ceiling, the round-2 and round-3 mat-vec loops with their parts switchable, f64 MFMA layout)
 #   mixed    [tag] [args]   the mixed-precision sweep: a 3-step bench with its --mixed-steps leg (rate, bytes by operand, curve against
@@ -65,6 +68,29 @@ pmc() {
       $O/${TAG}_pmc_bench_FETCH_SIZE.log $O/${TAG}_pmc_summary.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 0 $QUICK (256 eta, 4096^2)" > $O/${TAG}_pmc_summary.txt 2>&1
   head -12 $O/${TAG}_pmc_summary.txt
 }
+pmc_modeler() {
+  pmc_of modeler "bench.py --objective chisq --steps 1 --warmup 0 --no-cpu-baseline" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --objective chisq --steps 1 --warmup 0 --no-cpu-baseline (256 eta, 4096^2)"
+  python tools/pmc_modeler_summary.py $(find $O/${TAG}_pmc_modeler_FETCH_SIZE -name "*.db" | head -1) $(find $O/${TAG}_pmc_modeler_WRITE_SIZE -name "*.db" | head -1) \
+      $O/${TAG}_pmc_modeler_FETCH_SIZE.log $O/${TAG}_pmc_modeler_summary.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --objective chisq --steps 1 --warmup 0 --no-cpu-baseline (256 eta, 4096^2)" > $O/${TAG}_pmc_modeler_summary.txt 2>&1
+  head -12 $O/${TAG}_pmc_modeler_summary.txt
+}
+counters_of() {  # name, command: the counters of profiles/r03_*_counters.txt in two passes (8 SQ slots + 2 GRBM slots per pass on gfx950)
+  i=0
+  for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" \
+           "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace -d $O/${TAG}_ctr_$1_$i -o ctr -- python $R/$2 > $O/${TAG}_ctr_$1_$i.log 2>&1 )
+    python tools/pmc_any.py $(find $O/${TAG}_ctr_$1_$i -name "*.db" | head -1) >> $O/${TAG}_$1_counters_raw.txt 2>&1
+  done
+  grep -E "matvec|cert_resid|gather|rev_gather|sspec" $O/${TAG}_$1_counters_raw.txt | head -40
+}
+counters() { rm -f $O/${TAG}_bench_counters_raw.txt; counters_of bench "bench.py --steps 1 --warmup 0 $QUICK $EXTRA"; }
+mixedev() {
+  trace_of mixed "--precision mixed --steps 3 --warmup 1 $QUICK"
+  pmc_of mixed "bench.py --precision mixed --steps 1 --warmup 0 $QUICK" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --precision mixed --steps 1 --warmup 0 $QUICK"
+  grep '"metric"' $O/${TAG}_pmc_mixed_FETCH_SIZE.log | tail -1 > $O/${TAG}_mixed_pmc_benchline.json
+  rm -f $O/${TAG}_mixed_counters_raw.txt; counters_of mixed "bench.py --precision mixed --steps 1 --warmup 0 $QUICK"
+}
 fft() {
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_fft -o fft -- python $R/tools/time_fft.py > $O/${TAG}_prof_fft.log 2>&1 )
   db=$(find $O/${TAG}_prof_fft -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/${TAG}_fft_kernel_stats.csv > /dev/null
@@ -87,8 +113,8 @@ probes() {
   done
 }
 case $CMD in
-  suite|bench|quick|configs|trace|modeler|pmc|fft|probes|mixed) $CMD ;;
-  all) suite; bench; configs; trace; modeler; pmc; fft; mixed ;;
+  suite|bench|quick|configs|trace|modeler|pmc|pmc_modeler|counters|mixedev|fft|probes|mixed) $CMD ;;
+  all) suite; bench; configs; trace; modeler; pmc; pmc_modeler; fft; mixed ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
 find $O -name "*.db" -size +20M -delete
