@@ -156,8 +156,10 @@ int32_t scint_sweep_precision(int32_t mode);
  * its loop, ththmod.py:788-799, is sequential): chunks queued ahead of the convergence flags the host has seen (`depth`,
  * 1 or 2), Lanczos passes between convergence checks (`check_every`, 1..16), slot groups on separate streams (`groups`,
  * 1 or 2).  0 restores the measured default, -1 leaves a setting as it is.  Initial values: SCINT_SWEEP_DEPTH /
- * SCINT_CHECK_EVERY / SCINT_SWEEP_GROUPS in the environment, read once.  No setting changes a bit of any result
- * (tests/test_gpu_edges.py); they exist for that test and for bench.py's one-slot-group leg. */
+ * SCINT_CHECK_EVERY / SCINT_SWEEP_GROUPS in the environment, read once.  `depth` and `groups` change no bit of any result;
+ * `check_every` decides after which passes the stopping rule is looked at, so a curvature may stop a pass earlier or later
+ * -- a value inside the same tolerance, not the same bits (tests/test_gpu_edges.py).  They exist for that test and for
+ * bench.py's one-slot-group leg. */
 int32_t scint_sweep_schedule(int32_t depth, int32_t check_every, int32_t groups);
 /* Diagnostics of the calling thread's last sweep (any of the sweep entry points), for the roofline accounting:
  * out[0] algorithmic bytes of its complex64 passes (4 n (n + 1) each), out[1] of its complex128 passes (8 n (n + 1)),

@@ -28,6 +28,7 @@ UNITS = {
     "arcnorm.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+COMMON += os.environ.get("SCINT_VARIANT_FLAGS", "").split()    # tools/build_variant.sh only (experiment builds, forced)
 
 
 def _hipcc():

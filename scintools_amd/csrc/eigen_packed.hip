@@ -68,8 +68,6 @@ __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
     return conj(jb.tiles[(tile_offset(jb.nb, bc) + (br - bc)) * kTileElems + (c % kTB) * kTB + (r % kTB)]);
 }
 
-constexpr int kMaxStrip = 16;    // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS)
-
 constexpr int kRedGroups = 4;    // wavefronts per reduce block: each sums every 4th partial vector.  8 KiB of LDS: the block fits
                                  // beside the two 76-KiB mat-vec workgroups of a CU.  With 16 wavefronts (32 KiB) it had to wait for
                                  // a mat-vec workgroup of the OTHER slot group to retire: 22 us alone, 170-270 us in the sweep;
@@ -266,9 +264,10 @@ __global__ void __launch_bounds__(kCoefRows) pk2_coef_kernel(const PackedJob* __
 // region) -- hence two rows per workgroup: half of it.
 // x_I: eight distinct rows per instruction, read from LDS.  256 threads, 76 KiB of LDS, 196 registers: two
 // workgroups per CU.
-constexpr int kLdsXs = 0, kLdsCol = 2048, kLdsXi = 4096, kLdsRsum = 4352, kLdsElems = 4864;   // complex elements
+constexpr int kLdsXs = 0, kLdsCol = kMaxStrip * kTB * 2, kLdsXi = 2 * kLdsCol, kLdsRsum = kLdsXi + kRows64 * kTB * 2,
+              kLdsElems = kLdsRsum + 4 * kTB * 2;   // complex elements: X_J blocks, column partials, X_I of the rows, row sums of the four waves
 constexpr size_t kMatvecLdsBytes = sizeof(cplx) * kLdsElems;
-static_assert(kLdsCol - kLdsXs == kMaxStrip * kTB * 2 && kLdsXi - kLdsCol == kMaxStrip * kTB * 2, "LDS carve of the mat-vec");
+static_assert(kMatvecLdsBytes <= 80 * 1024, "two mat-vec workgroups per CU (160 KiB of LDS)");
 
 __device__ __forceinline__ void pk2_half(const cplx (&a)[8], int h, const cplx (*__restrict__ xir)[2],
                                         const cplx (&xJ1)[2], const cplx (&xJ2)[2], cplx (&acc1)[8], cplx (&acc2)[8],
@@ -400,7 +399,7 @@ __device__ __forceinline__ void pk2_matvec_body(const Strip* __restrict__ sp, in
     const int cg = lane & 7, rg = lane >> 3, col = 16 * w + cg;
     const int ntile = sp->ntile;
     const int lane_off = rg * kTB + col;                                        // row rg, first column of the lane
-    const cplx* __restrict__ tp = sp->tiles + lane_off;
+    const cplx* __restrict__ tp = sp->tiles[0] + lane_off;
     cplx a0[8];                                                                 // element 2 jj + cc: row 8 (4h + jj) + rg, column col + 8 cc
 #pragma unroll
     for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tp + (8 * (k >> 1)) * kTB + 8 * (k & 1));
@@ -408,27 +407,28 @@ __device__ __forceinline__ void pk2_matvec_body(const Strip* __restrict__ sp, in
     const cplx* __restrict__ X = sp->Q + (int64_t)(step % sp->qslots) * sp->qstride * 2;   // Q_j
     const int I = sp->I, J0 = sp->J0, nrows = sp->nrows;
     // X_I of both rows and the strip's X_J blocks: contiguous copies of rows of Q_j (the first tile's loads stay in flight)
-    if (threadIdx.x < nrows * 2 * kTB) lds[kLdsXi + threadIdx.x] = gload(X + 2 * I * kTB + threadIdx.x);
+    for (int idx = threadIdx.x; idx < nrows * 2 * kTB; idx += 256) lds[kLdsXi + idx] = gload(X + 2 * I * kTB + idx);
     for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) lds[kLdsXs + idx] = gload(X + 2 * J0 * kTB + idx);
     if (done >= sp->gen) return;                 // finished job (workgroup-uniform): its loads were harmless
     __syncthreads();
     const cplx (*__restrict__ xi)[2] = reinterpret_cast<const cplx (*)[2]>(lds + kLdsXi);
     // this lane's slot in a tile's [64][2] column partial: column col + 8 (rg >> 1 & 1), vector rg & 1
     cplx* __restrict__ cslot = lds + kLdsCol + 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
-    pk2_row<false>(tp, a0, 0, ntile, -1, xs, xi + rg, cslot, nullptr, rsum, sp->rowpart, lane, w, col, cg, rg);
-    if (nrows == 2) {
-        // block row I+1 over the same columns: its tiles start at column max(J0, I+1); its diagonal tile (I+1, I+1)
+    pk2_row<false>(tp, a0, 0, ntile, -1, xs, xi + rg, cslot, nullptr, rsum, sp->rowpart[0], lane, w, col, cg, rg);
+#pragma unroll 1
+    for (int r = 1; r < nrows; ++r) {
+        // block row I+r over the same columns: its tiles start at column max(J0, I+r); its diagonal tile (I+r, I+r)
         // adds no column partial
-        const int t0 = J0 == I ? 1 : 0;
+        const int t0 = max(0, I + r - J0);
         if (t0 < ntile) {
-            const cplx* __restrict__ tpB = sp->tilesB + lane_off;
+            const cplx* __restrict__ tpB = sp->tiles[r] + lane_off;
 #pragma unroll
             for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tpB + (8 * (k >> 1)) * kTB + 8 * (k & 1));
             // (scratch elements of the upper row groups: the first row's X_I block, dead since that row's barrier)
-            pk2_row<true>(tpB, a0, t0, ntile, I + 1 - J0, xs, xi + kTB + rg, cslot, lds + kLdsXi + 32 * w + (lane & 31), rsum,
-                          sp->rowpartB, lane, w, col, cg, rg);
+            pk2_row<true>(tpB, a0, t0, ntile, I + r - J0, xs, xi + r * kTB + rg, cslot, lds + kLdsXi + 32 * w + (lane & 31), rsum,
+                          sp->rowpart[r], lane, w, col, cg, rg);
         } else if (threadIdx.x < 2 * kTB) {
-            gstore(sp->rowpartB + threadIdx.x, mk(0.0, 0.0));   // one-tile strips (tests): row I+1 has nothing in this column range
+            gstore(sp->rowpart[r] + threadIdx.x, mk(0.0, 0.0));   // short strips (tests): row I+r has nothing in this column range
         }
     }
     // the strip's column partials in one burst (the slot of a diagonal tile is written too; nobody reads it)
@@ -820,7 +820,7 @@ static int strip_len32_for(int nb) { return std::min(strip_len_for(nb), kMaxStri
 static int max_strips(int nb) {
     const int S = strip_len_for(nb);
     int n = 0;
-    for (int I = 0; I < nb; ++I) n += row_strip_count(nb, I, S);
+    for (int I = 0; I < nb; ++I) n += row_strip_count(nb, I, S, kRows64);
     return n;
 }
 static int max_strips32(int nb) {
@@ -956,8 +956,8 @@ int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t ma
 
 // Scheduling switches (scint_sweep_schedule; initial values from SCINT_SWEEP_DEPTH / SCINT_CHECK_EVERY / SCINT_SWEEP_GROUPS,
 // read ONCE per process -- until round 4 run_sweep called getenv three times per sweep).  0 = the measured default.  None
-// selects a different kernel or changes a result bit: they exist for the tests that prove exactly that, and for bench.py's
-// one-slot-group leg.
+// selects a different kernel; depth and groups change no result bit (the check cadence moves the pass a curvature stops at,
+// i.e. its value inside the tolerance): they exist for the tests that prove exactly that, and for bench.py's one-slot-group leg.
 struct SweepSchedule { std::atomic<int> depth{0}, check_every{0}, groups{0}; };
 static SweepSchedule& sweep_schedule() {
     static SweepSchedule sc;
@@ -1145,7 +1145,7 @@ struct SweepGroup {
             J.gen = ++slot_gen[(size_t)s];
             J.eig_out = S.eigs_out + e; J.status_out = S.status_out + e;
             J.iters_out = S.iters_out ? S.iters_out + e : nullptr;
-            J.use32 = S.mixed ? 1 : 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = S.mixed ? kRows32Lg : 1;
+            J.use32 = S.mixed ? 1 : 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = S.mixed ? kRows32Lg : kRows64Lg;
             J.scale32 = S.mixed ? S.scales_dev + c : nullptr;
             J.tol = S.mixed ? 0.5 * S.tol : S.tol;      // (the certificate then passes at the first attempt: measured 1.00 passes per curvature)
             slot_phase[(size_t)s] = 0;
@@ -1155,7 +1155,7 @@ struct SweepGroup {
         // the LAST pass of this chunk, so that the chunk's check sees its first (and, as a rule, only) step.
         for (const auto& rs : restart) {
             PackedJob& J = jobs[(size_t)rs.first];
-            J.use32 = 0; J.certify = 1; J.iters_base = rs.second; J.rowgroup_lg = 1;
+            J.use32 = 0; J.certify = 1; J.iters_base = rs.second; J.rowgroup_lg = kRows64Lg;
             J.strip_len = strip_len_for(J.nb);
             J.start = launch0 + S.check_every - 1;
             J.gen = ++slot_gen[(size_t)rs.first];
@@ -1210,24 +1210,20 @@ struct SweepGroup {
                     }
                     continue;
                 }
-                for (int I = 0; I < J.nb; I += 2) {                // rows I and I+1 together, cut on row I's column grid
-                    const int nrows = I + 1 < J.nb ? 2 : 1;
+                for (int I = 0; I < J.nb; I += kRows64) {          // rows I .. I+kRows64-1 together, cut on row I's column grid
+                    const int nrows = std::min(kRows64, J.nb - I);
                     int k = 0;
                     for (int J0 = I; J0 < J.nb; J0 += J.strip_len, ++k) {
                         Strip& st = hs[nstrips++];
-                        const int64_t t0 = tile_offset(J.nb, I) + (J0 - I);
-                        st.tiles = J.tiles + t0 * kTileElems;
                         st.Q = J.Q; st.qstride = J.qstride; st.qslots = J.qslots;
-                        st.rowpart = J.rowpart + 2 * (int64_t)(rs0[I] + k) * kTB;
-                        st.colpart = J.colpart + 2 * t0 * kTB;
+                        st.colpart = J.colpart + 2 * (tile_offset(J.nb, I) + (J0 - I)) * kTB;
                         st.state = J.state;
                         st.I = I; st.J0 = J0; st.ntile = std::min(J.nb, J0 + J.strip_len) - J0;
                         st.start = J.start; st.gen = J.gen; st.max_steps = J.max_steps; st.nrows = nrows;
-                        st.tilesB = st.tiles; st.rowpartB = st.rowpart;
-                        if (nrows == 2) {
-                            const int JB = std::max(J0, I + 1);
-                            st.tilesB = J.tiles + (tile_offset(J.nb, I + 1) + (JB - (I + 1))) * kTileElems;
-                            st.rowpartB = J.rowpart + 2 * (int64_t)(rs0[I + 1] + k) * kTB;
+                        for (int r = 0; r < kRows64; ++r) {
+                            const int Ir = std::min(I + r, J.nb - 1), JB = std::max(J0, Ir);
+                            st.tiles[r] = J.tiles + (tile_offset(J.nb, Ir) + (JB - Ir)) * kTileElems;
+                            st.rowpart[r] = J.rowpart + 2 * (int64_t)(rs0[Ir] + k) * kTB;
                         }
                     }
                 }
@@ -1409,6 +1405,8 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
         SCINT_REQUIRE(geom[c].dtau > 0 && geom[c].dfd > 0, "sweep: tau and fd must be increasing");
         SCINT_REQUIRE(geom[c].ntau == geom[0].ntau && geom[c].nfd == geom[0].nfd,
                       "sweep: all conjugate spectra must have one shape");
+        SCINT_REQUIRE((int64_t)geom[c].ntau * (int64_t)geom[c].nfd < ((int64_t)1 << 31),
+                      "sweep: a conjugate spectrum of 2^31 elements or more (the packed gather indexes it with 32 bits)");
     }
     SCINT_REQUIRE(!want_vec || (vec_out && vstride >= M), "sweep: bad eigenvector output");
     hipStream_t stream = (hipStream_t)stream_;
@@ -1505,7 +1503,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             PackedJob& J = grp.jobs[(size_t)s];
             J.tiles = (cplx*)(sl + L.tiles);
             J.tiles32 = S.mixed ? (c32*)(sl + L.tiles32) : nullptr;
-            J.scale32 = nullptr; J.use32 = 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = 1;
+            J.scale32 = nullptr; J.use32 = 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = kRows64Lg;
             J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
             J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
             J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);

@@ -40,10 +40,19 @@ __host__ __device__ inline int64_t tile_count(int nb) { return (int64_t)nb * (nb
 // strips: consecutive tiles (I, J0..J1) of one block row handled by one workgroup
 // (long strips amortise the per-workgroup prologue/epilogue; the length depends on nb only, so
 // the summation order -- and every bit of the result -- is independent of the batch)
+#ifndef SCINT_ROWS64
+#define SCINT_ROWS64 4          // (a build constant for the A/B of round 4 only: tools/build_variant.sh -DSCINT_ROWS64=2)
+#endif
+constexpr int kRows64 = SCINT_ROWS64;     // block rows per workgroup of the complex128 mat-vec: they share the X_J blocks and ONE column
+                                          // partial per column tile (round 3: 2 rows x <= 16 tiles; round 4: 4 x <= 14, the shape of the
+                                          // complex64 kernel -- 18 partial vectors per 56 tiles instead of 18 per 32)
+constexpr int kRows64Lg = kRows64 == 4 ? 2 : 1;
+static_assert(kRows64 == 2 || kRows64 == 4, "kRows64 must be 2 or 4");
+constexpr int kMaxStrip = kRows64 == 4 ? 14 : 16;    // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS)
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced > 16 ? 16 : forced;   // tests of schedule independence (16 = kMaxStrip of the mat-vec kernel)
-    return nb >= 32 ? 16 : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
+    if (forced > 0) return forced > kMaxStrip ? kMaxStrip : forced;   // tests of schedule independence
+    return nb >= 32 ? kMaxStrip : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
 }
 
 struct PackedJob {
@@ -60,7 +69,7 @@ struct PackedJob {
     int32_t use32;          // 1: the mat-vec of this job streams tiles32 (iteration phase of the mixed sweep)
     int32_t certify;        // 1: restarted on the complex128 tiles from the Ritz vectors of the iteration phase
     int32_t iters_base;     // passes of the iteration phase (certify: added to the reported count; restart: its T_k has 2 iters_base rows)
-    int32_t rowgroup_lg;    // log2 of the block rows that share one column partial: 1 (complex128 strips), 2 (complex64)
+    int32_t rowgroup_lg;    // log2 of the block rows that share one column partial: kRows64Lg (complex128 strips), kRows32Lg (complex64)
     // ---- Lanczos state -----------------------------------------------------------
     int32_t max_steps, strip_len;
     int32_t start, gen;     // launch index of this job's Lanczos step 0; generation of the slot (>= 1)
@@ -85,30 +94,25 @@ struct PackedJob {
     double tol;             // target relative accuracy of the eigenvalue
 };
 
-// One mat-vec workgroup's work: the tiles (I, J0 .. J0+ntile-1) of block row I and -- when nrows = 2 -- the
-// tiles of block row I+1 over the same columns (its first one is skipped when J0 = I: below the diagonal).
-// The two rows share the blocks X_J in LDS and ONE column partial per column tile (stored in the slots of
-// row I's tiles): half the partial-vector traffic of a row at a time, and that traffic is what a byte of
-// it costs four times a byte read (profiles/r03_pk2e_probe.txt).  The record carries every pointer the
-// workgroup needs, so that its tile loads are issued after ONE dependent load (this record) instead of
-// three (strip -> job table -> state word).
+// One mat-vec workgroup's work: the tiles (I + r, J0 .. J0+ntile-1) of the block rows I + r, r = 0 .. nrows-1 <= kRows64
+// (row I + r starts at column max(J0, I + r): nothing below the diagonal is stored).  The rows share the blocks X_J in
+// LDS and ONE column partial per column tile (stored in the slots of row I's tiles): a byte of partial-vector traffic
+// costs four times a byte read (profiles/r03_pk2e_probe.txt).  The record carries every pointer the workgroup needs, so
+// that its tile loads are issued after ONE dependent load (this record) instead of three (strip -> job table -> state word).
 struct __attribute__((aligned(16))) Strip {
-    const cplx* tiles;        // first tile of the strip, row I
-    const cplx* tilesB;       // first tile of row I+1 in the strip (column max(J0, I+1)); unused when nrows = 1
-    const cplx* Q;            // the job's Q ring (slot j % qslots holds Q_j, slots qstride*2 elements apart)
-    cplx* rowpart;            // row I's [64][2] row partials of this strip
-    cplx* rowpartB;           // row I+1's
-    cplx* colpart;            // [ntile][64][2] column partials, first column tile of the strip first
-    const int32_t* state;     // the slot's state word (job done <=> state[0] >= gen)
+    const cplx* tiles[kRows64];   // first tile of row I + r in the strip (column max(J0, I + r))
+    cplx* rowpart[kRows64];       // row I + r's [64][2] row partials of this strip
+    const cplx* Q;                // the job's Q ring (slot j % qslots holds Q_j, slots qstride*2 elements apart)
+    cplx* colpart;                // [ntile][64][2] column partials, first column tile of the strip first
+    const int32_t* state;         // the slot's state word (job done <=> state[0] >= gen)
     int64_t qstride;
     int32_t I, J0, ntile, qslots;
     int32_t start, gen, max_steps, nrows;
 };
 
-// Rows are paired (0,1), (2,3), ...; an unpaired last row (odd nb) runs alone.  The second row of a pair is
-// cut on the FIRST row's column grid, so both have the same number of strips.
-// (R = 4 rows per group for the complex64 strips: rows of a group are all cut on the FIRST row's grid.)
-inline int row_strip_count(int nb, int I, int S, int R = 2) {
+// Rows are grouped (0..R-1), (R..2R-1), ...; a short last group runs with the rows it has.  Every row of a group is
+// cut on the FIRST row's column grid, so all have the same number of strips.
+inline int row_strip_count(int nb, int I, int S, int R) {
     const int lead = I - I % R;                        // the row whose grid this row is cut on
     return (nb - lead + S - 1) / S;
 }

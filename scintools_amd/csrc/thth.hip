@@ -6,6 +6,7 @@
 // and the reference evaluates those expressions with one IEEE rounding per NumPy
 // ufunc.  A fused multiply-add would flip pixels.
 #include <map>
+#include <type_traits>
 #include <float.h>
 #include <math.h>
 
@@ -100,10 +101,11 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 //
 // Non-finite geometry (a_tau or a_fd NaN/inf) gives q = NaN -> the range test fails -> 0, which
 // is what the reference's  pnts  mask does with the int-converted NaN as well.
-struct GatherElem { int64_t off; double wgt; };
+struct GatherElem { int32_t off; double wgt; };   // off: element index into the conjugate spectrum (launch_gather_packed
+                                                  // refuses spectra of 2^31 elements or more), -1 = zero, -2 = NaN marker
 
 // Branch-free: `live` false (outside the matrix, the diagonal, the anti-diagonal) gives off = -1.
-__device__ inline GatherElem gather_elem(const GeomDev& g, double eta, double two_eta, double t2, double t1,
+__device__ inline GatherElem gather_elem(const GeomDev& g, int nfd, double eta, double two_eta, double t2, double t1,
                                          double sq2, double sq1, bool live) {
     // (theta2 = t2, theta1 = t1): ththmod.py:94-97 in the reference's operation order
     const double a_tau = ((eta * (sq1 - sq2)) - g.tau0) + g.half_dtau;
@@ -117,9 +119,9 @@ __device__ inline GatherElem gather_elem(const GeomDev& g, double eta, double tw
     const bool wrap_ok = qf >= -g.nfd_d;
     const int it = __double2int_rz(qt);                 // saturating conversions: harmless when !in
     int jf = __double2int_rz(qf);
-    jf += jf < 0 ? (int)g.nfd : 0;                      // NumPy's negative-index wrap
+    jf += jf < 0 ? nfd : 0;                             // NumPy's negative-index wrap
     GatherElem e;
-    e.off = in ? (wrap_ok ? (int64_t)it * g.nfd + jf : -2) : -1;
+    e.off = in ? (wrap_ok ? it * nfd + jf : -2) : -1;   // (in range: it < ntau, 0 <= jf < nfd, ntau nfd < 2^31)
     e.wgt = sqrt(fabs(two_eta * (t2 - t1)));
     return e;
 }
@@ -168,9 +170,16 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
     const int i_l = I * kTB + 16 * w + (lane & 15);
     const int ki_l = i_l < n ? gload(keep + i_l) : 0;
     const double thi_l = i_l < n ? gload(th + ki_l) : 0.0;
+    const int nfd = (int)g.nfd;
+    const int Mm1 = (int)(M - 1);
     GatherElem el[2][8];
     cplx val[2][8];
-    auto index_and_load = [&](int b) {
+    // DIAG is uniform over the workgroup (the tile's coordinates): an off-diagonal tile (2016 of the 2080 at N = 4095) has
+    // i < j for every element, so the selects between "upper element" and "conjugate of the mirrored one" -- four
+    // 64-bit selects and a sign per element -- exist only in the copy of the loop the 64 diagonal tiles run (round 4:
+    // 126 vector instructions per element before, profiles/r03_sweep_counters.txt)
+    auto index_and_load = [&](int b, auto diag_c) {
+        constexpr bool DIAG = decltype(diag_c)::value;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = I * kTB + 16 * w + 8 * b + k;    // wave-uniform
@@ -178,25 +187,30 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
             const double th_i = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(thi_l), 8 * b + k),
                                                  __builtin_amdgcn_readlane(__double2loint(thi_l), 8 * b + k));
             const double sq_i = th_i * th_i;
-            // upper element (i < j) reads (theta2 = th_i, theta1 = th_j); the lower half of a
-            // diagonal tile is the conjugate of the mirrored upper element
-            const bool up = !diag || i < j;
-            const bool live = i < n && jin && i != j && ((int64_t)ki + kj != M - 1);   // anti-diagonal: ththmod.py:113
-            el[b][k] = gather_elem(g, eta, two_eta, up ? th_i : th_j, up ? th_j : th_i, up ? sq_i : sq_j,
-                                   up ? sq_j : sq_i, live);
-            if (!up) el[b][k].wgt = -el[b][k].wgt;         // sign carries "conjugate"
+            const bool anti = ki + kj == Mm1;              // anti-diagonal: ththmod.py:113
+            if (DIAG) {
+                // upper element (i < j) reads (theta2 = th_i, theta1 = th_j); the lower half of a
+                // diagonal tile is the conjugate of the mirrored upper element
+                const bool up = i < j;
+                const bool live = i < n && jin && i != j && !anti;
+                el[b][k] = gather_elem(g, nfd, eta, two_eta, up ? th_i : th_j, up ? th_j : th_i, up ? sq_i : sq_j,
+                                       up ? sq_j : sq_i, live);
+                if (!up) el[b][k].wgt = -el[b][k].wgt;     // sign carries "conjugate"
+            } else {
+                el[b][k] = gather_elem(g, nfd, eta, two_eta, th_i, th_j, sq_i, sq_j, i < n && jin && !anti);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) val[b][k] = gload(cs + (el[b][k].off >= 0 ? el[b][k].off : 0));
     };
-    auto weight_and_store = [&](int b) {
+    auto weight_and_store = [&](int b, auto diag_c) {
+        constexpr bool DIAG = decltype(diag_c)::value;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const GatherElem e = el[b][k];
             const double aw = fabs(e.wgt);
-            const bool cj = e.wgt < 0.0;
             double vx = nan_to_num(val[b][k].x * aw), vy = nan_to_num(val[b][k].y * aw);
-            vy = cj ? -vy : vy;
+            if (DIAG) vy = e.wgt < 0.0 ? -vy : vy;
             // off == -1: outside the CS / diagonal / anti-diagonal -> 0;  off == -2: NumPy would
             // raise IndexError (cannot happen in a Hermitian job) -> NaN marker
             const double none = e.off == -2 ? nan("") : 0.0;
@@ -207,13 +221,20 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
     };
     // batch by batch (8 reads in flight per lane, ~100 VGPRs, 4 waves per SIMD); issuing both
     // batches' reads first (168 VGPRs, 3 waves) measured the same
-    index_and_load(0); weight_and_store(0); index_and_load(1); weight_and_store(1);
+    if (diag) {
+        const std::true_type d;
+        index_and_load(0, d); weight_and_store(0, d); index_and_load(1, d); weight_and_store(1, d);
+    } else {
+        const std::false_type d;
+        index_and_load(0, d); weight_and_store(0, d); index_and_load(1, d); weight_and_store(1, d);
+    }
 }
 
 int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJob* jobs_dev,
                              const int32_t* slots_dev, int njobs, int nbmax, hipStream_t stream, bool with32) {
     if (njobs <= 0 || nbmax <= 0) return SCINT_OK;
     SCINT_REQUIRE(nbmax <= 32767 && njobs <= 65535, "gather: grid too large");
+    SCINT_REQUIRE(M <= INT32_MAX, "gather: theta grid too large");
     const int slot = profiler().begin(kProfGather, stream);
     const dim3 grid((unsigned)tile_count(nbmax), (unsigned)njobs);
     if (with32) hipLaunchKernelGGL(thth_gather_packed_kernel<true>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);

@@ -426,6 +426,34 @@ def test_modeler_and_chisq_sweep(emu, to, case):
     np.testing.assert_allclose(chis, refc, rtol=1e-9)
 
 
+@pytest.mark.parametrize("nf,nt", [(96, 80), (97, 81), (64, 90)])
+def test_chisq_sweep_by_parseval_against_the_oracle(emu, to, nf, nt):
+    """npad = 0, no mask, finite dspec: scint_chisq_sweep takes chi^2 from recov and fft2(dspec) by Parseval's identity
+    (chisq_parseval_kernel) instead of transforming the model back -- even and odd axis lengths (the partner index
+    2 h - p mod P), against the oracle's chisq_calc (the reference's time-domain sum, ththmod.py:330-368) and against
+    the product's own per-eta chisq_calc, which still goes through the model.  A NaN pixel in dspec sends the sweep down
+    the model route (chisq_calc's default mask is then not all-true): same bar."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(nf, nt, seed=11, nimg=8, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 70)
+    CS = to.conjugate_spectrum(dyn, 0)
+    assert CS.shape == dyn.shape
+    etas = np.array([0.7, 1.0, 1.6]) * eta_true
+    got = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0)
+    ref = np.array([to.chisq_calc(dyn, CS, tau, fd, e, edges, 3.0) for e in etas])
+    np.testing.assert_allclose(got, ref, rtol=1e-9)
+    one = np.array([emu.chisq_calc(dyn, CS, tau, fd, e, edges, 3.0) for e in etas])
+    np.testing.assert_allclose(got, one, rtol=1e-11)
+    assert np.array_equal(got, emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0))
+    holed = dyn.copy()
+    holed[3, 5] = np.nan
+    got_h = emu.chisq_sweep(holed, CS, tau, fd, etas, edges, 3.0)
+    ref_h = np.array([to.chisq_calc(holed, CS, tau, fd, e, edges, 3.0) for e in etas])
+    np.testing.assert_allclose(got_h, ref_h, rtol=1e-9)
+
+
 def test_chunk_retrieval_in_byte_bounded_groups(emu, to, capsys):
     """the batched phase retrieval stacks conjugate spectra only up to a byte budget (groups, as the fit path
     does), and a chunk that cannot be prepared is left zero with its error printed while the others go on -- the reference's

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Build an experimental variant of libscint_hip.so without touching the tree:
-#   tools/build_variant.sh <name> [patch ...]      -> variants/<name>.so   (git-ignored, travels with gpurun)
+#   tools/build_variant.sh <name> [patch | -DNAME=VALUE ...]      -> variants/<name>.so   (git-ignored, travels with gpurun)
 # The patches (git diff format, relative to the repository root) are applied to a scratch copy of
-# scintools_amd/ + include/.  On the GPU box an A/B swaps the library file:
+# scintools_amd/ + include/; -D arguments are passed to every compile (then every unit is rebuilt).  On the GPU box an A/B swaps the library file:
 #   cp variants/<name>.so scintools_amd/libscint_hip.so
 set -eu
 name=$1; shift
@@ -13,7 +13,13 @@ cp -rp "$R/include" "$W/include"
 mkdir -p "$W/scintools_amd"
 cp -p "$R"/scintools_amd/*.py "$W/scintools_amd/"
 cp -rp "$R/scintools_amd/csrc" "$W/scintools_amd/csrc"     # with the objects: only patched units are rebuilt
-for p in "$@"; do (cd "$W" && patch -p1 -s < "$p"); done
-(cd "$W" && python -c "from scintools_amd import build; build.build(verbose=False)")
+flags=""; force=False
+for p in "$@"; do
+  case "$p" in
+    -D*) flags="$flags $p"; force=True ;;
+    *) (cd "$W" && patch -p1 -s < "$p") ;;
+  esac
+done
+(cd "$W" && SCINT_VARIANT_FLAGS="$flags" python -c "from scintools_amd import build; build.build(force=$force, verbose=False)")
 cp "$W/scintools_amd/libscint_hip.so" "$R/variants/$name.so"
 echo "variants/$name.so"
