@@ -30,9 +30,17 @@ def cases():
             ("wide_bins", 300, 40, 400, 1.0, False, 0.9),
             ("sparse_theta", 256, 256, 60, 1.0, False, 1.0),
             ("chunks_and_slabs", 2200, 48, 1200, 1.0, False, 1.0),
-            ("chunks_and_slabs_steep", 2500, 40, 1100, 3.0, True, 1.0)):
+            ("chunks_and_slabs_steep", 2500, 40, 1100, 3.0, True, 1.0),
+            # round 4 (paired columns of the rank-1 Hermitian back-map): odd axis lengths (mirror column S - c with
+            # S = n - 1), three delay slabs of the paired kernel, and axes that are NOT symmetric about 0 (plain kernel)
+            ("odd_axes", 97, 81, 120, 1.0, False, 1.0),
+            ("odd_axes_slabs", 1301, 37, 500, 1.3, True, 1.0),
+            ("shifted_axes", 96, 80, 100, 1.0, False, 1.0)):
         tau = (np.arange(ntau) - ntau // 2) * 0.0137
         fd = (np.arange(nfd) - nfd // 2) * 0.211
+        if name == "shifted_axes":
+            tau = tau + 0.3 * 0.0137
+            fd = fd - 0.4 * 0.211
         edges = np.linspace(-span * fd.max() / 2, span * fd.max() / 2, nedge)
         if irregular:
             edges = np.sort(edges + rng.uniform(-0.3, 0.3, nedge) * (edges[1] - edges[0]))
