@@ -685,6 +685,15 @@ def main():
                     "eta_per_s": neta * min(args.steps, 3) / one["elapsed"],
                     "note": "the mat-vec kernel with the GPU to itself: same sweep, one slot group on one stream "
                             "(launches do not overlap; achieved = algorithmic bytes / sum of the launch durations)"}
+            one_ga_s = one["busy_ms"][0] / 1e3
+            if one_ga_s > 0:
+                ga_one = gather_bytes / args.steps * min(args.steps, 3)
+                out["gather"]["one_slot_group"] = {
+                    "achieved_GBs": ga_one / one_ga_s / 1e9, "frac": ga_one / one_ga_s / 1e9 / HBM_PEAK_GBS,
+                    "avg_launch_ms": one["sum_ms"][0] / max(1, one["launches"][0]),
+                    "note": "the gather kernel with the GPU to itself (the one-slot-group sweep above: nothing runs beside "
+                            "it); `frac` of this object's parent is its rate while the other group's mat-vec and the "
+                            "reduce blocks share the GPU with it"}
         if world == 1 and args.objective == "chisq" and len(dyns) == 1:
             # the chi^2 objective as the headline region (tools/gpu_run.sh modeler / pmc_modeler): the same object
             out["modeler"] = modeler_objects(head, args.steps, neta, etas, eta_true, 16.0 * R * C, 8.0 * size * size)

@@ -995,7 +995,11 @@ static char* pinned_staging(size_t bytes) {
 // `tail[kTailLanes]` (chi^2 sweep only) run the per-curvature model steps of the retired curvatures, round robin.
 // (Measured in round 3, profiles/r03_tail_schedule_ab.json: highest stream priority for the tail streams costs
 // 6 %, 1 / 2 / 4 lanes and 36-KiB / 144-KiB back-map workgroups are within 3 % of each other -- the chi^2 sweep
-// is bound by the SUM of the mat-vec's and the tail kernels' GPU time, not by how they interleave.)
+// is bound by the SUM of the mat-vec's and the tail kernels' GPU time, not by how they interleave.  Round 4,
+// profiles/r04_tail_schedule_ab.txt, confirmed it from the other side: LOWEST priority for the tail streams, a
+// back-map capped at 256 / 512 / 1024 resident workgroups, 320- and 512-row slabs that fit beside two mat-vec
+// workgroups, three or four mat-vec workgroups per CU: all within +-2 % or worse.  What moves the sweep is less
+// GPU time in the tail kernels themselves.)
 // The sweep's events live here too, created once with the streams (until round 4 run_sweep created and destroyed ~20 of them
 // per call): a sweep drains every stream before it returns, so the next sweep of the thread finds them all idle.
 constexpr int kTabsEv = 3;   // = kTabs (declared below)

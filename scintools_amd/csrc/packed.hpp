@@ -48,7 +48,11 @@ constexpr int kRows64 = SCINT_ROWS64;     // block rows per workgroup of the com
                                           // complex64 kernel -- 18 partial vectors per 56 tiles instead of 18 per 32)
 constexpr int kRows64Lg = kRows64 == 4 ? 2 : 1;
 static_assert(kRows64 == 2 || kRows64 == 4, "kRows64 must be 2 or 4");
-constexpr int kMaxStrip = kRows64 == 4 ? 14 : 16;    // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS)
+#ifndef SCINT_MAXSTRIP
+#define SCINT_MAXSTRIP (SCINT_ROWS64 == 4 ? 14 : 16)
+#endif
+constexpr int kMaxStrip = SCINT_MAXSTRIP;            // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS:
+                                                     // 14 -> 72 KiB, two workgroups per CU; 9 -> 52 KiB, three; 6 -> 40 KiB, four)
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced > kMaxStrip ? kMaxStrip : forced;   // tests of schedule independence

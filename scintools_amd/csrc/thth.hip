@@ -6,7 +6,6 @@
 // and the reference evaluates those expressions with one IEEE rounding per NumPy
 // ufunc.  A fused multiply-add would flip pixels.
 #include <map>
-#include <stdio.h>
 #include <type_traits>
 #include <float.h>
 #include <math.h>
@@ -356,17 +355,11 @@ struct RevParams {
     int64_t centre;   // flat index of the pixel the i == j terms poison, or -1
     cplx* recov;      // [ntau, nfd], or its transpose [nfd, ntau] when `transposed`
     int transposed;   // column-major output: every workgroup writes one contiguous run (chi^2 sweep)
-    const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel)
-    // paired columns (rev_gather_kernel<.., SYM>; rank-1 Hermitian model, axes symmetric about 0): a workgroup evaluates
-    // a pair (i, j) ONCE and adds it to column c and, conjugated, to the mirror column sym_fd - c.  sym_fd / sym_tau are
-    // only where the mirror pixel is EXPECTED (column c <-> sym_fd - c, row r <-> sym_tau - r): every bin is settled
-    // exactly from the pair's own coordinates, as in the plain kernel.
-    int sym_fd, sym_tau;
-    int col0;                          // SYM: direct column of workgroup x is col0 + x
-    int nplain; int plain_cols[4];     // plain kernel over these columns only (nplain > 0) instead of all nfd
+    const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel);
+                                       // [2..6] the per-image constants of rev_setup_kernel (RevConsts)
+    double inv_tau1_step;              // 1 / tau1_step (host: the same IEEE quotient the kernel used to form per wavefront)
 };
 
-constexpr int kRevSymExtra = 8;    // rows the mirror slab of a paired workgroup may have beyond `slab` (|sym_tau - ntau| <= 4)
 constexpr int kRevSlab = 1024;     // most tau rows accumulated per workgroup: 1024 * 36 B = 36 KiB of LDS
 constexpr int kRevThreadsK = 256;  // threads per workgroup
 // Round 2 ran one 1024-thread workgroup with 144 KiB of LDS per Doppler column (all 4096 delay rows):
@@ -474,6 +467,29 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
     return a;
 }
 
+// Per-IMAGE constants, formed once by one thread instead of by each of the 65 536 wavefronts of a 4096^2 back-map
+// (round 4: with the walk and the pair arithmetic switched off the kernel still took 0.116 of its 0.295 ms -- prologue,
+// pre-pass and epilogue; the split grid alone is a frexp, two ldexp, a square root and a division, the window two more
+// divisions): the split grid of rev_split_for, the mean theta spacing and the window width.  Same expressions, same bits.
+constexpr int kRevWin = 8;   // widest candidate window (theta centres per fd bin, + 2)
+enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6 };
+__global__ void __launch_bounds__(64) rev_setup_kernel(RevParams p, GeomDev g, unsigned long long* bound) {
+    if (threadIdx.x != 0) return;
+    const double aw = p.rank1 ? fabs(gload(p.w)) : 0.0;
+    const double vmax = __longlong_as_double((long long)bound[0]);
+    const RevSplit sp = rev_split_for(p.rank1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)bound[1]),
+                                      p.two_eta, !p.rank1 && p.hermitian);
+    const int N = p.N;
+    // window width from the mean theta spacing (the window START depends on the column and stays in the gather)
+    const double th_step = N > 1 ? (gload(p.th + N - 1) - gload(p.th)) / (double)(N - 1) : 0.0;
+    const int W = th_step > 0.0 ? (int)fmin(ceil(g.fd1_step / th_step) + 2.0, (double)kRevWin) : 0;
+    bound[kRevS1] = (unsigned long long)__double_as_longlong(sp.s1);
+    bound[kRevS2] = (unsigned long long)__double_as_longlong(sp.s2);
+    bound[kRevExact] = sp.exact ? 1ull : 0ull;
+    bound[kRevThStep] = (unsigned long long)__double_as_longlong(th_step);
+    bound[kRevW] = (unsigned long long)(W < 0 ? 0 : W);
+}
+
 // One workgroup owns the `slab` tau rows [blockIdx.y*slab, ...) of ONE fd column of recov
 // and gathers every theta-theta pixel that np.histogram2d would drop there
 // (ththmod.py:207-262): for each i the j with fd_map[i, j] in the column form one short
@@ -494,103 +510,63 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // (j, i) exactly where the direct image of (i, j) falls (negation is exact in floating
 // point), so pixel (i, j) contributes  w_ij + conj(w_ji)  with count 2.  For the rank-1
 // Hermitian model w_ji == conj(w_ij) exactly, and sum and count are both halved.
-constexpr int kRevWin = 8;   // widest candidate window (theta centres per fd bin, + 2)
-constexpr int kRevBlock = 16;       // lanes per block of the chunk pre-pass
+constexpr int kRevBlock = 256;      // lanes per block of the chunk pre-pass: a whole chunk (round 3 used 16-lane blocks so that every thread had
+                                    // one; the hull argument below does not care about the block length, and with one block per chunk
+                                    // three of the four wavefronts skip the pre-pass instead of issuing it)
 constexpr int kRevLiveWords = 64;   // 32 chunks per word: N <= 524288 is pruned, beyond that every chunk is walked
 
-template <int kRevThreads, bool RANK1, bool SYM>
+template <int kRevThreads, bool RANK1>
 __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
-    static_assert(!SYM || RANK1, "paired columns: rank-1 Hermitian model only");
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
     // rev_lds[0 .. 4 slab): real hi, real lo, imag hi, imag lo grids; then the counts.  Always
     // indexed off the __shared__ array itself so that every access stays an LDS instruction.
-    // SYM: a second set of the same for the mirror column, slab2 = slab + kRevSymExtra rows, 5 slab doubles on.
-    const int slab2 = slab + kRevSymExtra;
-    const int set2 = (9 * slab + 1) / 2;               // (counts take half a double per row: 4.5 slab doubles per set)
+    uint32_t* cnt = (uint32_t*)(rev_lds + 4 * slab);
     // columns of 4 neighbouring workgroups of one XCD are adjacent, so their 16 B stores
     // complete 64 B lines in that XCD's L2
     int64_t col = blockIdx.x;
-    if (SYM) col = p.col0 + (int64_t)blockIdx.x;
-    else if (p.nplain > 0) col = p.plain_cols[blockIdx.x];
-    else if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);
-    const int64_t colm = SYM ? (int64_t)p.sym_fd - col : 0;            // the mirror column (host: 0 <= colm < nfd, colm != col)
+    if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);
     const int64_t row0 = (int64_t)blockIdx.y * slab;
     const int rows = (int)min((int64_t)slab, g.ntau - row0);
-    // mirror rows of the slab: [S - (row0 + rows) + 1, S - row0] -- consecutive slabs tile the mirror column downwards --
-    // with the first slab taking everything up to ntau - 1 and the last one everything down to 0
-    int64_t mrow0 = 0; int mrows = 0;
-    if (SYM) {
-        int64_t mhi = (int64_t)p.sym_tau - row0, mlo = (int64_t)p.sym_tau - (row0 + rows) + 1;
-        if (row0 == 0) mhi = g.ntau - 1;
-        if (row0 + rows >= g.ntau) mlo = 0;
-        mhi = min(mhi, g.ntau - 1); mlo = max(mlo, (int64_t)0);
-        mrow0 = mlo; mrows = (int)max((int64_t)0, min(mhi - mlo + 1, (int64_t)slab2));
-    }
     for (int r = threadIdx.x; r < rows; r += kRevThreads) {
         rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0; rev_lds[2 * slab + r] = 0.0; rev_lds[3 * slab + r] = 0.0;
         ((uint32_t*)(rev_lds + 4 * slab))[r] = 0u;
     }
-    if (SYM)
-        for (int r = threadIdx.x; r < mrows; r += kRevThreads) {
-            rev_lds[set2 + r] = 0.0; rev_lds[set2 + slab2 + r] = 0.0; rev_lds[set2 + 2 * slab2 + r] = 0.0; rev_lds[set2 + 3 * slab2 + r] = 0.0;
-            ((uint32_t*)(rev_lds + set2 + 4 * slab2))[r] = 0u;
-        }
     __syncthreads();
 
     const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;        // histogram edges of the column
     const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
     const bool last = (col == g.nfd - 1);                              // last bin is closed on the right
-    const double lom = ((double)colm - 0.5) * g.fd1_step + g.fd0;      // ... and of the mirror column
-    const double him = ((double)(colm + 1) - 0.5) * g.fd1_step + g.fd0;
-    const bool lastm = (colm == g.nfd - 1);
-    // x = th_j - th_i is wanted when it lies in the column (direct image) or when -x lies in the mirror column (the
-    // image of (j, i), which this workgroup adds too): the candidates are those of the hull [ulo, uhi] of both intervals
-    const double ulo = SYM ? fmin(lo, -him) : lo, uhi = SYM ? fmax(hi, -lom) : hi;
     const double aw = RANK1 ? fabs(gload(p.w)) : 0.0;
-    const double vmax = __longlong_as_double((long long)p.bound[0]);
-    const RevSplit sp = rev_split_for(RANK1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)p.bound[1]),
-                                      p.two_eta, !RANK1 && p.hermitian);
+    // the image's constants (rev_setup_kernel): uniform loads
+    RevSplit sp;
+    sp.s1 = __longlong_as_double((long long)p.bound[kRevS1]);
+    sp.s2 = __longlong_as_double((long long)p.bound[kRevS2]);
+    sp.exact = p.bound[kRevExact] != 0ull;
     const int N = p.N;
-    // window start relative to i, and its width, from the mean theta spacing
-    const double th_step = N > 1 ? (gload(p.th + N - 1) - gload(p.th)) / (double)(N - 1) : 0.0;
-    const bool grid_ok = th_step > 0.0 && isfinite(ulo / th_step) && fabs(ulo / th_step) < 1e9;
-    const int s0 = grid_ok ? (int)floor(ulo / th_step) - 1 : 0;
-    const int W = grid_ok ? (int)fmin(ceil((uhi - ulo) / th_step) + 2.0, (double)kRevWin) : 0;
+    // window start relative to i (its width W comes with the constants), from the mean theta spacing
+    const double th_step = __longlong_as_double((long long)p.bound[kRevThStep]);
+    const double q0 = lo / th_step;
+    const bool grid_ok = th_step > 0.0 && isfinite(q0) && fabs(q0) < 1e9;
+    const int s0 = grid_ok ? (int)floor(q0) - 1 : 0;
+    const int W = grid_ok ? (int)p.bound[kRevW] : 0;
     const bool usable = g.fd1_step > 0.0 && g.tau1_step > 0.0;
 
-    const double inv_tstep = 1.0 / g.tau1_step;
-    // the delay rows a pair has to come near to matter here, as estimates of bin + 0.5 of its DIRECT image: the slab,
-    // and (SYM) the rows whose mirror is the mirror slab
-    const int64_t prow0 = SYM ? min(row0, (int64_t)p.sym_tau - (mrow0 + mrows - 1)) : row0;
-    const int64_t prow1 = SYM ? max(row0 + rows, (int64_t)p.sym_tau - mrow0 + 1) : row0 + rows;
-    const double row_lo = (double)prow0 - 2.0, row_hi = (double)prow1 + 1.0;
+    const double inv_tstep = p.inv_tau1_step;
+    const double row_lo = (double)row0 - 2.0, row_hi = (double)(row0 + rows) + 1.0;   // estimate of bin + 0.5
     auto beyond = [&](double x) { return last ? (x > hi) : (x >= hi); };
-    auto beyond_u = [&](double x) { return SYM ? (x > uhi) : beyond(x); };     // past every candidate
-    auto in_direct = [&](double x) { return x >= lo && !beyond(x); };
-    auto in_mirror = [&](double x) { const double xm = -x; return xm >= lom && !(lastm ? (xm > him) : (xm >= him)); };
     // What pair (i, j) adds to the slab: ONE guarded region per test (slab estimate, exact bin) -- results that
     // leave a chain of early returns as a struct cost a move or a select per field and per exit
     // (profiles/r03_revmap_counters.txt: 58 % of the kernel's vector instructions were neither arithmetic nor index work).
-    auto pair = [&](int i, int j, double th_i, double th_j, bool dir, bool mir) {
+    auto pair = [&](int i, int j, double th_i, double th_j) {
         const double y = p.eta * (th_j * th_j - th_i * th_i);          // tau_map[i, j] (ththmod.py:208-210)
         // cheap slab test first (two rows of slack cover the rounding of this estimate): the exact
         // bin, the weight and the loads are only paid for by the slab that owns the pixel
         const double est = (y - g.tau0) * inv_tstep;
         if (i == j || est < row_lo || est > row_hi) return;            // i == j lands in the poisoned centre bin
-        int by = -1, bm = -1;
-        if (dir) {
-            const int bin = hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, (int)g.ntau);
-            const int b = bin - (int)row0;
-            by = (bin >= 0 && b >= 0 && b < rows) ? b : -1;
-        }
-        if (SYM && mir) {
-            // tau_map[j, i] = -y exactly (negation commutes with every rounding above); its bin from its own value
-            const int bin = hist_bin_rcp(-y, g.tau0, g.tau1_step, inv_tstep, (int)g.ntau);
-            const int b = bin - (int)mrow0;
-            bm = (bin >= 0 && b >= 0 && b < mrows) ? b : -1;
-        }
-        if (by < 0 && bm < 0) return;
+        const int bin = hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, (int)g.ntau);
+        const int by = bin - (int)row0;
+        if (bin < 0 || by < 0 || by >= rows) return;
         // thth / sqrt(|2 eta fd_map.T|): NumPy divides complex by real as v * (1/c)
         const double scl = rsqrt(fabs(p.two_eta * (th_i - th_j)));   // (1 / sqrt costs a division on top: 25 instructions against 10)
         double wr, wi;
@@ -607,47 +583,29 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
                 c = 2u;
             }
         }
-        // (the image of (j, i) is the conjugate, bit for bit: mulc(v_j, v_i) = conj(mulc(v_i, v_j)) and |th_j - th_i| is the
-        //  same number; rounding to the split grid is odd, so its parts are the negated parts)
         if (sp.exact) {
             const double rh = (wr + sp.s1) - sp.s1, ih = (wi + sp.s1) - sp.s1;
-            const double rl = ((wr - rh) + sp.s2) - sp.s2, il = ((wi - ih) + sp.s2) - sp.s2;
-            if (by >= 0) {
-                atomicAdd(&rev_lds[by], rh);
-                atomicAdd(&rev_lds[2 * slab + by], ih);
-                atomicAdd(&rev_lds[slab + by], rl);
-                atomicAdd(&rev_lds[3 * slab + by], il);
-            }
-            if (SYM && bm >= 0) {
-                atomicAdd(&rev_lds[set2 + bm], rh);
-                atomicAdd(&rev_lds[set2 + 2 * slab2 + bm], -ih);
-                atomicAdd(&rev_lds[set2 + slab2 + bm], rl);
-                atomicAdd(&rev_lds[set2 + 3 * slab2 + bm], -il);
-            }
+            atomicAdd(&rev_lds[by], rh);
+            atomicAdd(&rev_lds[2 * slab + by], ih);
+            atomicAdd(&rev_lds[slab + by], ((wr - rh) + sp.s2) - sp.s2);
+            atomicAdd(&rev_lds[3 * slab + by], ((wi - ih) + sp.s2) - sp.s2);
         } else {
-            if (by >= 0) {
-                atomicAdd(&rev_lds[by], wr);
-                atomicAdd(&rev_lds[2 * slab + by], wi);
-            }
-            if (SYM && bm >= 0) {
-                atomicAdd(&rev_lds[set2 + bm], wr);
-                atomicAdd(&rev_lds[set2 + 2 * slab2 + bm], -wi);
-            }
+            atomicAdd(&rev_lds[by], wr);
+            atomicAdd(&rev_lds[2 * slab + by], wi);
         }
-        if (by >= 0) atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
-        if (SYM && bm >= 0) atomicAdd((uint32_t*)(rev_lds + set2 + 4 * slab2) + bm, c);
+        atomicAdd((uint32_t*)(rev_lds + 4 * slab) + by, c);
     };
     // (Summing the runs of lanes that hit one accumulator in registers first -- a segmented scan over the
     // wave, legal because the grid-split addends sum exactly in any association -- was measured in round 3:
     // 0.58 ms against 0.38 ms per 4096^2 image.  The kernel is bound by its fp64 arithmetic per pair
     // (exact bin, 1/sqrt, split), not by the LDS atomics.)
-    const double lo_hi_min = fmin(ulo, uhi), lo_hi_max = fmax(ulo, uhi);
-    // Every pair of theta_i in this column has x = th_j - th_i in [ulo, uhi] and y = eta x (2 th_i + x): a parabola
+    const double lo_hi_min = fmin(lo, hi), lo_hi_max = fmax(lo, hi);
+    // Every pair of theta_i in this column has x = th_j - th_i in [lo, hi] and y = eta x (2 th_i + x): a parabola
     // in x, extremal at the interval ends or at its vertex x = -th_i.  If that range of y misses the slab by more
     // than a row on either side of the slack `pair` already allows, no pair of theta_i lands here.  (NaNs compare
     // false: such a lane goes on.)
     auto delay_range = [&](double th_i, double& ymin, double& ymax) {
-        const double ya = p.eta * (ulo * (2.0 * th_i + ulo)), yb = p.eta * (uhi * (2.0 * th_i + uhi));
+        const double ya = p.eta * (lo * (2.0 * th_i + lo)), yb = p.eta * (hi * (2.0 * th_i + hi));
         ymin = fmin(ya, yb); ymax = fmax(ya, yb);
         if (-th_i >= lo_hi_min && -th_i <= lo_hi_max) {
             const double yv = -(p.eta * (th_i * th_i));
@@ -659,19 +617,21 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
     };
     // Which 256-lane chunks of theta_i can reach the slab at all?  A slab is reached by a contiguous run of i, and
     // four slabs of a column used to walk all N lanes each -- a quarter of the kernel's vector instructions
-    // (profiles/r03_revmap_counters.txt).  One pass over BLOCKS of 16 lanes instead: for a fixed x the delay is
+    // (profiles/r03_revmap_counters.txt).  One pass over BLOCKS of lanes instead (kRevBlock): for a fixed x the delay is
     // monotone in theta_i (also as computed: every operation of `delay_range` is monotone in its rounded operand),
     // so the range of any lane of a block lies in the hull of the ranges of the block's two end lanes -- plus the
     // vertex values a lane in between may add (theta^2 is monotone on either side of 0).  That needs theta
     // increasing, which the bound pre-pass has checked (its minimum spacing is 0 otherwise).
     __shared__ uint32_t live[kRevLiveWords];
+    __shared__ double rcp_small[64];                                   // 1 / count of the epilogue (an IEEE division per PIXEL was a tenth of the kernel)
+    if (threadIdx.x < 64) rcp_small[threadIdx.x] = 1.0 / (double)threadIdx.x;
     static_assert(kRevThreads % kRevBlock == 0, "a block of the pre-pass lies inside one chunk");
     const int nchunk = (N + kRevThreads - 1) / kRevThreads;
     const bool prune = usable && nchunk <= 32 * kRevLiveWords && __longlong_as_double((long long)p.bound[1]) > 0.0;
     if (threadIdx.x < kRevLiveWords) live[threadIdx.x] = prune ? 0u : ~0u;
     __syncthreads();
     if (prune) {
-        for (int ia = (int)threadIdx.x * kRevBlock; ia < N; ia += kRevThreads * kRevBlock) {
+        for (int ia = (int)threadIdx.x * kRevBlock; ia < N; ia += kRevThreads * kRevBlock) {      // (one wavefront's work at N <= 16 384)
             const double ta = gload(p.th + ia), tb = gload(p.th + min(N - 1, ia + kRevBlock - 1));
             double ymin, ymax, ymin_b, ymax_b;
             delay_range(ta, ymin, ymax);
@@ -716,8 +676,8 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
         double t_hi = tj[1];                                           // tj[W + 1] without dynamic indexing
 #pragma unroll
         for (int k = 2; k < kRevWin + 2; ++k) t_hi = (k == W + 1) ? tj[k] : t_hi;
-        const bool below_ok = (g0 - 1 < 0) || !(tj[0] - th_i >= ulo);
-        const bool above_ok = (g0 + W >= N) || beyond_u(t_hi - th_i);
+        const bool below_ok = (g0 - 1 < 0) || !(tj[0] - th_i >= lo);
+        const bool above_ok = (g0 + W >= N) || beyond(t_hi - th_i);
         const bool windowed = active && W > 0 && below_ok && above_ok;
         // This lane's pairs are the j of ONE run ja .. ja + nj - 1 (fl(th[j] - th_i) is non-decreasing in j): from the
         // window when its guards bracket the column, else from a search.  One loop then serves every lane -- its trip
@@ -731,7 +691,7 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
                 if (k > W) break;                                      // W is uniform over the workgroup
                 const int j = g0 - 1 + k;
                 const double x = tj[k] - th_i;                         // fd_map[i, j]  (ththmod.py:207)
-                if ((unsigned)j < (unsigned)N && x >= ulo && !beyond_u(x)) {
+                if ((unsigned)j < (unsigned)N && x >= lo && !beyond(x)) {
                     if (kl < 0) kf = k;
                     kl = k;
                 }
@@ -739,9 +699,9 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
             ja = g0 - 1 + kf;
             nj = kl < 0 ? 0 : kl - kf + 1;
         } else if (active) {                                           // irregular grid
-            ja = rev_first_ge(p.th, N, th_i, ulo, g0);
+            ja = rev_first_ge(p.th, N, th_i, lo, g0);
             int jb = ja;
-            while (jb < N && !beyond_u(gload(p.th + jb) - th_i)) ++jb;
+            while (jb < N && !beyond(gload(p.th + jb) - th_i)) ++jb;
             nj = jb - ja;
         }
         for (int r = 0; __ballot(r < nj) != 0ull; ++r) {
@@ -749,10 +709,9 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
                 const int j = ja + r;
                 const double th_j = gload(p.th + j);
                 const double x = th_j - th_i;
-                // (every position is tested on its own: a position outside the column may sit between two inside it
-                // when theta is not monotone to the last bit, and the hull of two columns is wider than either)
-                const bool dir = in_direct(x), mir = SYM && in_mirror(x);
-                if (dir || mir) pair(i, j, th_i, th_j, dir, mir);
+                // (inside a window every position is tested on its own, as a position outside the column may sit
+                // between two inside it when theta is not monotone to the last bit)
+                if (!windowed || (x >= lo && !beyond(x))) pair(i, j, th_i, th_j);
             }
         }
     }
@@ -763,23 +722,14 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
         const int64_t o = (row0 + r) * g.nfd + col;
         cplx out = mk(0.0, 0.0);
         if (o != p.centre) {
-            const double scl = 1.0 / (double)((uint32_t*)(rev_lds + 4 * slab))[r];
+            const uint32_t c = cnt[r];
+            double scl;
+            if (c < 64u) scl = rcp_small[c]; else scl = 1.0 / (double)c;
             out = mk(nan_to_num((rev_lds[r] + rev_lds[slab + r]) * scl),
                      nan_to_num((rev_lds[2 * slab + r] + rev_lds[3 * slab + r]) * scl));
         }
         gstore(p.recov + (p.transposed ? col * g.ntau + (row0 + r) : o), out);
     }
-    if (SYM)
-        for (int r = threadIdx.x; r < mrows; r += kRevThreads) {
-            const int64_t o = (mrow0 + r) * g.nfd + colm;
-            cplx out = mk(0.0, 0.0);
-            if (o != p.centre) {
-                const double scl = 1.0 / (double)((uint32_t*)(rev_lds + set2 + 4 * slab2))[r];
-                out = mk(nan_to_num((rev_lds[set2 + r] + rev_lds[set2 + slab2 + r]) * scl),
-                         nan_to_num((rev_lds[set2 + 2 * slab2 + r] + rev_lds[set2 + 3 * slab2 + r]) * scl));
-            }
-            gstore(p.recov + (p.transposed ? colm * g.ntau + (mrow0 + r) : o), out);
-        }
 }
 
 RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, int rank1, const double* th, int N,
@@ -798,13 +748,12 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     p.recov = recov;
     p.transposed = 0;
     p.bound = nullptr;
-    p.sym_fd = p.sym_tau = 0; p.col0 = 0; p.nplain = 0;
-    for (int& c : p.plain_cols) c = 0;
+    p.inv_tau1_step = 1.0 / g.tau1_step;
     return p;
 }
 
 // Enqueue the back-map: bound pre-pass (max |value|, min theta spacing) + the column gather.
-int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound /*[2] device scratch*/,
+int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound /*[8] device scratch*/,
                        hipStream_t stream) {
     // bound[0] = 0.0 (max), bound[1] = 0x7f7f7f7f7f7f7f7f = 1.4e306 (min: above any spacing) as bit patterns,
     // written by the device (no host buffer involved: a pageable source would make this an in-line staged
@@ -814,56 +763,16 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     const int64_t nvals = p.rank1 ? (int64_t)p.N : (int64_t)p.N * p.N;
     const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
     hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
+    hipLaunchKernelGGL(rev_setup_kernel, dim3(1), dim3(64), 0, stream, p, g, bound);
     p.bound = bound;
-    // Paired columns for the rank-1 Hermitian model when both axes are symmetric about 0 (fftshift-ed fft axes are): the
-    // image of (j, i) is the conjugate of the image of (i, j) at the mirrored coordinates, so a workgroup that owns
-    // column c and column S_fd - c evaluates every pair once (half the pair arithmetic of the image).  The mirror
-    // guesses S only decide which pixels a workgroup owns; every bin is computed exactly from the pair's coordinates.
-    static const bool no_sym = [] { const char* e = getenv("SCINT_REV_PLAIN"); return e && atoi(e) != 0; }();
-    bool sym = p.rank1 && p.hermitian && !no_sym && g.fd1_step > 0.0 && g.tau1_step > 0.0 && g.nfd >= 8 && g.ntau >= 8;
-    int64_t S_fd = 0, S_tau = 0;
-    if (sym) {
-        const double sf = -2.0 * g.fd0 / g.fd1_step, st = -2.0 * g.tau0 / g.tau1_step;
-        sym = isfinite(sf) && isfinite(st) && fabs(sf - rint(sf)) < 1e-6 && fabs(st - rint(st)) < 1e-6;
-        if (sym) {
-            S_fd = (int64_t)rint(sf); S_tau = (int64_t)rint(st);
-            sym = llabs(S_fd - g.nfd) <= 2 && llabs(S_tau - g.ntau) <= 4;
-        }
-    }
-    int plain[4], nplain = 0;
-    int64_t c_first = 0, c_last = -1;
-    if (sym) {
-        // direct columns c in (S/2, min(nfd - 1, S)], mirror S - c in [0, S/2); what is left runs the plain kernel
-        c_first = S_fd / 2 + 1; c_last = std::min<int64_t>(g.nfd - 1, S_fd);
-        for (int64_t c = 0; c < g.nfd && sym; ++c) {
-            const int64_t d = std::max(c, S_fd - c);                // the direct column of c's pair
-            const bool paired = S_fd - c >= 0 && S_fd - c < g.nfd && S_fd - c != c && d >= c_first && d <= c_last;
-            if (!paired) { if (nplain < 4) plain[nplain++] = (int)c; else sym = false; }
-        }
-        sym = sym && c_last >= c_first;
-    }
-    if (sym) {
-        RevParams q = p;
-        q.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)(kRevSlab / 2)));     // two sets of accumulators: half the rows each
-        q.sym_fd = (int)S_fd; q.sym_tau = (int)S_tau; q.col0 = (int)c_first;
-        const dim3 grid((unsigned)(c_last - c_first + 1), (unsigned)ceil_div(g.ntau, q.slab));
-        SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-        const size_t lds = sizeof(double) * (size_t)((9 * q.slab + 1) / 2 + (9 * (q.slab + kRevSymExtra) + 1) / 2);
-        if (getenv("SCINT_REV_TRACE")) fprintf(stderr, "rev sym: cols %lld..%lld S_fd %lld S_tau %lld slab %d plain %d\n", (long long)c_first, (long long)c_last, (long long)S_fd, (long long)S_tau, q.slab, nplain);
-        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, true, true>), grid, dim3(kRevThreadsK), lds, stream, q, g);
-        SCINT_LAUNCH_CHECK();
-        if (nplain == 0) return SCINT_OK;
-        p.nplain = nplain;
-        for (int k = 0; k < nplain; ++k) p.plain_cols[k] = plain[k];
-    }
     // equal slabs of at most kRevSlab delay rows
     p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));
-    dim3 grid((unsigned)(p.nplain > 0 ? p.nplain : g.nfd), (unsigned)ceil_div(g.ntau, p.slab));
+    dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
     if (p.rank1)
-        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, true, false>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
+        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, true>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
     else
-        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, false, false>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
+        hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, false>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

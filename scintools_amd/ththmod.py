@@ -402,20 +402,81 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
     return eigs
 
 
+def _keep_ranges(grid, etas_v):
+    """The crop of thth_redmap (ththmod.py:153-155) as index RANGES: (first[neta], n[neta]) with keep_i =
+    arange(first_i, first_i + n_i), or None when the crop need not be one run of centres (theta not sorted, a negative
+    curvature).  On sorted centres ``(th**2 * eta < tau_max) * (|th| < fd_max / 2)`` is a prefix of the centres
+    >= 0 and a suffix of those < 0 (every operation is monotone in its rounded operand), so both ends come from a
+    bisection with the reference's own expression at the probes: 2 x 13 vector steps over the curvatures instead of
+    neta masks over all M centres (the Python loop of :func:`_sweep_inputs` was 1 % of a 4096^2 / 256-eta chi^2 step)."""
+    th = grid.th_cents
+    M = th.shape[0]
+    if M < 1 or not np.all(np.diff(th) >= 0) or np.any(etas_v < 0) or not np.all(np.isfinite(th)):
+        return None
+    th2, inside, tau_max = th**2, np.abs(th) < grid.geom.fd_max / 2, grid.geom.tau_max
+    z = int(np.searchsorted(th, 0.0, side="left"))        # th[z:] >= 0
+
+    def kept(i):                                            # the reference's mask at centre i[k] for curvature k
+        return (th2[i] * etas_v < tau_max) * inside[i]
+
+    def first_false(lo, hi, flip):
+        """per curvature: the number of kept centres walking from `lo` towards `hi` (exclusive), ascending or descending"""
+        lo = np.full(etas_v.shape, lo, dtype=np.int64)
+        hi = np.full(etas_v.shape, hi, dtype=np.int64)
+        while np.any(lo < hi):
+            mid = np.minimum((lo + hi) // 2, hi - 1)         # (a finished curvature probes a valid centre and ignores it)
+            mid = np.maximum(mid, 0)
+            ok = kept(z - 1 - mid if flip else z + mid) & (lo < hi)
+            lo = np.where(ok, mid + 1, lo)
+            hi = np.where(ok | (lo >= hi), hi, mid)
+        return lo
+    npos = first_false(0, M - z, False) if M > z else np.zeros(etas_v.shape, dtype=np.int64)
+    nneg = first_false(0, z, True) if z > 0 else np.zeros(etas_v.shape, dtype=np.int64)
+    return (z - nneg).astype(np.int64), (nneg + npos).astype(np.int32)
+
+
 def _sweep_inputs(grid, etas_v):
     """Crop of thth_redmap (ththmod.py:153-155) for every curvature: keep_idx[neta, M]
     (left-packed ascending indices) and keep_n[neta]; same element-wise arithmetic as
-    ``_Grid.keep`` with the eta-independent parts hoisted."""
+    ``_Grid.keep`` with the eta-independent parts hoisted.  Curvatures that keep the same run of centres
+    (:func:`_keep_ranges`) share one row."""
     th = grid.th_cents
     neta, M = etas_v.shape[0], grid.M
-    th2, inside, tau_max = th**2, np.abs(th) < grid.geom.fd_max / 2, grid.geom.tau_max
     keep_idx = np.zeros((neta, M), dtype=np.int32)
     keep_n = np.zeros(neta, dtype=np.int32)
+    rng = _keep_ranges(grid, etas_v)
+    if rng is not None:
+        first, keep_n = rng
+        ar = np.arange(M, dtype=np.int32)
+        for a, n in {(int(a), int(n)) for a, n in zip(first, keep_n) if n > 0}:
+            keep_idx[(first == a) & (keep_n == n), :n] = ar[a:a + n]
+        return keep_idx, keep_n
+    th2, inside, tau_max = th**2, np.abs(th) < grid.geom.fd_max / 2, grid.geom.tau_max
     for i, e in enumerate(etas_v):
         k = np.nonzero((th2 * e < tau_max) * inside)[0]
         keep_n[i] = k.shape[0]
         keep_idx[i, : k.shape[0]] = k
     return keep_idx, keep_n
+
+
+def _reduced_centres(grid, keep_idx, keep_n):
+    """th_red[neta, M]: the centres of the reduced edges, re-derived as rev_map does (ththmod.py:204-205 on :157-172),
+    one evaluation per DISTINCT crop (on the bench workload 161 of 256 curvatures keep all 4095 centres)."""
+    neta, M = keep_idx.shape
+    th_red = np.zeros((neta, M))
+    done = {}
+    for i in range(neta):
+        n = int(keep_n[i])
+        if n < 3:                                   # (two centres have no mean edge step: the reference's rev_map raises)
+            continue
+        key = (int(keep_idx[i, 0]), int(keep_idx[i, n - 1]), n)
+        j = done.get(key)
+        if j is not None and (key[1] - key[0] + 1 == n or np.array_equal(keep_idx[i, :n], keep_idx[j, :n])):
+            th_red[i, :n] = th_red[j, :n]
+        else:
+            th_red[i, :n] = _theta_centres(grid.edges_red(keep_idx[i, :n]))
+            done[key] = i
+    return th_red
 
 
 def _sweep_inputs_dev(grid, etas_v):
@@ -491,12 +552,7 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     d_t = _dv.to_device(dspec, torch.float64)
     nf, nt = (int(v) for v in d_t.shape)
     m_t = None if mask is None else _dv.to_device(np.asarray(mask, dtype=np.uint8), torch.uint8)
-    # centres of the reduced edges, re-derived as rev_map does (ththmod.py:204-205 on :157-172)
-    th_red = np.zeros((neta, M))
-    for i in range(neta):
-        n = int(keep_n[i])
-        if n >= 2:
-            th_red[i, :n] = _theta_centres(grid.edges_red(keep_idx[i, :n]))
+    th_red = _reduced_centres(grid, keep_idx, keep_n)
     th_red_t = _dv.to_device(th_red, torch.float64)
     keep_t = _dv.to_device(keep_idx, torch.int32)
     need = ctypes.c_size_t()
@@ -515,7 +571,7 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     _lib.check(rc, "scint_chisq_sweep")
     st = st_t.cpu().numpy()
     chis = out.cpu().numpy()
-    chis[st[0] != 0] = np.nan                 # failed curvatures (the reference's loop would raise there)
+    chis[(st[0] != 0) | (keep_n < 3)] = np.nan   # failed curvatures (the reference's loop would raise there)
     if return_info:
         w = w_t.cpu().numpy()
         w[st[0] != 0] = np.nan

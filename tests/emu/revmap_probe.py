@@ -31,8 +31,7 @@ def cases():
             ("sparse_theta", 256, 256, 60, 1.0, False, 1.0),
             ("chunks_and_slabs", 2200, 48, 1200, 1.0, False, 1.0),
             ("chunks_and_slabs_steep", 2500, 40, 1100, 3.0, True, 1.0),
-            # round 4 (paired columns of the rank-1 Hermitian back-map): odd axis lengths (mirror column S - c with
-            # S = n - 1), three delay slabs of the paired kernel, and axes that are NOT symmetric about 0 (plain kernel)
+            # round 4: odd axis lengths, three delay slabs on an irregular grid, axes that are NOT symmetric about 0
             ("odd_axes", 97, 81, 120, 1.0, False, 1.0),
             ("odd_axes_slabs", 1301, 37, 500, 1.3, True, 1.0),
             ("shifted_axes", 96, 80, 100, 1.0, False, 1.0)):

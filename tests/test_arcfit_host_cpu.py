@@ -138,3 +138,36 @@ def test_parabola_fits_match_reference_goldens(golden):
     got = arcfit.fit_log_parabola(eta_array[pk - i1:pk + i2], spec[pk - i1:pk + i2])
     ref = ao.fit_log_parabola(eta_array[pk - i1:pk + i2], spec[pk - i1:pk + i2])
     assert got[1] == ref[1] and got[2] == ref[2] and np.array_equal(got[0], ref[0])
+
+
+def test_crop_tables_by_bisection_equal_the_reference_masks():
+    """ththmod._sweep_inputs finds each curvature's crop (ththmod.py:153-155) by a bisection with the reference's own
+    expression and shares rows between curvatures that keep the same centres; _reduced_centres evaluates the reduced
+    edges (ththmod.py:157-172, 204-205) once per distinct crop.  Both must equal the per-curvature loop, bit for bit --
+    symmetric and lopsided edges, odd and even counts, curvatures that keep nothing / everything, 0, inf and NaN; a
+    negative curvature or unsorted centres take the loop itself."""
+    from scintools_amd import ththmod
+    rng = np.random.default_rng(3)
+    for nedge, lo, hi, jitter in ((100, -1.0, 1.0, 0.0), (102, -1.0, 1.0, 0.0), (65, -0.3, 1.4, 0.0), (257, -2.0, 0.7, 0.3),
+                                  (40, 0.1, 1.0, 0.0), (33, -1.0, -0.2, 0.2)):
+        tau = (np.arange(96) - 48) * 0.0137
+        fd = (np.arange(80) - 40) * 0.0311
+        edges = np.linspace(lo, hi, nedge)
+        if jitter:
+            edges = np.sort(edges + rng.uniform(-jitter, jitter, nedge) * (edges[1] - edges[0]))
+        grid = ththmod._Grid(tau, fd, edges)
+        eta0 = np.abs(tau).max() / (np.abs(fd).max() / 2) ** 2
+        etas = np.concatenate((np.geomspace(0.01, 300.0, 57) * eta0, [0.0, np.inf, np.nan, 1e-300, 1e300]))
+        ki, kn = ththmod._sweep_inputs(grid, etas)
+        for i, e in enumerate(etas):
+            ref = grid.keep(e)
+            assert kn[i] == ref.shape[0], (nedge, e)
+            assert np.array_equal(ki[i, :kn[i]], ref) and not ki[i, kn[i]:].any()
+        th_red = ththmod._reduced_centres(grid, ki, kn)
+        for i in range(len(etas)):
+            n = int(kn[i])
+            want = ththmod._theta_centres(grid.edges_red(ki[i, :n])) if n >= 3 else np.zeros(0)
+            assert np.array_equal(th_red[i, :len(want)], want) and not th_red[i, len(want):].any()
+        assert ththmod._keep_ranges(grid, np.array([1.0, -2.0])) is None           # the loop handles these
+        ki2, kn2 = ththmod._sweep_inputs(grid, np.array([eta0, -eta0]))
+        assert np.array_equal(ki2[1, :kn2[1]], grid.keep(-eta0))

@@ -495,11 +495,11 @@ def test_rev_map_explicit_matrix(emu, to, case):
 def test_back_map_bits_are_pinned(emu):
     """rev_map images of the interpreted kernel on 29 grids (rank-1 and explicit, Hermitian or not, irregular theta,
     several delay slabs and 256-lane chunks, pairs pushed off the delay axis; odd axis lengths and axes that are not
-    symmetric about 0) have the SHA-256 they had before the round-3 rewrite of rev_gather_kernel (one copy of the pair
-    arithmetic, chunk pre-pass, loop-free bin) and before round 4's paired columns (a workgroup adds a pair to its
-    column and, conjugated, to the mirror column: rev_gather_kernel<.., SYM>; the seven digests added in round 4 were
-    written with SCINT_REV_PLAIN=1, i.e. by the unpaired kernel): the sums are order-independent by construction, so a
-    rewrite may not change a bit."""
+    symmetric about 0 -- the seven digests added in round 4) have the SHA-256 they had before the round-3 rewrite of
+    rev_gather_kernel (one copy of the pair arithmetic, chunk pre-pass, loop-free bin) and before round 4's changes (per-image
+    constants from rev_setup_kernel, chunk-long pre-pass blocks, reciprocal table; the paired-column kernel that was
+    measured and dropped produced the same bits too): the sums are order-independent by construction, so a rewrite may
+    not change a bit."""
     import json
     import revmap_probe
     got = revmap_probe.digests(revmap_probe.images(emu))
