@@ -102,7 +102,8 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
 
     Algorithmic bytes per curvature: eigenPAIR passes x 8 N (N + 1) (upper triangle of the packed Hermitian
     theta-theta once per two-vector pass) + 16 N^2 for the gather + 16 ntau nfd written by the rank-1 back-map (recov) +
-    16 ntau nfd read by the model transform + 8 nf nt of the dynamic spectrum read by the chi^2 sink.  `achieved` is those
+    16 ntau nfd (recov) read back + 8 nf nt of the dynamic spectrum for chi^2 (the Parseval kernel reads fft2(dspec), 16 ntau nfd,
+    in its place: its traffic is above this floor by that difference).  `achieved` is those
     bytes over the WALL time of the step -- the mat-vecs, back-maps and model transforms of different curvatures share the
     GPU on four streams, so the objective as a whole, not one kernel, is what the fraction describes; `parts` gives each
     kernel's own bytes over the union of its launch intervals."""
@@ -142,7 +143,8 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
                      "traffic_note": (f"HBM bytes per eta = {ratio:.3f} x algorithmic (every kernel of a chi^2 step; rocprofv3 "
                                       f"PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), {src}") if ratio else None,
                      "parts": {"pk2_matvec_kernel": part(mv, 1), "thth_gather_packed_kernel": part(ga, 0),
-                               "rev_gather_kernel (rank-1)": part(rv, 3), "model transform + chi^2 sink": part(mt, 4)}}}
+                               "rev_gather_kernel (rank-1)": part(rv, 3),
+                               "chi^2 step (chisq_parseval_kernel; model transform + sink when cropped or masked)": part(mt, 4)}}}
 
 
 def parse():
@@ -179,13 +181,19 @@ def parse():
                     help="N=1, --precision f64: also time this many steps of the mixed sweep on the same workload and "
                          "compare its curve with the float64 one (object 'mixed_precision' of the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed region's own sweep: no CPU baseline, no modeler / mixed / one-slot-group legs "
+                         "(profiling runs: every kernel launch of the process then belongs to the headline schedule)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="etas timed on the CPU oracle (spread over the sweep)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU sample (the median is reported)")
     ap.add_argument("--cpu-pool", type=int, default=-1,
                     help="workers of the eta-parallel oracle baseline (multiprocessing.Pool, one BLAS thread "
                          "each: how a user parallelises the reference, dynspec.py:1715-1719); -1 = every "
                          "core the host memory allows, 0 = skip")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline, args.modeler_steps, args.mixed_steps = True, 0, 0
+    return args
 
 
 NPROF = 5      # kernels scint_profile_end reports on (include/scint_hip.h)
@@ -259,7 +267,7 @@ def lanczos_block():
     """(vectors per Lanczos pass, name of the mat-vec kernel): the one recurrence the library ships
     (eigen_packed.hip); the single-vector and the four- / eight-vector families were measured
     and removed (profiles/r03_wide_blocks_ab.json)."""
-    return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec; two block rows per workgroup)"
+    return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec; four block rows x <= 14 column tiles per workgroup)"
 
 
 def blas_threads():
@@ -667,7 +675,7 @@ def main():
                 out["mixed_precision"] = mixed_leg(mx, args.mixed_steps, neta, eigs, out["value"])
             except Exception as exc:
                 out["mixed_precision"] = {"error": repr(exc)}
-        if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta and not mixed:
+        if world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta and not mixed and not args.headline_only:
             # the same sweep with ONE slot group (scint_sweep_schedule): every mat-vec launch has the
             # GPU to itself, so this is the kernel's own rate; in the headline schedule two groups' launches and the
             # small kernels share the GPU and `achieved` above is bytes / (time any mat-vec launch is in flight)

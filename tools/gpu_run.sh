@@ -5,7 +5,7 @@
 # Output goes to gpurun_out/<tag>_*; summaries worth keeping are copied into profiles/ by hand.
 #   suite    [tag]          pytest -m gpu (whole suite, durations)
 #   bench    [tag] [args]   the driver's bench command (--gpus 1 --steps 20 --warmup 5) + extra args
-#   quick    [tag] [args]   bench.py --steps 5 --warmup 2 --no-cpu-baseline --modeler-steps 0 + extra args
+#   quick    [tag] [args]   bench.py --steps 5 --warmup 2 --headline-only (no CPU baseline, no modeler / mixed / one-slot-group legs) + extra args
 #   configs  [tag]          BASELINE configs 4 / 5, npad = 3 and the 4096^2 reference-Simulation screen
 #   trace    [tag] [args]   rocprofv3 --kernel-trace --stats of a 3-step bench -> per-kernel stats + interval unions
 #   modeler  [tag]          the same trace of the chi^2 (modeler) objective
@@ -23,7 +23,7 @@ R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 CMD=${1:-all}; TAG=${2:-m}; shift; shift || true
 EXTRA="$*"
-QUICK="--no-cpu-baseline --modeler-steps 0"
+QUICK="--headline-only"
 
 suite() {
   timeout 1200 python -m pytest tests -m gpu -q --durations=8 > $O/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> $O/${TAG}_pytest.log
@@ -98,7 +98,7 @@ fft() {
   pmc_of fft "tools/time_fft.py" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/time_fft.py"
 }
 mixed() {
-  timeout 200 python bench.py --steps 3 --warmup 1 $QUICK --mixed-steps 3 $EXTRA > $O/${TAG}_mixed.json 2> $O/${TAG}_mixed.err; echo "bench rc=$?"
+  timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --modeler-steps 0 --mixed-steps 3 $EXTRA > $O/${TAG}_mixed.json 2> $O/${TAG}_mixed.err; echo "bench rc=$?"
   python tools/bench_line.py $O/${TAG}_mixed.json; python -c "
 import json,sys
 d=json.loads([l for l in open('$O/${TAG}_mixed.json') if l.startswith('{')][-1]); m=d.get('mixed_precision',{})
