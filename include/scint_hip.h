@@ -294,6 +294,8 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
  * by the batched Lanczos sweep (as scint_eigvec_sweep); as each curvature retires, its model step --
  * rank-1 rev_map of |w| V V^H, inverse FFT, chi^2 against dspec[nf, nt] -- is chained on an internal
  * stream beside the Lanczos steps of the curvatures still resident, without returning to the host.
+ * When the model is not cropped (ntau == nf, nfd == nt), mask is NULL and dspec is finite, chi^2 is taken
+ * from recov and fft2(dspec) by Parseval's identity instead (the same sum to rounding; no inverse FFT).
  *   th_red   DEVICE [neta, M]: row e = the N_e centres of the reduced edges (ththmod.py:157-172 then
  *            :204-205), host-computed like the other grid quantities;
  *   mask     DEVICE uint8[nf*nt] or NULL (= isfinite(dspec));

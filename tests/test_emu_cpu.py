@@ -586,3 +586,29 @@ def test_sweep_on_noise_spectra_vs_lapack(emu, to):
         eigs, info = emu.eval_sweep(CS, tau, fd, etas, edges, return_info=True)
         assert np.all(info["status"] == 0)
         np.testing.assert_allclose(eigs, np.abs(ref), rtol=1e-11)
+
+
+def test_chisq_sweep_curvature_that_keeps_two_centres_is_nan(emu, to):
+    """A curvature whose crop (ththmod.py:153-155) keeps only two theta centres has no mean edge step (ththmod.py:166:
+    the mean of an empty difference): the reference's chisq_calc raises there, the sweep reports NaN for it and goes on
+    with the others (as it does for the curvatures that keep fewer than two)."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(64, 48, seed=2, nimg=6)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    CS = to.conjugate_spectrum(dyn, 0)
+    s = fd.max() / 2
+    edges = np.array([-1.95, -0.05, 0.05, 0.15, 1.85]) * s / 2      # centres -1, 0, 0.1, 1 (x s / 2)
+    th = (edges[1:] + edges[:-1]) / 2
+    th = th - th[np.abs(th) == np.abs(th).min()]
+    eta_all = 0.5 * np.abs(tau).max() / th[-1] ** 2                 # keeps all four centres
+    eta_two = 0.5 * (np.abs(tau).max() / th[2] ** 2 + np.abs(tau).max() / th[-1] ** 2)   # keeps 0 and the small one
+    eta_one = 4.0 * np.abs(tau).max() / th[2] ** 2                  # keeps the centre only
+    assert [len(np.nonzero((th**2 * e < np.abs(tau.max())) * (np.abs(th) < np.abs(fd.max()) / 2))[0])
+            for e in (eta_all, eta_two, eta_one)] == [4, 2, 1]
+    got = emu.chisq_sweep(dyn, CS, tau, fd, np.array([eta_all, eta_two, eta_one, eta_all]), edges, 2.0)
+    ref = to.chisq_calc(dyn, CS, tau, fd, eta_all, edges, 2.0)
+    np.testing.assert_allclose(got[[0, 3]], [ref, ref], rtol=1e-9)
+    assert np.isnan(got[1]) and np.isnan(got[2])
+    with pytest.raises(Exception):
+        to.chisq_calc(dyn, CS, tau, fd, eta_two, edges, 2.0)
