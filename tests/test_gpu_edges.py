@@ -37,6 +37,25 @@ def test_crop_to_nothing_gives_nan_like_the_reference(env):
     assert fit[2] is None or np.isfinite(fit[0])
 
 
+def test_chisq_sweep_with_curvatures_that_keep_one_two_or_all_centres(env):
+    """Lopsided edges whose centres are -1, 0, 0.1, 1 (x fd.max / 4): a curvature that keeps all four gives the oracle's chi^2,
+    one that keeps two (no mean edge step: the reference's rev_map raises, ththmod.py:166) or one is NaN, and the sweep goes on."""
+    thth, to, p = env
+    s = p["fd"].max() / 2
+    edges = np.array([-1.95, -0.05, 0.05, 0.15, 1.85]) * s / 2
+    th = (edges[1:] + edges[:-1]) / 2
+    th = th - th[np.abs(th) == np.abs(th).min()]
+    tmax = np.abs(p["tau"]).max()
+    etas = np.array([0.5 * tmax / th[-1] ** 2, 0.5 * (tmax / th[2] ** 2 + tmax / th[-1] ** 2), 4.0 * tmax / th[2] ** 2,
+                     0.25 * tmax / th[-1] ** 2])
+    got = thth.chisq_sweep(p["dyn"], p["CS"], p["tau"], p["fd"], etas, edges, 2.0)
+    ref = [to.chisq_calc(p["dyn"], p["CS"], p["tau"], p["fd"], e, edges, 2.0) for e in etas[[0, 3]]]
+    np.testing.assert_allclose(got[[0, 3]], ref, rtol=1e-9)
+    assert np.isnan(got[1]) and np.isnan(got[2])
+    with pytest.raises(Exception):
+        to.chisq_calc(p["dyn"], p["CS"], p["tau"], p["fd"], etas[1], edges, 2.0)
+
+
 def test_all_masked_cs_gives_zero(env):
     thth, to, p = env
     eigs = thth.eval_sweep(np.zeros_like(p["CS"]), p["tau"], p["fd"], np.array([p["eta"]]), p["edges"])
