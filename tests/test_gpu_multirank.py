@@ -169,3 +169,45 @@ def test_bench_shard_eta_gathers_the_one_gpu_curve():
     assert 0 < c["per_rank_eta_per_s"]["min"] <= c["per_rank_eta_per_s"]["max"]
     # whole-sweep bookkeeping (gathered outside the timed region), not rank 0's share of it
     assert 1.0 <= c["eta_share_balance"]["max_over_mean_matvec_bytes_per_rank"] < 1.2
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    from scintools_amd import sweep
+    from scintools_amd import ththmod as thth
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    dyn, freqs, times, tau, fd, etas, edges = _problem()
+    cs = thth.conjugate_spectrum(dyn, 0, pad_value=0.0)
+    full = sweep.sharded_eval_sweep(cs, tau, fd, etas, edges)       # its all-gather runs on DEVICE tensors through RCCL
+    probe = [torch.empty(4, dtype=torch.float64, device="cuda")]
+    dist.all_gather(probe, torch.arange(4, dtype=torch.float64, device="cuda"))
+    q.put((full, probe[0].cpu().numpy(), dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eta_sharding_over_rccl_with_one_rank():
+    """backend "nccl" (= RCCL on ROCm) cannot put two ranks on the one GPU of the test box, so the multi-rank tests above
+    travel over gloo.  What one GPU CAN show is that the same sharding code initialises RCCL, keeps its gather buffers on
+    the device and gets the curve back through an RCCL all-gather: world size 1, the curve equal to the plain sweep's bits."""
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("torch.distributed was built without the nccl (RCCL) backend")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    full, probe, backend = q.get(timeout=480)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and backend == "nccl"
+    assert np.array_equal(probe, np.arange(4.0))
+    from scintools_amd import ththmod as thth
+    dyn, freqs, times, tau, fd, etas, edges = _problem()
+    ref = thth.eval_sweep(thth.conjugate_spectrum(dyn, 0, pad_value=0.0), tau, fd, etas, edges)
+    assert np.array_equal(full, ref)
