@@ -335,6 +335,12 @@ def default_batch(nmax, neta, eigenvalues_only=True):
     want = -(-11000 // max(strips, 1))     # measured on MI355X at N = 4095: 48 / 56 / 70 slots -> 1079 / 1084 / 1094 eta/s
     per_slot = 8 * (nb * 64) ** 2 + 1
     mode = _lib.load().scint_sweep_precision(-1)
+    if eigenvalues_only and mode == 0:
+        # round 4 (four block rows per mat-vec workgroup: a quarter of the workgroups per matrix): 69 / 92 / 100 / 108 / 116 slots ->
+        # +0 / +0.3 / +0.6 / +0.8 / +1.0 % on the headline sweep (three interleaved rounds; +0.1-0.2 % on a fourth box), 20 -> 30
+        # slots at N = 8191 +0.7 %, 69 -> 108 with npad = 3 +1.6 %.  The eigenPAIR sweeps (chi^2 objective: 836 / 832 / 827 eta/s at
+        # 69 / 100 / 128) and the mixed sweep (2388 eta/s at its 138 slots, 2309 at 146) keep their batches
+        want = -(-17000 // max(strips, 1))
     if mode == 2 or (eigenvalues_only and mode == 1):
         # mixed sweep: a workgroup of the complex64 mat-vec covers four block rows (half as many workgroups per matrix),
         # and a slot idles for two of its ~19 chunks around the certificate pass: twice the slots for the same fill;
