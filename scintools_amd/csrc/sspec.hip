@@ -56,19 +56,41 @@ __global__ void __launch_bounds__(256) sspec_prep_kernel(const double* __restric
     __shared__ double red[4];
     const int c0 = (int)blockIdx.x * 64, r0 = (int)blockIdx.y * 64;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = c0 + lane;
-    const double wc = (wt && c < nt) ? wt[c] : 1.0;
     double sd = 0.0, swd = 0.0, sw = 0.0;
+    if ((nt & 1) == 0 && ((uintptr_t)dyn & 15) == 0) {
+        // even row length (and an aligned plane): every pair of adjacent columns is one aligned 16-byte load (a wave instruction reads two 512-byte row
+        // segments; half the load instructions of the scalar form below -- round 4: the copy ran at 4.1 TB/s where a plain
+        // copy of the same bytes reaches 7 with the Infinity Cache's help)
+        const int cp = lane & 31, c = c0 + 2 * cp, rsub = (lane >> 5) + 2 * w;
+        const bool in = c < nt;                                   // (nt even: c + 1 < nt too)
+        const double wc0 = (wt && in) ? wt[c] : 1.0, wc1 = (wt && in) ? wt[c + 1] : 1.0;
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int rr = w + 4 * i, r = r0 + rr;
-        double d = 0.0;
-        if (r < nf && c < nt) {
-            d = dyn[(int64_t)r * nt + c];
-            const double ww = wf ? wf[r] * wc : 1.0;
-            sd += d; swd += ww * d; sw += ww;
+        for (int i = 0; i < 8; ++i) {
+            const int rr = rsub + 8 * i, r = r0 + rr;
+            v2d d; d.x = 0.0; d.y = 0.0;
+            if (r < nf && in) {
+                d = *(const SCINT_GLOBAL v2d*)(dyn + (int64_t)r * nt + c);
+                const double f = wf ? wf[r] : 1.0;
+                const double w0 = wf ? f * wc0 : 1.0, w1 = wf ? f * wc1 : 1.0;
+                sd += d.x; swd += w0 * d.x; sw += w0;
+                sd += d.y; swd += w1 * d.y; sw += w1;
+            }
+            tile[rr][2 * cp] = d.x; tile[rr][2 * cp + 1] = d.y;
         }
-        tile[rr][lane] = d;
+    } else {
+        const int c = c0 + lane;
+        const double wc = (wt && c < nt) ? wt[c] : 1.0;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int rr = w + 4 * i, r = r0 + rr;
+            double d = 0.0;
+            if (r < nf && c < nt) {
+                d = dyn[(int64_t)r * nt + c];
+                const double ww = wf ? wf[r] * wc : 1.0;
+                sd += d; swd += ww * d; sw += ww;
+            }
+            tile[rr][lane] = d;
+        }
     }
     __syncthreads();
     // pair pp of the tile, row `lane`: 16 bytes per lane, 1 KiB per wave instruction
