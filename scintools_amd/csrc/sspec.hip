@@ -189,7 +189,8 @@ struct LastStage {
 template <int N> struct ColsBlock { static constexpr int value = (N / kEPT) >= 256 ? (N / kEPT) : 256; };
 
 template <int R0, int R1, int R2, int R3>
-__global__ void __launch_bounds__(ColsBlock<R0 * R1 * R2 * R3>::value, 4) sspec_cols_kernel(SspecCols a) {
+__global__ void __launch_bounds__(ColsBlock<R0 * R1 * R2 * R3>::value, (ColsBlock<R0 * R1 * R2 * R3>::value >= 512 ? 2 : 4))   // (8192 points: 512 threads and 68 KiB of LDS -- two workgroups per CU whatever the bound says; 4 capped it at 64 registers and spilled)
+sspec_cols_kernel(SspecCols a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
     using LS = LastStage<R0, R1, R2, R3>;
@@ -490,7 +491,7 @@ __device__ inline double ten_log10(double x, const double (*tab)[2]) {
 // both halves in sequence, each storing as soon as it has its bins, 313 us; side by side 255 us.  The
 // instruction floor of the kernel is 136 us (no loads, no stores).
 template <int R0, int R1, int R2, int R3>
-__global__ void __launch_bounds__((R0 * R1 * R2 * R3 / kEPT) >= 256 ? (R0 * R1 * R2 * R3 / kEPT) : 256, 3)   // three waves per SIMD: 168 registers, no spills (41 spilled at 128)
+__global__ void __launch_bounds__((R0 * R1 * R2 * R3 / kEPT) >= 256 ? (R0 * R1 * R2 * R3 / kEPT) : 256, (R0 * R1 * R2 * R3 / kEPT) >= 512 ? 2 : 3)   // three waves per SIMD: 168 registers, no spills (41 spilled at 128); 8192 points: 512 threads, 70 KiB of LDS: two workgroups per CU
 sspec_rows_kernel(SspecRows a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
