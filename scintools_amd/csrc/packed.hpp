@@ -41,18 +41,20 @@ __host__ __device__ inline int64_t tile_count(int nb) { return (int64_t)nb * (nb
 // (long strips amortise the per-workgroup prologue/epilogue; the length depends on nb only, so
 // the summation order -- and every bit of the result -- is independent of the batch)
 #ifndef SCINT_ROWS64
-#define SCINT_ROWS64 4          // (a build constant for the A/B of round 4 only: tools/build_variant.sh -DSCINT_ROWS64=2)
+#define SCINT_ROWS64 8          // (a build constant for the A/Bs of round 4 only: tools/build_variant.sh -DSCINT_ROWS64=2|4|16)
 #endif
 constexpr int kRows64 = SCINT_ROWS64;     // block rows per workgroup of the complex128 mat-vec: they share the X_J blocks and ONE column
-                                          // partial per column tile (round 3: 2 rows x <= 16 tiles; round 4: 4 x <= 14, the shape of the
-                                          // complex64 kernel -- 18 partial vectors per 56 tiles instead of 18 per 32)
-constexpr int kRows64Lg = kRows64 == 4 ? 2 : 1;
-static_assert(kRows64 == 2 || kRows64 == 4, "kRows64 must be 2 or 4");
+                                          // partial per column tile.  Round 3: 2 rows x <= 16 tiles; round 4: 4 x <= 14 (18 partial vectors per 56
+                                          // tiles instead of per 32: 1435 -> 1494 eta/s), then 8 x <= 12 (20 per 96: +1.1-1.4 % on two boxes, mat-vec
+                                          // 5.63 -> 5.74 TB/s in the sweep; 16 rows x 8 / 6 tiles: no better / worse -- profiles/r04_tail_schedule_ab.txt)
+constexpr int kRows64Lg = kRows64 == 16 ? 4 : (kRows64 == 8 ? 3 : (kRows64 == 4 ? 2 : 1));
+static_assert(kRows64 == 2 || kRows64 == 4 || kRows64 == 8 || kRows64 == 16, "kRows64 must be 2, 4, 8 or 16");
 #ifndef SCINT_MAXSTRIP
-#define SCINT_MAXSTRIP (SCINT_ROWS64 == 4 ? 14 : 16)
+#define SCINT_MAXSTRIP (SCINT_ROWS64 == 8 ? 12 : (SCINT_ROWS64 == 4 ? 14 : (SCINT_ROWS64 == 16 ? 8 : 16)))
 #endif
 constexpr int kMaxStrip = SCINT_MAXSTRIP;            // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS:
-                                                     // 14 -> 72 KiB, two workgroups per CU; 9 -> 52 KiB, three; 6 -> 40 KiB, four)
+                                                     // 8 rows x 12 tiles -> 72 KiB, two workgroups per CU and 12 KiB left for the reduce blocks;
+                                                     // 4 x 14 -> 72 KiB; 4 x 9 -> 52 KiB, three per CU; 4 x 6 -> 40 KiB, four: both measured slower)
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced > kMaxStrip ? kMaxStrip : forced;   // tests of schedule independence
