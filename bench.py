@@ -267,7 +267,7 @@ def lanczos_block():
     """(vectors per Lanczos pass, name of the mat-vec kernel): the one recurrence the library ships
     (eigen_packed.hip); the single-vector and the four- / eight-vector families were measured
     and removed (profiles/r03_wide_blocks_ab.json)."""
-    return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec; four block rows x <= 14 column tiles per workgroup)"
+    return 2, "pk2_matvec_kernel (two-vector block Lanczos mat-vec; eight block rows x <= 12 column tiles per workgroup)"
 
 
 def blas_threads():
