@@ -27,10 +27,16 @@ constexpr int kTileElems = kTB * kTB;         // 4096 complex = 64 KiB
 // "f32-stored iteration, f64 certificate"); the eigenvalue that is returned never comes from it
 struct __attribute__((aligned(8))) c32 { float x, y; };
 static_assert(sizeof(c32) == 8, "c32 must be two floats");
-constexpr int kRows32 = 4;        // block rows per workgroup of the complex64 mat-vec (same tile bytes per workgroup as two complex128 rows)
-constexpr int kRows32Lg = kRows32 == 4 ? 2 : (kRows32 == 2 ? 1 : 0);
-static_assert((1 << kRows32Lg) == kRows32, "kRows32 must be 1, 2 or 4");
-constexpr int kMaxStrip32 = 14;   // its column tiles per strip: 28 + 28 KiB of X_J blocks and column partials, 72 KiB of LDS in all
+#ifndef SCINT_ROWS32
+#define SCINT_ROWS32 4            // (build constant for A/Bs: 8 rows x <= 12 tiles is what paid for the complex128 kernel at the end of round 4;
+#endif                            //  the complex64 kernel passes the interpreter's mixed tests with it, its GPU A/B is open -- DESIGN 9.4)
+constexpr int kRows32 = SCINT_ROWS32;   // block rows per workgroup of the complex64 mat-vec (4: the tile bytes of two complex128 rows per column tile)
+constexpr int kRows32Lg = kRows32 == 8 ? 3 : (kRows32 == 4 ? 2 : (kRows32 == 2 ? 1 : 0));
+static_assert((1 << kRows32Lg) == kRows32, "kRows32 must be 1, 2, 4 or 8");
+#ifndef SCINT_MAXSTRIP32
+#define SCINT_MAXSTRIP32 (SCINT_ROWS32 == 8 ? 12 : 14)
+#endif
+constexpr int kMaxStrip32 = SCINT_MAXSTRIP32;   // its column tiles per strip: X_J blocks and column partials in LDS, 72 KiB in all (14 with 4 rows, 12 with 8)
 
 __host__ __device__ inline int64_t tile_offset(int nb, int I) {
     return (int64_t)I * nb - (int64_t)I * (I - 1) / 2;

@@ -25,7 +25,11 @@ CSRC = os.path.join(REPO, "scintools_amd", "csrc")
 #   LD_PRELOAD=$(python tests/emu/build_emu.py --asan-runtime) ASAN_OPTIONS=detect_leaks=0 \
 #   SCINT_EMU_SANITIZE=address python -m pytest tests/test_emu_cpu.py
 SANITIZE = os.environ.get("SCINT_EMU_SANITIZE", "")
-OUT = os.path.join(HERE, "_build" + ("_" + SANITIZE if SANITIZE else ""))
+# SCINT_EMU_DEFINES="-DSCINT_ROWS32=8 ...": extra definitions for the kernel sources (the build constants of csrc/packed.hpp), in a build
+# directory of their own -- to run the interpreter tests on a variant before it is sent to a GPU (tools/build_variant.sh takes the same -D)
+DEFINES = os.environ.get("SCINT_EMU_DEFINES", "").split()
+OUT = os.path.join(HERE, "_build" + ("_" + SANITIZE if SANITIZE else "") +
+                   ("_" + "".join(c if c.isalnum() else "_" for c in "".join(DEFINES)) if DEFINES else ""))
 LIB = os.path.join(OUT, "libscint_emu_test.so")
 
 # same per-unit floating-point contraction as the product build (scintools_amd/build.py)
@@ -85,7 +89,7 @@ def build(force=False, verbose=False):
     src_out, _ = _stage_sources()
     common = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-fno-omit-frame-pointer",
               "-I", os.path.join(HERE, "include"), "-Wno-unused-result", "-Wno-unknown-attributes",
-              "-Wno-ignored-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed"]
+              "-Wno-ignored-attributes", "-Wno-unknown-pragmas", "-Wno-pass-failed"] + DEFINES
     link_extra = []
     if SANITIZE:
         common += [f"-fsanitize={SANITIZE}", "-shared-libsan"]
