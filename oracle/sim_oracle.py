@@ -26,7 +26,8 @@ class Simulation:
     dt, df, eta [s^3], plus the screen (xyp) and the field spectrum (spe)."""
 
     def __init__(self, mb2=2, rf=1, ds=0.01, alpha=5 / 3, ar=1, psi=0, inner=0.001, ns=256, nf=256,
-                 dlam=0.25, seed=None, nx=None, ny=None, dx=None, dy=None, freq=1400, dt=30, mjd=60000):
+                 dlam=0.25, seed=None, nx=None, ny=None, dx=None, dy=None, freq=1400, dt=30, mjd=60000, workers=1):
+        self.workers = int(workers)
         self.mb2, self.rf, self.ds, self.alpha, self.ar, self.psi, self.inner = mb2, rf, ds, alpha, ar, psi, inner
         self.dx = dx if dx is not None else ds
         self.dy = dy if dy is not None else ds
@@ -115,25 +116,66 @@ class Simulation:
                                                         filt[1:(nx2 - 1), 1:(ny2 - 1)])
         return xye
 
+    def _field_column(self, ifreq):                                      # body of the loop of scint_sim.py:215-235
+        frfreq = 1.0 + self.dlam * (-0.5 + ifreq / self.nf)
+        scale = 1 / frfreq
+        xye = fft2(np.exp(1j * self.xyp * scale))
+        xye = self._frfilt3(xye, scale)
+        xye = ifft2(xye)
+        return xye[:, int(np.floor(self.ny / 2))]
+
     def _get_intensity(self):                                            # scint_sim.py:209-236
         spe = np.zeros([self.nx, self.nf], dtype=np.dtype(np.csingle)) + \
             1j * np.zeros([self.nx, self.nf], dtype=np.dtype(np.csingle))
-        for ifreq in range(0, self.nf):
-            frfreq = 1.0 + self.dlam * (-0.5 + ifreq / self.nf)
-            scale = 1 / frfreq
-            xye = fft2(np.exp(1j * self.xyp * scale))
-            xye = self._frfilt3(xye, scale)
-            xye = ifft2(xye)
-            spe[:, ifreq] = xye[:, int(np.floor(self.ny / 2))]
+        if self.workers > 1 and self.nf >= 4 * self.workers:
+            # The frequencies are independent (each is two FFTs of the same screen): dealt to worker processes in contiguous
+            # blocks, every column is the same single-threaded NumPy arithmetic as in the loop below -- the same bits
+            # (tests/test_oracle_golden.py compares both with the reference's own array) -- in a fraction of the 3 minutes a
+            # 4096^2 screen takes one core.  Spawned, not forked: bench.py calls this with a HIP context alive.
+            import multiprocessing as mp
+            bounds = np.linspace(0, self.nf, self.workers * 4 + 1).astype(int)
+            jobs = [(self._worker_state(), int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+            done = np.zeros(self.nf, dtype=bool)
+            try:
+                with mp.get_context("spawn").Pool(self.workers) as pool:
+                    it = pool.imap_unordered(_field_columns, jobs)
+                    for _ in jobs:
+                        # bounded wait: a pool whose workers die at start-up (a main module that cannot be re-imported)
+                        # respawns them for ever -- an input generator must never hang its caller
+                        a, cols = it.next(timeout=120 + 0.05 * self.nx * self.ny * (self.nf / len(jobs)) / 1e4)
+                        spe[:, a:a + cols.shape[1]] = cols
+                        done[a:a + cols.shape[1]] = True
+            except Exception:      # noqa: BLE001 -- whatever went wrong, the serial loop below still gives the same array
+                pass
+            for ifreq in np.nonzero(~done)[0]:
+                spe[:, ifreq] = self._field_column(int(ifreq))
+        else:
+            for ifreq in range(0, self.nf):
+                spe[:, ifreq] = self._field_column(ifreq)
         self.spe = spe
+
+    def _worker_state(self):
+        return dict(xyp=self.xyp, nx=self.nx, ny=self.ny, nf=self.nf, dlam=self.dlam, ffconx=self.ffconx, ffcony=self.ffcony)
+
+
+def _field_columns(job):
+    """Worker of Simulation._get_intensity: the field columns of frequencies a .. b-1 (complex64, as the loop stores them)."""
+    state, a, b = job
+    sim = Simulation.__new__(Simulation)
+    sim.__dict__.update(state)
+    out = np.zeros([sim.nx, b - a], dtype=np.dtype(np.csingle))
+    for k, ifreq in enumerate(range(a, b)):
+        out[:, k] = sim._field_column(ifreq)
+    return a, out
 
 
 BASELINE_SCREEN = dict(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.25, freq=1400, dt=30)
 
 
-def baseline_dynspec(size, seed, ny=128):
-    """The `Simulation` input of a BASELINE config: size x size, anisotropic screen."""
-    return Simulation(nx=size, nf=size, ny=ny, seed=seed, **BASELINE_SCREEN)
+def baseline_dynspec(size, seed, ny=128, workers=1):
+    """The `Simulation` input of a BASELINE config: size x size, anisotropic screen.
+    `workers` > 1 deals the frequencies to that many processes (same bits, see _get_intensity)."""
+    return Simulation(nx=size, nf=size, ny=ny, seed=seed, workers=workers, **BASELINE_SCREEN)
 
 
 def checksum(a):

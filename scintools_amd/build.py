@@ -28,7 +28,11 @@ UNITS = {
     "arcnorm.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
-COMMON += os.environ.get("SCINT_VARIANT_FLAGS", "").split()    # tools/build_variant.sh only (experiment builds, forced)
+# Experiment builds (tools/build_variant.sh: -DSCINT_ROWS64=4 ...).  The flag string is recorded beside the objects and every unit
+# is rebuilt when it changes -- a variable left exported can therefore never leave stale experiment constants in the product
+# library -- and it is printed whenever it is not empty.
+VARIANT_FLAGS = os.environ.get("SCINT_VARIANT_FLAGS", "").split()
+STAMP = os.path.join(OBJ, "variant_flags.txt")
 
 
 def _hipcc():
@@ -48,6 +52,16 @@ def _newer(target, sources):
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
+    flags = " ".join(VARIANT_FLAGS)
+    try:
+        with open(STAMP) as fh:
+            built_with = fh.read().strip()
+    except OSError:
+        built_with = ""
+    if flags != built_with:
+        force = True
+    if flags:
+        print(f"scintools_amd.build: SCINT_VARIANT_FLAGS = {flags!r} (an EXPERIMENT build, not the product's constants)", flush=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "scint_hip.h"))
     objs, cmds = [], []
@@ -56,7 +70,7 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers + [__file__]):
-            cmds.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
+            cmds.append([hipcc] + COMMON + VARIANT_FLAGS + extra + ["-c", s, "-o", o])
     if cmds:  # independent translation units: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
 
@@ -66,6 +80,8 @@ def build(force=False, verbose=True):
             subprocess.run(cmd, check=True)
         with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as pool:
             list(pool.map(run, cmds))
+    with open(STAMP, "w") as fh:
+        fh.write(flags + "\n")
     if force or _newer(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         // eigenvector wanted: same gap-aware rule as the single-vector check (pk_check_kernel)
         const double prev2 = jb.result[1], gap2 = theta - theta2;
         const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
-        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= 30.0 * jb.tol * gap2);
+        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= kVecGapFactor * jb.tol * gap2);
         // (the iteration phase of a mixed eigenPAIR sweep runs to the eigenVALUE rule: its vector is finished on the complex128 tiles)
         const bool ok = (jb.want_vec && !jb.use32) ? vec_ok : (err <= jb.tol * at && settled);
         const bool conv = finite && (ok || exact);
@@ -808,7 +808,7 @@ __global__ void __launch_bounds__(64) pk2_restart_kernel(const PackedJob* jobs, 
 // host side
 // ------------------------------------------------------------------------------
 struct SlabLayout {
-    size_t tiles, tiles32, U0, U1, Q, svec, rowpart, colpart, row_strip0, apart0, apart1, upart0, upart1,
+    size_t tiles, tiles32, U0, U1, Q, svec, rowpart, colpart, apart0, apart1, upart0, upart1,
         coef, alpha, beta, result, total;
     int qslots;
 };
@@ -851,7 +851,6 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, bool mixe
     L.svec = take(sizeof(cplx) * (size_t)std::max<int64_t>(bw * (int64_t)(max_steps + 2), 2 * kSvecStride));   // eigenvector(s) of T_k
     L.rowpart = take(sizeof(cplx) * (size_t)smax * kTB * bw);
     L.colpart = take(sizeof(cplx) * (size_t)tile_count(nbmax) * kTB * bw);
-    L.row_strip0 = take(sizeof(int32_t) * (size_t)(nbmax + 1));
     L.apart0 = take(sizeof(double) * (size_t)nbmax * sc);
     L.apart1 = take(sizeof(double) * (size_t)nbmax * sc);
     L.upart0 = take(sizeof(double) * (size_t)nbmax * sc);
@@ -869,8 +868,8 @@ constexpr int kTabs = 3;   // rotating copies of the per-chunk tables (job table
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, strips32, states, slots, fin_slots, restart, fin_eta, geoms, scales, scale_bits, total;   // table offsets: copy 0; copies are *_stride apart
-    size_t jobs_stride, strips_stride, strips32_stride, list_stride, fin_eta_stride;
+    size_t jobs, strips, strips32, states, slots, fin_slots, restart, fin_eta, rs, geoms, scales, scale_bits, total;   // table offsets: copy 0; copies are *_stride apart
+    size_t jobs_stride, strips_stride, strips32_stride, list_stride, fin_eta_stride, rs_stride;
 };
 
 static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_vec, int64_t ncs, bool mixed) {
@@ -894,6 +893,10 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_
     B.fin_slots = take(B.list_stride * kTabs);
     B.restart = take(B.list_stride * kTabs);
     B.fin_eta = take(B.fin_eta_stride * kTabs);
+    // first strip of every block row, every slot: [nbatch][nbmax + 1] per table copy (ONE upload per changed chunk; until round 5 the
+    // table lived in each slot's slab and every fresh slot cost an upload of its own -- 20 of them when 20 curvatures retire together)
+    B.rs_stride = align_up(sizeof(int32_t) * (size_t)nbatch * (size_t)(nbmax + 1), 256);
+    B.rs = take(B.rs_stride * kTabs);
     B.geoms = take(sizeof(GeomDev) * (size_t)ncs);
     B.scales = take(sizeof(double) * (size_t)ncs);
     B.scale_bits = take(sizeof(unsigned long long) * (size_t)ncs);
@@ -1097,6 +1100,9 @@ struct SweepGroup {
     Strip32* d_strips32(int t) const {
         return (Strip32*)(P->base + P->BL.strips32 + P->BL.strips32_stride * (size_t)t) + (size_t)slot0 * (size_t)P->BL.smax;
     }
+    int32_t* d_rs(int t) const {
+        return (int32_t*)(P->base + P->BL.rs + P->BL.rs_stride * (size_t)t) + (size_t)slot0 * (size_t)(P->nbmax + 1);
+    }
     int64_t* d_fin_eta(int t) const { return (int64_t*)(P->base + P->BL.fin_eta + P->BL.fin_eta_stride * (size_t)t) + slot0; }
 
     // retire what chunk `c` finished (its flags are on the host)
@@ -1238,20 +1244,14 @@ struct SweepGroup {
             std::stable_sort(hs32, hs32 + nstrips32, [](const Strip32& a, const Strip32& b) {
                 return a.ntile * a.nrows > b.ntile * b.nrows;
             });
-            std::vector<int32_t> redo;                            // slots whose strip grid is new: fresh ones and restarts
-            redo.assign(fresh.begin(), fresh.end());
-            for (const auto& rs : restart) { redo.push_back(rs.first); h_restart[tab][&rs - restart.data()] = rs.first; }
+            for (const auto& rs : restart) h_restart[tab][&rs - restart.data()] = rs.first;
+            // every running job's row-strip table travels with this table copy (one upload; the jobs of the copy point into it)
+            for (int s = 0; s < nslots; ++s) jobs[(size_t)s].row_strip0 = d_rs(tab) + (size_t)s * (size_t)(S.nbmax + 1);
             std::copy(jobs.begin(), jobs.end(), h_jobs[tab]);
             std::copy(fresh.begin(), fresh.end(), h_fresh[tab]);
             int nb_fresh = 0;
             for (int s : fresh) nb_fresh = std::max(nb_fresh, jobs[(size_t)s].nb);
-            for (int s : redo) {
-                const PackedJob& J = jobs[(size_t)s];
-                he = hipMemcpyAsync(S.base + L.total * (size_t)(slot0 + s) + L.row_strip0,
-                                    hrs + (size_t)s * (size_t)(S.nbmax + 1), sizeof(int32_t) * (size_t)(J.nb + 1),
-                                    hipMemcpyHostToDevice, stream);
-                if (he != hipSuccess) break;
-            }
+            he = hipMemcpyAsync(d_rs(tab), hrs, sizeof(int32_t) * (size_t)nslots * (size_t)(S.nbmax + 1), hipMemcpyHostToDevice, stream);
             if (he == hipSuccess)
                 he = hipMemcpyAsync(d_jobs(tab), h_jobs[tab], sizeof(PackedJob) * (size_t)nslots, hipMemcpyHostToDevice, stream);
             if (he == hipSuccess && nstrips > 0)
@@ -1294,9 +1294,11 @@ struct SweepGroup {
                 he = hipEventRecord(export_done[tab], stream);
                 for (int l = 0; l < kTailLanes && he == hipSuccess; ++l) he = hipStreamWaitEvent(S.tail[l], export_done[tab], 0);
                 if (he != hipSuccess) return hip_fail(he, "sweep tail hand-off", __FILE__, __LINE__);
-                for (int64_t e : fin_eta) {
+                const int bm = std::max(1, S.tail_hook->batch_max());
+                for (size_t k0 = 0; k0 < fin_eta.size(); k0 += (size_t)bm) {
                     const int l = S.tail_rr++ % kTailLanes;
-                    const int32_t rc = S.tail_hook->retire(e, S.tail[l], l);
+                    const int32_t rc = S.tail_hook->retire_batch(fin_eta.data() + k0, (int)std::min<size_t>((size_t)bm, fin_eta.size() - k0),
+                                                                 S.tail[l], l);
                     if (rc != SCINT_OK) return rc;
                 }
             }
@@ -1512,7 +1514,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
             J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
             J.rowpart = (cplx*)(sl + L.rowpart); J.colpart = (cplx*)(sl + L.colpart);
-            J.row_strip0 = (const int32_t*)(sl + L.row_strip0);
+            J.row_strip0 = nullptr;       // set per table copy (SweepGroup::enqueue)
             J.apart[0] = (double*)(sl + L.apart0); J.apart[1] = (double*)(sl + L.apart1);
             J.upart[0] = (double*)(sl + L.upart0); J.upart[1] = (double*)(sl + L.upart1);
             J.coef = (double*)(sl + L.coef);

@@ -1319,9 +1319,21 @@ constexpr int kChisqPartials = 8192;   // per-workgroup chi^2 sums of the fused 
 // of its partner are equal: a workgroup takes a row p of the half hp <= p < P (and row 0 when P is even) and counts it
 // twice unless the row is its own partner.  Every element of recov is read once (as itself or as a partner), D on
 // the half plane only: 0.40 GB at 4096^2.  Fixed summation order: bit-reproducible.
-__global__ void __launch_bounds__(256) chisq_parseval_kernel(const cplx* __restrict__ A, const cplx* __restrict__ S, int P, int Q,
-                                                             double* __restrict__ partial) {
+// Round 5: (a) several curvatures per launch (grid.y; RevBatch of thth.hpp -- the per-curvature tail cost the sweep's host thread 11 API
+// calls per curvature), (b) only the delay rows q of the curvature's band are read: recov is exactly 0 outside it (and not even
+// written there by the batched back-map), so those rows contribute sum |D|^2, which comes from prefix / suffix sums of
+//     colsum[q] = sum_{p in the half plane} weight_p |S[p][q]|^2      (chisq_colsum_kernel, chisq_prefix_kernel: once per sweep).
+// The band is symmetric about q = Q / 2 and does not contain row 0 unless it is the whole axis (rev_prep_batch_kernel), so
+// the partner row of a row in the band is in the band.
+__global__ void __launch_bounds__(256) chisq_parseval_batch_kernel(RevBatch bt, const RevJobDev* __restrict__ jobs,
+                                                                   const cplx* __restrict__ S, int P, int Q,
+                                                                   const double* __restrict__ pre, const double* __restrict__ suf,
+                                                                   double* __restrict__ partial_base, int partial_stride) {
     __shared__ double red[4];
+    const cplx* __restrict__ A = bt.recov[blockIdx.y];
+    const unsigned long long* __restrict__ bound = jobs[bt.job[blockIdx.y]].bound;
+    double* __restrict__ partial = partial_base + (int64_t)blockIdx.y * partial_stride;
+    const int qlo = (int)bound[kRevBandLo], qhi = (int)bound[kRevBandHi];
     const int hp = P / 2, hq = Q / 2, nhalf = hp + 1;
     double tot = 0.0;
     for (int hb = (int)blockIdx.x; hb < nhalf; hb += (int)gridDim.x) {
@@ -1337,14 +1349,68 @@ __global__ void __launch_bounds__(256) chisq_parseval_kernel(const cplx* __restr
             const double re = 0.5 * (x.x + y.x) - z.x, im = 0.5 * (x.y - y.y) - z.y;
             return re * re + im * im;
         };
-        int q = (int)threadIdx.x;
-        for (; q + 768 < Q; q += 1024) { a0 += term(q); a1 += term(q + 256); a2 += term(q + 512); a3 += term(q + 768); }
-        for (; q < Q; q += 256) a0 += term(q);
+        int q = qlo + (int)threadIdx.x;
+        for (; q + 768 <= qhi; q += 1024) { a0 += term(q); a1 += term(q + 256); a2 += term(q + 512); a3 += term(q + 768); }
+        for (; q <= qhi; q += 256) a0 += term(q);
         const double row = (a0 + a1) + (a2 + a3);
         tot += pp == p ? row : 2.0 * row;
     }
     tot = block_sum(tot, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {                         // the rows outside the band: |D|^2 alone
+            partial[gridDim.x] = gload(pre + qlo);
+            partial[gridDim.x + 1] = gload(suf + qhi + 1);
+        }
+    }
+}
+// colsum[q] of the kernel above: threads along q (coalesced), the half-plane rows in the kernel's own order
+__global__ void __launch_bounds__(256) chisq_colsum_kernel(const cplx* __restrict__ S, int P, int Q, double* __restrict__ colsum) {
+    const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (q >= Q) return;
+    const int hp = P / 2, nhalf = hp + 1;
+    double acc = 0.0;
+    for (int hb = 0; hb < nhalf; ++hb) {
+        const int p = hp + hb < P ? hp + hb : 0;
+        int pp = 2 * hp - p; pp += pp < 0 ? P : 0; pp -= pp >= P ? P : 0;
+        const cplx z = gload(S + (int64_t)p * Q + q);
+        const double v = z.x * z.x + z.y * z.y;
+        acc += pp == p ? v : 2.0 * v;
+    }
+    colsum[q] = acc;
+}
+// pre[q] = sum_{q' < q} colsum[q'], suf[q] = sum_{q' >= q} colsum[q'], q = 0 .. Q: one workgroup, a contiguous segment per
+// thread, fixed order
+__global__ void __launch_bounds__(256) chisq_prefix_kernel(const double* __restrict__ colsum, int Q, double* __restrict__ pre,
+                                                           double* __restrict__ suf) {
+    __shared__ double seg[256], base_pre[256], base_suf[256];
+    const int t = (int)threadIdx.x, len = (Q + 255) / 256, q0 = min(t * len, Q), q1 = min(q0 + len, Q);
+    double acc = 0.0;
+    for (int q = q0; q < q1; ++q) acc += colsum[q];
+    seg[t] = acc;
+    __syncthreads();
+    if (t == 0) {
+        double run = 0.0;
+        for (int k = 0; k < 256; ++k) { base_pre[k] = run; run += seg[k]; }
+        run = 0.0;
+        for (int k = 255; k >= 0; --k) { base_suf[k] = run; run += seg[k]; }      // sum of the segments AFTER k
+    }
+    __syncthreads();
+    double run = base_pre[t];
+    for (int q = q0; q < q1; ++q) { pre[q] = run; run += colsum[q]; }
+    run = base_suf[t];
+    for (int q = q1 - 1; q >= q0; --q) { run += colsum[q]; suf[q] = run; }
+    if (t == 255) { pre[Q] = base_pre[255] + seg[255]; suf[Q] = 0.0; }
+}
+// chisq_out[job] = scale * sum(partial[0 .. np)) for every curvature of the batch (fixed order)
+__global__ void __launch_bounds__(256) chisq_final_batch_kernel(RevBatch bt, const double* __restrict__ partial_base, int partial_stride,
+                                                                int np, double scale, double* __restrict__ chisq_out) {
+    __shared__ double red[4];
+    const double* __restrict__ partial = partial_base + (int64_t)blockIdx.x * partial_stride;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) chisq_out[bt.job[blockIdx.x]] = acc * scale;
 }
 // 1.0 per non-finite value (the mask chisq_calc builds when none is given, ththmod.py:357-358, is then not all-true)
 struct NonFiniteValue {
@@ -1357,13 +1423,49 @@ struct ChisqTail : SweepTail {
     const cplx* vec; int64_t vstride; const double* w; const double* th_red; int64_t M;
     const double* dspecT; int64_t nf, nt; const uint8_t* maskT; double noise_n; double* chisq_out;
     const cplx* specT = nullptr;      // fftshift(fft2(dspec^T)): set when chi^2 goes by Parseval (no model transform)
+    const RevJobDev* jobs_dev = nullptr; const double* pre = nullptr; const double* suf = nullptr;   // Parseval route: per-curvature table, |D|^2 sums
+    int images = 1;                   // image buffers (and partial-sum sets) per tail lane
     // one set of scratch buffers per tail lane
     cplx* recovT_[kTailLanes]; double* modelT_[kTailLanes]; void* fft_ws_[kTailLanes]; size_t fft_ws_bytes;
     double* partial_[kTailLanes]; void* rev_scratch_[kTailLanes];
 
+    int batch_max() const override { return specT ? images : 1; }
+
+    // Parseval route: the curvatures a chunk retired, <= `images` of them, in four launches (thth.hpp)
+    int32_t retire_batch(const int64_t* es, int count, hipStream_t tail, int lane) override {
+        if (!specT) return SweepTail::retire_batch(es, count, tail, lane);
+        RevBatch b;
+        b.n = 0; b.pad = 0;
+        const size_t image = (size_t)g.ntau * (size_t)g.nfd;
+        for (int k = 0; k < count; ++k) {
+            if (keep_n[es[k]] < 3) continue;           // crop to fewer than three centres: chi^2 stays NaN (no mean edge step)
+            SCINT_REQUIRE(b.n < images && b.n < kRevBatchMax, "chisq sweep: tail batch too large");
+            b.job[b.n] = (int32_t)es[k];
+            b.recov[b.n] = recovT_[lane] + image * (size_t)b.n;
+            ++b.n;
+        }
+        for (int k = b.n; k < kRevBatchMax; ++k) { b.job[k] = 0; b.recov[k] = nullptr; }
+        if (b.n == 0) return SCINT_OK;
+        const int ps = profiler().begin(kProfRevmap, tail);
+        int32_t rc = launch_rev_map_rank1_batch(jobs_dev, b, g, tail);
+        profiler().end(kProfRevmap, ps, tail);
+        if (rc != SCINT_OK) return rc;
+        const int pm = profiler().begin(kProfModel, tail);
+        const int P = (int)g.nfd, Q = (int)g.ntau;
+        const int nblk = std::min(P / 2 + 1, kChisqPartials);
+        hipLaunchKernelGGL(chisq_parseval_batch_kernel, dim3((unsigned)nblk, (unsigned)b.n), dim3(256), 0, tail, b, jobs_dev, specT,
+                           P, Q, pre, suf, partial_[lane], kChisqPartials + 8);
+        hipLaunchKernelGGL(chisq_final_batch_kernel, dim3((unsigned)b.n), dim3(256), 0, tail, b, partial_[lane], kChisqPartials + 8,
+                           nblk + 2, 1.0 / ((double)P * (double)Q) / noise_n, chisq_out);
+        if (hipGetLastError() != hipSuccess) rc = SCINT_E_HIP;
+        profiler().end(kProfModel, pm, tail);
+        return rc;
+    }
+
+    // model route (a cropped model, a mask, a non-finite dspec): one curvature at a time through the complex-to-real transform
     int32_t retire(int64_t e, hipStream_t tail, int lane) override {
         const int64_t n = keep_n[e];
-        if (n < 2) return SCINT_OK;                       // crop-to-nothing: chi^2 stays NaN
+        if (n < 3) return SCINT_OK;                       // crop to fewer than three centres: chi^2 stays NaN
         cplx* recovT = recovT_[lane]; double* modelT = modelT_[lane]; void* fft_ws = fft_ws_[lane];
         double* partial = partial_[lane]; void* rev_scratch = rev_scratch_[lane];
         const int ps = profiler().begin(kProfRevmap, tail);
@@ -1372,16 +1474,6 @@ struct ChisqTail : SweepTail {
         profiler().end(kProfRevmap, ps, tail);
         if (rc != SCINT_OK) return rc;
         const int pm = profiler().begin(kProfModel, tail);
-        if (specT) {
-            const int P = (int)g.nfd, Q = (int)g.ntau;
-            const int nblk = std::min(P / 2 + 1, kChisqPartials);
-            hipLaunchKernelGGL(chisq_parseval_kernel, dim3((unsigned)nblk), dim3(256), 0, tail, recovT, specT, P, Q, partial);
-            hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, tail, partial, nblk,
-                               1.0 / ((double)P * (double)Q) / noise_n, chisq_out + e);
-            if (hipGetLastError() != hipSuccess) rc = SCINT_E_HIP;
-            profiler().end(kProfModel, pm, tail);
-            return rc;
-        }
         RealPairChisq fuse{}; fuse.dspec = dspecT; fuse.mask = maskT; fuse.partial = partial;
         int nblk = 0;
         rc = model_from_recov(recovT, g.nfd, g.ntau, modelT, nf, nt, nf, fft_ws, fft_ws_bytes, tail,
@@ -1399,7 +1491,15 @@ struct ChisqTail : SweepTail {
 
 struct ChisqSweepLayout {
     size_t recov[kTailLanes], model[kTailLanes], dspecT, maskT, specT, fft[kTailLanes], partial[kTailLanes], rev[kTailLanes], sweep, total, fft_bytes, sweep_bytes;
+    size_t jobs, bounds, colsum, pre, suf;     // Parseval route: RevJobDev table, per-curvature constants, |D|^2 sums along the delay axis
+    int images;                                // image buffers per tail lane (tail batches)
 };
+// Image buffers per tail lane: as many curvatures as a tail batch may hold (thth.hpp), within 2 GiB per lane (8 at 4096^2, 2 at 8192^2)
+static int chisq_images_per_lane(int64_t ntau, int64_t nfd, int64_t nf, int64_t nt) {
+    if (!(nf == ntau && nt == nfd)) return 1;                      // cropped model: the per-curvature model route only
+    const size_t image = sizeof(cplx) * (size_t)ntau * (size_t)nfd;
+    return (int)std::max<size_t>(1, std::min<size_t>(kRevBatchMax, ((size_t)2 << 30) / std::max<size_t>(image, 1)));
+}
 static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, int64_t ntau, int64_t nfd,
                                   int64_t nf, int64_t nt, ChisqSweepLayout* L) {
     size_t off = 0;
@@ -1408,11 +1508,18 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
     L->maskT = take((size_t)nf * (size_t)nt);
     L->specT = take((nf == ntau && nt == nfd) ? sizeof(cplx) * (size_t)ntau * (size_t)nfd : 0);   // Parseval route only
     L->fft_bytes = fft2_general_ws(nfd, ntau, nfd);
+    L->images = chisq_images_per_lane(ntau, nfd, nf, nt);
+    const bool parseval_shape = nf == ntau && nt == nfd;
+    L->jobs = take(parseval_shape ? sizeof(RevJobDev) * (size_t)neta : 0);
+    L->bounds = take(parseval_shape ? sizeof(unsigned long long) * kRevWords * (size_t)neta : 0);
+    L->colsum = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
+    L->pre = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
+    L->suf = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
     for (int l = 0; l < kTailLanes; ++l) {
-        L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd);
+        L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd * (size_t)L->images);
         L->model[l] = take(sizeof(double) * (size_t)nf * (size_t)nt);
         L->fft[l] = take(L->fft_bytes);
-        L->partial[l] = take(sizeof(double) * (kChisqPartials + 8));
+        L->partial[l] = take(sizeof(double) * (kChisqPartials + 8) * (size_t)L->images);
         L->rev[l] = take(256);
     }
     int32_t rc = sweep_workspace_bytes(M, neta, batch, max_iter, true, 1, &L->sweep_bytes);
@@ -1490,6 +1597,24 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
             rc = scint_cs(dspecT, nt, nf, 0, 0.0, 0, 0, 0, (scint_c128*)specT, t.fft_ws_[0], L.fft_bytes, stream);
             if (rc != SCINT_OK) return rc;
             t.specT = specT;
+            // |D|^2 summed over the Doppler half plane for every delay row, and its prefix / suffix sums: what the rows
+            // outside a curvature's band contribute to its chi^2
+            const int P = (int)geom->nfd, Q = (int)geom->ntau;
+            double* colsum = (double*)(base + L.colsum);
+            hipLaunchKernelGGL(chisq_colsum_kernel, dim3((unsigned)ceil_div(Q, 256)), dim3(256), 0, st, specT, P, Q, colsum);
+            hipLaunchKernelGGL(chisq_prefix_kernel, dim3(1), dim3(256), 0, st, colsum, Q, (double*)(base + L.pre), (double*)(base + L.suf));
+            SCINT_LAUNCH_CHECK();
+            t.pre = (const double*)(base + L.pre); t.suf = (const double*)(base + L.suf);
+            // the per-curvature table of the batched tail (thth.hpp): everything but the image buffer is known now
+            std::vector<RevJobDev> table((size_t)neta);
+            unsigned long long* bounds = (unsigned long long*)(base + L.bounds);
+            for (int64_t e = 0; e < neta; ++e)
+                table[(size_t)e] = make_rev_job((const cplx*)vec_out + e * vec_stride, w_out + e, th_red + e * M, keep_n[e], t.g,
+                                                etas[e], bounds + (size_t)e * kRevWords);
+            SCINT_HIP(hipMemcpyAsync(base + L.jobs, table.data(), sizeof(RevJobDev) * (size_t)neta, hipMemcpyHostToDevice, st));
+            SCINT_HIP(hipStreamSynchronize(st));       // (the table is a local: the copy has left it)
+            t.jobs_dev = (const RevJobDev*)(base + L.jobs);
+            t.images = L.images;
         }
     }
     return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,

@@ -61,6 +61,17 @@ static_assert(kRows64 == 2 || kRows64 == 4 || kRows64 == 8 || kRows64 == 16, "kR
 constexpr int kMaxStrip = SCINT_MAXSTRIP;            // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS:
                                                      // 8 rows x 12 tiles -> 72 KiB, two workgroups per CU and 12 KiB left for the reduce blocks;
                                                      // 4 x 14 -> 72 KiB; 4 x 9 -> 52 KiB, three per CU; 4 x 6 -> 40 KiB, four: both measured slower)
+// Eigenvector sweeps (modeler, chi^2, retrieval) stop when the Ritz residual is below kVecGapFactor * tol of the spectral gap
+// theta_1 - theta_2 (pk2_check_kernel): the angle between the Ritz vector and the eigenvector is then <= kVecGapFactor * tol, and
+// so is the relative error of the rank-1 model |w| V V^H that is compared with the reference's at 1e-9.  Rounds 1-4: 30 (3e-11);
+// round 5: 100 (1e-10, ten times inside the bar; measured deviations are another 10-60 times below the bound --
+// tools/experiments/vec_factor_passes.py: <= 1.1e-11 at 512^2 on the arc and on a reference Simulation screen).  With the check every
+// two passes the change is worth 0.2 passes per curvature; 300 and 1000 would save 1.1 and 1.8 of 28 and were not taken.
+#ifndef SCINT_VEC_GAP_FACTOR
+#define SCINT_VEC_GAP_FACTOR 100.0
+#endif
+constexpr double kVecGapFactor = SCINT_VEC_GAP_FACTOR;
+
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced > kMaxStrip ? kMaxStrip : forced;   // tests of schedule independence
@@ -159,6 +170,16 @@ struct SweepTail {
     // `lane` (0 .. kTailLanes-1) names the tail stream: work of one lane is ordered, the lanes overlap, so
     // an implementation keeps one set of scratch buffers per lane
     virtual int32_t retire(int64_t eta_index, hipStream_t tail, int lane) = 0;
+    // The curvatures ONE chunk retired, at most batch_max() of them per call (round 5: a chunk retires 20-30 curvatures at once,
+    // and a tail that costs the host a dozen API calls per curvature starves both slot groups of their next chunk).  Default: one by one.
+    virtual int32_t retire_batch(const int64_t* eta_index, int n, hipStream_t tail, int lane) {
+        for (int k = 0; k < n; ++k) {
+            const int32_t rc = retire(eta_index[k], tail, lane);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+    virtual int batch_max() const { return 1; }
     virtual ~SweepTail() {}
 };
 

@@ -472,22 +472,24 @@ __device__ inline int rev_first_ge(const double* th, int N, double thi, double l
 // pre-pass and epilogue; the split grid alone is a frexp, two ldexp, a square root and a division, the window two more
 // divisions): the split grid of rev_split_for, the mean theta spacing and the window width.  Same expressions, same bits.
 constexpr int kRevWin = 8;   // widest candidate window (theta centres per fd bin, + 2)
-enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6 };
-__global__ void __launch_bounds__(64) rev_setup_kernel(RevParams p, GeomDev g, unsigned long long* bound) {
-    if (threadIdx.x != 0) return;
-    const double aw = p.rank1 ? fabs(gload(p.w)) : 0.0;
-    const double vmax = __longlong_as_double((long long)bound[0]);
-    const RevSplit sp = rev_split_for(p.rank1 ? aw * vmax * vmax : vmax, __longlong_as_double((long long)bound[1]),
-                                      p.two_eta, !p.rank1 && p.hermitian);
-    const int N = p.N;
+// (the word indices kRevS1 .. kRevBandHi are in thth.hpp)
+__device__ inline void rev_setup_consts(bool rank1, bool hermitian, const double* w, const double* th, int N, double two_eta,
+                                        const GeomDev& g, double vmax, double dmin, unsigned long long* bound) {
+    const double aw = rank1 ? fabs(gload(w)) : 0.0;
+    const RevSplit sp = rev_split_for(rank1 ? aw * vmax * vmax : vmax, dmin, two_eta, !rank1 && hermitian);
     // window width from the mean theta spacing (the window START depends on the column and stays in the gather)
-    const double th_step = N > 1 ? (gload(p.th + N - 1) - gload(p.th)) / (double)(N - 1) : 0.0;
+    const double th_step = N > 1 ? (gload(th + N - 1) - gload(th)) / (double)(N - 1) : 0.0;
     const int W = th_step > 0.0 ? (int)fmin(ceil(g.fd1_step / th_step) + 2.0, (double)kRevWin) : 0;
     bound[kRevS1] = (unsigned long long)__double_as_longlong(sp.s1);
     bound[kRevS2] = (unsigned long long)__double_as_longlong(sp.s2);
     bound[kRevExact] = sp.exact ? 1ull : 0ull;
     bound[kRevThStep] = (unsigned long long)__double_as_longlong(th_step);
     bound[kRevW] = (unsigned long long)(W < 0 ? 0 : W);
+}
+__global__ void __launch_bounds__(64) rev_setup_kernel(RevParams p, GeomDev g, unsigned long long* bound) {
+    if (threadIdx.x != 0) return;
+    rev_setup_consts(p.rank1 != 0, p.hermitian != 0, p.w, p.th, p.N, p.two_eta, g, __longlong_as_double((long long)bound[0]),
+                     __longlong_as_double((long long)bound[1]), bound);
 }
 
 // One workgroup owns the `slab` tau rows [blockIdx.y*slab, ...) of ONE fd column of recov
@@ -516,7 +518,7 @@ constexpr int kRevBlock = 256;      // lanes per block of the chunk pre-pass: a 
 constexpr int kRevLiveWords = 64;   // 32 chunks per word: N <= 524288 is pruned, beyond that every chunk is walked
 
 template <int kRevThreads, bool RANK1>
-__global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
+__device__ __forceinline__ void rev_gather_body(const RevParams& p, const GeomDev& g, const int64_t col_in, const int slab_index) {
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
     // rev_lds[0 .. 4 slab): real hi, real lo, imag hi, imag lo grids; then the counts.  Always
@@ -524,9 +526,9 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
     uint32_t* cnt = (uint32_t*)(rev_lds + 4 * slab);
     // columns of 4 neighbouring workgroups of one XCD are adjacent, so their 16 B stores
     // complete 64 B lines in that XCD's L2
-    int64_t col = blockIdx.x;
+    int64_t col = col_in;
     if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);
-    const int64_t row0 = (int64_t)blockIdx.y * slab;
+    const int64_t row0 = (int64_t)slab_index * slab;
     const int rows = (int)min((int64_t)slab, g.ntau - row0);
     for (int r = threadIdx.x; r < rows; r += kRevThreads) {
         rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0; rev_lds[2 * slab + r] = 0.0; rev_lds[3 * slab + r] = 0.0;
@@ -732,6 +734,91 @@ __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, Ge
     }
 }
 
+template <int kRevThreads, bool RANK1>
+__global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
+    rev_gather_body<kRevThreads, RANK1>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
+}
+
+// ---- several curvatures per launch (chi^2 sweep; thth.hpp) -------------------------------------------------------------
+// One workgroup per curvature: what rev_bound_kernel + rev_setup_kernel do for one image (the same maxima, the same expressions:
+// the same bits), without atomics and memsets -- a rank-1 image has only N values to look at -- plus the delay band.
+// Band: every pair has tau_map = eta (th_j^2 - th_i^2) with |tau_map| <= Y = |eta| max th^2 also as computed (a difference of
+// two non-negative squares is at most the larger one, and every rounding involved is monotone); the histogram bin is monotone in
+// its argument, so all pixels that receive a pair lie in the delay rows bin(-Y) .. bin(Y); one row of slack each side, then the
+// hull with its own mirror image about tau = 0 (row ntau / 2 of the shifted axis), which is what the chi^2 kernel needs:
+// the partner (-fd, -tau) of a pixel in the band is in the band.  A band that touches either end of the axis is the whole axis.
+// Everything outside the band is exactly 0 in the full image (no pair: count 0 -> 0/0 -> nan_to_num -> 0).
+__global__ void __launch_bounds__(256) rev_prep_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g) {
+    __shared__ double red[3][4];
+    const RevJobDev jb = jobs[b.job[blockIdx.x]];
+    const int N = jb.N;
+    double vmax = 0.0, dmin = INFINITY, t2max = 0.0;
+    bool bad = false;
+    for (int k = threadIdx.x; k < N; k += 256) {
+        const cplx v = gload(jb.vec + k);
+        const double a = fmax(fabs(v.x), fabs(v.y));
+        bad |= !(a == a);
+        vmax = fmax(vmax, a);
+        const double t = gload(jb.th + k);
+        t2max = fmax(t2max, t * t);
+        bad |= !(t == t);
+        if (k + 1 < N) {
+            const double d = gload(jb.th + k + 1) - t;
+            bad |= !(d > 0.0);
+            dmin = fmin(dmin, d);
+        }
+    }
+    if (bad) { vmax = INFINITY; dmin = 0.0; t2max = INFINITY; }   // poisons the bound -> plain adds; the whole axis
+    for (int o = 32; o > 0; o >>= 1) {
+        vmax = fmax(vmax, __shfl_xor(vmax, o, 64));
+        dmin = fmin(dmin, __shfl_xor(dmin, o, 64));
+        t2max = fmax(t2max, __shfl_xor(t2max, o, 64));
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = vmax; red[1][w] = dmin; red[2][w] = t2max; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    vmax = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3])) * 1.4142135623730951;   // |v| <= sqrt2 max(|re|, |im|)
+    dmin = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
+    t2max = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+    if (N < 2) dmin = __longlong_as_double(0x7f7f7f7f7f7f7f7fll);        // (what the memset of the one-image path leaves when no spacing exists)
+    unsigned long long* bound = jb.bound;
+    bound[0] = (unsigned long long)__double_as_longlong(vmax);
+    bound[1] = (unsigned long long)__double_as_longlong(dmin);
+    rev_setup_consts(true, true, jb.w, jb.th, N, jb.two_eta, g, vmax, dmin, bound);
+    int64_t lo = 0, hi = g.ntau - 1;
+    const double Y = fabs(jb.eta) * t2max;
+    if (Y == Y && Y < INFINITY && g.tau1_step > 0.0) {
+        const int64_t bl = hist_bin(-Y, g.tau0, g.tau1_step, g.ntau), bh = hist_bin(Y, g.tau0, g.tau1_step, g.ntau);
+        // (-1: the value lies off the axis -- the band then runs to that end of it)
+        lo = bl < 0 ? 0 : bl - 1;
+        hi = bh < 0 ? g.ntau - 1 : bh + 1;
+        const int64_t hq = g.ntau / 2;
+        const int64_t mlo = 2 * hq - hi, mhi = 2 * hq - lo;
+        lo = lo < mlo ? lo : mlo;
+        hi = hi > mhi ? hi : mhi;
+        if (lo <= 0 || hi >= g.ntau - 1) { lo = 0; hi = g.ntau - 1; }
+    }
+    bound[kRevBandLo] = (unsigned long long)lo;
+    bound[kRevBandHi] = (unsigned long long)hi;
+}
+
+__global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g, int slab) {
+    const RevJobDev jb = jobs[b.job[blockIdx.z]];
+    // slabs that miss the curvature's delay band leave at once: nothing of them is read afterwards
+    const int64_t row0 = (int64_t)blockIdx.y * slab;
+    if (row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) return;
+    RevParams p;
+    p.thth = nullptr; p.ld = jb.N;
+    p.vec = jb.vec; p.w = jb.w; p.rank1 = 1;
+    p.th = jb.th; p.N = jb.N;
+    p.eta = jb.eta; p.two_eta = jb.two_eta;
+    p.hermitian = 1; p.slab = slab; p.centre = jb.centre;
+    p.recov = b.recov[blockIdx.z]; p.transposed = 1;
+    p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
+    rev_gather_body<kRevThreadsK, true>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
+}
+
 RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, int rank1, const double* th, int N,
                           const GeomDev& g, double eta, int hermitian, cplx* recov) {
     RevParams p;
@@ -782,6 +869,27 @@ int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th,
     RevParams p = make_rev_params(nullptr, vec, w, 1, th, (int)N, g, eta, 1, recov);
     p.transposed = transposed ? 1 : 0;
     return launch_rev_map(p, g, (unsigned long long*)scratch, stream);
+}
+
+RevJobDev make_rev_job(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g, double eta,
+                       unsigned long long* bound) {
+    const RevParams p = make_rev_params(nullptr, vec, w, 1, th, (int)N, g, eta, 1, nullptr);
+    RevJobDev j;
+    j.vec = vec; j.w = w; j.th = th;
+    j.eta = eta; j.two_eta = p.two_eta; j.inv_tau1_step = p.inv_tau1_step;
+    j.centre = p.centre; j.bound = bound; j.N = (int32_t)N; j.pad = 0;
+    return j;
+}
+
+int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, hipStream_t stream) {
+    SCINT_REQUIRE(b.n >= 1 && b.n <= kRevBatchMax, "rev_map batch: bad count");
+    hipLaunchKernelGGL(rev_prep_batch_kernel, dim3((unsigned)b.n), dim3(256), 0, stream, jobs_dev, b, g);
+    const int slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));     // the slabs of launch_rev_map
+    dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, slab), (unsigned)b.n);
+    SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
+    hipLaunchKernelGGL(rev_gather_batch_kernel, grid, dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, b, g, slab);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
 }
 
 }  // namespace scint

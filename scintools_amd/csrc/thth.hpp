@@ -117,4 +117,34 @@ int32_t launch_gather(const cplx* cs, const GeomDev& g, const double* th_cents, 
 int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g,
                              double eta, cplx* recov, bool transposed, void* scratch, hipStream_t stream);
 
+
+// ---- the same back-map for SEVERAL retired curvatures in one set of launches (chi^2 sweep, round 5) -----------------------
+// A chunk of the sweep retires its curvatures together (they start together and need about the same number of passes: 20-30 per
+// chunk at 4096^2), and the per-curvature tail -- two memsets, bound, setup, back-map, chi^2, final sum, four profiling events --
+// cost the sweep's ONE host thread 11 API calls each, during which neither slot group got its next chunk: the mat-vec was in
+// flight for only 85 % of a chi^2 step (profiles/r04_timeline.txt; 97.5 % in the eigenvalue sweep).  Batched: four launches
+// per <= kRevBatchMax curvatures, whatever their number.
+constexpr int kRevBatchMax = 8;
+struct RevJobDev {                 // one per curvature of the sweep, built on the host before the sweep starts
+    const cplx* vec; const double* w; const double* th;   // eigenvector [N], |w| (device scalar), centres of the reduced edges [N]
+    double eta, two_eta, inv_tau1_step;
+    int64_t centre;                // flat index of the pixel the i == j terms poison, or -1
+    unsigned long long* bound;     // [kRevWords] this curvature's constants (rev_prep_batch_kernel writes, the gather and chi^2 read)
+    int32_t N, pad;
+};
+constexpr int kRevWords = 16;      // words per curvature: max |v| sqrt 2, min spacing, the RevConsts, the delay band
+struct RevBatch {                  // by value in the kernel arguments
+    int32_t n, pad;
+    int32_t job[kRevBatchMax];     // index into the RevJobDev table
+    cplx* recov[kRevBatchMax];     // transposed image [nfd, ntau] of each
+};
+RevJobDev make_rev_job(const cplx* vec, const double* w, const double* th, int64_t N, const GeomDev& g, double eta,
+                       unsigned long long* bound);
+// bound pre-pass + constants + delay band (one workgroup per curvature), then the column gather over grid.z = curvature.
+// Only the delay rows a curvature can reach -- |tau| <= |eta| max theta^2, widened to a band that is symmetric about
+// tau = 0 -- are computed and written (whole slabs that miss the band leave at once); the band is left in
+// bound[kRevBandLo], bound[kRevBandHi] for the consumer (chisq_parseval_batch_kernel), which must not read outside it.
+int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, hipStream_t stream);
+enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6, kRevBandLo = 7, kRevBandHi = 8 };
+
 }  // namespace scint

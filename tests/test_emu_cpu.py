@@ -454,6 +454,48 @@ def test_chisq_sweep_by_parseval_against_the_oracle(emu, to, nf, nt):
     np.testing.assert_allclose(got_h, ref_h, rtol=1e-9)
 
 
+def test_chisq_sweep_tail_batches_and_delay_band(emu, to):
+    """Round 5: the chi^2 sweep hands the curvatures a chunk retires to its tail in batches (four launches per <= 8 curvatures
+    instead of eleven API calls per curvature), and back-map and chi^2 touch only the delay rows a curvature can reach
+    (|tau| <= |eta| max theta^2, made symmetric about tau = 0); the rows outside contribute sum |fft2(dspec)|^2 from prefix sums.
+    Two delay slabs (ntau = 1100), curvatures from a band of a few rows to the whole axis and into the crop, more curvatures
+    than one batch holds: against the oracle's chisq_calc (1e-9), against the product's per-eta chisq_calc through the model
+    transform (1e-11), and bit-identical whatever the batch a curvature lands in (subset, reversed order, one slot group)."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(1100, 48, seed=21, nimg=8, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 60)
+    CS = to.conjugate_spectrum(dyn, 0)
+    th = emu._Grid(tau, fd, edges).th_cents
+    eta_full = np.abs(tau).max() / (th**2).max()                    # tau_map reaches the end of the delay axis here
+    etas = np.array([0.004, 0.03, 0.11, 0.3, 0.45, 0.49, 0.51, 0.7, 0.95, 1.05, 1.6, 3.0, 0.2, 0.6, 0.02, 0.8, 2.0, 0.25]) * eta_full
+    got = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0)
+    assert np.all(np.isfinite(got))
+    sample = [0, 2, 5, 6, 9, 11]
+    ref = np.array([to.chisq_calc(dyn, CS, tau, fd, etas[i], edges, 3.0) for i in sample])
+    np.testing.assert_allclose(got[sample], ref, rtol=1e-9)
+    one = np.array([emu.chisq_calc(dyn, CS, tau, fd, e, edges, 3.0) for e in etas])
+    np.testing.assert_allclose(got, one, rtol=1e-11)
+    assert np.array_equal(got[::-1], emu.chisq_sweep(dyn, CS, tau, fd, etas[::-1], edges, 3.0))
+    assert np.array_equal(got[3:9], emu.chisq_sweep(dyn, CS, tau, fd, etas[3:9], edges, 3.0))
+    assert np.array_equal(got, emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, batch=3))
+    # the claim behind the band, on the full image of the one-image back-map: no pair falls outside the rows
+    # bin(-Y) .. bin(Y), Y = eta max theta^2 (so nothing is lost by not computing them)
+    import torch
+    for i in (0, 1, 3, 8):
+        red, V, w, recov, model, keep = emu._modeler_dev(emu.to_device(CS, torch.complex128), emu._Grid(tau, fd, edges), float(etas[i]))
+        img = recov.numpy()
+        thr = emu._theta_centres(emu._Grid(tau, fd, edges).edges_red(keep))
+        Y = abs(etas[i]) * (thr**2).max()
+        step = tau[1] - tau[0]
+        rows = np.nonzero(np.abs(img).sum(axis=1))[0]
+        lo, hi = np.floor((-Y - tau[0]) / step + 0.5), np.floor((Y - tau[0]) / step + 0.5)
+        assert rows.min() >= lo - 1 and rows.max() <= hi + 1, (i, rows.min(), rows.max(), lo, hi)
+        if i < 3:
+            assert hi - lo < 0.5 * len(tau)          # (these curvatures do have a narrow band: the test is not vacuous)
+
+
 def test_chunk_retrieval_in_byte_bounded_groups(emu, to, capsys):
     """the batched phase retrieval stacks conjugate spectra only up to a byte budget (groups, as the fit path
     does), and a chunk that cannot be prepared is left zero with its error printed while the others go on -- the reference's
