@@ -57,31 +57,58 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def library_fingerprint():
+    """What the loaded library was built from: SHA-256 over the kernel sources and the C header (sorted by name), and over
+    the shared library file itself.  The PMC summaries under profiles/ record the first (the tools copy it from the bench
+    line of the profiled run); a summary taken from other sources is refused below (a kernel change
+    without a new PMC pass carried a stale ratio)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "scintools_amd", "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")))
+    for path in [os.path.join(csrc, f) for f in names] + [os.path.join(REPO, "include", "scint_hip.h")]:
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
+    so = hashlib.sha256()
+    try:
+        with open(os.path.join(REPO, "scintools_amd", "libscint_hip.so"), "rb") as fh:
+            so.update(fh.read())
+        so_hex = so.hexdigest()
+    except OSError:
+        so_hex = None
+    return {"csrc_sha256": h.hexdigest(), "so_sha256": so_hex}
+
+
+def _newest_summary(pattern, key):
+    """(ratio, source, note) from the newest profiles/<pattern> whose recorded source fingerprint is THIS library's."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))
+    if not files:
+        return None, None, "no PMC summary committed"
+    mine = library_fingerprint()["csrc_sha256"]
+    with open(files[-1]) as fh:
+        summ = json.load(fh)
+    rel = os.path.relpath(files[-1], REPO)
+    theirs = summ.get("csrc_sha256")
+    if theirs != mine:
+        return None, rel, (f"{rel} was measured on other kernel sources (csrc_sha256 {str(theirs)[:12]} != {mine[:12]}): "
+                           "no traffic figure is quoted until `tools/gpu_run.sh pmc` has been re-run on this library")
+    return key(summ), rel, None
+
+
 def pmc_traffic_ratio():
     """HBM bytes / algorithmic bytes of the dominant kernel, from the newest committed PMC
     summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same script,
-    gfx950 FETCH x2 correction -- tools/pmc_summary.py).  None if no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as fh:
-        summ = json.load(fh)
-    k = summ["kernels"].get(summ.get("dominant_kernel", "scint::pk_matvec_kernel"), {})
-    return k.get("traffic_over_algorithmic"), os.path.relpath(files[-1], REPO)
+    gfx950 FETCH x2 correction -- tools/pmc_summary.py) -- if it was measured on this library's sources."""
+    return _newest_summary("*_pmc_summary.json", lambda summ: summ["kernels"].get(
+        summ.get("dominant_kernel", "scint::pk_matvec_kernel"), {}).get("traffic_over_algorithmic"))
 
 
 def pmc_modeler_ratio():
     """HBM bytes / algorithmic bytes of ONE WHOLE STEP of the modeler / chi^2 objective (every kernel of the step), from the
     newest committed summary of `tools/gpu_run.sh pmc_modeler` (separate FETCH_SIZE / WRITE_SIZE passes of
-    `bench.py --objective chisq`, tools/pmc_modeler_summary.py).  None if no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_modeler_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as fh:
-        summ = json.load(fh)
-    return summ.get("traffic_over_algorithmic"), os.path.relpath(files[-1], REPO)
+    `bench.py --objective chisq`, tools/pmc_modeler_summary.py) -- if it was measured on this library's sources."""
+    return _newest_summary("*_pmc_modeler_summary.json", lambda summ: summ.get("traffic_over_algorithmic"))
 
 
 def port_vs_reference():
@@ -114,7 +141,8 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
     rv, mt = neta * geom_bytes, neta * (geom_bytes + dspec_bytes)
     per_step = mv + ga + rv + mt
     el = mod["elapsed"] / msteps
-    ratio, src = pmc_modeler_ratio()
+    ratio, src, stale = pmc_modeler_ratio()
+    images = neta * msteps
 
     def part(bytes_per_step, k):
         busy = mod["busy_ms"][k] / 1e3 / msteps
@@ -141,10 +169,16 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
                                                            "back_map_write": rv / neta, "model_read_plus_dspec": mt / neta},
                      "traffic": ratio * per_step / neta if ratio else None,
                      "traffic_note": (f"HBM bytes per eta = {ratio:.3f} x algorithmic (every kernel of a chi^2 step; rocprofv3 "
-                                      f"PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), {src}") if ratio else None,
+                                      f"PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), {src}") if ratio else stale,
                      "parts": {"pk2_matvec_kernel": part(mv, 1), "thth_gather_packed_kernel": part(ga, 0),
-                               "rev_gather_kernel (rank-1)": part(rv, 3),
-                               "chi^2 step (chisq_parseval_kernel; model transform + sink when cropped or masked)": part(mt, 4)}}}
+                               "rev_gather_kernel (rank-1)": dict(
+                                   part(rv, 3), images_per_launch=images / max(1, mod["launches"][3]),
+                                   avg_ms_per_image=mod["sum_ms"][3] / max(1, images),
+                                   note="launches cover the <= 8 curvatures one chunk retired (tail batches); only the delay band "
+                                        "a curvature reaches is computed and written, the algorithmic bytes are the full image's"),
+                               "chi^2 step (chisq_parseval_batch_kernel; model transform + sink when cropped or masked)": dict(
+                                   part(mt, 4), images_per_launch=images / max(1, mod["launches"][4]),
+                                   avg_ms_per_image=mod["sum_ms"][4] / max(1, images))}}}
 
 
 def parse():
@@ -180,6 +214,17 @@ def parse():
     ap.add_argument("--mixed-steps", type=int, default=3,
                     help="N=1, --precision f64: also time this many steps of the mixed sweep on the same workload and "
                          "compare its curve with the float64 one (object 'mixed_precision' of the line)")
+    ap.add_argument("--sim-steps", type=int, default=3,
+                    help="N=1: also time this many steps of the same sweep on a reference-`Simulation` screen of the same size "
+                         "(oracle/sim_oracle.py, SURVEY.md 8d settings, generated outside every timed region; object "
+                         "'simulation_screen' of the line); 0 = skip")
+    ap.add_argument("--share-steps", type=int, default=3,
+                    help="N=1: also time rank 0's and the last rank's interleaved share etas[R::W] of the sweep alone on this GPU for "
+                         "W = 2, 4, 8 (config.predicted_strong_scaling: what --shard eta would give if nothing but the shares' own "
+                         "time mattered); 0 = skip")
+    ap.add_argument("--tol", type=float, default=None,
+                    help="Ritz tolerance of the eigenvalue sweeps (default ththmod.DEFAULT_TOL = 1e-12, 1000x inside the 1e-9 parity "
+                         "bar); for the tolerance A/Bs of profiles/ -- the headline is quoted at the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed region's own sweep: no CPU baseline, no modeler / mixed / one-slot-group legs "
@@ -192,7 +237,7 @@ def parse():
                          "core the host memory allows, 0 = skip")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_cpu_baseline, args.modeler_steps, args.mixed_steps = True, 0, 0
+        args.no_cpu_baseline, args.modeler_steps, args.mixed_steps, args.sim_steps, args.share_steps = True, 0, 0, 0, 0
     return args
 
 
@@ -388,6 +433,60 @@ def cpu_baseline_pool(dyn, tau, fd, edges, etas, nproc, npad=0):
                       f"{len(idx)} of {len(etas)} etas, {dt:.1f} s"}
 
 
+def simulation_screen_leg(args, size, neta, nedge, wl, main_wl, timed, ththmod):
+    """The `simulation_screen` object: the headline sweep on the input SURVEY.md 8d's config 3 actually specifies -- a reference
+    `Simulation` screen (scint_sim.py:23-415; mb2=20, ar=10, Kolmogorov, seed 3), restated bit for bit by oracle/sim_oracle.py
+    and generated here OUTSIDE every timed region (an input generator; nothing of it is measured).  On such a screen
+    lambda_2 / lambda_1 -> 0.99 on the flat ends of the curve and a curvature needs ~1.65x the passes of the analytic arc: this
+    is the rate a user's observation gets.  The values at the golden indices are compared with the reference's own Eval_calc
+    run (tests/golden/sim_sweep_4096.npz, committed; generated by tests/golden/make_golden.py from the unmodified reference)."""
+    try:
+        from oracle import sim_oracle
+        from scintools_amd.ththmod import fft_axis
+        import torch
+        t0 = time.perf_counter()
+        workers = sim_oracle.default_workers(64)
+        sim = sim_oracle.baseline_dynspec(size, 3, workers=workers)
+        gen_s = time.perf_counter() - t0
+        d = np.array(sim.dyn, dtype=np.float64)
+        d -= d.mean()
+        fd = fft_axis(sim.times, 1000.0, args.npad)
+        tau = fft_axis(sim.freqs, 1.0, args.npad)
+        edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge)
+        etas = np.geomspace(0.25, 4.0, neta) * float(sim.eta)
+        k = args.sim_steps
+        wl.update(main_wl, dyns=[ththmod.to_device(d, torch.float64)], tau=tau, fd=fd, edges=edges, etas=etas)
+        try:
+            r = timed("eig", k, 1)
+        finally:
+            wl.update(main_wl)
+        info, eigs = r["info"], r["curves"][0]
+        passes = info["iters"]
+        hist = {str(int(p)): int(c) for p, c in zip(*np.unique(passes, return_counts=True))}
+        leg = {"what": f"the same {neta}-eta sweep on a reference Simulation screen {size}x{size} (oracle/sim_oracle.baseline_dynspec({size}, 3): "
+                       "mb2=20, ar=10, psi=0, alpha=5/3, dlam=0.25, ny=128), nedge and eta range as the headline",
+               "value": neta * k / r["elapsed"], "unit": "eta-points/s", "steps": k, "ms_per_step": 1e3 * r["elapsed"] / k,
+               "ratio_to_headline_input": None,
+               "lanczos_steps_mean": float(passes.mean()), "passes_per_eta_histogram": hist,
+               "failed_etas": int(np.sum(info["status"] != 0)), "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
+               "matvec_GBs": r["mv_bytes"] / (r["busy_ms"][1] / 1e3) / 1e9 if r["busy_ms"][1] > 0 else 0.0,
+               "matvec_share_of_step_time": r["busy_ms"][1] / 1e3 / r["elapsed"],
+               "eta_fit_over_sim_eta": float(r["fit"][0] / sim.eta) if np.isfinite(r["fit"][0]) else None,
+               "input_generation_s": gen_s, "input_workers": workers, "input_sha256": sim_oracle.checksum(sim.dyn)[:16]}
+        gpath = os.path.join(REPO, "tests", "golden", f"sim_sweep_{size}.npz")
+        if os.path.exists(gpath) and args.npad == 0 and nedge == size:
+            with np.load(gpath) as g:
+                same_input = sim_oracle.checksum(sim.dyn) == str(g["sha256"])
+                idx = g["idx"]
+                if same_input and neta == 256 and np.array_equal(g["etas"], etas[idx]):
+                    leg["max_rel_diff_vs_reference_values"] = float(np.max(np.abs(eigs[idx] - g["eigs"]) / np.abs(g["eigs"])))
+                    leg["reference_values"] = f"tests/golden/sim_sweep_{size}.npz: the unmodified reference's Eval_calc at eta indices {idx.tolist()}"
+                leg["input_is_the_reference_screen"] = bool(same_input)
+        return leg
+    except Exception as exc:                       # a reported leg must never take the headline down
+        return {"error": repr(exc)}
+
+
 def sspec_timing(torch, size):
     """Dynspec.calc_sspec (window, zero-padded real-to-complex 2-D FFT, |.|^2, shift, dB;
     dynspec.py:3665-3721) on a size^2 and a (2 size)^2 dynamic spectrum resident in HBM.
@@ -471,34 +570,41 @@ def main():
     stack = torch.empty((max(1, len(dyns)), R, C), dtype=torch.complex128, device="cuda") if len(dyns) > 1 else None
     gathered = [torch.empty((per_rank_max, neta), dtype=torch.float64, device=comm_dev) for _ in range(world)]
 
+    # the workload a step runs on: the headline's, or -- for the reported legs below -- a dict that overrides parts of it
+    # (another observation with its axes: the simulation-screen leg; a rank's share of the curvatures: the rank-share leg)
+    main_wl = {"dyns": dyns, "tau": tau, "fd": fd, "edges": edges, "etas": etas, "batch": args.batch}
+    tol = args.tol if args.tol else ththmod.DEFAULT_TOL
+    wl = dict(main_wl)
+
     def step(objective):
         """One pass of the hot path over this rank's observations: the body of single_search
         (ththmod.py:773-859) -- CS once per observation, the eta loop, the peak fit."""
-        curves = np.full((per_rank_max, neta), np.nan)
+        dyns, tau, fd, edges, etas, batch = (wl[k] for k in ("dyns", "tau", "fd", "edges", "etas", "batch"))
+        curves = np.full((per_rank_max, len(etas)), np.nan)
         fit, info = (np.nan, np.nan, None), None
         if objective == "chisq":
             for k, d_t in enumerate(dyns):
                 cs_t = ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True)
-                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True)
+                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True, tol=tol)
                 fit = (etas[np.nanargmin(curves[k])], np.nan, None)
         elif shard_eta:
             # ONE observation, this rank's interleaved share of the curvatures; the all-gather is inside
             from scintools_amd import sweep
             cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
-            curves[0], info = sweep.sharded_eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
+            curves[0], info = sweep.sharded_eval_sweep(cs_t, tau, fd, etas, edges, batch=batch, tol=tol, return_info=True)
             fit = ththmod.fit_eig_peak(etas, curves[0], 0.1)
             return curves, info, fit
         elif len(dyns) == 1:
             cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
-            curves[0], info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, return_info=True)
-            fit = ththmod.fit_eig_peak(etas, curves[0], 0.1)
+            curves[0], info = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=batch, tol=tol, return_info=True)
+            fit = ththmod.fit_eig_peak(etas, curves[0], 0.1) if len(etas) >= 8 else (np.nan, np.nan, None)
         elif dyns:
             # several observations on this GPU: all conjugate spectra in one stack, all
             # (observation, eta) pairs in ONE continuously batched sweep
             for k, d_t in enumerate(dyns):
                 ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True, out=stack[k])
             eig_list, info = ththmod.eval_sweep_multi(stack, [(tau, fd, edges)] * len(dyns), [etas] * len(dyns),
-                                                      batch=args.batch, return_info=True)
+                                                      batch=batch, tol=tol, return_info=True)
             for k, e in enumerate(eig_list):
                 curves[k] = e
                 fit = ththmod.fit_eig_peak(etas, e, 0.1)
@@ -600,7 +706,7 @@ def main():
         mv_s, ga_s = head["busy_ms"][mvk] / 1e3, head["busy_ms"][0] / 1e3
         alg_bytes = head["stats"][0] if mixed else head["mv_bytes"]
         achieved = alg_bytes / mv_s / 1e9 if mv_s > 0 else 0.0
-        ratio, ratio_src = pmc_traffic_ratio() if not mixed else (None, None)
+        ratio, ratio_src, ratio_stale = pmc_traffic_ratio() if not mixed else (None, None, None)
         launches = head["launches"]
         alg_per_launch = alg_bytes / max(1, launches[mvk])
         what = ("theta-theta eigenvalue sweep (Eval_calc loop of single_search)" if args.objective == "eig"
@@ -618,6 +724,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" if not args.dyn_npz else f"synthetic ({os.path.basename(args.dyn_npz)})",
+            "library": library_fingerprint(),
             "config": {"workload": f"{size}x{size} dynspec, {neta}-eta {what}, nedge={nedge}, npad={args.npad}, "
                                    + ("ONE observation, curvatures dealt interleaved to the GPUs (sweep.sharded_eval_sweep)" if shard_eta
                                       else f"{args.obs_total} observations dealt round-robin to the GPUs"
@@ -631,7 +738,7 @@ def main():
                                       f"all_gather of float64 [{per_rank_max}, {neta}] per rank per step ({backend})")
                        if world > 1 else None,
                        "sweep_precision": args.precision if args.objective == "eig" else "f64",
-                       "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": ththmod.DEFAULT_TOL,
+                       "eta_range": "geomspace(0.25, 4.0) * eta_true", "tol": tol,
                        "N_min": int(info["N"].min()), "N_max": int(info["N"].max()),
                        "lanczos_steps_mean": float(info["iters"].mean()),
                        "lanczos_vectors_per_step": lanczos_block()[0],
@@ -645,7 +752,7 @@ def main():
                          "traffic": (ratio * alg_per_launch) if ratio else None,
                          "traffic_note": (f"HBM bytes per launch = {ratio:.3f} x algorithmic bytes; ratio measured "
                                           f"with rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, "
-                                          f"separate passes), {ratio_src}") if ratio else None,
+                                          f"separate passes), {ratio_src}") if ratio else ratio_stale,
                          "avg_launch_ms": head["sum_ms"][mvk] / max(1, launches[mvk]), "launches": int(launches[mvk]),
                          "busy_ms": head["busy_ms"][mvk],
                          "timing_note": "achieved = algorithmic bytes / busy_ms; busy_ms = union of this kernel's "
@@ -702,6 +809,45 @@ def main():
                     "note": "the gather kernel with the GPU to itself (the one-slot-group sweep above: nothing runs beside "
                             "it); `frac` of this object's parent is its rate while the other group's mat-vec and the "
                             "reduce blocks share the GPU with it"}
+        legs_ok = world == 1 and args.objective == "eig" and len(dyns) == 1 and not shard_eta and not mixed and not args.headline_only
+        if legs_ok and args.share_steps > 0:
+            # Strong scaling of --shard eta, as far as ONE GPU can show it: a rank of a W-rank job sweeps etas[R::W] (sweep.eta_share)
+            # and nothing else, so T_1 / (W x T_share) is the efficiency the job reaches if the ranks do not disturb each
+            # other (they share nothing but the host).  What it exposes is the small-share regime: 32 curvatures for 107
+            # slots, no refill, the step is mostly its own low-occupancy tail.  Both ends of the rank range are timed (the
+            # shares are balanced in bytes, tests/test_sharding_cpu.py), with the slot groups sweep.share_schedule picks.
+            try:
+                from scintools_amd import sweep
+                k = args.share_steps
+                t1 = elapsed / args.steps
+                pred = {"T1_ms": 1e3 * t1, "note": "predicted efficiency = T1 / (W x slowest timed share), one GPU, unmeasured on a multi-GPU node"}
+                for W in (2, 4, 8):
+                    if neta < 2 * W:
+                        continue
+                    per = {}
+                    for R in sorted({0, W - 1}):
+                        idx = sweep.eta_share(neta, W, R)
+                        groups = sweep.share_schedule(len(idx), int(info["batch"]))
+                        if os.environ.get("SCINT_BENCH_SHARE_GROUPS"):      # A/B of the rule itself (1 = one group, 2 = two)
+                            groups = 1 if os.environ["SCINT_BENCH_SHARE_GROUPS"] == "1" else 0
+                        wl.update(main_wl, etas=etas[idx])
+                        lib.scint_sweep_schedule(-1, -1, groups)
+                        try:
+                            r = timed("eig", k, 1)
+                        finally:
+                            lib.scint_sweep_schedule(-1, -1, 0)
+                            wl.update(main_wl)
+                        per[f"rank{R}"] = {"etas": int(len(idx)), "ms_per_step": 1e3 * r["elapsed"] / k, "slot_groups": groups or 2,
+                                           "matvec_GBs": r["mv_bytes"] / (r["busy_ms"][1] / 1e3) / 1e9 if r["busy_ms"][1] > 0 else 0.0}
+                    slow = max(v["ms_per_step"] for v in per.values()) / 1e3
+                    pred[str(W)] = dict(per, efficiency=t1 / (W * slow), eta_per_s=neta / slow)
+                out["config"]["predicted_strong_scaling"] = pred
+            except Exception as exc:               # a reported leg must never take the headline down
+                out["config"]["predicted_strong_scaling"] = {"error": repr(exc)}
+        if legs_ok and args.sim_steps > 0 and not args.dyn_npz:
+            out["simulation_screen"] = simulation_screen_leg(args, size, neta, nedge, wl, main_wl, timed, ththmod)
+            if "value" in out["simulation_screen"]:
+                out["simulation_screen"]["ratio_to_headline_input"] = out["simulation_screen"]["value"] / out["value"]
         if world == 1 and args.objective == "chisq" and len(dyns) == 1:
             # the chi^2 objective as the headline region (tools/gpu_run.sh modeler / pmc_modeler): the same object
             out["modeler"] = modeler_objects(head, args.steps, neta, etas, eta_true, 16.0 * R * C, 8.0 * size * size)

@@ -172,6 +172,16 @@ def _field_columns(job):
 BASELINE_SCREEN = dict(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.25, freq=1400, dt=30)
 
 
+def default_workers(cap=32):
+    """Worker processes for the larger screens: the cores this process may use, at most `cap`."""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return max(1, min(cap, n))
+
+
 def baseline_dynspec(size, seed, ny=128, workers=1):
     """The `Simulation` input of a BASELINE config: size x size, anisotropic screen.
     `workers` > 1 deals the frequencies to that many processes (same bits, see _get_intensity)."""

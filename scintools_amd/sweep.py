@@ -50,6 +50,15 @@ def eta_share(n, world, rank):
     return np.arange(rank, n, world)
 
 
+def share_schedule(n_share, batch):
+    """Slot groups for a rank's share of a sweep (argument of ``scint_sweep_schedule``: 0 = the library's default of two
+    groups on two streams, 1 = one group).  The two groups exist so that one's launch gaps, checks and refills fall beside
+    the other's mat-vec; a share that does not even fill the resident slots once (``n_share <= batch``: no refill will ever
+    happen) and is split in two leaves each group's launches half as large without anything to hide, so it runs as one
+    group.  (bench.py times both ends of the rank range with this rule: config.predicted_strong_scaling.)"""
+    return 1 if n_share <= max(1, batch) // 2 else 0
+
+
 def share_imbalance(cost, world, shares=eta_share):
     """max over ranks / mean over ranks of the summed `cost` (one number per curvature, e.g. 8 N (N + 1) x passes)
     under the partition `shares(n, world, rank)`: 1.0 is perfect, and 1 / it bounds the strong-scaling efficiency."""

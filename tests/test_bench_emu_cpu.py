@@ -41,6 +41,16 @@ def test_default_line_with_its_mixed_leg():
     assert mp["certified_per_step"] == 6 and mp["certificate_passes_mean"] >= 1.0
     assert mp["complex64_bytes_per_step"] > 0 and mp["complex128_bytes_per_step"] > 0
     assert mp["matvec32"]["launches"] > 0
+    # round 5: the legs that describe what a user's observation and a rank of --shard eta get
+    sim = d["simulation_screen"]
+    assert "error" not in sim, sim
+    assert sim["value"] > 0 and sim["failed_etas"] == 0 and sum(sim["passes_per_eta_histogram"].values()) == 6
+    assert sim["ratio_to_headline_input"] == pytest.approx(sim["value"] / d["value"])
+    pred = d["config"]["predicted_strong_scaling"]
+    assert "error" not in pred, pred
+    assert set(pred) - {"T1_ms", "note"} == {"2"} and pred["2"]["efficiency"] > 0          # 6 curvatures: only two ranks get >= 2 each
+    assert len(d["library"]["csrc_sha256"]) == 64
+    assert d["roofline"]["traffic"] is None or "csrc_sha256" not in (d["roofline"]["traffic_note"] or "")
 
 
 @pytest.mark.timeout(900)

@@ -300,6 +300,9 @@ def test_sim_oracle_is_bit_identical_to_the_reference_simulator(golden):
     assert np.array_equal(s.freqs, g["freqs"]) and np.array_equal(s.times, g["times"])
     assert s.eta == float(g["sim_eta"]) and s.dt == float(g["dt"]) and s.df == float(g["df"])
     w = golden("sim_sweep.npz")
-    big = so.baseline_dynspec(1024, int(w["s1024_seed"]))
-    assert so.checksum(big.dyn) == str(w["s1024_sha256"])
+    big = so.baseline_dynspec(1024, int(w["s1024_seed"]), workers=so.default_workers(8))    # frequencies dealt to worker processes:
+    assert so.checksum(big.dyn) == str(w["s1024_sha256"])                                    # the same bits as the loop
+    par = so.Simulation(mb2=20, ar=10, psi=0, alpha=5 / 3, inner=0.001, ds=0.01, dlam=0.03, freq=1400, dt=30,
+                        nx=128, ny=64, nf=96, seed=1234, workers=3)
+    assert np.array_equal(par.dyn, g["dyn"])
     assert big.eta == float(w["s1024_sim_eta"]) and np.array_equal(big.freqs[:2], w["s1024_freqs01"])

@@ -203,3 +203,12 @@ def test_world2_gloo_with_the_interpreted_kernels(monkeypatch, precision):
     for rank, full, obs in results:
         assert np.array_equal(full, single), rank     # same bits on every rank as in one process
         assert np.array_equal(obs, single_obs), rank
+
+
+def test_share_schedule_rule():
+    """sweep.share_schedule: a rank's share that cannot fill half of the resident slots runs as ONE slot group (nothing to
+    hide behind a second one, and its launches stay twice as large); anything larger keeps the library's two groups."""
+    from scintools_amd import sweep
+    assert sweep.share_schedule(32, 107) == 1 and sweep.share_schedule(53, 107) == 1
+    assert sweep.share_schedule(64, 107) == 0 and sweep.share_schedule(128, 107) == 0 and sweep.share_schedule(256, 107) == 0
+    assert sweep.share_schedule(1, 1) == 0 and sweep.share_schedule(0, 8) == 1

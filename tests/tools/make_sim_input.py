@@ -13,6 +13,6 @@ import numpy as np  # noqa: E402
 from oracle import sim_oracle  # noqa: E402
 
 size, seed, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
-sim = sim_oracle.baseline_dynspec(size, seed)
+sim = sim_oracle.baseline_dynspec(size, seed, workers=sim_oracle.default_workers())
 np.savez(out, dyn=sim.dyn, freqs=sim.freqs, times=sim.times, eta=sim.eta)
 print(out, sim.dyn.shape, "eta", sim.eta, "sha256", sim_oracle.checksum(sim.dyn)[:16])

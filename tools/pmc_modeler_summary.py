@@ -22,7 +22,8 @@ def main(fetch_db, write_db, bench_log, out_path, command):
     f, w = per_kernel(fetch_db), per_kernel(write_db)
     out = {"command": command, "fetch_correction": 2.0, "write_correction": 1.0, "steps": bench["steps"], "curvatures_per_step": neta,
            "algorithmic_bytes": alg, "algorithmic_bytes_per_eta_by_part": m["roofline"]["algorithmic_bytes_per_eta_by_part"],
-           "lanczos_steps_mean": m["lanczos_steps_mean"], "kernels": {}}
+           "lanczos_steps_mean": m["lanczos_steps_mean"], "kernels": {},
+           "csrc_sha256": (bench.get("library") or {}).get("csrc_sha256")}
     total = 0.0
     for k in sorted(set(f) | set(w)):
         nf, fb = f.get(k, (0, 0.0))

@@ -29,7 +29,10 @@ def main(fetch_db, write_db, fetch_log, out_path, command=None):
     f, w = per_kernel(fetch_db), per_kernel(write_db)
     summary = {"command": command or "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 "
                                      "--warmup 0 --no-cpu-baseline --modeler-steps 0",
-               "fetch_correction": 2.0, "write_correction": 1.0, "kernels": {}}
+               "fetch_correction": 2.0, "write_correction": 1.0, "kernels": {},
+               # the kernel sources of the profiled library (bench.py: library_fingerprint); bench.py quotes this summary's ratio
+               # only while the sources it runs on hash to the same value
+               "csrc_sha256": (bench.get("library") or {}).get("csrc_sha256")}
     for k in sorted(set(f) | set(w)):
         nf, fb = f.get(k, (0, 0.0))
         nw, wb = w.get(k, (0, 0.0))
