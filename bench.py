@@ -222,6 +222,14 @@ def parse():
                     help="N=1: also time rank 0's and the last rank's interleaved share etas[R::W] of the sweep alone on this GPU for "
                          "W = 2, 4, 8 (config.predicted_strong_scaling: what --shard eta would give if nothing but the shares' own "
                          "time mattered); 0 = skip")
+    ap.add_argument("--workload", choices=["sweep", "fit_thetatheta", "tutorial_fit", "wavefield", "fit_arc"], default="sweep",
+                    help="sweep (default): the headline line above.  The others time the user entry points either side of the path "
+                         "(SURVEY.md 8f) end to end on ONE GPU, each with the CPU oracle timed on a bounded sample beside it, and print "
+                         "a line of their own: fit_thetatheta / wavefield = Dynspec.fit_thetatheta / calc_wavefield of a --size^2 "
+                         "observation in --chunk^2 chunks (dynspec.py:1657-1856); tutorial_fit = the reference's tutorial recipe on "
+                         "its Sample_Data (tests/golden/fit_thetatheta.npz); fit_arc = Dynspec.fit_arc(lamsteps=True) "
+                         "(dynspec.py:970-1346)")
+    ap.add_argument("--chunk", type=int, default=256, help="--workload fit_thetatheta / wavefield: cwf = cwt")
     ap.add_argument("--tol", type=float, default=None,
                     help="Ritz tolerance of the eigenvalue sweeps (default ththmod.DEFAULT_TOL = 1e-12, 1000x inside the 1e-9 parity "
                          "bar); for the tolerance A/Bs of profiles/ -- the headline is quoted at the default")
@@ -515,8 +523,195 @@ def sspec_timing(torch, size):
     return res
 
 
+class _Obs:
+    """The attribute set Dynspec.load_dyn_obj copies (dynspec.py:378-419)."""
+
+    def __init__(self, dyn, freqs, times, name):
+        self.dyn, self.freqs, self.times, self.name = dyn, freqs, times, name
+        self.dt, self.df = float(times[1] - times[0]), float(freqs[1] - freqs[0])
+
+
+def _median_time(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def workload_main(args):
+    """`--workload X`: the (f) rows of SURVEY.md 8 end to end on one GPU.  One JSON line each:
+    seconds per call (median of --steps calls after --warmup), the work it covers, where the GPU time goes (the library's
+    hipEvent brackets: gather, mat-vec, back-map), a parity figure against the oracle on a sample, and `cpu_baseline` -- the
+    oracle (kind "port") timed here on a bounded sample of the same work and scaled, sample stated."""
+    import torch
+    from scintools_amd import _lib, ththmod
+    from scintools_amd.device import require_gpu
+    from scintools_amd.dynspec import Dynspec
+    from scintools_amd.synth import arc_dynspec
+    torch.cuda.set_device(0)
+    require_gpu()
+    lib = _lib.load()
+    size, cw, steps, warm = args.size, args.chunk, max(1, args.steps), max(1, args.warmup)
+    out = {"metric": f"{args.workload}_seconds", "unit": "s", "higher_is_better": False, "n_gpus": 1, "steps": steps, "warmup": warm,
+           "dtype": "f64", "data": "synthetic", "library": library_fingerprint()}
+
+    def profiled(fn):
+        """median seconds of `steps` calls + the library's per-kernel busy time over them"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        lib.scint_profile_begin()
+        med, ts = _median_time(lambda: (fn(), torch.cuda.synchronize()), steps)
+        ms, ms_sum, launches = (ctypes.c_double * NPROF)(), (ctypes.c_double * NPROF)(), (ctypes.c_int64 * NPROF)()
+        lib.scint_profile_end(ms, ms_sum, launches, NPROF)
+        tot = sum(ts)
+        names = ("thth_gather_packed_kernel", "pk2_matvec_kernel", "pk2_matvec32_kernel", "rev_gather_kernel", "model / chi^2 step")
+        return med, ts, {n: {"busy_share_of_wall": ms[k] / 1e3 / tot, "launches_per_call": launches[k] / steps,
+                             "avg_launch_us": 1e3 * ms_sum[k] / max(1, launches[k])} for k, n in enumerate(names) if launches[k]}
+
+    if args.workload in ("fit_thetatheta", "wavefield"):
+        from oracle import thth_oracle
+        dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
+        d = Dynspec(dyn=_Obs(dyn, freqs, times, f"arc {size}x{size}"), process=False, verbose=False)
+        kw = dict(cwf=cw, cwt=cw, eta_min=0.5 * eta_true, eta_max=2.0 * eta_true, npad=args.npad if args.npad else 3)
+        if args.nedge:
+            kw["nedge"] = args.nedge
+        d.prep_thetatheta(**kw)
+        nchunk = d.ncf_fit * d.nct_fit
+        cfg = {"workload": f"Dynspec.{'fit_thetatheta' if args.workload == 'fit_thetatheta' else 'calc_wavefield'} on a {size}x{size} "
+                           f"observation, cwf = cwt = {cw}, npad = {d.npad} (chunk CS {(d.npad + 1) * cw}^2), {d.edges.shape[0]} edges, "
+                           f"{d.neta} curvatures per chunk (eta_min .. eta_max = 0.5 .. 2 eta_true, fw = {d.fw})",
+               "fit_chunks": nchunk, "neta": int(d.neta), "nedge": int(d.edges.shape[0]), "chunk_cs": [(d.npad + 1) * cw] * 2}
+        if args.workload == "fit_thetatheta":
+            med, ts, kern = profiled(lambda: d.fit_thetatheta())
+            jobs = nchunk * d.neta
+            # parity sample + CPU port: single_search of the oracle on a few chunks
+            sample = [(0, 0), (d.ncf_fit // 2, d.nct_fit // 2)][: max(1, args.cpu_sample // 8)]
+            t_cpu, diffs = [], []
+            for cf, ct in sample:
+                p_ = d._search_params(cf, ct)
+                t0 = time.perf_counter()
+                r = thth_oracle.single_search(p_[0], p_[1], p_[2], p_[3], p_[4], fw=d.fw, npad=d.npad)
+                t_cpu.append(time.perf_counter() - t0)
+                diffs.append(abs(d.eta_evo[cf, ct] - r[0]) / abs(r[0]))
+                diffs.append(float(np.nanmax(np.abs(d.thth_eigs[cf, ct] - r[4]) / np.abs(r[4]))))
+            out.update(value=med, seconds_all=ts, config=dict(cfg, chunk_eta_jobs=jobs),
+                       chunk_eta_points_per_s=jobs / med, kernels=kern,
+                       eta_fit_over_true_median=float(np.nanmedian(d.eta_evo) / eta_true),
+                       parity_sample={"chunks": sample, "max_rel_diff_eta_fit_vs_oracle": float(max(diffs[0::2])),
+                                      "max_rel_diff_eigs_vs_oracle": float(max(diffs[1::2]))},
+                       cpu_baseline={"value": float(np.median(t_cpu)) * nchunk, "unit": "s", "kind": "port", "cores": int(blas_threads()),
+                                     "host_cores": os.cpu_count(),
+                                     "sample": f"oracle.thth_oracle.single_search on {len(sample)} of {nchunk} chunks "
+                                               f"({[round(t, 1) for t in t_cpu]} s), median x {nchunk}"})
+            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+        else:
+            d.fit_thetatheta()
+            nret = d.ncf_ret * d.nct_ret
+
+            def once():
+                if hasattr(d, "chunks"):
+                    del d.chunks
+                d.calc_wavefield()
+            med, ts, kern = profiled(once)
+            sample = [(0, 0), (d.ncf_ret // 2, d.nct_ret // 2)][: max(1, args.cpu_sample // 8)]
+            t_cpu, diffs = [], []
+            for cf, ct in sample:
+                fs = slice(cf * (cw // 2), cf * (cw // 2) + cw)
+                tsl = slice(ct * (cw // 2), ct * (cw // 2) + cw)
+                freq2, time2 = d.freqs[fs], d.times[tsl]
+                dspec2 = np.nan_to_num(d.dyn[fs, tsl] - np.nanmean(d.dyn[fs, tsl]))
+                eta = d.ththeta * (d.fref / freq2.mean()) ** 2
+                t0 = time.perf_counter()
+                ref = thth_oracle.single_chunk_retrieval(dspec2, d.edges * (freq2.mean() / d.fref), time2, freq2, eta, d.npad)
+                t_cpu.append(time.perf_counter() - t0)
+                got = d.chunks[cf, ct]
+                ph = np.vdot(ref, got)
+                ph /= abs(ph)
+                diffs.append(float(np.abs(got / ph - ref).max() / np.abs(ref).max()))
+            out.update(value=med, seconds_all=ts, config=dict(cfg, retrieval_chunks=nret), chunks_per_s=nret / med, kernels=kern,
+                       parity_sample={"chunks": sample, "max_rel_diff_vs_oracle_modulo_global_phase": float(max(diffs))},
+                       cpu_baseline={"value": float(np.median(t_cpu)) * nret, "unit": "s", "kind": "port", "cores": int(blas_threads()),
+                                     "host_cores": os.cpu_count(),
+                                     "sample": f"oracle.thth_oracle.single_chunk_retrieval on {len(sample)} of {nret} chunks "
+                                               f"({[round(t, 1) for t in t_cpu]} s), median x {nret} (mosaic not included: host NumPy in both)"})
+            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+    elif args.workload == "tutorial_fit":
+        from oracle import thth_oracle
+        with np.load(os.path.join(REPO, "tests", "golden", "fit_thetatheta.npz")) as g:
+            obs = _Obs(np.array(g["dspec"], dtype=float), g["freq"], g["time"], "Sample_Data (tutorial)")
+            ref_evo, ref_ththeta = np.array(g["eta_evo"]), float(g["ththeta"])
+        d = Dynspec(dyn=obs, process=False, verbose=False)
+
+        def once():
+            d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50)        # the recipe of dynspec_thth.rst:146-170
+            d.fit_thetatheta()
+        med, ts, kern = profiled(once)
+        p_ = d._search_params(0, 0)
+        idx = np.unique(np.linspace(0, d.neta - 1, 8).astype(int))
+        fd_, tau_ = thth_oracle.fft_axis(p_[2], 1000.0, d.npad), thth_oracle.fft_axis(p_[1], 1.0, d.npad)
+        t0 = time.perf_counter()
+        CS = thth_oracle.conjugate_spectrum(p_[0], d.npad, tau_, 0.0)
+        vals = [thth_oracle.Eval_calc(CS, tau_, fd_, p_[3][i], p_[4]) for i in idx]
+        dt_cpu = time.perf_counter() - t0
+        nchunk = d.ncf_fit * d.nct_fit
+        timing = None
+        try:
+            with open(os.path.join(REPO, "tests", "golden", "reference_workload_timing.json")) as fh:
+                timing = json.load(fh).get("tutorial_fit_thetatheta")
+        except (OSError, ValueError):
+            pass
+        out.update(value=med, seconds_all=ts, kernels=kern,
+                   config={"workload": "the reference's tutorial: prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50) + "
+                                       "fit_thetatheta on Sample_Data (448 x 150), npad = 3", "fit_chunks": nchunk, "neta": int(d.neta),
+                           "nedge": int(d.edges.shape[0])},
+                   parity={"max_rel_diff_eta_evo_vs_reference_run": float(np.nanmax(np.abs(d.eta_evo - ref_evo) / np.abs(ref_evo))),
+                           "rel_diff_ththeta_vs_reference_run": abs(d.ththeta - ref_ththeta) / abs(ref_ththeta),
+                           "max_rel_diff_eigs_vs_oracle_sample": float(max(abs(d.thth_eigs[0, 0][i] - v) / abs(v) for i, v in zip(idx, vals)))},
+                   cpu_baseline={"value": dt_cpu / len(idx) * d.neta * nchunk, "unit": "s", "kind": "port", "cores": int(blas_threads()),
+                                 "host_cores": os.cpu_count(),
+                                 "sample": f"oracle CS + Eval_calc on {len(idx)} of {d.neta} curvatures of chunk 0 ({dt_cpu:.1f} s), "
+                                           f"x {d.neta} / {len(idx)} x {nchunk} chunks",
+                                 "reference_itself": timing})
+        out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+    else:   # fit_arc
+        from oracle import arcfit_oracle
+        dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
+        obs = _Obs(dyn, freqs, times, f"arc {size}x{size}")
+        d = Dynspec(dyn=obs, process=False, verbose=False)
+
+        def once():
+            for a in ("lamsspec", "lamdyn", "betaeta"):
+                if hasattr(d, a):
+                    delattr(d, a)
+            d.fit_arc(lamsteps=True, numsteps=1e4)
+        med, ts, kern = profiled(once)
+        # CPU port on the top-left quarter (size/2)^2 of the same observation: the chain is O(pixels log pixels)
+        h = size // 2
+        t0 = time.perf_counter()
+        o = arcfit_oracle.calc_sspec_lam(dyn[:h, :h], freqs[:h], obs.dt, obs.df)
+        t1 = time.perf_counter()
+        fa = arcfit_oracle.fit_arc(o["lamsspec"], o["beta"], o["tdel"], o["beta"], o["fdop"], float(np.mean(freqs[:h])),
+                                   lamsteps=True, numsteps=1e4)
+        t2 = time.perf_counter()
+        out.update(value=med, seconds_all=ts, kernels=kern,
+                   config={"workload": f"Dynspec.fit_arc(lamsteps=True, numsteps=1e4) from the raw {size}x{size} dynspec: cubic-spline "
+                                       "resample to equal wavelength steps, secondary spectrum, norm_sspec, parabola fit"},
+                   betaeta=float(d.betaeta), betaetaerr=float(d.betaetaerr),
+                   cpu_baseline={"value": 4.0 * (t2 - t0), "unit": "s", "kind": "port", "cores": int(blas_threads()), "host_cores": os.cpu_count(),
+                                 "sample": f"oracle scale_dyn + calc_sspec ({t1 - t0:.1f} s) + fit_arc ({t2 - t1:.1f} s) on the top-left "
+                                           f"{h}x{h} quarter of the same observation, x 4 (pixel count)",
+                                 "betaeta_of_the_quarter": float(fa["betaeta"])})
+        out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload != "sweep":
+        return workload_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -585,7 +780,7 @@ def main():
         if objective == "chisq":
             for k, d_t in enumerate(dyns):
                 cs_t = ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True)
-                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True, tol=tol)
+                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True, tol=tol, batch=batch)
                 fit = (etas[np.nanargmin(curves[k])], np.nan, None)
         elif shard_eta:
             # ONE observation, this rank's interleaved share of the curvatures; the all-gather is inside
@@ -815,7 +1010,8 @@ def main():
             # and nothing else, so T_1 / (W x T_share) is the efficiency the job reaches if the ranks do not disturb each
             # other (they share nothing but the host).  What it exposes is the small-share regime: 32 curvatures for 107
             # slots, no refill, the step is mostly its own low-occupancy tail.  Both ends of the rank range are timed (the
-            # shares are balanced in bytes, tests/test_sharding_cpu.py), with the slot groups sweep.share_schedule picks.
+            # shares are balanced in bytes, tests/test_sharding_cpu.py), with the slot groups sweep.share_schedule picks
+            # (two, as measured: profiles/r05_rank_share_ab.json).
             try:
                 from scintools_amd import sweep
                 k = args.share_steps
@@ -828,8 +1024,6 @@ def main():
                     for R in sorted({0, W - 1}):
                         idx = sweep.eta_share(neta, W, R)
                         groups = sweep.share_schedule(len(idx), int(info["batch"]))
-                        if os.environ.get("SCINT_BENCH_SHARE_GROUPS"):      # A/B of the rule itself (1 = one group, 2 = two)
-                            groups = 1 if os.environ["SCINT_BENCH_SHARE_GROUPS"] == "1" else 0
                         wl.update(main_wl, etas=etas[idx])
                         lib.scint_sweep_schedule(-1, -1, groups)
                         try:

@@ -165,6 +165,22 @@ int32_t scint_sweep_schedule(int32_t depth, int32_t check_every, int32_t groups)
  * out[0] algorithmic bytes of its complex64 passes (4 n (n + 1) each), out[1] of its complex128 passes (8 n (n + 1)),
  * out[2] curvatures that went through a certificate, out[3] complex128 passes those certificates took. */
 int32_t scint_sweep_stats(double* out /*HOST[4]*/);
+/* Mat-vec workgroups ONE theta-theta matrix of `nb` 64-row blocks contributes to a launch of the sweep (`complex64` != 0: of the
+ * complex64 kernel of the mixed sweep) -- block rows per workgroup and column tiles per strip are build constants of the library
+ * (csrc/packed.hpp).  For callers that size the `batch` argument of the sweeps: resident curvatures x this = workgroups per
+ * launch (scintools_amd/ththmod.py: default_batch).  Returns the count (>= 1), or -SCINT_E_ARG for nb < 1. */
+int32_t scint_sweep_workgroups(int32_t nb, int32_t complex64);
+/* Environment variables the library reads (each ONCE per process; none selects another kernel family or changes a result
+ * beyond what is said here):
+ *   SCINT_SWEEP_PRECISION = f64 | mixed | mixed-all   initial value of scint_sweep_precision();
+ *   SCINT_SWEEP_DEPTH, SCINT_CHECK_EVERY, SCINT_SWEEP_GROUPS   initial values of scint_sweep_schedule();
+ *   SCINT_STRIP_LEN = n   column tiles per mat-vec workgroup, at most the build's maximum (csrc/packed.hpp): for the test that
+ *                         proves a sweep's values do not depend on the strip shape beyond rounding (tests/test_emu_cpu.py).
+ * (SCINT_CHISQ_MODEL and SCINT_SSPEC_GENERIC of round 4 are gone: no test used them; the model route of the chi^2 sweep is
+ *  reached with a mask or a non-finite dspec, the generic calc_sspec route with halve = 0 or lengths outside 256..8192.) */
+/* Limits common to every sweep entry point below (eval / eigvec / chisq, single and _multi): a conjugate spectrum must hold
+ * fewer than 2^31 elements (ntau * nfd; the packed gather indexes it with 32 bits) -- SCINT_E_ARG otherwise, before anything
+ * is queued.  scint_thth_map / scint_rev_map / scint_modeler index with 64 bits and have no such limit. */
 int32_t scint_eval_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/,
                          const double* th_cents, int64_t M,
                          const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
@@ -295,12 +311,16 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
  * rank-1 rev_map of |w| V V^H, inverse FFT, chi^2 against dspec[nf, nt] -- is chained on an internal
  * stream beside the Lanczos steps of the curvatures still resident, without returning to the host.
  * When the model is not cropped (ntau == nf, nfd == nt), mask is NULL and dspec is finite, chi^2 is taken
- * from recov and fft2(dspec) by Parseval's identity instead (the same sum to rounding; no inverse FFT).
+ * from recov and fft2(dspec) by Parseval's identity instead (the same sum to rounding; no inverse FFT); on that route
+ * the curvatures one chunk of the sweep retires go through their model step TOGETHER (<= 8 per set of launches), and
+ * back-map and chi^2 touch only the delay rows |tau| <= |eta| max theta^2 a curvature can reach (recov is exactly 0
+ * elsewhere; those rows contribute sum |fft2(dspec)|^2).  The workspace holds up to 8 images per internal stream for it.
  *   th_red   DEVICE [neta, M]: row e = the N_e centres of the reduced edges (ththmod.py:157-172 then
  *            :204-205), host-computed like the other grid quantities;
  *   mask     DEVICE uint8[nf*nt] or NULL (= isfinite(dspec));
- *   chisq_out DEVICE [neta]: sum((model[:nf,:nt]-dspec)[mask]**2)/noise_n; entries of curvatures whose
- *            reduced matrix has < 2 points are left untouched (pre-fill with NaN);
+ *   chisq_out DEVICE [neta]: sum((model[:nf,:nt]-dspec)[mask]**2)/noise_n; NaN-filled by the call, and left NaN for a
+ *            curvature whose crop keeps fewer than THREE centres (two have no mean edge step: the reference's
+ *            rev_map raises there, ththmod.py:166) or whose eigen-solve failed (see status_out);
  *   w_out / vec_out / status_out / iters_out as in scint_eigvec_sweep.
  * Synchronous like the other sweep entry points (returns with all internal streams drained). */
 int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,

@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(64) pk2_check_kernel(const PackedJob* jobs, in
         // eigenvector wanted: same gap-aware rule as the single-vector check (pk_check_kernel)
         const double prev2 = jb.result[1], gap2 = theta - theta2;
         const bool gap_ok = gap2 > 0.0 && fabs(theta2 - prev2) <= 0.02 * gap2;
-        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= kVecGapFactor * jb.tol * gap2);
+        const bool vec_ok = (resid <= jb.tol * at) || (gap_ok && settled && resid <= jb.vec_gap_factor * jb.tol * gap2);
         // (the iteration phase of a mixed eigenPAIR sweep runs to the eigenVALUE rule: its vector is finished on the complex128 tiles)
         const bool ok = (jb.want_vec && !jb.use32) ? vec_ok : (err <= jb.tol * at && settled);
         const bool conv = finite && (ok || exact);
@@ -1521,6 +1521,7 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.alpha = (double*)(sl + L.alpha); J.beta = (double*)(sl + L.beta);
             J.result = (double*)(sl + L.result); J.state = S.states_dev + 4 * (grp.slot0 + s);
             J.tol = tol; J.gen = 0;
+            J.vec_gap_factor = tail_hook ? kVecGapFactorChisq : kVecGapFactor;     // (packed.hpp: the chi^2 sweep's product is a scalar)
             J.n = 0; J.nb = 1; J.max_steps = 0; J.start = 0; J.strip_len = 1;
             J.eta = 0; J.two_eta = 0; J.keep = keep_idx;
             J.cs = (const cplx*)cs; J.th = th_cents; J.geom = 0; J.pad1 = 0;
@@ -1603,6 +1604,14 @@ extern "C" int32_t scint_sweep_schedule(int32_t depth, int32_t check_every, int3
     if (check_every >= 0) sc.check_every = check_every;
     if (groups >= 0) sc.groups = groups;
     return SCINT_OK;
+}
+
+extern "C" int32_t scint_sweep_workgroups(int32_t nb, int32_t complex64) {
+    if (nb < 1) { set_error("scint: sweep_workgroups: nb must be >= 1"); return -SCINT_E_ARG; }   // (a count is returned: errors are negative)
+    const int R = complex64 ? kRows32 : kRows64, S = complex64 ? strip_len32_for(nb) : strip_len_for(nb);
+    int n = 0;
+    for (int I = 0; I < nb; I += R) n += row_strip_count(nb, I, S, R);     // the strips SweepGroup::enqueue builds for one job
+    return n;
 }
 
 extern "C" int32_t scint_sweep_stats(double* out) {

@@ -1364,29 +1364,37 @@ __global__ void __launch_bounds__(256) chisq_parseval_batch_kernel(RevBatch bt, 
         }
     }
 }
-// colsum[q] of the kernel above: threads along q (coalesced), the half-plane rows in the kernel's own order
-__global__ void __launch_bounds__(256) chisq_colsum_kernel(const cplx* __restrict__ S, int P, int Q, double* __restrict__ colsum) {
+// colsum[q] of the kernel above: threads along q (coalesced); the half-plane rows in kColsumChunks contiguous chunks
+// (grid.y), each summed in the kernel's own order into part[chunk][q]; chisq_prefix_kernel adds the chunks in order
+constexpr int kColsumChunks = 64;
+__global__ void __launch_bounds__(256) chisq_colsum_kernel(const cplx* __restrict__ S, int P, int Q, double* __restrict__ part) {
     const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
     if (q >= Q) return;
     const int hp = P / 2, nhalf = hp + 1;
+    const int per = (nhalf + kColsumChunks - 1) / kColsumChunks, h0 = (int)blockIdx.y * per, h1 = min(h0 + per, nhalf);
     double acc = 0.0;
-    for (int hb = 0; hb < nhalf; ++hb) {
+    for (int hb = h0; hb < h1; ++hb) {
         const int p = hp + hb < P ? hp + hb : 0;
         int pp = 2 * hp - p; pp += pp < 0 ? P : 0; pp -= pp >= P ? P : 0;
         const cplx z = gload(S + (int64_t)p * Q + q);
         const double v = z.x * z.x + z.y * z.y;
         acc += pp == p ? v : 2.0 * v;
     }
-    colsum[q] = acc;
+    part[(int64_t)blockIdx.y * Q + q] = acc;
 }
 // pre[q] = sum_{q' < q} colsum[q'], suf[q] = sum_{q' >= q} colsum[q'], q = 0 .. Q: one workgroup, a contiguous segment per
 // thread, fixed order
-__global__ void __launch_bounds__(256) chisq_prefix_kernel(const double* __restrict__ colsum, int Q, double* __restrict__ pre,
-                                                           double* __restrict__ suf) {
+__global__ void __launch_bounds__(256) chisq_prefix_kernel(const double* __restrict__ part, double* __restrict__ colsum, int Q,
+                                                           double* __restrict__ pre, double* __restrict__ suf) {
     __shared__ double seg[256], base_pre[256], base_suf[256];
     const int t = (int)threadIdx.x, len = (Q + 255) / 256, q0 = min(t * len, Q), q1 = min(q0 + len, Q);
     double acc = 0.0;
-    for (int q = q0; q < q1; ++q) acc += colsum[q];
+    for (int q = q0; q < q1; ++q) {
+        double c = 0.0;
+        for (int k = 0; k < kColsumChunks; ++k) c += part[(int64_t)k * Q + q];
+        colsum[q] = c;
+        acc += c;
+    }
     seg[t] = acc;
     __syncthreads();
     if (t == 0) {
@@ -1512,7 +1520,7 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
     const bool parseval_shape = nf == ntau && nt == nfd;
     L->jobs = take(parseval_shape ? sizeof(RevJobDev) * (size_t)neta : 0);
     L->bounds = take(parseval_shape ? sizeof(unsigned long long) * kRevWords * (size_t)neta : 0);
-    L->colsum = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
+    L->colsum = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) * (size_t)(kColsumChunks + 1) : 0);   // [0]: the sums; then the chunks' partials
     L->pre = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
     L->suf = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
     for (int l = 0; l < kTailLanes; ++l) {
@@ -1581,8 +1589,7 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
         t.fft_ws_[l] = base + L.fft[l];
         t.partial_[l] = (double*)(base + L.partial[l]); t.rev_scratch_[l] = base + L.rev[l];
     }
-    static const bool no_parseval = [] { const char* e = getenv("SCINT_CHISQ_MODEL"); return e && atoi(e) != 0; }();
-    if (nf == geom->ntau && nt == geom->nfd && !mask && !no_parseval && nf >= 2 && nt >= 2 &&
+    if (nf == geom->ntau && nt == geom->nfd && !mask && nf >= 2 && nt >= 2 &&
         geom->ntau <= INT32_MAX / 2 && geom->nfd <= INT32_MAX / 2) {
         // chi^2 by Parseval (chisq_parseval_kernel): possible when every pixel of an uncropped model counts.  One
         // host round trip per sweep decides it (a non-finite pixel of dspec leaves chisq_calc's default mask).
@@ -1601,8 +1608,9 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
             // outside a curvature's band contribute to its chi^2
             const int P = (int)geom->nfd, Q = (int)geom->ntau;
             double* colsum = (double*)(base + L.colsum);
-            hipLaunchKernelGGL(chisq_colsum_kernel, dim3((unsigned)ceil_div(Q, 256)), dim3(256), 0, st, specT, P, Q, colsum);
-            hipLaunchKernelGGL(chisq_prefix_kernel, dim3(1), dim3(256), 0, st, colsum, Q, (double*)(base + L.pre), (double*)(base + L.suf));
+            double* part = colsum + (Q + 1);
+            hipLaunchKernelGGL(chisq_colsum_kernel, dim3((unsigned)ceil_div(Q, 256), (unsigned)kColsumChunks), dim3(256), 0, st, specT, P, Q, part);
+            hipLaunchKernelGGL(chisq_prefix_kernel, dim3(1), dim3(256), 0, st, part, colsum, Q, (double*)(base + L.pre), (double*)(base + L.suf));
             SCINT_LAUNCH_CHECK();
             t.pre = (const double*)(base + L.pre); t.suf = (const double*)(base + L.suf);
             // the per-curvature table of the batched tail (thth.hpp): everything but the image buffer is known now

@@ -28,9 +28,9 @@ constexpr int kTileElems = kTB * kTB;         // 4096 complex = 64 KiB
 struct __attribute__((aligned(8))) c32 { float x, y; };
 static_assert(sizeof(c32) == 8, "c32 must be two floats");
 #ifndef SCINT_ROWS32
-#define SCINT_ROWS32 4            // (build constant for A/Bs: 8 rows x <= 12 tiles is what paid for the complex128 kernel at the end of round 4;
-#endif                            //  the complex64 kernel passes the interpreter's mixed tests with it, its GPU A/B is open -- DESIGN 9.4)
-constexpr int kRows32 = SCINT_ROWS32;   // block rows per workgroup of the complex64 mat-vec (4: the tile bytes of two complex128 rows per column tile)
+#define SCINT_ROWS32 8            // (round 5, call 1, interleaved: 8 rows x <= 12 tiles 2399 / 2400 eta/s against 2353 / 2350 with 4 x <= 14 --
+#endif                            //  the step that gave the complex128 kernel its last 2 % gives the complex64 one the same)
+constexpr int kRows32 = SCINT_ROWS32;   // block rows per workgroup of the complex64 mat-vec
 constexpr int kRows32Lg = kRows32 == 8 ? 3 : (kRows32 == 4 ? 2 : (kRows32 == 2 ? 1 : 0));
 static_assert((1 << kRows32Lg) == kRows32, "kRows32 must be 1, 2, 4 or 8");
 #ifndef SCINT_MAXSTRIP32
@@ -61,16 +61,22 @@ static_assert(kRows64 == 2 || kRows64 == 4 || kRows64 == 8 || kRows64 == 16, "kR
 constexpr int kMaxStrip = SCINT_MAXSTRIP;            // column tiles per mat-vec workgroup (their X_J blocks and column partials live in LDS:
                                                      // 8 rows x 12 tiles -> 72 KiB, two workgroups per CU and 12 KiB left for the reduce blocks;
                                                      // 4 x 14 -> 72 KiB; 4 x 9 -> 52 KiB, three per CU; 4 x 6 -> 40 KiB, four: both measured slower)
-// Eigenvector sweeps (modeler, chi^2, retrieval) stop when the Ritz residual is below kVecGapFactor * tol of the spectral gap
-// theta_1 - theta_2 (pk2_check_kernel): the angle between the Ritz vector and the eigenvector is then <= kVecGapFactor * tol, and
-// so is the relative error of the rank-1 model |w| V V^H that is compared with the reference's at 1e-9.  Rounds 1-4: 30 (3e-11);
-// round 5: 100 (1e-10, ten times inside the bar; measured deviations are another 10-60 times below the bound --
-// tools/experiments/vec_factor_passes.py: <= 1.1e-11 at 512^2 on the arc and on a reference Simulation screen).  With the check every
-// two passes the change is worth 0.2 passes per curvature; 300 and 1000 would save 1.1 and 1.8 of 28 and were not taken.
+// Eigenvector sweeps stop when the Ritz residual is below `vec_gap_factor * tol` of the spectral gap theta_1 - theta_2
+// (pk2_check_kernel): the angle between the Ritz vector and the eigenvector is then <= vec_gap_factor * tol.
+//   kVecGapFactor       30 (3e-11): eigvec sweeps whose VECTOR is the product -- modeler and the phase retrieval, where the
+//                       chunks' wavefields are stitched by their relative phases and the mosaic is compared with the reference's
+//                       at 1e-9 (measured 1.3e-10; with 100 the GPU suite measured 1.16e-9 on the tutorial mosaic: round 5, call 1);
+//   kVecGapFactorChisq  100 (1e-10): the chi^2 sweep, whose product is the scalar chi^2 (every chi^2 parity test holds its 1e-9
+//                       with it: GPU suite of the same call); 829 -> 867 (batched tail) -> 878 eta/s with it, 896 with 300 (not taken:
+//                       tools/experiments/vec_factor_passes.py shows model deviations of 6e-11 there, a 3x margin only).
 #ifndef SCINT_VEC_GAP_FACTOR
-#define SCINT_VEC_GAP_FACTOR 100.0
+#define SCINT_VEC_GAP_FACTOR 30.0
+#endif
+#ifndef SCINT_VEC_GAP_FACTOR_CHISQ
+#define SCINT_VEC_GAP_FACTOR_CHISQ 100.0
 #endif
 constexpr double kVecGapFactor = SCINT_VEC_GAP_FACTOR;
+constexpr double kVecGapFactorChisq = SCINT_VEC_GAP_FACTOR_CHISQ;
 
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
@@ -115,6 +121,7 @@ struct PackedJob {
                             //     phase of a mixed sweep has converged and hands over to a certificate run (the host restarts the slot), -
     double* eig_out; int32_t* status_out; int32_t* iters_out;
     double tol;             // target relative accuracy of the eigenvalue
+    double vec_gap_factor;  // want_vec: stop when the Ritz residual <= vec_gap_factor * tol * (theta_1 - theta_2)
 };
 
 // One mat-vec workgroup's work: the tiles (I + r, J0 .. J0+ntile-1) of the block rows I + r, r = 0 .. nrows-1 <= kRows64
@@ -165,7 +172,10 @@ int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t 
 
 // What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
 // on the host while the sweep runs; enqueues on a tail stream that already waits for the export.
-constexpr int kTailLanes = 4;   // tail streams of the chi^2 sweep (model steps of retired curvatures in flight at once)
+#ifndef SCINT_TAIL_LANES
+#define SCINT_TAIL_LANES 4
+#endif
+constexpr int kTailLanes = SCINT_TAIL_LANES;   // tail streams of the chi^2 sweep (model steps of retired curvatures in flight at once)
 struct SweepTail {
     // `lane` (0 .. kTailLanes-1) names the tail stream: work of one lane is ordered, the lanes overlap, so
     // an implementation keeps one set of scratch buffers per lane

@@ -595,8 +595,6 @@ static int32_t dispatch_rows(int64_t n, const SspecRows& a, hipStream_t s) {
 
 bool sspec_fast_supported(int64_t nf, int64_t nt, int32_t halve) {
     if (!halve || nf < 3 || nt < 3) return false;
-    static const int off = [] { const char* e = getenv("SCINT_SSPEC_GENERIC"); return e ? atoi(e) : 0; }();
-    if (off) return false;        // tests compare the two paths
     const int64_t nr = next_pow2(nf), nc = next_pow2(nt);   // R/2, C/2
     return nr >= 256 && nr <= 8192 && nc >= 256 && nc <= 8192;
 }

@@ -121,7 +121,10 @@ __device__ inline GatherElem gather_elem(const GeomDev& g, int nfd, double eta, 
     int jf = __double2int_rz(qf);
     jf += jf < 0 ? nfd : 0;                             // NumPy's negative-index wrap
     GatherElem e;
-    e.off = in ? (wrap_ok ? it * nfd + jf : -2) : -1;   // (in range: it < ntau, 0 <= jf < nfd, ntau nfd < 2^31)
+    // (in range: it < ntau, 0 <= jf < nfd, ntau nfd < 2^31.  Out of range `it` is saturated and the product would overflow a
+    //  signed int -- undefined, though the select discards it -- so the index is formed in unsigned arithmetic: ADVICE r4)
+    const int idx = (int)((unsigned)it * (unsigned)nfd + (unsigned)jf);
+    e.off = in ? (wrap_ok ? idx : -2) : -1;
     e.wgt = sqrt(fabs(two_eta * (t2 - t1)));
     return e;
 }
@@ -360,7 +363,14 @@ struct RevParams {
     double inv_tau1_step;              // 1 / tau1_step (host: the same IEEE quotient the kernel used to form per wavefront)
 };
 
-constexpr int kRevSlab = 1024;     // most tau rows accumulated per workgroup: 1024 * 36 B = 36 KiB of LDS
+#ifndef SCINT_REV_SLAB
+#define SCINT_REV_SLAB 1024        // (build constants of the round-5 A/Bs: tools/build_variant.sh -DSCINT_REV_SLAB=320 -DSCINT_REV_CAP=512 ...)
+#endif
+#ifndef SCINT_REV_CAP
+#define SCINT_REV_CAP 0
+#endif
+constexpr int kRevSlab = SCINT_REV_SLAB;     // most tau rows accumulated per workgroup: 1024 * 36 B = 36 KiB of LDS
+constexpr int kRevCap = SCINT_REV_CAP;       // batched back-map: workgroups of a launch (each walks the launch's work items with this stride); 0 = one workgroup per item
 constexpr int kRevThreadsK = 256;  // threads per workgroup
 // Round 2 ran one 1024-thread workgroup with 144 KiB of LDS per Doppler column (all 4096 delay rows):
 // alone 0.41 ms per 4096^2 image, but inside the chi^2 sweep 1.95 ms -- a workgroup that needs a whole
@@ -803,20 +813,29 @@ __global__ void __launch_bounds__(256) rev_prep_batch_kernel(const RevJobDev* __
     bound[kRevBandHi] = (unsigned long long)hi;
 }
 
-__global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g, int slab) {
-    const RevJobDev jb = jobs[b.job[blockIdx.z]];
-    // slabs that miss the curvature's delay band leave at once: nothing of them is read afterwards
-    const int64_t row0 = (int64_t)blockIdx.y * slab;
-    if (row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) return;
-    RevParams p;
-    p.thth = nullptr; p.ld = jb.N;
-    p.vec = jb.vec; p.w = jb.w; p.rank1 = 1;
-    p.th = jb.th; p.N = jb.N;
-    p.eta = jb.eta; p.two_eta = jb.two_eta;
-    p.hermitian = 1; p.slab = slab; p.centre = jb.centre;
-    p.recov = b.recov[blockIdx.z]; p.transposed = 1;
-    p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
-    rev_gather_body<kRevThreadsK, true>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
+__global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g, int slab,
+                                                                         int nslab) {
+    // work item w = (image, slab, Doppler column), columns fastest; a launch has one workgroup per item, or -- kRevCap -- fewer
+    // that walk the items with the grid's stride
+    const int64_t total = g.nfd * (int64_t)nslab * (int64_t)b.n;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t col = w % g.nfd;
+        const int sl = (int)((w / g.nfd) % nslab), img = (int)(w / (g.nfd * (int64_t)nslab));
+        const RevJobDev jb = jobs[b.job[img]];
+        // slabs that miss the curvature's delay band are skipped: nothing of them is read afterwards
+        const int64_t row0 = (int64_t)sl * slab;
+        if (row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) continue;
+        RevParams p;
+        p.thth = nullptr; p.ld = jb.N;
+        p.vec = jb.vec; p.w = jb.w; p.rank1 = 1;
+        p.th = jb.th; p.N = jb.N;
+        p.eta = jb.eta; p.two_eta = jb.two_eta;
+        p.hermitian = 1; p.slab = slab; p.centre = jb.centre;
+        p.recov = b.recov[img]; p.transposed = 1;
+        p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
+        rev_gather_body<kRevThreadsK, true>(p, g, col, sl);
+        __syncthreads();            // (the next item zeroes the accumulators this one has just read)
+    }
 }
 
 RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, int rank1, const double* th, int N,
@@ -885,9 +904,11 @@ int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b,
     SCINT_REQUIRE(b.n >= 1 && b.n <= kRevBatchMax, "rev_map batch: bad count");
     hipLaunchKernelGGL(rev_prep_batch_kernel, dim3((unsigned)b.n), dim3(256), 0, stream, jobs_dev, b, g);
     const int slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));     // the slabs of launch_rev_map
-    dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, slab), (unsigned)b.n);
-    SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
-    hipLaunchKernelGGL(rev_gather_batch_kernel, grid, dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, b, g, slab);
+    const int nslab = (int)ceil_div(g.ntau, slab);
+    const int64_t total = g.nfd * (int64_t)nslab * (int64_t)b.n;
+    SCINT_REQUIRE(total < ((int64_t)1 << 31), "rev_map batch: too many work items");
+    const unsigned grid = (unsigned)(kRevCap > 0 ? std::min<int64_t>(total, kRevCap) : total);
+    hipLaunchKernelGGL(rev_gather_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, b, g, slab, nslab);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

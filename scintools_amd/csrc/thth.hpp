@@ -124,7 +124,10 @@ int32_t launch_rev_map_rank1(const cplx* vec, const double* w, const double* th,
 // cost the sweep's ONE host thread 11 API calls each, during which neither slot group got its next chunk: the mat-vec was in
 // flight for only 85 % of a chi^2 step (profiles/r04_timeline.txt; 97.5 % in the eigenvalue sweep).  Batched: four launches
 // per <= kRevBatchMax curvatures, whatever their number.
-constexpr int kRevBatchMax = 8;
+#ifndef SCINT_REV_BATCH
+#define SCINT_REV_BATCH 8
+#endif
+constexpr int kRevBatchMax = SCINT_REV_BATCH;
 struct RevJobDev {                 // one per curvature of the sweep, built on the host before the sweep starts
     const cplx* vec; const double* w; const double* th;   // eigenvector [N], |w| (device scalar), centres of the reduced edges [N]
     double eta, two_eta, inv_tau1_step;

@@ -52,11 +52,13 @@ def eta_share(n, world, rank):
 
 def share_schedule(n_share, batch):
     """Slot groups for a rank's share of a sweep (argument of ``scint_sweep_schedule``: 0 = the library's default of two
-    groups on two streams, 1 = one group).  The two groups exist so that one's launch gaps, checks and refills fall beside
-    the other's mat-vec; a share that does not even fill the resident slots once (``n_share <= batch``: no refill will ever
-    happen) and is split in two leaves each group's launches half as large without anything to hide, so it runs as one
-    group.  (bench.py times both ends of the rank range with this rule: config.predicted_strong_scaling.)"""
-    return 1 if n_share <= max(1, batch) // 2 else 0
+    groups on two streams, 1 = one group).  Measured on one MI355X with the headline sweep's shares etas[R::W] (round 5, call 1,
+    profiles/r05_rank_share_ab.json): two groups win at every share size, also where a share no longer fills the resident
+    slots once -- 32 curvatures (W = 8): 22.9 ms per share with two groups against 26.0 with one (predicted efficiency 0.908 /
+    0.799); 64 (W = 4): 0.970 / 0.920; 128 (W = 2): 0.971 / 0.946.  The second group's launches fall into the first one's
+    check / reduce / refill gaps whatever the share's size, so the rule is: keep the default.  (One group is only forced for
+    shares too small to split: fewer than four curvatures, where run_sweep does the same.)"""
+    return 1 if n_share < 4 else 0
 
 
 def share_imbalance(cost, world, shares=eta_share):

@@ -156,6 +156,20 @@ def to_device(CS, dtype=torch.complex128):
     return _dv.to_device(CS, dtype)
 
 
+SWEEP_MAX_CS_ELEMENTS = (1 << 31) - 1    # the packed gather of the sweeps indexes the conjugate spectrum with 32 bits
+
+
+def _check_sweep_cs(ntau, nfd):
+    """The sweeps (eval / eigvec / chisq, single or multi, and the batched retrieval) refuse a conjugate spectrum of 2^31
+    elements or more -- 32 GiB of complex128, e.g. a 16384^2 dynspec with npad = 3 -- inside the library (SCINT_E_ARG from
+    run_sweep).  Say so here, before any workspace is allocated; the per-curvature entry points (thth_map,
+    thth_redmap, modeler, Eval_calc through them) index with 64 bits and take such a spectrum."""
+    if int(ntau) * int(nfd) > SWEEP_MAX_CS_ELEMENTS:
+        raise ValueError(f"conjugate spectrum of {ntau} x {nfd} = {int(ntau) * int(nfd)} elements: the batched sweeps index it "
+                         f"with 32 bits (limit {SWEEP_MAX_CS_ELEMENTS}); use a smaller npad, chunk the observation, or call "
+                         "thth_redmap / modeler per curvature")
+
+
 def _cs_dev(CS, grid):
     t = to_device(CS, torch.complex128)
     if tuple(t.shape) != (grid.geom.ntau, grid.geom.nfd):
@@ -327,25 +341,32 @@ def chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask=None):
 
 
 def default_batch(nmax, neta, eigenvalues_only=True):
-    """Curvatures resident per launch: enough tile strips (one workgroup each) to fill the
-    256 CUs several times over, within the HBM budget for the packed matrices (8 N^2 bytes)."""
+    """Curvatures resident per launch: enough mat-vec workgroups to fill the 256 CUs several times over, within the HBM
+    budget for the packed matrices (8 N^2 bytes each).
+
+    The unit is the library's own: ``scint_sweep_workgroups(nb)`` mat-vec workgroups per matrix (block rows per workgroup and
+    tiles per strip are build constants of the library -- ADVICE r4: the rule used to model the round-2 kernel's strips).  The
+    targets are the slot counts measured on MI355X at N = 4095 (nb = 64: 27 workgroups per matrix, complex128 or complex64:
+    eight block rows x <= 12 tiles each) times that unit:
+      eigenvalue sweep, float64      107 slots (round 4: 69 / 92 / 100 / 108 / 116 -> +0 / +0.3 / +0.6 / +0.8 / +1.0 %; 20 -> 30 at
+                                     N = 8191 +0.7 %; 69 -> 108 with npad = 3 +1.6 %)                        -> 2889 workgroups
+      eigenPAIR sweeps, float64       69 slots (chi^2 objective: 836 / 832 / 827 eta/s at 69 / 100 / 128)      -> 1863
+      mixed eigenvalue sweep         214 slots wanted, 157 within the HBM budget (a slot idles two of its ~19   -> 5778
+                                     chunks around the certificate pass; 2400 eta/s, round 5 call 1)
+      mixed-all eigenPAIR sweeps     138 slots                                                                 -> 3726"""
     nb = -(-nmax // 64)
-    strip = 16 if nb >= 32 else (8 if nb >= 16 else (4 if nb >= 8 else (2 if nb >= 4 else 1)))
-    strips = sum(-(-(nb - i) // strip) for i in range(nb))
-    want = -(-11000 // max(strips, 1))     # measured on MI355X at N = 4095: 48 / 56 / 70 slots -> 1079 / 1084 / 1094 eta/s
+    lib = _lib.load()
+    mode = lib.scint_sweep_precision(-1)
+    use32 = mode == 2 or (eigenvalues_only and mode == 1)
+    wg = max(1, int(lib.scint_sweep_workgroups(nb, 1 if use32 else 0)))
+    if use32:
+        target = 5778 if eigenvalues_only else 3726
+    else:
+        target = 2889 if eigenvalues_only else 1863
+    want = -(-target // wg)
     per_slot = 8 * (nb * 64) ** 2 + 1
-    mode = _lib.load().scint_sweep_precision(-1)
-    if eigenvalues_only and mode == 0:
-        # round 4 (four block rows per mat-vec workgroup: a quarter of the workgroups per matrix): 69 / 92 / 100 / 108 / 116 slots ->
-        # +0 / +0.3 / +0.6 / +0.8 / +1.0 % on the headline sweep (three interleaved rounds; +0.1-0.2 % on a fourth box), 20 -> 30
-        # slots at N = 8191 +0.7 %, 69 -> 108 with npad = 3 +1.6 %.  The eigenPAIR sweeps (chi^2 objective: 836 / 832 / 827 eta/s at
-        # 69 / 100 / 128) and the mixed sweep (2388 eta/s at its 138 slots, 2309 at 146) keep their batches
-        want = -(-17000 // max(strips, 1))
-    if mode == 2 or (eigenvalues_only and mode == 1):
-        # mixed sweep: a workgroup of the complex64 mat-vec covers four block rows (half as many workgroups per matrix),
-        # and a slot idles for two of its ~19 chunks around the certificate pass: twice the slots for the same fill;
-        # a slot also holds the complex64 copy and the Q history (ththmod.DEFAULT_BATCH_BYTES is a budget, not a limit)
-        want *= 2
+    if use32:
+        # a slot of the mixed sweeps also holds the complex64 copy and the Q history (ththmod.DEFAULT_BATCH_BYTES is a budget, not a limit)
         per_slot = per_slot * 3 // 2 + 130 * 32 * nb * 64
     cap = max(1, DEFAULT_BATCH_BYTES // per_slot)
     return int(max(1, min(neta, 256, want, cap)))
@@ -380,6 +401,7 @@ def eval_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_I
     returns a dict with per-eta matrix sizes N, Lanczos steps and status."""
     lib = _lib.load()
     grid = _Grid(tau, fd, edges)
+    _check_sweep_cs(grid.geom.ntau, grid.geom.nfd)
     cs_t = _cs_dev(CS, grid)
     etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
     neta, M = etas_v.shape[0], grid.M
@@ -509,6 +531,7 @@ def eigvec_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX
     N_i = len(keep_i) entries, unit norm, arbitrary phase --, info dict)."""
     lib = _lib.load()
     grid = _Grid(tau, fd, edges)
+    _check_sweep_cs(grid.geom.ntau, grid.geom.nfd)
     cs_t = _cs_dev(CS, grid)
     etas_v = np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float)
     neta, M = etas_v.shape[0], grid.M
@@ -549,6 +572,7 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     on -- no per-eta round trip through Python."""
     lib = _lib.load()
     grid = _Grid(tau, fd, edges)
+    _check_sweep_cs(grid.geom.ntau, grid.geom.nfd)
     cs_t = _cs_dev(CS, grid)
     etas_v = np.ascontiguousarray(np.atleast_1d(units.strip(etas, "etas", "s3", warn=False)).astype(float))
     neta, M = etas_v.shape[0], grid.M
@@ -580,7 +604,7 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     chis[(st[0] != 0) | (keep_n < 3)] = np.nan   # failed curvatures (the reference's loop would raise there)
     if return_info:
         w = w_t.cpu().numpy()
-        w[st[0] != 0] = np.nan
+        w[(st[0] != 0) | (keep_n < 3)] = np.nan      # as chis: no model exists for these curvatures
         return chis, {"w": w, "N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch}
     return chis
 
@@ -610,6 +634,7 @@ def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAU
     M = G[0].M
     if any(g.M != M or (g.geom.ntau, g.geom.nfd) != tuple(cs_t.shape[1:]) for g in G):
         raise ValueError("all chunks must share the CS shape and the number of edges")
+    _check_sweep_cs(G[0].geom.ntau, G[0].geom.nfd)
     etas_all, cs_index, keep_rows, keep_n = [], [], [], []
     for c, (g, et) in enumerate(zip(G, etas_list)):
         et = np.atleast_1d(units.strip(et, "etas", "s3", warn=False)).astype(float)
@@ -666,6 +691,7 @@ def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEF
     M = G[0].M
     if any(g.M != M or (g.geom.ntau, g.geom.nfd) != tuple(cs_t.shape[1:]) for g in G):
         raise ValueError("all chunks must share the CS shape and the number of edges")
+    _check_sweep_cs(G[0].geom.ntau, G[0].geom.nfd)
     etas_all, cs_index, keep_rows, keep_n = [], [], [], []
     for c, (g, et) in enumerate(zip(G, etas_list)):
         et = np.atleast_1d(units.strip(et, "etas", "s3", warn=False)).astype(float)
@@ -883,6 +909,9 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
             if verbose:
                 print("Chunk %d success" % (g0 + k), flush=True)
         out[g0 + np.asarray(live)] = out_t.cpu().numpy()
+        # release this group's device buffers BEFORE the next group allocates its own: while the names are bound the caching
+        # allocator cannot reuse the blocks and the peak would be two groups -- the bound is `group_bytes`, not twice it
+        del stack, V_t, out_t
     return out
 
 

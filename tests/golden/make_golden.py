@@ -224,6 +224,33 @@ def gen_fit_thetatheta():
          ththeta=V(dyn.ththeta), ththetaerr=V(dyn.ththetaerr))
 
 
+def gen_fit_thetatheta_256():
+    """The same tutorial data with ONE 256-channel fitting chunk (the first 256 of its 448 channels; npad = 3: a 1024 x 600
+    conjugate spectrum, the default edges of min_edges): parity of thetatheta_single / fit_thetatheta beyond the 64-channel
+    chunks of the tutorial recipe.  Also records how long the reference took."""
+    import time
+    from scintools.dynspec import BasicDyn
+    d = np.load("/root/reference/scintools/examples/data/ththsims/Sample_Data.npz")
+    nchan = 256
+    dspec = (np.abs(d["Espec"]) ** 2)[:nchan]
+    freq, tme = d["f_MHz"][:nchan], d["t_s"]
+    b = BasicDyn(name="Sample Data", header=["Sample Data"], times=tme, freqs=freq, dyn=dspec,
+                 nsub=tme.shape[0], nchan=freq.shape[0], dt=(tme[1] - tme[0]), df=(freq[1] - freq[0]))
+    dyn = Dynspec(dyn=b, process=False, verbose=False)
+    dyn.prep_thetatheta(verbose=False, cwf=256, edges_lim=.3, eta_min=30 * u.s**3, eta_max=50 * u.s**3)
+    t0 = time.perf_counter()
+    etas0, eigs0, popt0 = dyn.thetatheta_single(cf=0, ct=0, plot=False, arrays=True)
+    t1 = time.perf_counter()
+    dyn.fit_thetatheta(verbose=False)
+    t2 = time.perf_counter()
+    save("fit_thetatheta_256.npz", nchan=nchan, edges=V(dyn.edges), neta=dyn.neta, npad=dyn.npad, fw=dyn.fw, fref=V(dyn.fref),
+         eta_min=V(dyn.eta_min), eta_max=V(dyn.eta_max), cwf=dyn.cwf, cwt=dyn.cwt,
+         single_etas=V(etas0), single_eigs=eigs0, single_popt=np.array(popt0),
+         eta_evo=V(dyn.eta_evo), eta_evo_err=V(dyn.eta_evo_err), f0s=V(dyn.f0s), t0s=V(dyn.t0s),
+         ththeta=V(dyn.ththeta), ththetaerr=V(dyn.ththetaerr),
+         reference_seconds=np.array([t1 - t0, t2 - t1]), host_cores=os.cpu_count())
+
+
 # ---------------------------------------------------------------------------
 # 6. phase retrieval: thetatheta_chunks -> mosaic -> Gerchberg-Saxton (dynspec.py:1765-1875)
 # ---------------------------------------------------------------------------
@@ -419,3 +446,5 @@ if __name__ == "__main__":
         gen_sim_sweep()
     if "simsweep4096" in which:    # ~15 min: not in the default list
         gen_sim_sweep_4096()
+    if "fit256" in which:          # one 256-channel chunk of the tutorial data: minutes, not in the default list
+        gen_fit_thetatheta_256()

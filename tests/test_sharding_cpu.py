@@ -206,9 +206,7 @@ def test_world2_gloo_with_the_interpreted_kernels(monkeypatch, precision):
 
 
 def test_share_schedule_rule():
-    """sweep.share_schedule: a rank's share that cannot fill half of the resident slots runs as ONE slot group (nothing to
-    hide behind a second one, and its launches stay twice as large); anything larger keeps the library's two groups."""
+    """sweep.share_schedule: the slot groups a rank's share of a sweep runs with -- the library's two groups at every share
+    size that can be split (measured: profiles/r05_rank_share_ab.json), one group below four curvatures."""
     from scintools_amd import sweep
-    assert sweep.share_schedule(32, 107) == 1 and sweep.share_schedule(53, 107) == 1
-    assert sweep.share_schedule(64, 107) == 0 and sweep.share_schedule(128, 107) == 0 and sweep.share_schedule(256, 107) == 0
-    assert sweep.share_schedule(1, 1) == 0 and sweep.share_schedule(0, 8) == 1
+    assert [sweep.share_schedule(n, 107) for n in (1, 3, 4, 32, 64, 128, 256)] == [1, 1, 0, 0, 0, 0, 0]
