@@ -249,7 +249,7 @@ def parse():
     return args
 
 
-NPROF = 5      # kernels scint_profile_end reports on (include/scint_hip.h)
+NPROF = 8      # kernels scint_profile_end reports on (include/scint_hip.h): 0-4 the sweeps', 5-7 calc_sspec's three
 
 
 def free_port():
@@ -495,7 +495,40 @@ def simulation_screen_leg(args, size, neta, nedge, wl, main_wl, timed, ththmod):
         return {"error": repr(exc)}
 
 
-def sspec_timing(torch, size):
+def sspec_roofline(n, ms, parts_ms):
+    """`roofline` of calc_sspec at n x n: which roof binds each of its three kernels, from the committed per-kernel HBM bytes and
+    instruction counts of THIS library's kernels (profiles/*_sspec_roofline_<n>.json: rocprofv3 PMC, tools/sspec_roofline.py)
+    and the kernel times measured live (hipEvent brackets inside scint_sspec).  A kernel's floor is the larger of its HBM floor
+    (measured bytes at the ~6.3 TB/s the guide calls achievable) and its issue floor (VALU instructions x wavefronts x 4
+    cycles over 1024 SIMDs at 2.4 GHz); `frac` = floor / measured time says how far the kernel is from the roof that binds it."""
+    summ_ratio, src, stale = _newest_summary(f"*_sspec_roofline_{n}.json", lambda summ: summ)
+    if summ_ratio is None:
+        return {"note": stale}
+    summ = summ_ratio
+    kern, floor_total = {}, 0.0
+    for name, live in zip(("prep", "cols", "rows"), parts_ms):
+        k = summ["kernels"].get(name)
+        if not k:
+            continue
+        hb, iss = k["hbm_floor_us"] / 1e3, k["issue_floor_us"] / 1e3
+        extra = summ["kernels"].get("prep_means", {}).get("duration_under_counters_us", 0.0) / 1e3 if name == "prep" else 0.0
+        floor = max(hb, iss)
+        floor_total += floor
+        kern[name] = {"ms": live, "hbm_bytes": k["hbm_bytes_per_launch"], "hbm_floor_ms": hb, "valu_insts_per_wavefront": k["valu_insts_per_wavefront"],
+                      "wavefronts": k["wavefronts"], "issue_floor_ms": iss, "bound": "valu-issue" if iss > hb else "hbm",
+                      "frac_of_binding_roof": floor / live if live > 0 else None}
+        if extra:
+            kern[name]["includes_the_one_block_sum_kernel_ms"] = extra
+    alg = 8.0 * n * n + 8.0 * n * (2 * n)
+    return {"source": src, "traffic": summ["hbm_bytes"], "traffic_over_algorithmic": summ["traffic_over_algorithmic"],
+            "algorithmic_floor_ms": 1e3 * alg / 6.3e12, "two_trip_floor_ms": 1e3 * (alg + 2 * 8.0 * n * (2 * n)) / 6.3e12,
+            "sum_of_binding_floors_ms": floor_total, "frac": floor_total / ms if ms > 0 else None,
+            "bound": "valu-issue" if sum(1 for v in kern.values() if v["bound"] == "valu-issue") >= 2 else "hbm", "kernels": kern,
+            "note": "frac = sum over the three kernels of max(HBM floor at 6.3 TB/s of its MEASURED bytes, VALU-issue floor of its MEASURED "
+                    "instruction count) / time of a call; the algorithmic and the two-trip byte floors are given beside it"}
+
+
+def sspec_timing(torch, size, lib=None):
     """Dynspec.calc_sspec (window, zero-padded real-to-complex 2-D FFT, |.|^2, shift, dB;
     dynspec.py:3665-3721) on a size^2 and a (2 size)^2 dynamic spectrum resident in HBM.
     Algorithmic bytes: 8 nf nt read + 8 (nrfft/2) ncfft written."""
@@ -517,6 +550,18 @@ def sspec_timing(torch, size):
             alg = 8.0 * n * n + 8.0 * n * (2 * n)          # nrfft/2 = n rows kept, ncfft = 2n columns
             res[f"{n}x{n}"] = {"ms": ms, "algorithmic_bytes": alg, "GBs": alg / ms / 1e6,
                                "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBS}
+            if lib is not None:
+                # the same calls again with the library's own brackets around its three kernels (their events would sit between
+                # the kernels of the timing loop above)
+                lib.scint_profile_begin()
+                for _ in range(reps):
+                    sspec_device(x)
+                pm, ps, pl = (ctypes.c_double * NPROF)(), (ctypes.c_double * NPROF)(), (ctypes.c_int64 * NPROF)()
+                lib.scint_profile_end(pm, ps, pl, NPROF)
+                parts = [ps[k] / max(1, pl[k]) for k in (5, 6, 7)]
+                if all(pl[k] > 0 for k in (5, 6, 7)):
+                    res[f"{n}x{n}"]["kernels_ms"] = dict(zip(("prep", "cols", "rows"), parts))
+                    res[f"{n}x{n}"]["roofline"] = sspec_roofline(n, ms, parts)
             del x
         except Exception as exc:
             res[f"{n}x{n}"] = {"error": repr(exc)}
@@ -587,6 +632,16 @@ def workload_main(args):
         if args.workload == "fit_thetatheta":
             med, ts, kern = profiled(lambda: d.fit_thetatheta())
             jobs = nchunk * d.neta
+            st = (ctypes.c_double * 4)()
+            lib.scint_sweep_stats(st)                  # the last call's sweep (all chunks are one sweep while their stack fits 8 GiB)
+            mv = kern.get("pk2_matvec_kernel")
+            if mv and st[1] > 0:
+                mv["algorithmic_GB_per_call"] = st[1] / 1e9
+                mv["GBs_in_flight"] = st[1] / 1e9 / (mv["busy_share_of_wall"] * med)
+                mv["frac_of_hbm_peak"] = mv["GBs_in_flight"] / HBM_PEAK_GBS
+                mv["note"] = ("8 N (N + 1) bytes per pass summed by the library (scint_sweep_stats) over the time a mat-vec launch is in "
+                              "flight; matrices this small (N ~ 1200: 11 MB) stay in the 256 MiB Infinity Cache between the passes of a "
+                              "chunk of launches, so the rate may exceed what HBM alone delivers")
             # parity sample + CPU port: single_search of the oracle on a few chunks
             sample = [(0, 0), (d.ncf_fit // 2, d.nct_fit // 2)][: max(1, args.cpu_sample // 8)]
             t_cpu, diffs = [], []
@@ -595,7 +650,8 @@ def workload_main(args):
                 t0 = time.perf_counter()
                 r = thth_oracle.single_search(p_[0], p_[1], p_[2], p_[3], p_[4], fw=d.fw, npad=d.npad)
                 t_cpu.append(time.perf_counter() - t0)
-                diffs.append(abs(d.eta_evo[cf, ct] - r[0]) / abs(r[0]))
+                both_nan = not np.isfinite(d.eta_evo[cf, ct]) and not np.isfinite(r[0])        # (the parabola fit fails on both sides alike)
+                diffs.append(0.0 if both_nan else abs(d.eta_evo[cf, ct] - r[0]) / abs(r[0]))
                 diffs.append(float(np.nanmax(np.abs(d.thth_eigs[cf, ct] - r[4]) / np.abs(r[4]))))
             out.update(value=med, seconds_all=ts, config=dict(cfg, chunk_eta_jobs=jobs),
                        chunk_eta_points_per_s=jobs / med, kernels=kern,
@@ -665,7 +721,7 @@ def workload_main(args):
             pass
         out.update(value=med, seconds_all=ts, kernels=kern,
                    config={"workload": "the reference's tutorial: prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50) + "
-                                       "fit_thetatheta on Sample_Data (448 x 150), npad = 3", "fit_chunks": nchunk, "neta": int(d.neta),
+                                       f"fit_thetatheta on Sample_Data ({obs.dyn.shape[0]} x {obs.dyn.shape[1]}), npad = 3", "fit_chunks": nchunk, "neta": int(d.neta),
                            "nedge": int(d.edges.shape[0])},
                    parity={"max_rel_diff_eta_evo_vs_reference_run": float(np.nanmax(np.abs(d.eta_evo - ref_evo) / np.abs(ref_evo))),
                            "rel_diff_ththeta_vs_reference_run": abs(d.ththeta - ref_ththeta) / abs(ref_ththeta),
@@ -703,7 +759,7 @@ def workload_main(args):
                    cpu_baseline={"value": 4.0 * (t2 - t0), "unit": "s", "kind": "port", "cores": int(blas_threads()), "host_cores": os.cpu_count(),
                                  "sample": f"oracle scale_dyn + calc_sspec ({t1 - t0:.1f} s) + fit_arc ({t2 - t1:.1f} s) on the top-left "
                                            f"{h}x{h} quarter of the same observation, x 4 (pixel count)",
-                                 "betaeta_of_the_quarter": float(fa["betaeta"])})
+                                 "betaeta_of_the_quarter": float(fa["sides"][0]["eta"])})
         out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
     print(json.dumps(out))
 
@@ -1021,8 +1077,8 @@ def main():
                     if neta < 2 * W:
                         continue
                     per = {}
-                    for R in sorted({0, W - 1}):
-                        idx = sweep.eta_share(neta, W, R)
+                    for rk in sorted({0, W - 1}):
+                        idx = sweep.eta_share(neta, W, rk)
                         groups = sweep.share_schedule(len(idx), int(info["batch"]))
                         wl.update(main_wl, etas=etas[idx])
                         lib.scint_sweep_schedule(-1, -1, groups)
@@ -1031,7 +1087,7 @@ def main():
                         finally:
                             lib.scint_sweep_schedule(-1, -1, 0)
                             wl.update(main_wl)
-                        per[f"rank{R}"] = {"etas": int(len(idx)), "ms_per_step": 1e3 * r["elapsed"] / k, "slot_groups": groups or 2,
+                        per[f"rank{rk}"] = {"etas": int(len(idx)), "ms_per_step": 1e3 * r["elapsed"] / k, "slot_groups": groups or 2,
                                            "matvec_GBs": r["mv_bytes"] / (r["busy_ms"][1] / 1e3) / 1e9 if r["busy_ms"][1] > 0 else 0.0}
                     slow = max(v["ms_per_step"] for v in per.values()) / 1e3
                     pred[str(W)] = dict(per, efficiency=t1 / (W * slow), eta_per_s=neta / slow)
@@ -1069,7 +1125,7 @@ def main():
             except Exception as exc:               # a reported leg must never take the line down
                 out["modeler"]["mixed_all"] = {"error": repr(exc)}
         if world == 1 and args.objective == "eig" and msteps > 0:
-            out["sspec"] = sspec_timing(torch, size)
+            out["sspec"] = sspec_timing(torch, size, lib)
         if world == 1 and not args.no_cpu_baseline and args.objective == "eig":
             cb, ref_vals = cpu_baseline(dyn, tau, fd, edges, etas, args.cpu_sample, args.npad, args.cpu_reps)
             out["cpu_baseline"] = cb

@@ -77,10 +77,12 @@ int32_t scint_device_count(void);
  * in milliseconds of the UNION of its launch intervals (the sweep drives two streams, so
  * launches may overlap), the plain SUM of the individual launch spans (sum / launches is the
  * average a kernel trace reports) and the launch counts.  HOST arrays of `count` entries; the
- * library fills min(count, 5) of them and never writes beyond `count` (since version 101: the
+ * library fills min(count, 8) of them and never writes beyond `count` (since version 101: the
  * entry point wrote a fixed 2, then 3, entries before): [2] is the complex64 mat-vec of the
  * mixed-precision sweep (scint_sweep_precision), [3] the rank-1 back-map and [4] the model
- * transform + chi^2 of the model steps of scint_chisq_sweep.  Not thread-safe; off by default. */
+ * transform + chi^2 of the model steps of scint_chisq_sweep; since version 102 [5], [6], [7] are the
+ * three kernels of the two-trip scint_sspec (input copy + sums, strided axis, row transforms with
+ * |.|^2 / dB).  Not thread-safe; off by default. */
 int32_t scint_profile_begin(void);
 int32_t scint_profile_end(double* ms_out /*HOST[count]*/, double* ms_sum_out /*HOST[count]*/,
                           int64_t* launches_out /*HOST[count]*/, int32_t count);

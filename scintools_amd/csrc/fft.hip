@@ -1502,11 +1502,12 @@ struct ChisqSweepLayout {
     size_t jobs, bounds, colsum, pre, suf;     // Parseval route: RevJobDev table, per-curvature constants, |D|^2 sums along the delay axis
     int images;                                // image buffers per tail lane (tail batches)
 };
-// Image buffers per tail lane: as many curvatures as a tail batch may hold (thth.hpp), within 2 GiB per lane (8 at 4096^2, 2 at 8192^2)
+// Image buffers per tail lane: as many curvatures as a tail batch may hold (thth.hpp), within 8 GiB over all lanes (8 per lane at
+// 4096^2, 4 at 8192^2)
 static int chisq_images_per_lane(int64_t ntau, int64_t nfd, int64_t nf, int64_t nt) {
     if (!(nf == ntau && nt == nfd)) return 1;                      // cropped model: the per-curvature model route only
     const size_t image = sizeof(cplx) * (size_t)ntau * (size_t)nfd;
-    return (int)std::max<size_t>(1, std::min<size_t>(kRevBatchMax, ((size_t)2 << 30) / std::max<size_t>(image, 1)));
+    return (int)std::max<size_t>(1, std::min<size_t>(kRevBatchMax, (((size_t)8 << 30) / kTailLanes) / std::max<size_t>(image, 1)));
 }
 static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_t max_iter, int64_t ntau, int64_t nfd,
                                   int64_t nf, int64_t nt, ChisqSweepLayout* L) {

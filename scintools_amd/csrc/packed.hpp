@@ -173,7 +173,7 @@ int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t 
 // What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
 // on the host while the sweep runs; enqueues on a tail stream that already waits for the export.
 #ifndef SCINT_TAIL_LANES
-#define SCINT_TAIL_LANES 4
+#define SCINT_TAIL_LANES 2        // (round 5, call 2: 2 lanes 870 eta/s against 857 / 861 with 4 on the chi^2 objective: batches of <= 8 curvatures keep a lane busy)
 #endif
 constexpr int kTailLanes = SCINT_TAIL_LANES;   // tail streams of the chi^2 sweep (model steps of retired curvatures in flight at once)
 struct SweepTail {

@@ -10,7 +10,9 @@ namespace scint {
 
 // (2: the complex64 mat-vec of the mixed sweep; 3, 4: the model step of the chi^2 sweep -- rank-1 back-map with its bound kernel,
 //  complex-to-real model transform with the chi^2 sink and the final sum)
-enum ProfKernel { kProfGather = 0, kProfMatvec = 1, kProfMatvec32 = 2, kProfRevmap = 3, kProfModel = 4, kProfCount = 5 };
+//  5, 6, 7: the three kernels of the two-trip calc_sspec -- input copy + sums, strided axis, row transforms + |.|^2 / dB)
+enum ProfKernel { kProfGather = 0, kProfMatvec = 1, kProfMatvec32 = 2, kProfRevmap = 3, kProfModel = 4,
+                  kProfSspecPrep = 5, kProfSspecCols = 6, kProfSspecRows = 7, kProfCount = 8 };
 
 struct Profiler {
     bool enabled = false;

@@ -31,6 +31,7 @@
 // fragment traffic of the row kernel -- 32-byte loads, 8-byte stores -- on top of its 136-us instruction floor).
 // Shapes outside 256 <= R/2, C/2 <= 8192 and `halve = 0` keep the generic path (fft.hip).
 #include "sspec.hpp"
+#include "prof.hpp"
 
 #include "fft.hpp"
 
@@ -630,23 +631,30 @@ int32_t sspec_fast(const double* dyn, int64_t nf, int64_t nt, const double* win_
     double* dynp = (double*)(base + ws.dynp);
     double* partial = (double*)(base + ws.partial);
     double* scal = (double*)(base + ws.scal);
+    const int p0 = profiler().begin(kProfSspecPrep, stream);
     hipLaunchKernelGGL(sspec_prep_kernel, dim3((unsigned)ws.tiles_x, (unsigned)ws.tiles_y), dim3(256), 0, stream, dyn, win_t,
                        win_f, (int)nf, (int)nt, dynp, partial);
     hipLaunchKernelGGL(sspec_prep_means_kernel, dim3(1), dim3(256), 0, stream, partial, ws.tiles_x * ws.tiles_y,
                        (double)(nf * nt), scal);
+    profiler().end(kProfSspecPrep, p0, stream);
     SCINT_LAUNCH_CHECK();
     SspecCols ca{};
     ca.in = SspecIn{dynp, win_t, win_f, scal, (int)nf, (int)nt, (int)nf_eff, (int)nt_eff, prewhite};
     ca.npairs = (int)ceil_div(nt_eff, 2);
     ca.Y = (cplx*)(base + ws.Y); ca.ldY = 2 * ca.npairs;
     ca.tw_n = tw_r; ca.tw_2n = tw_2r;
+    const int p1 = profiler().begin(kProfSspecCols, stream);
     int32_t rc = dispatch_cols(nr, ca, stream);
+    profiler().end(kProfSspecCols, p1, stream);
     if (rc != SCINT_OK) return rc;
     SspecRows ra{};
     ra.Y = ca.Y; ra.npairs = ca.npairs; ra.nt_eff = (int)nt_eff; ra.nrows = (int)nr; ra.C = (int)(2 * nc);
     ra.tw_n = tw_c; ra.tw_2n = tw_2c; ra.out = sec_out;
     ra.prewhite = prewhite; ra.pd_fd = pd_fd; ra.pd_td = pd_td;
-    return dispatch_rows(nc, ra, stream);
+    const int p2 = profiler().begin(kProfSspecRows, stream);
+    rc = dispatch_rows(nc, ra, stream);
+    profiler().end(kProfSspecRows, p2, stream);
+    return rc;
 }
 
 }  // namespace scint

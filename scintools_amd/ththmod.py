@@ -350,7 +350,8 @@ def default_batch(nmax, neta, eigenvalues_only=True):
     eight block rows x <= 12 tiles each) times that unit:
       eigenvalue sweep, float64      107 slots (round 4: 69 / 92 / 100 / 108 / 116 -> +0 / +0.3 / +0.6 / +0.8 / +1.0 %; 20 -> 30 at
                                      N = 8191 +0.7 %; 69 -> 108 with npad = 3 +1.6 %)                        -> 2889 workgroups
-      eigenPAIR sweeps, float64       69 slots (chi^2 objective: 836 / 832 / 827 eta/s at 69 / 100 / 128)      -> 1863
+      eigenPAIR sweeps, float64       90 slots (round 4, per-curvature tail: 836 / 832 / 827 eta/s at 69 / 100 / 128; round 5, batched  -> 2430
+                                     tail: 854 / 857-861 / 873 / 870 at 56 / 69 / 90 / 107 on the chi^2 objective)
       mixed eigenvalue sweep         214 slots wanted, 157 within the HBM budget (a slot idles two of its ~19   -> 5778
                                      chunks around the certificate pass; 2400 eta/s, round 5 call 1)
       mixed-all eigenPAIR sweeps     138 slots                                                                 -> 3726"""
@@ -362,7 +363,7 @@ def default_batch(nmax, neta, eigenvalues_only=True):
     if use32:
         target = 5778 if eigenvalues_only else 3726
     else:
-        target = 2889 if eigenvalues_only else 1863
+        target = 2889 if eigenvalues_only else 2430
     want = -(-target // wg)
     per_slot = 8 * (nb * 64) ** 2 + 1
     if use32:

@@ -659,18 +659,18 @@ def test_chisq_sweep_curvature_that_keeps_two_centres_is_nan(emu, to):
 def test_default_batch_follows_the_librarys_workgroup_count(emu):
     """the resident-curvature rule counts the mat-vec workgroups the BUILT kernel launches per matrix
     (scint_sweep_workgroups: block rows per workgroup x tiles per strip are build constants), and reproduces the slot counts
-    that were measured at N = 4095 -- 107 / 69 for the float64 eigenvalue / eigenpair sweeps, 214 / 138 for the mixed ones."""
+    that were measured at N = 4095 -- 107 / 90 for the float64 eigenvalue / eigenpair sweeps, 214 / 138 for the mixed ones."""
     from scintools_amd import _lib
     lib = _lib.load()
     assert lib.scint_sweep_workgroups(64, 0) == sum(-(-(64 - i) // 12) for i in range(0, 64, 8)) == 27
     assert lib.scint_sweep_workgroups(64, 1) == 27 and lib.scint_sweep_workgroups(1, 0) == 1 and lib.scint_sweep_workgroups(0, 0) < 0
-    assert emu.default_batch(4095, 256) == 107 and emu.default_batch(4095, 256, eigenvalues_only=False) == 69
+    assert emu.default_batch(4095, 256) == 107 and emu.default_batch(4095, 256, eigenvalues_only=False) == 90
     assert emu.default_batch(4095, 40) == 40
     assert emu.default_batch(8191, 256) in (30, 31) and emu.default_batch(2047, 256) == 256
     prev = emu.sweep_precision("mixed")
     try:
         # (214 wanted; the 32-GiB budget for resident matrices -- a mixed slot also holds the complex64 copy -- caps it at 157)
-        assert emu.default_batch(4095, 256) == 157 and emu.default_batch(4095, 256, eigenvalues_only=False) == 69
+        assert emu.default_batch(4095, 256) == 157 and emu.default_batch(4095, 256, eigenvalues_only=False) == 90
         assert emu.default_batch(2047, 1000) == 256
         emu.sweep_precision("mixed-all")
         assert emu.default_batch(4095, 256, eigenvalues_only=False) == 138

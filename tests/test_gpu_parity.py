@@ -324,6 +324,30 @@ def test_fit_thetatheta_vs_reference_golden(golden):
     assert abs(d.ththeta - 44.0 * (1332.0 + 64.0) ** 0 ) < 10     # same arc as the known answer
 
 
+def test_fit_thetatheta_256_channel_chunk_vs_reference_golden(golden):
+    """thetatheta_single / fit_thetatheta beyond the tutorial's 64-channel chunks: ONE 256-channel
+    chunk of the same data (npad = 3: CS 1024 x 600; 1166 default edges, N up to 1165, 52 curvatures) against the reference's
+    own run (tests/golden/fit_thetatheta_256.npz, make_golden.py fit256: 76 + 83 s of the reference)."""
+    from scintools_amd.dynspec import Dynspec
+    g, f = golden("fit_thetatheta_256.npz"), golden("fit_thetatheta.npz")
+    n = int(g["nchan"])
+
+    class B:
+        dyn, freqs, times, dt, df = f["dspec"][:n], f["freq"][:n], f["time"], float(f["dt"]), float(f["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=256, edges_lim=.3, eta_min=30, eta_max=50)
+    np.testing.assert_allclose(d.edges, g["edges"], rtol=1e-13)
+    assert d.neta == int(g["neta"]) and d.cwt == int(g["cwt"])
+    etas, eigs, popt = d.thetatheta_single(cf=0, ct=0, plot=False, arrays=True)
+    np.testing.assert_allclose(etas, g["single_etas"], rtol=1e-14)
+    np.testing.assert_allclose(eigs, g["single_eigs"], rtol=1e-9)
+    np.testing.assert_allclose(popt, g["single_popt"], rtol=1e-6)
+    d.fit_thetatheta()
+    np.testing.assert_allclose(d.eta_evo, g["eta_evo"], rtol=1e-6)
+    np.testing.assert_allclose(d.eta_evo_err, g["eta_evo_err"], rtol=1e-4)
+    assert d.ththeta == pytest.approx(float(g["ththeta"]), rel=1e-6)
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_eigvec_and_chisq_sweep_vs_reference_golden(thth, golden, tag):
     """The batched modeler sweep (eigenpairs of all etas in one call, then per-eta back-map,

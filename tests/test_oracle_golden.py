@@ -195,6 +195,23 @@ def test_retrieval_chunks_mosaic_gs(golden):
     assert np.abs(_align(gs, ref) - ref).max() <= 1e-7 * np.abs(ref).max()
 
 
+def test_one_256_channel_chunk_of_the_tutorial_data(golden):
+    """The oracle's Eval_calc on ONE 256-channel fitting chunk of the tutorial data (npad = 3: a 1024 x 600 conjugate spectrum,
+    1166 default edges) against the reference's own thetatheta_single curve of tests/golden/fit_thetatheta_256.npz
+    (make_golden.py fit256: 76 s of the reference for the 52 curvatures; four of them here)."""
+    g, f = golden("fit_thetatheta_256.npz"), golden("fit_thetatheta.npz")
+    n = int(g["nchan"])
+    dspec, freq, time = f["dspec"][:n], f["freq"][:n], f["time"]
+    d2 = np.copy(dspec)
+    d2 -= np.nanmean(d2)
+    npad = int(g["npad"])
+    fd, tau = to.fft_axis(time, 1000.0, npad), to.fft_axis(freq, 1.0, npad)
+    CS = to.conjugate_spectrum(np.nan_to_num(d2), npad, tau, 0.0)
+    edges = g["edges"] * (freq.mean() / float(g["fref"]))
+    for i in (0, 17, 34, 51):
+        assert to.Eval_calc(CS, tau, fd, g["single_etas"][i], edges) == pytest.approx(g["single_eigs"][i], rel=1e-10)
+
+
 def test_calc_asymmetry(golden):
     g = golden("retrieval.npz")
     f = golden("fit_thetatheta.npz")

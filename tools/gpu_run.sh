@@ -14,6 +14,7 @@
 #   mixedev  [tag]          evidence set of the mixed sweep with THIS library: kernel trace, FETCH/WRITE PMC, six hardware counters
 #   counters [tag] [args]   two --pmc passes (instruction counts + activity; cycles + waits) of a 1-step bench, tools/pmc_any.py
 #   fft      [tag]          kernel trace + PMC passes of tools/time_fft.py (calc_sspec and CS, 2048^2 .. 8192^2)
+#   sspecroof [tag]         FETCH / WRITE / instruction-count passes of calc_sspec alone at 4096^2 and 8192^2 -> <tag>_sspec_roofline_<size>.json (bench.py: sspec.roofline)
 #   probes   [tag]          tools/probes/*.hip (stream ceiling, the round-2 and round-3 mat-vec loops with their parts switchable, f64 MFMA layout)
 #   mixed    [tag] [args]   the mixed-precision sweep: a 3-step bench with its --mixed-steps leg (rate, bytes by operand, curve against
 #                           the float64 one), then tests/test_gpu_zz_mixed.py
@@ -97,6 +98,17 @@ fft() {
   grep -E "sspec|cs " $O/${TAG}_prof_fft.log | head -12
   pmc_of fft "tools/time_fft.py" "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/time_fft.py"
 }
+sspecroof() {  # HBM bytes + instruction counts of calc_sspec's kernels at 4096^2 and 8192^2 -> <tag>_sspec_roofline_<size>.json (tools/sspec_roofline.py)
+  for n in 4096 8192; do
+    i=0
+    for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+      i=$((i+1))
+      ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace -d $O/${TAG}_sspecroof_${n}_$i -o p -- python $R/tools/time_fft.py $n sspec > $O/${TAG}_sspecroof_${n}_$i.log 2>&1 )
+    done
+    python tools/sspec_roofline.py $(find $O/${TAG}_sspecroof_${n}_1 -name "*.db" | head -1) $(find $O/${TAG}_sspecroof_${n}_2 -name "*.db" | head -1) \
+        $(find $O/${TAG}_sspecroof_${n}_3 -name "*.db" | head -1) $n $O/${TAG}_sspec_roofline_$n.json
+  done
+}
 mixed() {
   timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --modeler-steps 0 --mixed-steps 3 $EXTRA > $O/${TAG}_mixed.json 2> $O/${TAG}_mixed.err; echo "bench rc=$?"
   python tools/bench_line.py $O/${TAG}_mixed.json; python -c "
@@ -113,7 +125,7 @@ probes() {
   done
 }
 case $CMD in
-  suite|bench|quick|configs|trace|modeler|pmc|pmc_modeler|counters|mixedev|fft|probes|mixed) $CMD ;;
+  suite|bench|quick|configs|trace|modeler|pmc|pmc_modeler|counters|mixedev|fft|sspecroof|probes|mixed) $CMD ;;
   all) suite; bench; configs; trace; modeler; pmc; pmc_modeler; fft; mixed ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
