@@ -127,7 +127,10 @@ class Simulation:
     def _get_intensity(self):                                            # scint_sim.py:209-236
         spe = np.zeros([self.nx, self.nf], dtype=np.dtype(np.csingle)) + \
             1j * np.zeros([self.nx, self.nf], dtype=np.dtype(np.csingle))
-        if self.workers > 1 and self.nf >= 4 * self.workers:
+        import multiprocessing as _mp
+        # (never from inside a worker process: a caller without a `__main__` guard is re-imported by every spawned child, and each
+        #  copy would start a pool of its own)
+        if self.workers > 1 and self.nf >= 4 * self.workers and _mp.parent_process() is None:
             # The frequencies are independent (each is two FFTs of the same screen): dealt to worker processes in contiguous
             # blocks, every column is the same single-threaded NumPy arithmetic as in the loop below -- the same bits
             # (tests/test_oracle_golden.py compares both with the reference's own array) -- in a fraction of the 3 minutes a

@@ -81,7 +81,9 @@ constexpr double kVecGapFactorChisq = SCINT_VEC_GAP_FACTOR_CHISQ;
 inline int strip_len_for(int nb) {
     static const int forced = [] { const char* e = getenv("SCINT_STRIP_LEN"); return e ? atoi(e) : 0; }();
     if (forced > 0) return forced > kMaxStrip ? kMaxStrip : forced;   // tests of schedule independence
-    return nb >= 32 ? kMaxStrip : (nb >= 16 ? 8 : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1)));
+    // (16 <= nb < 32, N = 961 .. 1984 -- the chunks of Dynspec.fit_thetatheta with cwf = cwt = 256, npad = 3: 8 tiles until round 5; measured on
+    //  bench.py --workload fit_thetatheta, 35 840 (chunk, eta) jobs at nb = 19: 4 / 6 / 8 / 12 tiles -> 1.675 / 1.734 / 1.599 / 1.558 s per fit)
+    return nb >= 16 ? kMaxStrip : (nb >= 8 ? 4 : (nb >= 4 ? 2 : 1));
 }
 
 struct PackedJob {

@@ -17,7 +17,13 @@ from oracle import thth_oracle as O
 from scintools_amd.synth import arc_dynspec
 from scintools_amd.ththmod import fft_axis
 size = int(sys.argv[1]); neta = 256
-dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
+if "--sim" in sys.argv:        # a reference Simulation screen (oracle/sim_oracle.py) instead of the analytic arc: round 5, VERDICT r4 next 3
+    sys.argv.remove("--sim")
+    from oracle import sim_oracle
+    sim = sim_oracle.baseline_dynspec(size, 3)      # (serial: this script has no __main__ guard for spawned workers)
+    dyn, freqs, times, eta_true = np.array(sim.dyn, dtype=float), sim.freqs, sim.times, float(sim.eta)
+else:
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
 dyn -= dyn.mean()
 fd = fft_axis(times, 1000.0, 0); tau = fft_axis(freqs, 1.0, 0)
 edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
@@ -56,6 +62,7 @@ def block_lanczos(A, X0, tol=1e-12, maxit=300):
         Bs.append(Bk); Qprev = Qs[-1]; Bprev = Bk; Qs.append(Qn)
     return th1, maxit
 tot = {1: 0, 2: 0, 3: 0, 4: 0, 6: 0, 8: 0}
+bytes_rel = {b: 0.0 for b in tot}
 idx = list(range(4, 256, int(sys.argv[2]) if len(sys.argv) > 2 else 17))
 for i in idx:
     A, _ = O.thth_redmap(CS, tau, fd, etas[i], edges)
@@ -65,6 +72,7 @@ for i in idx:
     for b in tot:
         X0 = np.stack([A[r % n, :].conj() for r in rows[:b]], axis=1)
         th, k = block_lanczos(A, X0)
-        tot[b] += k; out.append((b, k))
+        tot[b] += k; out.append((b, k)); bytes_rel[b] += k * n * (n + 1.0)
     print(i, n, out, flush=True)
-print({b: tot[b] / len(idx) for b in tot})
+print("passes per curvature", {b: round(tot[b] / len(idx), 2) for b in tot})
+print("matrix bytes relative to two vectors", {b: round(bytes_rel[b] / bytes_rel[2], 3) for b in tot})
