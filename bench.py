@@ -233,6 +233,9 @@ def parse():
     ap.add_argument("--tol", type=float, default=None,
                     help="Ritz tolerance of the eigenvalue sweeps (default ththmod.DEFAULT_TOL = 1e-12, 1000x inside the 1e-9 parity "
                          "bar); for the tolerance A/Bs of profiles/ -- the headline is quoted at the default")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="run the timed regions on a non-default torch stream (the sweeps queue on torch's CURRENT stream; the default is "
+                         "the legacy null stream, which blocking streams synchronise with implicitly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed region's own sweep: no CPU baseline, no modeler / mixed / one-slot-group legs "
@@ -911,6 +914,8 @@ def main():
     mixed = args.precision == "mixed" and args.objective == "eig"
     if mixed:
         ththmod.sweep_precision("mixed")
+    if args.side_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
     head = timed(args.objective, args.steps, args.warmup)
 
     share_balance = None

@@ -1021,6 +1021,8 @@ static SideStreams* side_streams() {
     if (hipStreamCreateWithFlags(&s.aux, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (auto& c : s.chk)
         if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // (round 5, call 5: tail streams confined to every 2nd / 3rd / 4th compute unit by hipExtStreamCreateWithCUMask lose 3.5 % or more --
+    //  profiles/r05_call5_cu_mask.txt: the confined tail falls behind and the mat-vec streams no faster beside it; the code is gone)
     for (auto& t : s.tail)
         if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) != hipSuccess) return nullptr;
     auto mk_ev = [](hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };

@@ -539,7 +539,9 @@ sspec_rows_kernel(SspecRows a) {
                 p = p / d;
             }
             *(SCINT_GLOBAL double*)(orow + col) = ten_log10(p, tlog);    // (non-temporal: same at 4096^2, 2.5 % slower at 8192^2)
-            __builtin_amdgcn_sched_barrier(0);   // one bin at a time: sixteen interleaved log sequences spill
+            __builtin_amdgcn_sched_barrier(0);   // one bin at a time: sixteen interleaved log sequences spill (round 5, call 6: fences every 2 / 4 / 8 / 16
+                                                 // bins instead -- 140 registers, no spill in any -- are all within 1 % at 4096^2 and 8192^2: the kernel does
+                                                 // not wait on its logarithms; profiles/r05_sspec_log_group_ab.txt)
         }
     }
 }

@@ -18,7 +18,8 @@
 #   probes   [tag]          tools/probes/*.hip (stream ceiling, the round-2 and round-3 mat-vec loops with their parts switchable, f64 MFMA layout)
 #   mixed    [tag] [args]   the mixed-precision sweep: a 3-step bench with its --mixed-steps leg (rate, bytes by operand, curve against
 #                           the float64 one), then tests/test_gpu_zz_mixed.py
-#   all      [tag]          suite, bench, configs, trace, modeler, pmc, fft, mixed  (the closing call of a round)
+#   workloads [tag]         bench.py --workload fit_thetatheta | wavefield | tutorial_fit | fit_arc (the (f) rows end to end, CPU port beside them)
+#   all      [tag]          suite, bench, configs, trace, modeler, pmc, pmc_modeler, counters, fft, sspecroof, workloads, mixed  (the closing call of a round)
 set -u
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
@@ -109,6 +110,15 @@ sspecroof() {  # HBM bytes + instruction counts of calc_sspec's kernels at 4096^
         $(find $O/${TAG}_sspecroof_${n}_3 -name "*.db" | head -1) $n $O/${TAG}_sspec_roofline_$n.json
   done
 }
+workloads() {  # the (f) rows end to end: bench.py --workload X -> <tag>_wl_X.json (one line each, CPU port on a sample beside the GPU time)
+  for w in fit_thetatheta wavefield tutorial_fit fit_arc; do
+    timeout 900 python bench.py --workload $w --steps 3 --warmup 1 > $O/${TAG}_wl_$w.json 2> $O/${TAG}_wl_$w.err; echo "workload $w rc=$?"
+    python -c "
+import json
+d=json.loads([l for l in open('$O/${TAG}_wl_$w.json') if l.startswith('{')][-1])
+print('  ', round(d['value'],4), 's; cpu port', round(d['cpu_baseline']['value'],1), 's; x', round(d['speedup_vs_cpu_baseline']), {k: round(v['busy_share_of_wall'],3) for k,v in d.get('kernels',{}).items()})"
+  done
+}
 mixed() {
   timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --modeler-steps 0 --mixed-steps 3 $EXTRA > $O/${TAG}_mixed.json 2> $O/${TAG}_mixed.err; echo "bench rc=$?"
   python tools/bench_line.py $O/${TAG}_mixed.json; python -c "
@@ -125,8 +135,8 @@ probes() {
   done
 }
 case $CMD in
-  suite|bench|quick|configs|trace|modeler|pmc|pmc_modeler|counters|mixedev|fft|sspecroof|probes|mixed) $CMD ;;
-  all) suite; bench; configs; trace; modeler; pmc; pmc_modeler; fft; mixed ;;
+  suite|bench|quick|configs|trace|modeler|pmc|pmc_modeler|counters|mixedev|fft|sspecroof|workloads|probes|mixed) $CMD ;;
+  all) suite; bench; configs; trace; modeler; pmc; pmc_modeler; counters; fft; sspecroof; workloads; mixed ;;
   *) echo "unknown sub-command $CMD"; exit 2 ;;
 esac
 find $O -name "*.db" -size +20M -delete
