@@ -236,6 +236,9 @@ def parse():
     ap.add_argument("--side-stream", action="store_true",
                     help="run the timed regions on a non-default torch stream (the sweeps queue on torch's CURRENT stream; the default is "
                          "the legacy null stream, which blocking streams synchronise with implicitly)")
+    ap.add_argument("--no-share-walk", action="store_true",
+                    help="chi^2 objective: every back-map walks the theta centres itself (the A/B of the partner table that same-crop "
+                         "curvatures share; results are bit-identical either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed region's own sweep: no CPU baseline, no modeler / mixed / one-slot-group legs "
@@ -839,7 +842,8 @@ def main():
         if objective == "chisq":
             for k, d_t in enumerate(dyns):
                 cs_t = ththmod.conjugate_spectrum(d_t, args.npad, tau, 0.0, True)
-                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True, tol=tol, batch=batch)
+                curves[k], info = ththmod.chisq_sweep(d_t, cs_t, tau, fd, etas, edges, 1.0, return_info=True, tol=tol, batch=batch,
+                                                      share_walk=not args.no_share_walk)
                 fit = (etas[np.nanargmin(curves[k])], np.nan, None)
         elif shard_eta:
             # ONE observation, this rank's interleaved share of the curvatures; the all-gather is inside

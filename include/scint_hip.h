@@ -319,6 +319,10 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
  * elsewhere; those rows contribute sum |fft2(dspec)|^2).  The workspace holds up to 8 images per internal stream for it.
  *   th_red   DEVICE [neta, M]: row e = the N_e centres of the reduced edges (ththmod.py:157-172 then
  *            :204-205), host-computed like the other grid quantities;
+ *   crop_group HOST [neta] or NULL: curvatures with the same non-negative id keep the same theta centres (their th_red rows
+ *            are equal element for element: the caller's promise); -1 = on its own.  Which theta_j pair with theta_i in a
+ *            Doppler column does not depend on the curvature, so the back-maps of the two largest groups (>= 8 members)
+ *            share one partner table per group instead of walking the centres per curvature (since version 103);
  *   mask     DEVICE uint8[nf*nt] or NULL (= isfinite(dspec));
  *   chisq_out DEVICE [neta]: sum((model[:nf,:nt]-dspec)[mask]**2)/noise_n; NaN-filled by the call, and left NaN for a
  *            curvature whose crop keeps fewer than THREE centres (two have no mean edge step: the reference's
@@ -331,7 +335,8 @@ int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch
 int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* geom /*HOST*/, const double* th_cents,
                           int64_t M, const int32_t* keep_idx, const int32_t* keep_n /*HOST*/,
                           const double* etas /*HOST*/, int64_t neta, double tol, int32_t max_iter,
-                          int64_t batch, const double* th_red, const double* dspec, int64_t nf, int64_t nt,
+                          int64_t batch, const double* th_red, const int32_t* crop_group /*HOST[neta] or NULL*/,
+                          const double* dspec, int64_t nf, int64_t nt,
                           const uint8_t* mask, double noise_n, double* chisq_out, double* w_out,
                           scint_c128* vec_out, int64_t vec_stride, int32_t* status_out, int32_t* iters_out,
                           void* workspace, size_t workspace_bytes, void* stream);

@@ -50,6 +50,7 @@ __device__ inline cplx gload_nt(const cplx* p) {
 }
 __device__ inline double gload(const double* p) { return *(const SCINT_GLOBAL double*)p; }
 __device__ inline int32_t gload(const int32_t* p) { return *(const SCINT_GLOBAL int32_t*)p; }
+__device__ inline uint8_t gload(const uint8_t* p) { return *(const SCINT_GLOBAL uint8_t*)p; }
 __device__ inline void gstore(cplx* p, cplx v) {
     v2d t; t.x = v.x; t.y = v.y;
     *(SCINT_GLOBAL v2d*)p = t;

@@ -1497,9 +1497,12 @@ struct ChisqTail : SweepTail {
     }
 };
 
+constexpr int kRevWalkTables = 2;      // crops that get a partner table (the largest same-crop groups of a sweep)
+constexpr int kRevWalkMinGroup = 8;    // ... if at least this many curvatures share the crop (a table costs about one back-map's walk)
 struct ChisqSweepLayout {
     size_t recov[kTailLanes], model[kTailLanes], dspecT, maskT, specT, fft[kTailLanes], partial[kTailLanes], rev[kTailLanes], sweep, total, fft_bytes, sweep_bytes;
     size_t jobs, bounds, colsum, pre, suf;     // Parseval route: RevJobDev table, per-curvature constants, |D|^2 sums along the delay axis
+    size_t walk[kRevWalkTables];               // partner tables of the back-map for the largest groups of same-crop curvatures (thth.hpp)
     int images;                                // image buffers per tail lane (tail batches)
 };
 // Image buffers per tail lane: as many curvatures as a tail batch may hold (thth.hpp), within 8 GiB over all lanes (8 per lane at
@@ -1524,6 +1527,7 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
     L->colsum = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) * (size_t)(kColsumChunks + 1) : 0);   // [0]: the sums; then the chunks' partials
     L->pre = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
     L->suf = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
+    for (int t = 0; t < kRevWalkTables; ++t) L->walk[t] = take(parseval_shape ? (size_t)nfd * (size_t)(M + 1) : 0);    // masks [nfd][M], then col_ok [nfd]
     for (int l = 0; l < kTailLanes; ++l) {
         L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd * (size_t)L->images);
         L->model[l] = take(sizeof(double) * (size_t)nf * (size_t)nt);
@@ -1553,7 +1557,7 @@ extern "C" int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, in
 extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* geom, const double* th_cents,
                                      int64_t M, const int32_t* keep_idx, const int32_t* keep_n,
                                      const double* etas, int64_t neta, double tol, int32_t max_iter,
-                                     int64_t batch, const double* th_red, const double* dspec, int64_t nf,
+                                     int64_t batch, const double* th_red, const int32_t* crop_group, const double* dspec, int64_t nf,
                                      int64_t nt, const uint8_t* mask, double noise_n, double* chisq_out,
                                      double* w_out, scint_c128* vec_out, int64_t vec_stride,
                                      int32_t* status_out, int32_t* iters_out, void* workspace,
@@ -1620,6 +1624,28 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
             for (int64_t e = 0; e < neta; ++e)
                 table[(size_t)e] = make_rev_job((const cplx*)vec_out + e * vec_stride, w_out + e, th_red + e * M, keep_n[e], t.g,
                                                 etas[e], bounds + (size_t)e * kRevWords);
+            // partner tables of the back-map for the largest groups of curvatures that keep the same theta centres (thth.hpp)
+            if (crop_group) {
+                std::map<int32_t, std::vector<int64_t>> groups;
+                for (int64_t e = 0; e < neta; ++e)
+                    if (crop_group[e] >= 0 && keep_n[e] >= 3) groups[crop_group[e]].push_back(e);
+                std::vector<const std::vector<int64_t>*> big;
+                for (const auto& kv : groups)
+                    if ((int)kv.second.size() >= kRevWalkMinGroup) big.push_back(&kv.second);
+                std::sort(big.begin(), big.end(), [](const std::vector<int64_t>* a, const std::vector<int64_t>* b) { return a->size() > b->size(); });
+                for (size_t ti = 0; ti < big.size() && ti < (size_t)kRevWalkTables; ++ti) {
+                    const std::vector<int64_t>& members = *big[ti];
+                    const int64_t e0 = members[0], n0 = keep_n[e0];
+                    bool same = true;
+                    for (int64_t e : members) same = same && keep_n[e] == n0;      // (a caller's promise, checked as far as the host can)
+                    if (!same) continue;
+                    uint8_t* masks = (uint8_t*)(base + L.walk[ti]);
+                    uint8_t* col_ok = masks + (size_t)geom->nfd * (size_t)n0;
+                    rc = launch_rev_walk_table(th_red + e0 * M, n0, t.g, masks, col_ok, st);
+                    if (rc != SCINT_OK) return rc;
+                    for (int64_t e : members) { table[(size_t)e].walk = masks; table[(size_t)e].walk_col = col_ok; }
+                }
+            }
             SCINT_HIP(hipMemcpyAsync(base + L.jobs, table.data(), sizeof(RevJobDev) * (size_t)neta, hipMemcpyHostToDevice, st));
             SCINT_HIP(hipStreamSynchronize(st));       // (the table is a local: the copy has left it)
             t.jobs_dev = (const RevJobDev*)(base + L.jobs);

@@ -361,6 +361,8 @@ struct RevParams {
     const unsigned long long* bound;   // [2] bit patterns: max |value|, min theta spacing (rev_bound_kernel);
                                        // [2..6] the per-image constants of rev_setup_kernel (RevConsts)
     double inv_tau1_step;              // 1 / tau1_step (host: the same IEEE quotient the kernel used to form per wavefront)
+    const uint8_t* walk;               // partner masks of the crop (thth.hpp: launch_rev_walk_table), or nullptr
+    const uint8_t* walk_col;
 };
 
 #ifndef SCINT_REV_SLAB
@@ -527,7 +529,7 @@ constexpr int kRevBlock = 256;      // lanes per block of the chunk pre-pass: a 
                                     // three of the four wavefronts skip the pre-pass instead of issuing it)
 constexpr int kRevLiveWords = 64;   // 32 chunks per word: N <= 524288 is pruned, beyond that every chunk is walked
 
-template <int kRevThreads, bool RANK1>
+template <int kRevThreads, bool RANK1, bool TABLE>
 __device__ __forceinline__ void rev_gather_body(const RevParams& p, const GeomDev& g, const int64_t col_in, const int slab_index) {
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
@@ -563,6 +565,7 @@ __device__ __forceinline__ void rev_gather_body(const RevParams& p, const GeomDe
     const int s0 = grid_ok ? (int)floor(q0) - 1 : 0;
     const int W = grid_ok ? (int)p.bound[kRevW] : 0;
     const bool usable = g.fd1_step > 0.0 && g.tau1_step > 0.0;
+    const bool col_tab = TABLE && p.walk != nullptr && gload(p.walk_col + col) != 0;     // uniform over the workgroup
 
     const double inv_tstep = p.inv_tau1_step;
     const double row_lo = (double)row0 - 2.0, row_hi = (double)(row0 + rows) + 1.0;   // estimate of bin + 0.5
@@ -674,6 +677,19 @@ __device__ __forceinline__ void rev_gather_body(const RevParams& p, const GeomDe
         }
         if (__ballot(active) == 0ull) continue;                        // wave-uniform
         const int g0 = i + s0;                                         // first candidate
+        if (TABLE && col_tab) {
+            // the partners of theta_i in this column come from the crop's table (thth.hpp): bit k - 1 <-> j = g0 - 1 + k
+            unsigned mask = active ? (unsigned)gload(p.walk + col * N + i) : 0u;
+            while (__ballot(mask != 0u) != 0ull) {
+                if (mask != 0u) {
+                    const int k = __ffs((int)mask);
+                    mask &= mask - 1u;
+                    const int j = g0 - 1 + k;
+                    pair(i, j, th_i, gload(p.th + j));
+                }
+            }
+            continue;
+        }
         // th[g0 - 1 .. g0 + W], every index clamped into the array and every lane loading (no predicate per position:
         // ten predicated loads were a fifth of the kernel's instructions).  A clamped GUARD is the array's end element:
         // if that is still outside the column it speaks for everything beyond it, and a guard position outside the
@@ -746,7 +762,7 @@ __device__ __forceinline__ void rev_gather_body(const RevParams& p, const GeomDe
 
 template <int kRevThreads, bool RANK1>
 __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
-    rev_gather_body<kRevThreads, RANK1>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
+    rev_gather_body<kRevThreads, RANK1, false>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---- several curvatures per launch (chi^2 sweep; thth.hpp) -------------------------------------------------------------
@@ -833,7 +849,8 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const Re
         p.hermitian = 1; p.slab = slab; p.centre = jb.centre;
         p.recov = b.recov[img]; p.transposed = 1;
         p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
-        rev_gather_body<kRevThreadsK, true>(p, g, col, sl);
+        p.walk = jb.walk; p.walk_col = jb.walk_col;
+        rev_gather_body<kRevThreadsK, true, true>(p, g, col, sl);
         __syncthreads();            // (the next item zeroes the accumulators this one has just read)
     }
 }
@@ -855,6 +872,7 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     p.transposed = 0;
     p.bound = nullptr;
     p.inv_tau1_step = 1.0 / g.tau1_step;
+    p.walk = nullptr; p.walk_col = nullptr;
     return p;
 }
 
@@ -897,7 +915,69 @@ RevJobDev make_rev_job(const cplx* vec, const double* w, const double* th, int64
     j.vec = vec; j.w = w; j.th = th;
     j.eta = eta; j.two_eta = p.two_eta; j.inv_tau1_step = p.inv_tau1_step;
     j.centre = p.centre; j.bound = bound; j.N = (int32_t)N; j.pad = 0;
+    j.walk = nullptr; j.walk_col = nullptr;
     return j;
+}
+
+// The window walk of rev_gather_body for every (column, theta_i) of one crop, without the curvature (thth.hpp).  Same
+// expressions as the kernel (window start s0 and width W from the mean theta spacing, clamped unconditional loads, guards).
+__global__ void __launch_bounds__(256) rev_walk_table_kernel(const double* __restrict__ th, int N, GeomDev g, uint8_t* __restrict__ masks,
+                                                             uint8_t* __restrict__ col_ok) {
+    __shared__ int bad;
+    const int64_t col = blockIdx.x;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;
+    const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
+    const bool last = (col == g.nfd - 1);
+    const double th_step = N > 1 ? (gload(th + N - 1) - gload(th)) / (double)(N - 1) : 0.0;        // rev_setup_consts
+    const int W0 = th_step > 0.0 ? (int)fmin(ceil(g.fd1_step / th_step) + 2.0, (double)kRevWin) : 0;
+    const double q0 = lo / th_step;
+    const bool grid_ok = th_step > 0.0 && isfinite(q0) && fabs(q0) < 1e9;
+    const int s0 = grid_ok ? (int)floor(q0) - 1 : 0;
+    const int W = grid_ok ? (W0 < 0 ? 0 : W0) : 0;
+    auto beyond = [&](double x) { return last ? (x > hi) : (x >= hi); };
+    bool ok = true;
+    for (int i = (int)threadIdx.x; i < N; i += 256) {
+        const double th_i = gload(th + i);
+        const int g0 = i + s0;
+        double tj[kRevWin + 2];
+#pragma unroll
+        for (int k = 0; k < kRevWin + 2; ++k) {
+            tj[k] = 0.0;
+            if (k > W + 1) continue;
+            tj[k] = gload(th + min(max(g0 - 1 + k, 0), N - 1));
+        }
+        double t_hi = tj[1];
+#pragma unroll
+        for (int k = 2; k < kRevWin + 2; ++k) t_hi = (k == W + 1) ? tj[k] : t_hi;
+        const bool below_ok = (g0 - 1 < 0) || !(tj[0] - th_i >= lo);
+        const bool above_ok = (g0 + W >= N) || beyond(t_hi - th_i);
+        const bool windowed = W > 0 && below_ok && above_ok;
+        unsigned mask = 0u;
+        if (windowed) {
+#pragma unroll
+            for (int k = 1; k <= kRevWin; ++k) {
+                if (k > W) break;
+                const int j = g0 - 1 + k;
+                const double x = tj[k] - th_i;
+                if ((unsigned)j < (unsigned)N && x >= lo && !beyond(x)) mask |= 1u << (k - 1);
+            }
+        } else {
+            ok = false;
+        }
+        masks[col * N + i] = (uint8_t)mask;
+    }
+    if (!ok) atomicOr(&bad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) col_ok[col] = bad ? 0 : 1;
+}
+
+int32_t launch_rev_walk_table(const double* th, int64_t N, const GeomDev& g, uint8_t* masks, uint8_t* col_ok, hipStream_t stream) {
+    SCINT_REQUIRE(th && masks && col_ok && N >= 1 && N < ((int64_t)1 << 31), "rev_map walk table: bad arguments");
+    hipLaunchKernelGGL(rev_walk_table_kernel, dim3((unsigned)g.nfd), dim3(256), 0, stream, th, (int)N, g, masks, col_ok);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
 }
 
 int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, hipStream_t stream) {

@@ -133,6 +133,8 @@ struct RevJobDev {                 // one per curvature of the sweep, built on t
     double eta, two_eta, inv_tau1_step;
     int64_t centre;                // flat index of the pixel the i == j terms poison, or -1
     unsigned long long* bound;     // [kRevWords] this curvature's constants (rev_prep_batch_kernel writes, the gather and chi^2 read)
+    const uint8_t* walk;           // [nfd][N] partner masks of the curvature's CROP (launch_rev_walk_table), or nullptr: walk in the kernel
+    const uint8_t* walk_col;       // [nfd]    1 = the column's masks are complete (every lane's window brackets the column)
     int32_t N, pad;
 };
 constexpr int kRevWords = 16;      // words per curvature: max |v| sqrt 2, min spacing, the RevConsts, the delay band
@@ -148,6 +150,13 @@ RevJobDev make_rev_job(const cplx* vec, const double* w, const double* th, int64
 // tau = 0 -- are computed and written (whole slabs that miss the band leave at once); the band is left in
 // bound[kRevBandLo], bound[kRevBandHi] for the consumer (chisq_parseval_batch_kernel), which must not read outside it.
 int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, hipStream_t stream);
+// Which theta_j are partners of theta_i in Doppler column c does not depend on the curvature -- fd_map = theta_j - theta_i
+// (ththmod.py:207) -- only on the theta centres, i.e. on the CROP.  Curvatures that keep the same centres (161 of the 256 of
+// the headline sweep keep all 4095) can therefore share the part of the back-map that finds those partners (40 % of the
+// kernel): masks[c][i] has bit k - 1 set iff theta_{i + s0(c) - 1 + k} is a partner of theta_i in column c (the kernel's own
+// window walk, k = 1 .. W <= 8), col_ok[c] = 1 iff every lane's window brackets the column (always on a near-uniform grid;
+// otherwise the column keeps the in-kernel walk).  One launch per crop; `masks` nfd * N bytes, `col_ok` nfd bytes.
+int32_t launch_rev_walk_table(const double* th, int64_t N, const GeomDev& g, uint8_t* masks, uint8_t* col_ok, hipStream_t stream);
 enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6, kRevBandLo = 7, kRevBandHi = 8 };
 
 }  // namespace scint

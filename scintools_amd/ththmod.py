@@ -488,11 +488,14 @@ def _sweep_inputs(grid, etas_v):
     return keep_idx, keep_n
 
 
-def _reduced_centres(grid, keep_idx, keep_n):
+def _reduced_centres(grid, keep_idx, keep_n, return_groups=False):
     """th_red[neta, M]: the centres of the reduced edges, re-derived as rev_map does (ththmod.py:204-205 on :157-172),
-    one evaluation per DISTINCT crop (on the bench workload 161 of 256 curvatures keep all 4095 centres)."""
+    one evaluation per DISTINCT crop (on the bench workload 161 of 256 curvatures keep all 4095 centres).
+    With `return_groups` also group[neta] int32: curvatures with the same id have the SAME row (copied, element for
+    element) -- what ``scint_chisq_sweep`` needs to share the back-map's partner table between them; -1 = no row."""
     neta, M = keep_idx.shape
     th_red = np.zeros((neta, M))
+    group = np.full(neta, -1, dtype=np.int32)
     done = {}
     for i in range(neta):
         n = int(keep_n[i])
@@ -502,10 +505,12 @@ def _reduced_centres(grid, keep_idx, keep_n):
         j = done.get(key)
         if j is not None and (key[1] - key[0] + 1 == n or np.array_equal(keep_idx[i, :n], keep_idx[j, :n])):
             th_red[i, :n] = th_red[j, :n]
+            group[i] = j
         else:
             th_red[i, :n] = _theta_centres(grid.edges_red(keep_idx[i, :n]))
             done[key] = i
-    return th_red
+            group[i] = i
+    return (th_red, group) if return_groups else th_red
 
 
 def _sweep_inputs_dev(grid, etas_v):
@@ -564,13 +569,14 @@ def eigvec_sweep(CS, tau, fd, etas, edges, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX
 
 
 def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False, tol=DEFAULT_TOL,
-                max_iter=DEFAULT_MAX_ITER, batch=None):
+                max_iter=DEFAULT_MAX_ITER, batch=None, share_walk=True):
     """chi**2 of the theta-theta model for every curvature: the loop
     ``[chisq_calc(dspec, CS, tau, fd, eta, edges, N, mask) for eta in etas]``
     (ththmod.py:330-368) as ONE device call (``scint_chisq_sweep``): the eigenpairs of all
     curvatures come from the batched Lanczos sweep, and as each curvature retires its rank-1
     back-map, inverse FFT and chi**2 reduction are chained on a side stream while the sweep goes
-    on -- no per-eta round trip through Python."""
+    on -- no per-eta round trip through Python.  ``share_walk`` (default): curvatures that keep the same theta centres
+    share the partner table of their back-maps (same pairs, same sums: not a bit changes; False exists for the test of that)."""
     lib = _lib.load()
     grid = _Grid(tau, fd, edges)
     _check_sweep_cs(grid.geom.ntau, grid.geom.nfd)
@@ -583,7 +589,10 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     d_t = _dv.to_device(dspec, torch.float64)
     nf, nt = (int(v) for v in d_t.shape)
     m_t = None if mask is None else _dv.to_device(np.asarray(mask, dtype=np.uint8), torch.uint8)
-    th_red = _reduced_centres(grid, keep_idx, keep_n)
+    th_red, crop_group = _reduced_centres(grid, keep_idx, keep_n, return_groups=True)
+    if not share_walk:
+        crop_group = np.full(neta, -1, dtype=np.int32)
+    crop_group = np.ascontiguousarray(crop_group, dtype=np.int32)
     th_red_t = _dv.to_device(th_red, torch.float64)
     keep_t = _dv.to_device(keep_idx, torch.int32)
     need = ctypes.c_size_t()
@@ -597,7 +606,8 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     rc = lib.scint_chisq_sweep(ptr(cs_t), ctypes.byref(grid.geom), ptr(grid.th_dev()), M, ptr(keep_t),
                                keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                etas_v.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), neta, tol, max_iter, batch,
-                               ptr(th_red_t), ptr(d_t), nf, nt, ptr(m_t), float(N), ptr(out), ptr(w_t), ptr(V_t), M,
+                               ptr(th_red_t), crop_group.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ptr(d_t), nf, nt, ptr(m_t),
+                               float(N), ptr(out), ptr(w_t), ptr(V_t), M,
                                ptr(st_t[0]), ptr(st_t[1]), ptr(ws), ws.numel(), stream_ptr())
     _lib.check(rc, "scint_chisq_sweep")
     st = st_t.cpu().numpy()

@@ -496,6 +496,38 @@ def test_chisq_sweep_tail_batches_and_delay_band(emu, to):
             assert hi - lo < 0.5 * len(tau)          # (these curvatures do have a narrow band: the test is not vacuous)
 
 
+@pytest.mark.parametrize("irregular", [False, True])
+def test_chisq_sweep_shares_the_backmap_walk_between_same_crop_curvatures(emu, to, irregular):
+    """Round 5: which theta_j pair with theta_i in a Doppler column does not depend on the curvature, so the curvatures of a
+    sweep that keep the same theta centres share ONE partner table (launch_rev_walk_table) instead of each walking the
+    centres in its back-map.  Same pairs, order-independent sums: chi^2 must be BIT-identical with the table (groups of >= 8
+    same-crop curvatures) and without it (share_walk=False), on a uniform theta grid and on an irregular one, where some
+    columns' windows do not bracket the column and keep the in-kernel walk; and equal to the oracle's chisq_calc."""
+    from scintools_amd.synth import arc_dynspec
+    # (theta spacing about half the Doppler step, as on the grids of the path: a window of W = 6 centres brackets every column of the
+    #  uniform grid, and of 65 of the 96 columns of the irregular one -- the other 31 keep the in-kernel walk)
+    dyn, freqs, times, eta_true = arc_dynspec(300, 96, seed=23, nimg=8, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 180)
+    if irregular:
+        rng = np.random.default_rng(3)
+        edges = np.sort(edges + rng.uniform(-0.45, 0.45, edges.shape[0]) * (edges[1] - edges[0]))
+    CS = to.conjugate_spectrum(dyn, 0)
+    th = emu._Grid(tau, fd, edges).th_cents
+    eta_full = np.abs(tau).max() / (th**2).max()
+    # ten curvatures that keep every centre (one crop: a table), then four that crop differently (on their own)
+    etas = np.concatenate([np.linspace(0.05, 0.95, 10), [1.3, 1.9, 2.6, 3.4]]) * eta_full
+    keep_idx, keep_n = emu._sweep_inputs(emu._Grid(tau, fd, edges), etas)
+    _, group = emu._reduced_centres(emu._Grid(tau, fd, edges), keep_idx, keep_n, return_groups=True)
+    assert np.sum(group == group[0]) >= 8 and len(set(group.tolist())) >= 4
+    shared = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0)
+    alone = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, share_walk=False)
+    assert np.all(np.isfinite(shared)) and np.array_equal(shared, alone)
+    ref = np.array([to.chisq_calc(dyn, CS, tau, fd, etas[i], edges, 3.0) for i in (0, 5, 9, 12)])
+    np.testing.assert_allclose(shared[[0, 5, 9, 12]], ref, rtol=1e-9)
+
+
 def test_chunk_retrieval_in_byte_bounded_groups(emu, to, capsys):
     """the batched phase retrieval stacks conjugate spectra only up to a byte budget (groups, as the fit path
     does), and a chunk that cannot be prepared is left zero with its error printed while the others go on -- the reference's
