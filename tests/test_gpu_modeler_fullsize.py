@@ -137,6 +137,24 @@ def test_chisq_sweep_vs_chisq_calc(env, case):
     assert abs(fine[np.argmin(chi_f)] / eta_true - 1) <= 0.06
 
 
+def test_chisq_sweep_partner_table_changes_no_bit(env, case):
+    """Round 5: the curvatures of a sweep that keep the same theta centres share one partner table for their back-maps
+    (launch_rev_walk_table; `crop_group` of scint_chisq_sweep) instead of each walking the centres.  At full size, twelve
+    curvatures that keep every centre (one group: a table) and three that crop on their own: chi^2 is the same BITS with the
+    table and without it (share_walk=False)."""
+    thth, to = env
+    c = case
+    dyn = c["dyn"]
+    eta_true = c["eta"] / 0.93
+    etas = np.concatenate([np.linspace(0.3, 1.3, 12), [3.0, 3.4, 3.8]]) * eta_true
+    cs_t = thth.to_device(c["CS"])
+    a, info = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], etas, c["edges"], float(dyn.size), return_info=True)
+    b = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], etas, c["edges"], float(dyn.size), share_walk=False)
+    assert np.all(info["status"] == 0) and np.all(np.isfinite(a))
+    assert np.sum(info["N"] == info["N"].max()) >= 8 and len(set(int(v) for v in info["N"])) >= 3
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.timeout(900)
 def test_cropped_modeler_4096_vs_oracle(env):
     """A curvature whose crop bites (3.5 eta_true at 4096^2: N = 2617 of M = 4095) against the ORACLE's modeler --

@@ -59,3 +59,30 @@ def test_experiment_patches_still_apply():
     for p in patches:
         out = subprocess.run(["git", "apply", "--check", p], cwd=repo, capture_output=True, text=True)
         assert out.returncode == 0, (os.path.basename(p), out.stderr[-500:])
+
+
+def test_bench_refuses_a_pmc_summary_taken_from_other_kernel_sources(monkeypatch, tmp_path):
+    """VERDICT r4 (weak 10): `roofline.traffic` is a committed PMC ratio times live bytes, so a kernel change without a new PMC
+    pass carried a stale ratio.  The summaries now record the SHA-256 of the kernel sources they were measured on
+    (bench.library_fingerprint, copied by tools/pmc_summary.py from the profiled run's own bench line) and bench.py quotes a
+    summary only while the sources hash to that value."""
+    import json
+    import bench
+    fp = bench.library_fingerprint()
+    assert len(fp["csrc_sha256"]) == 64 and fp == bench.library_fingerprint()           # deterministic
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    summ = {"dominant_kernel": "scint::pk2_matvec_kernel", "csrc_sha256": fp["csrc_sha256"],
+            "kernels": {"scint::pk2_matvec_kernel": {"traffic_over_algorithmic": 1.04}}}
+    (prof / "r99_pmc_summary.json").write_text(json.dumps(summ))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    monkeypatch.setattr(bench, "library_fingerprint", lambda: fp)
+    ratio, src, stale = bench.pmc_traffic_ratio()
+    assert ratio == 1.04 and src.endswith("r99_pmc_summary.json") and stale is None
+    monkeypatch.setattr(bench, "library_fingerprint", lambda: dict(fp, csrc_sha256="0" * 64))   # the sources changed
+    ratio, src, stale = bench.pmc_traffic_ratio()
+    assert ratio is None and "other kernel sources" in stale
+    (prof / "r99_pmc_summary.json").write_text(json.dumps({k: v for k, v in summ.items() if k != "csrc_sha256"}))   # a pre-round-5 file
+    monkeypatch.setattr(bench, "library_fingerprint", lambda: fp)
+    assert bench.pmc_traffic_ratio()[0] is None
+    assert bench.pmc_modeler_ratio() == (None, None, "no PMC summary committed")
