@@ -171,3 +171,28 @@ def test_crop_tables_by_bisection_equal_the_reference_masks():
         assert ththmod._keep_ranges(grid, np.array([1.0, -2.0])) is None           # the loop handles these
         ki2, kn2 = ththmod._sweep_inputs(grid, np.array([eta0, -eta0]))
         assert np.array_equal(ki2[1, :kn2[1]], grid.keep(-eta0))
+
+
+@pytest.mark.parametrize("nf,nt,nedge,span,irregular,shift", [(512, 512, 512, (0.25, 40.0), False, 0.0), (512, 300, 401, (0.1, 300.0), True, 0.0),
+                                                              (256, 256, 300, (0.5, 2000.0), False, 0.013), (256, 256, 256, (1.0, 30000.0), True, 0.0)])
+def test_reduced_centres_from_ranges_are_the_reference_expression_bit_for_bit(nf, nt, nedge, span, irregular, shift):
+    """ththmod._reduced_centres_of_ranges (round 5: the chi^2 sweep's host tables without the [neta, M] index table) against the
+    generic path, which evaluates the reference's expressions (ththmod.py:157-172, :83-84) per crop as they stand: every row
+    equal bit for bit, the same groups of identical rows -- regular, irregular and shifted grids, crops from the whole grid
+    down to a single centre (an end value closer to zero than any interior one takes the generic path inside)."""
+    from scintools_amd import ththmod as thth
+    from scintools_amd.synth import arc_axes
+    freqs, times, _, _ = arc_axes(nf, nt)
+    fd, tau = thth.fft_axis(times, 1000.0), thth.fft_axis(freqs, 1.0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, nedge) + shift
+    if irregular:
+        edges = np.sort(edges + np.random.default_rng(1).uniform(-0.4, 0.4, nedge) * (edges[1] - edges[0]))
+    grid = thth._Grid(tau, fd, edges)
+    etas = np.geomspace(span[0], span[1], 64) * 0.02
+    keep_idx, keep_n = thth._sweep_inputs(grid, etas)
+    ref, gref = thth._reduced_centres(grid, keep_idx, keep_n, return_groups=True)
+    first, n = thth._keep_ranges(grid, etas)
+    assert np.array_equal(n, keep_n)
+    got, ggot = thth._reduced_centres_of_ranges(grid, first, n)
+    assert np.array_equal(got, ref) and np.array_equal(ggot, gref)
+    assert len(set(gref.tolist())) > 20 and keep_n.min() < keep_n.max()
