@@ -691,6 +691,29 @@ def Eval_calc(CS, tau, fd, eta, edges):
     return float(eigs[0])
 
 
+def _multi_keep_dev(G, etas_all, th_stack):
+    """Crop tables of MANY chunks on the device: one [neta_total, M] index tensor, filled chunk by chunk by ``scint_sweep_keep``
+    (each chunk has its own theta centres and axes), and the counts on the host after ONE read-back.  Round 5: the host loop
+    of :func:`_sweep_inputs` over 256 chunks and the upload of its 171-MB table were a tenth of a ``fit_thetatheta`` of a 4096^2
+    observation (bench.py --workload fit_thetatheta)."""
+    lib = _lib.load()
+    M = G[0].M
+    total = int(sum(e.shape[0] for e in etas_all))
+    keep_t = empty((total, M), torch.int32)
+    n_t = empty((total,), torch.int32)
+    off = 0
+    for c, (g, et) in enumerate(zip(G, etas_all)):
+        ne = int(et.shape[0])
+        if ne == 0:
+            continue
+        et_c = np.ascontiguousarray(et, dtype=np.float64)
+        _lib.check(lib.scint_sweep_keep(th_stack[c].data_ptr(), M, et_c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ne,
+                                        float(g.geom.tau_max), float(g.geom.fd_max / 2), keep_t[off:off + ne].data_ptr(),
+                                        n_t[off:off + ne].data_ptr(), stream_ptr()), "scint_sweep_keep")
+        off += ne
+    return keep_t, np.ascontiguousarray(n_t.cpu().numpy(), dtype=np.int32)
+
+
 def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,
                      return_info=False):
     """Eigenvalue curves of MANY chunks in one batched device call -- the chunk loop of
@@ -709,26 +732,23 @@ def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAU
     if any(g.M != M or (g.geom.ntau, g.geom.nfd) != tuple(cs_t.shape[1:]) for g in G):
         raise ValueError("all chunks must share the CS shape and the number of edges")
     _check_sweep_cs(G[0].geom.ntau, G[0].geom.nfd)
-    etas_all, cs_index, keep_rows, keep_n = [], [], [], []
+    etas_all, cs_index = [], []
     for c, (g, et) in enumerate(zip(G, etas_list)):
         et = np.atleast_1d(units.strip(et, "etas", "s3", warn=False)).astype(float)
-        ki, kn = _sweep_inputs(g, et)
-        etas_all.append(et); keep_rows.append(ki); keep_n.append(kn)
+        etas_all.append(et)
         cs_index.append(np.full(et.shape[0], c, dtype=np.int32))
     etas_v = np.ascontiguousarray(np.concatenate(etas_all))
     cs_idx = np.ascontiguousarray(np.concatenate(cs_index))
-    keep_idx = np.ascontiguousarray(np.concatenate(keep_rows, axis=0))
-    keep_cnt = np.ascontiguousarray(np.concatenate(keep_n))
     neta = etas_v.shape[0]
-    if batch is None:
-        batch = default_batch(max(int(keep_cnt.max()), 1), neta)
     geoms = (_lib.CsGeom * ncs)(*[g.geom for g in G])
     th_stack = _dv.to_device(np.stack([g.th_cents for g in G]), torch.float64)
+    keep_t, keep_cnt = _multi_keep_dev(G, etas_all, th_stack)
+    if batch is None:
+        batch = default_batch(max(int(keep_cnt.max()), 1), neta)
     need = ctypes.c_size_t()
     _lib.check(lib.scint_eval_sweep_multi_workspace_bytes(M, neta, batch, max_iter, ncs, ctypes.byref(need)),
                "eval_sweep_multi_workspace_bytes")
     ws = workspace.get(need.value)
-    keep_t = _dv.to_device(keep_idx, torch.int32)
     eigs_t = empty((neta,), torch.float64)
     st_t = empty((2, neta), torch.int32)
     rc = lib.scint_eval_sweep_multi(ptr(cs_t), ncs, int(cs_t.shape[1] * cs_t.shape[2]),
@@ -766,26 +786,36 @@ def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEF
     if any(g.M != M or (g.geom.ntau, g.geom.nfd) != tuple(cs_t.shape[1:]) for g in G):
         raise ValueError("all chunks must share the CS shape and the number of edges")
     _check_sweep_cs(G[0].geom.ntau, G[0].geom.nfd)
-    etas_all, cs_index, keep_rows, keep_n = [], [], [], []
+    etas_all, cs_index = [], []
     for c, (g, et) in enumerate(zip(G, etas_list)):
         et = np.atleast_1d(units.strip(et, "etas", "s3", warn=False)).astype(float)
-        ki, kn = _sweep_inputs(g, et)
-        etas_all.append(et); keep_rows.append(ki); keep_n.append(kn)
+        etas_all.append(et)
         cs_index.append(np.full(et.shape[0], c, dtype=np.int32))
     etas_v = np.ascontiguousarray(np.concatenate(etas_all))
     cs_idx = np.ascontiguousarray(np.concatenate(cs_index))
-    keep_idx = np.ascontiguousarray(np.concatenate(keep_rows, axis=0))
-    keep_cnt = np.ascontiguousarray(np.concatenate(keep_n))
     neta = etas_v.shape[0]
-    if batch is None:
-        batch = default_batch(max(int(keep_cnt.max()), 1), neta, eigenvalues_only=False)
     geoms = (_lib.CsGeom * ncs)(*[g.geom for g in G])
     th_stack = _dv.to_device(np.stack([g.th_cents for g in G]), torch.float64)
+    keep_t, keep_cnt = _multi_keep_dev(G, etas_all, th_stack)
+    # the callers want the kept indices on the host too: from the crop RANGES where the crops are ranges (sorted centres, eta >= 0:
+    # the same expression at the bisection's probes), else from the device table
+    keeps, rows_host = [], None
+    for g, et in zip(G, etas_all):
+        rng = _keep_ranges(g, et)
+        for k in range(et.shape[0]):
+            i = len(keeps)
+            if rng is not None and int(rng[1][k]) == int(keep_cnt[i]):
+                keeps.append(np.arange(int(rng[0][k]), int(rng[0][k]) + int(rng[1][k]), dtype=np.int32))
+            else:
+                if rows_host is None:
+                    rows_host = keep_t.cpu().numpy()
+                keeps.append(rows_host[i, : keep_cnt[i]].copy())
+    if batch is None:
+        batch = default_batch(max(int(keep_cnt.max()), 1), neta, eigenvalues_only=False)
     need = ctypes.c_size_t()
     _lib.check(lib.scint_eigvec_sweep_multi_workspace_bytes(M, neta, batch, max_iter, ncs, ctypes.byref(need)),
                "eigvec_sweep_multi_workspace_bytes")
     ws = workspace.get(need.value)
-    keep_t = _dv.to_device(keep_idx, torch.int32)
     w_t = empty((neta,), torch.float64)
     V_t = empty((neta, M), torch.complex128)
     st_t = empty((2, neta), torch.int32)
@@ -801,7 +831,6 @@ def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEF
     st = st_t.cpu().numpy()
     w[st[0] != 0] = np.nan
     bounds = np.cumsum([0] + [e.shape[0] for e in etas_all])
-    keeps = [keep_idx[i, : keep_cnt[i]] for i in range(neta)]
     return ([w[bounds[i]:bounds[i + 1]] for i in range(ncs)], V_t, keeps,
             {"N": keep_cnt, "iters": st[1], "status": st[0], "batch": batch, "bounds": bounds})
 
