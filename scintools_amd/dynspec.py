@@ -413,14 +413,21 @@ class Dynspec:
         for g0 in range(0, len(group_all), per_group):
             group = group_all[g0:g0 + per_group]
             stack = empty((len(group), R, C), torch.complex128)
-            grids, etas_list = [], []
+            grids, etas_list, pads = [], [], []
+            # the group's chunks travel to the device in ONE array (an upload from pageable memory per chunk, and a device mean
+            # read back per chunk for the padding value, block the host once each: ththmod.chunk_retrieval_batch)
+            d_all = np.empty((len(group), self.cwf, self.cwt))
             for k, (cf, ct) in enumerate(group):
                 dspec2, freq2, time2, etas, edges = self._search_params(cf, ct)[:5]
                 fd = thth.fft_axis(time2, 1000.0, self.npad)          # ththmod.py:773
                 tau = thth.fft_axis(freq2, 1.0, self.npad)            # ththmod.py:774
-                thth.conjugate_spectrum(dspec2, self.npad, tau, self.thth_tau_mask, coher, out=stack[k])
+                d_all[k] = dspec2
+                pads.append(float(d_all[k].mean()))                   # the padding value (ththmod.py:783)
                 grids.append((tau, fd, edges))
                 etas_list.append(etas)
+            d_t = thth.to_device(d_all, torch.float64)
+            for k in range(len(group)):
+                thth.conjugate_spectrum(d_t[k], self.npad, grids[k][0], self.thth_tau_mask, coher, pad_value=pads[k], out=stack[k])
             eig_list = thth.eval_sweep_multi(stack, grids, etas_list)
             for k, (etas, eigs) in enumerate(zip(etas_list, eig_list)):
                 eta_fit, eta_sig, _ = thth.fit_eig_peak(etas, eigs, self.fw)   # ththmod.py:814-859

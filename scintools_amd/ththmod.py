@@ -937,17 +937,22 @@ def _ifft2_shifted_dev(x_t, scale=1.0, crop=None):
     return out
 
 
-def _wavefield_from_eigpair(grid, e, keep, V, w, shape):
+def _wavefield_from_eigpair(grid, e, keep, V, w, shape, row_t=None, th_t=None):
     """Chunk wavefield from the dominant eigenpair (ththmod.py:1457-1470): theta-theta of the E field with only
     its theta_2 = 0 row filled with conj(V) sqrt(w), non-Hermitian back-map, shifted inverse FFT cropped to the
-    chunk.  Returns a device tensor [nf, nt] complex128."""
+    chunk.  Returns a device tensor [nf, nt] complex128.  `row_t` / `th_t`: that row and the centres of the reduced edges
+    already on the device (:func:`chunk_retrieval_batch` uploads them for all its chunks at once: an upload from pageable
+    memory per chunk blocks the host until the stream has drained)."""
     n = int(keep.shape[0])
     dev = require_gpu()
     E_t = torch.zeros((n, n), dtype=torch.complex128, device=dev)                # allocation + memset
-    row = np.conjugate(np.asarray(V)[:n]) * np.sqrt(w)                            # n numbers: host
-    E_t[n // 2].copy_(torch.from_numpy(row))                                      # memcpy
-    th_red = _theta_centres(grid.edges_red(keep))
-    recov_E = _rev_map_dev(grid.geom, _dv.to_device(th_red, torch.float64), n, e, False, thth_t=E_t)
+    if row_t is None:
+        row = np.conjugate(np.asarray(V)[:n]) * np.sqrt(w)                        # n numbers: host
+        row_t = torch.from_numpy(row)
+    E_t[n // 2].copy_(row_t)                                                      # memcpy
+    if th_t is None:
+        th_t = _dv.to_device(_theta_centres(grid.edges_red(keep)), torch.float64)
+    recov_E = _rev_map_dev(grid.geom, th_t, n, e, False, thth_t=E_t)
     nf, nt = shape
     return _ifft2_shifted_dev(recov_E, scale=nf * nt / 4, crop=(nf, nt))
 
@@ -977,7 +982,12 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
     for g0 in range(0, len(chunks), per_group):
         group = chunks[g0:g0 + per_group]
         stack = torch.empty((len(group), R, C), dtype=torch.complex128, device=dev)
-        grids, etas, live = [], [], []
+        # Round 5: nothing is uploaded chunk by chunk any more.  An upload from pageable host memory blocks the host until the
+        # stream has drained, so the three per chunk (the chunk's pixels, the theta-theta row, the reduced centres) made host and GPU
+        # take turns (bench.py --workload wavefield: 1.4 ms per chunk with the mat-vec busy 4 % of the time).  The group's chunks
+        # travel in ONE array each way; the padding value of a chunk (its mean, ththmod.py:783) is taken on the host.
+        grids, etas, live, pads = [], [], [], []
+        d_all = np.empty((len(group), nf, nt))
         for k, (dspec2, edges, time, freq, eta) in enumerate(group):
             try:
                 fd = fft_axis(units.strip(time, "time2", "s", warn=False), 1000.0, npad)
@@ -986,7 +996,8 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
                 e = np.array([_eta_float(eta)])
                 if (grid.geom.ntau, grid.geom.nfd) != (R, C) or (grids and grid.M != grids[0].M):
                     raise ValueError("axes or edges of this chunk do not match the chunk shape (%d, %d)" % (nf, nt))
-                conjugate_spectrum(np.asarray(dspec2, dtype=float), npad, grid.tau, tauMask, True, out=stack[len(live)])
+                d_all[len(live)] = np.asarray(dspec2, dtype=float)
+                pads.append(float(d_all[len(live)].mean()))
             except Exception as exc:          # this chunk stays zero; the slot of the stack is reused by the next one
                 print("Chunk %d: %s" % (g0 + k, exc), flush=True)
                 continue
@@ -995,16 +1006,35 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
             live.append(k)
         if not live:
             continue
+        d_t = _dv.to_device(d_all[: len(live)], torch.float64)
+        for j in range(len(live)):
+            conjugate_spectrum(d_t[j], npad, grids[j].tau, tauMask, True, pad_value=pads[j], out=stack[j])
         w_list, V_t, keeps, info = eigvec_sweep_multi(stack[: len(live)], grids, etas)
         V = V_t.cpu().numpy()
+        M = grids[0].M
+        rows_all, th_all, ok = np.zeros((len(live), M), dtype=complex), np.zeros((len(live), M)), np.zeros(len(live), dtype=bool)
+        for j, k in enumerate(live):
+            n = int(keeps[j].shape[0])
+            if info["status"][j] != 0 or n < 2:
+                continue
+            try:
+                rows_all[j, :n] = np.conjugate(V[j][:n]) * np.sqrt(float(w_list[j][0]))      # ththmod.py:1459-1461
+                th_all[j, :n] = _theta_centres(grids[j].edges_red(keeps[j]))
+                ok[j] = True
+            except Exception as exc:
+                print("Chunk %d: %s" % (g0 + k, exc), flush=True)
+        rows_t, th_all_t = _dv.to_device(rows_all, torch.complex128), _dv.to_device(th_all, torch.float64)
         out_t = torch.zeros((len(live), nf, nt), dtype=torch.complex128, device=dev)
         for j, k in enumerate(live):
             if info["status"][j] != 0 or keeps[j].shape[0] < 2:
                 print("Chunk %d: eigen-decomposition failed" % (g0 + k), flush=True)
                 continue
+            if not ok[j]:
+                continue
             try:
+                n = int(keeps[j].shape[0])
                 out_t[j].copy_(_wavefield_from_eigpair(grids[j], float(etas[j][0]), keeps[j], V[j], float(w_list[j][0]),
-                                                       (nf, nt)))
+                                                       (nf, nt), row_t=rows_t[j, :n], th_t=th_all_t[j, :n]))
             except Exception as exc:
                 print("Chunk %d: %s" % (g0 + k, exc), flush=True)
                 out_t[j].zero_()
@@ -1014,7 +1044,7 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
         out[g0 + np.asarray(live)] = out_t.cpu().numpy()
         # release this group's device buffers BEFORE the next group allocates its own: while the names are bound the caching
         # allocator cannot reuse the blocks and the peak would be two groups -- the bound is `group_bytes`, not twice it
-        del stack, V_t, out_t
+        del stack, V_t, out_t, d_t, rows_t, th_all_t
     return out
 
 
