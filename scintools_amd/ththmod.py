@@ -801,6 +801,11 @@ def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEF
     # the same expression at the bisection's probes), else from the device table
     keeps, rows_host = [], None
     for g, et in zip(G, etas_all):
+        if et.shape[0] == 1:                       # (one curvature per chunk, the phase retrieval's case: the mask itself is cheaper than a bisection)
+            kk = g.keep(float(et[0]))
+            if kk.shape[0] == int(keep_cnt[len(keeps)]):
+                keeps.append(kk)
+                continue
         rng = _keep_ranges(g, et)
         for k in range(et.shape[0]):
             i = len(keeps)
@@ -839,6 +844,11 @@ def conjugate_spectrum(dspec, npad, tau=None, tau_mask=0.0, coher=True, pad_valu
     """Device conjugate spectrum of a chunk (ththmod.py:777-787): returns a CUDA
     complex128 tensor [(npad+1)*nf, (npad+1)*nt] (written into `out` when given)."""
     lib = _lib.load()
+    if pad_value is None and not isinstance(dspec, torch.Tensor):
+        # the reference's own expression for the padding value, `dspec.mean()` in NumPy (ththmod.py:783), while the chunk is still
+        # on the host: the same bits whether the chunk comes alone (single_search) or in a group's array (Dynspec._fit_chunks,
+        # chunk_retrieval_batch), and no device mean to read back
+        pad_value = float(np.ascontiguousarray(dspec, dtype=float).mean())
     d_t = to_device(dspec, torch.float64)
     nf, nt = (int(v) for v in d_t.shape)
     if pad_value is None:
@@ -1088,20 +1098,28 @@ def mosaic(chunks):
     (ththmod.py:1492-1554).  Host NumPy: one pass over the output, sequentially dependent."""
     nct, ncf, cwf, cwt = chunks.shape[1], chunks.shape[0], chunks.shape[2], chunks.shape[3]
     E_recov = np.zeros(((ncf - 1) * (cwf // 2) + cwf, (nct - 1) * (cwt // 2) + cwt), dtype=complex)
+    masks = {}          # the weight of a chunk depends only on which of its four sides have a neighbour: nine arrays, not one per chunk
+
+    def mask_of(cf, ct):
+        key = (cf > 0, cf < ncf - 1, ct > 0, ct < nct - 1)
+        if key not in masks:
+            mask = np.ones((cwf, cwt))
+            if key[0]:
+                mask[: cwf // 2, :] *= mask_func(cwf // 2)[:, np.newaxis]
+            if key[1]:
+                mask[cwf // 2:, :] *= 1 - mask_func(cwf // 2)[:, np.newaxis]
+            if key[2]:
+                mask[:, : cwt // 2] *= mask_func(cwt // 2)
+            if key[3]:
+                mask[:, cwt // 2:] *= 1 - mask_func(cwt // 2)
+            masks[key] = mask
+        return masks[key]
     for cf in range(ncf):
         for ct in range(nct):
             chunk_new = chunks[cf, ct, :, :]
             sl = (slice(cf * cwf // 2, cf * cwf // 2 + cwf), slice(ct * cwt // 2, ct * cwt // 2 + cwt))
             chunk_old = E_recov[sl]
-            mask = np.ones(chunk_new.shape)
-            if cf > 0:
-                mask[: cwf // 2, :] *= mask_func(cwf // 2)[:, np.newaxis]
-            if cf < ncf - 1:
-                mask[cwf // 2:, :] *= 1 - mask_func(cwf // 2)[:, np.newaxis]
-            if ct > 0:
-                mask[:, : cwt // 2] *= mask_func(cwt // 2)
-            if ct < nct - 1:
-                mask[:, cwt // 2:] *= 1 - mask_func(cwt // 2)
+            mask = mask_of(cf, ct)
             rot = np.angle((chunk_old * np.conjugate(chunk_new) * mask).mean())
             E_recov[sl] += chunk_new * mask * np.exp(1j * rot)
     return E_recov
