@@ -196,3 +196,15 @@ def test_reduced_centres_from_ranges_are_the_reference_expression_bit_for_bit(nf
     got, ggot = thth._reduced_centres_of_ranges(grid, first, n)
     assert np.array_equal(got, ref) and np.array_equal(ggot, gref)
     assert len(set(gref.tolist())) > 20 and keep_n.min() < keep_n.max()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 8, 6), (1, 4, 8, 6), (3, 1, 10, 12), (5, 4, 32, 20)])
+def test_mosaic_with_cached_masks_is_the_reference_loop_bit_for_bit(shape):
+    """ththmod.mosaic (ththmod.py:1492-1554; host NumPy, sequentially dependent) builds the chunk weight once per
+    combination of neighbours (nine arrays) instead of once per chunk: the same multiplications in the same order, so
+    the wavefield equals the oracle's restatement of the reference loop bit for bit."""
+    from oracle import thth_oracle as to
+    from scintools_amd import ththmod as thth
+    rng = np.random.default_rng(7)
+    chunks = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    assert np.array_equal(thth.mosaic(chunks), to.mosaic(chunks))

@@ -708,3 +708,25 @@ def test_default_batch_follows_the_librarys_workgroup_count(emu):
         assert emu.default_batch(4095, 256, eigenvalues_only=False) == 138
     finally:
         emu.sweep_precision(prev)
+
+
+def test_eval_sweep_multi_with_device_built_crop_tables(emu, to, case):
+    """Round 5: the multi-chunk sweeps (Dynspec.fit_thetatheta / thetatheta_chunks) build every chunk's crop table on the device
+    (scint_sweep_keep, chunk by chunk into one tensor) instead of on the host: the curves equal the per-chunk sweeps' bit for
+    bit, chunks with their own theta grids and eta ranges included, and the kept indices the eigenvector variant hands back
+    are the reference's mask (ththmod.py:153-155)."""
+    import torch
+    c = case
+    cs0 = emu.to_device(c["CS"], torch.complex128)
+    edges2 = c["edges"] * 0.9
+    etas2 = c["etas"][::-1] * 1.3
+    stack = torch.stack([cs0, cs0])
+    grids = [(c["tau"], c["fd"], c["edges"]), (c["tau"], c["fd"], edges2)]
+    multi, info = emu.eval_sweep_multi(stack, grids, [c["etas"], etas2], return_info=True)
+    one_a = emu.eval_sweep(cs0, c["tau"], c["fd"], c["etas"], c["edges"])
+    one_b = emu.eval_sweep(cs0, c["tau"], c["fd"], etas2, edges2)
+    assert np.array_equal(multi[0], one_a) and np.array_equal(multi[1], one_b)
+    w, V, keeps, vinfo = emu.eigvec_sweep_multi(stack, grids, [c["etas"][:2], etas2[:1]])
+    g2 = emu._Grid(c["tau"], c["fd"], edges2)
+    assert np.array_equal(keeps[2], g2.keep(float(etas2[0]))) and np.array_equal(vinfo["N"], [len(k) for k in keeps])
+    assert np.array_equal(keeps[0], emu._Grid(c["tau"], c["fd"], c["edges"]).keep(float(c["etas"][0])))
