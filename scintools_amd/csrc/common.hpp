@@ -76,6 +76,29 @@ __device__ inline v4f gload_nt4(const T* p) {
     return __builtin_nontemporal_load((const SCINT_GLOBAL v4f*)p);
 }
 
+// ---- buffer-resource accesses -------------------------------------------------------------------------
+// An array behind a 128-bit resource descriptor (SGPRs): a load is then base + 32-bit per-lane byte offset (ONE
+// register) + scalar byte offset, with a hardware bounds check (out of range reads 0).  In a persistent loop the
+// compiler turns sixteen global loads at constant distances into sixteen loop-carried 64-bit addresses (and spills
+// them); here the sixteen distances are scalar operands.  The array must be smaller than 4 GiB.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ inline BufRsrc make_rsrc(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(uint32_t)bytes, 0x00020000);
+}
+__device__ inline cplx bload_c(BufRsrc r, int voff, int soff) {
+    const v2d v = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return mk(v.x, v.y);
+}
+__device__ inline double bload_d(BufRsrc r, int voff, int soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ inline void bstore2(BufRsrc r, int voff, int soff, double x, double y) {
+    v2d v; v.x = x; v.y = y;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff, soff, 0);
+}
+
 // ---- workgroup barrier for LDS hand-offs ---------------------------------------------------------
 // __syncthreads() is a workgroup-scope fence + barrier: the fence also waits for every GLOBAL access
 // in flight (s_waitcnt vmcnt(0)), i.e. it drains the loads a kernel has prefetched for its next

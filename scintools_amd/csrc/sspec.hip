@@ -134,44 +134,49 @@ struct SspecCols {
     int xcd_remap;
 };
 
+// Workgroup barrier of the transforms.  LB = true: wait for the LDS counter only (lds_barrier) -- a persistent
+// kernel keeps the loads of its NEXT row / column pair in flight across the barriers of this one's transform;
+// __syncthreads() would drain them (its fence waits for vmcnt(0)).
+template <bool LB> __device__ inline void xbarrier() { if constexpr (LB) lds_barrier(); else __syncthreads(); }
+
 // one Stockham exchange through n doubles of LDS per slot: real parts, then imaginary parts
-template <int RP, int RN>
+template <int RP, int RN, bool LB = false>
 __device__ inline void split_exchange(cplx (&v)[kEPT], double* ldsd, int t, int Tr, int n, int Ns) {
-    __syncthreads();
+    xbarrier<LB>();
 #pragma unroll
     for (int q = 0; q < kEPT / RP; ++q)
 #pragma unroll
         for (int m = 0; m < RP; ++m) ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].x;
-    __syncthreads();
+    xbarrier<LB>();
     double re[kEPT];
 #pragma unroll
     for (int q = 0; q < kEPT / RN; ++q)
 #pragma unroll
         for (int m = 0; m < RN; ++m) re[q * RN + m] = ldsd[lds_pad(t + q * Tr + m * (n / RN))];
-    __syncthreads();
+    xbarrier<LB>();
 #pragma unroll
     for (int q = 0; q < kEPT / RP; ++q)
 #pragma unroll
         for (int m = 0; m < RP; ++m) ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].y;
-    __syncthreads();
+    xbarrier<LB>();
 #pragma unroll
     for (int q = 0; q < kEPT / RN; ++q)
 #pragma unroll
         for (int m = 0; m < RN; ++m) v[q * RN + m] = mk(re[q * RN + m], ldsd[lds_pad(t + q * Tr + m * (n / RN))]);
 }
 // the n-point transform of the 16 values a thread holds (stage-0 order in, last-stage order out)
-template <int R0, int R1, int R2, int R3>
+template <int R0, int R1, int R2, int R3, bool LB = false>
 __device__ inline void slot_fft(cplx (&v)[kEPT], double* lds, int t, const cplx* __restrict__ tw) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
     stockham_compute<R0>(v, t, Tr, n, 1, tw);
     if constexpr (R1 > 1) {
-        split_exchange<R0, R1>(v, lds, t, Tr, n, 1);
+        split_exchange<R0, R1, LB>(v, lds, t, Tr, n, 1);
         stockham_compute<R1>(v, t, Tr, n, R0, tw);
         if constexpr (R2 > 1) {
-            split_exchange<R1, R2>(v, lds, t, Tr, n, R0);
+            split_exchange<R1, R2, LB>(v, lds, t, Tr, n, R0);
             stockham_compute<R2>(v, t, Tr, n, R0 * R1, tw);
             if constexpr (R3 > 1) {
-                split_exchange<R2, R3>(v, lds, t, Tr, n, R0 * R1);
+                split_exchange<R2, R3, LB>(v, lds, t, Tr, n, R0 * R1);
                 stockham_compute<R3>(v, t, Tr, n, R0 * R1 * R2, tw);
             }
         }
@@ -182,6 +187,107 @@ struct LastStage {
     static constexpr int RL = (R3 > 1) ? R3 : (R2 > 1) ? R2 : (R1 > 1) ? R1 : R0;
     static constexpr int Ns = (R3 > 1) ? R0 * R1 * R2 : (R2 > 1) ? R0 * R1 : (R1 > 1) ? R0 : 1;
 };
+
+// The transforms of the persistent kernels take their stage twiddles from REGISTERS: a table read inside the transform would sit
+// behind the prefetched loads of the next row on the in-order vmcnt counter and drain them (s_waitcnt vmcnt(0) at the first
+// twiddle).  One table entry per thread and stage, read once per kernel: stage (Ns, R), butterfly q of the thread, needs
+// W_{Ns R}^k, k = (t + q n/16) mod Ns -- in the stages before the last q = 0 only; in the last stage Ns R = n and
+// W_n^(t + q n/16) = W_n^t W_16^q, the second factor a constant.
+template <int R>
+__device__ inline cplx stage_w(int t, int n, int Ns, const cplx* __restrict__ tw) {
+    return tw[(t & (Ns - 1)) * (n / (Ns * R))];
+}
+template <int R>
+__device__ inline void stockham_compute_w(cplx (&v)[kEPT], cplx w0in) {
+    // (opaque: the powers below are loop-invariant in a persistent kernel, and the compiler would keep all fifteen of every
+    //  stage in registers across the loop)
+    double w0x = w0in.x, w0y = w0in.y;
+    asm volatile("" : "+v"(w0x));
+    asm volatile("" : "+v"(w0y));
+    const cplx w0 = mk(w0x, w0y);
+    static_for<0, kEPT / R>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        cplx x[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) x[m] = v[q * R + m];
+        const cplx w1 = mul_w32<2 * q>(w0);
+        if constexpr (R >= 4) {                        // the powers by multiplication, two interleaved chains (stockham_compute)
+            const cplx w2 = mk(w1.x * w1.x - w1.y * w1.y, 2.0 * (w1.x * w1.y));
+            cplx wo = w1, we = w2;
+            x[1] = x[1] * wo;
+            x[2] = x[2] * we;
+#pragma unroll
+            for (int m = 3; m < R; m += 2) {
+                wo = wo * w2;
+                x[m] = x[m] * wo;
+                if (m + 1 < R) { we = we * w2; x[m + 1] = x[m + 1] * we; }
+            }
+        } else {
+            x[1] = x[1] * w1;
+        }
+        SmallFFT<R>::run(x);
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[q * R + m] = x[m];
+    });
+}
+template <int R0, int R1, int R2, int R3>
+struct StageW {
+    static_assert(R0 == kEPT && R1 == kEPT && (R3 == 1 || R2 == kEPT), "only the last stage may hold several butterflies per thread");
+    cplx w[3];
+    __device__ inline void load(int t, const cplx* __restrict__ tw) {
+        constexpr int n = R0 * R1 * R2 * R3;
+        w[0] = stage_w<R1>(t, n, R0, tw);
+        w[1] = R2 > 1 ? stage_w<R2>(t, n, R0 * R1, tw) : mk(1.0, 0.0);
+        w[2] = R3 > 1 ? stage_w<R3>(t, n, R0 * R1 * R2, tw) : mk(1.0, 0.0);
+    }
+};
+// slot_fft with the twiddles of StageW and LDS-only barriers
+template <int R0, int R1, int R2, int R3>
+__device__ inline void slot_fft_w(cplx (&v)[kEPT], double* lds, int t, const StageW<R0, R1, R2, R3>& sw) {
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
+    stockham_compute<R0>(v, t, Tr, n, 1, nullptr);
+    split_exchange<R0, R1, true>(v, lds, t, Tr, n, 1);
+    stockham_compute_w<R1>(v, sw.w[0]);
+    if constexpr (R2 > 1) {
+        split_exchange<R1, R2, true>(v, lds, t, Tr, n, R0);
+        stockham_compute_w<R2>(v, sw.w[1]);
+        if constexpr (R3 > 1) {
+            split_exchange<R2, R3, true>(v, lds, t, Tr, n, R0 * R1);
+            stockham_compute_w<R3>(v, sw.w[2]);
+        }
+    }
+}
+
+// ... and with whole complex values through LDS (n complex per slot, two barriers per exchange instead of four): for a kernel whose
+// workgroups per CU are set by registers, not by LDS
+template <int RP, int RN>
+__device__ inline void cplx_exchange(cplx (&v)[kEPT], cplx* lds, int t, int Tr, int n, int Ns) {
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < kEPT / RP; ++q)
+#pragma unroll
+        for (int m = 0; m < RP; ++m) lds[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m];
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < kEPT / RN; ++q)
+#pragma unroll
+        for (int m = 0; m < RN; ++m) v[q * RN + m] = lds[lds_pad(t + q * Tr + m * (n / RN))];
+}
+template <int R0, int R1, int R2, int R3>
+__device__ inline void slot_fft_wc(cplx (&v)[kEPT], cplx* lds, int t, const StageW<R0, R1, R2, R3>& sw) {
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
+    stockham_compute<R0>(v, t, Tr, n, 1, nullptr);
+    cplx_exchange<R0, R1>(v, lds, t, Tr, n, 1);
+    stockham_compute_w<R1>(v, sw.w[0]);
+    if constexpr (R2 > 1) {
+        cplx_exchange<R1, R2>(v, lds, t, Tr, n, R0);
+        stockham_compute_w<R2>(v, sw.w[1]);
+        if constexpr (R3 > 1) {
+            cplx_exchange<R2, R3>(v, lds, t, Tr, n, R0 * R1);
+            stockham_compute_w<R3>(v, sw.w[2]);
+        }
+    }
+}
 
 // Workgroup of the column kernel: 256 threads (one pair at n = 4096, four workgroups and sixteen independent
 // 4-wave barriers per CU).  Measured against 1024-thread workgroups holding four adjacent pairs (one
@@ -287,6 +393,155 @@ sspec_cols_kernel(SspecCols a) {
         cplx* out = a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
         gstore(out, mk(0.5 * (are[k] + bre[k]), 0.5 * (aim - bim)));
         gstore(out + 1, mk(0.5 * (aim + bim), -0.5 * (are[k] - bre[k])));
+    }
+}
+
+// Round 6: the strided-axis pass as a persistent, self-pipelined kernel (the reasoning is the row kernel's, sspec_rows2_kernel below):
+// a workgroup walks over column pairs and does BOTH halves of a pair from one read of it -- the windowed values stay in registers
+// through the even half's transform, the odd half takes them times W_2n^s = W_2n^t W_32^m, and the registers then receive the next
+// pair while the second transform runs.  The prewhitening stencil (PW) needs three more loads per value and is not prefetched.
+template <int R0, int R1, int R2, int R3, bool PW>
+__global__ void __launch_bounds__(ColsBlock<R0 * R1 * R2 * R3>::value, 2)
+sspec_cols2_kernel(SspecCols a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
+    static_assert(R0 == kEPT, "one radix-16 butterfly per thread in stage 0: input s = t + m n/16");
+    using LS = LastStage<R0, R1, R2, R3>;
+    const int i = (int)threadIdx.x / Tr, t = (int)threadIdx.x - i * Tr, G = (int)gridDim.x;
+    cplx* ldsc = reinterpret_cast<cplx*>(smem_raw) + (size_t)i * lds_pad(n);
+    int lb = (int)blockIdx.x;
+    if (a.xcd_remap) lb = (lb & 7) * (G >> 3) + (lb >> 3);
+    const SspecIn& in = a.in;
+    const bool windowed = in.wt != nullptr;
+    const double m1 = in.scal[0], m2 = in.scal[1];
+    const cplx wt2 = a.tw_2n[t];                                  // W_2n^t
+    StageW<R0, R1, R2, R3> sw;
+    sw.load(t, a.tw_n);
+    const int ntiles = (a.npairs + SPB - 1) / SPB;
+    // the raw pair [nf][2] of pair p at this thread's rows (x = column 2 p, y = column 2 p + 1), and its two time-window values;
+    // unconditional loads through a buffer resource: one per-lane byte offset, sixteen scalar distances (see the row kernel)
+    const bool full = in.nf_eff == n;
+    const int npairs_in = (in.nt + 1) / 2;                        // pairs of the pair-major copy
+    const BufRsrc dres = make_rsrc(in.dynp, (int64_t)npairs_in * in.nf * (int64_t)sizeof(cplx));
+    const BufRsrc fres = make_rsrc(in.wf, (int64_t)in.nf * (int64_t)sizeof(double));
+    constexpr int kStep = Tr * (int)sizeof(cplx);
+    // (no select between a load and its first use in the next iteration: values beyond a short column, and the time window beyond
+    //  the last sample, are zeroed where they are consumed)
+    auto load_pair = [&](int p, int tl, cplx (&r)[kEPT], double& w0, double& w1) {
+        const int pp = p < a.npairs ? p : 0;
+        if (windowed) { w0 = in.wt[2 * pp]; w1 = in.wt[2 * pp + 1 < in.nt ? 2 * pp + 1 : 2 * pp]; }
+        const int voff = (pp * in.nf + tl) * (int)sizeof(cplx);
+#pragma unroll
+        for (int m = 0; m < kEPT; ++m) r[m] = bload_c(dres, voff + ((full || tl + m * Tr < in.nf_eff) ? m * kStep : 0), 0);
+    };
+    cplx raw[kEPT];
+    double w0 = 1.0, w1 = 1.0;
+    int tile = lb;
+    if (!PW && tile < ntiles) load_pair(tile * SPB + i, t, raw, w0, w1);
+    for (; tile < ntiles; tile += G) {
+        const int p = tile * SPB + i;
+        const bool active = p < a.npairs;
+        const int c0 = 2 * p;
+        const bool has1 = active && c0 + 1 < in.nt_eff;          // the pair's second column exists
+        if constexpr (!PW) {
+            // the frequency window at this thread's rows: sixteen unconditional loads in one batch (under the row guard they
+            // were sixteen serialised round trips to the L2 per pair)
+            double f[kEPT];
+#pragma unroll
+            for (int m = 0; m < kEPT; ++m) f[m] = 1.0;
+            int tl = t; asm volatile("" : "+v"(tl));
+            if (windowed) {
+#pragma unroll
+                for (int m = 0; m < kEPT; ++m)
+                    f[m] = bload_d(fres, (tl + ((full || tl + m * Tr < in.nf) ? m * Tr : 0)) * (int)sizeof(double), 0);
+                if (c0 + 1 >= in.nt) w1 = 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < kEPT; ++m) {
+                const bool ok = active && (full || t + m * Tr < in.nf_eff);
+                const double d00 = sspec_d(raw[m].x, w0, f[m], m1, m2, windowed);
+                const double d01 = sspec_d(raw[m].y, w1, f[m], m1, m2, windowed);
+                raw[m] = mk(ok ? d00 : 0.0, (ok && has1) ? d01 : 0.0);
+            }
+        } else {
+            // convolve2d([[1,-1],[-1,1]], d', 'valid')  (dynspec.py:3681): pw[r, c] =
+            // d'[r+1, c+1] - d'[r+1, c] - d'[r, c+1] + d'[r, c], same association as fft.hip
+            double w2 = 1.0;
+            if (windowed && active) {
+                w0 = in.wt[c0];
+                w1 = c0 + 1 < in.nt ? in.wt[c0 + 1] : 0.0;
+                w2 = c0 + 2 < in.nt ? in.wt[c0 + 2] : 0.0;
+            }
+            const double* __restrict__ colp = in.dynp + (int64_t)(active ? p : 0) * in.nf * 2;
+            const double* __restrict__ coln = colp + (int64_t)in.nf * 2;
+#pragma unroll
+            for (int m = 0; m < kEPT; ++m) {
+                const int s = t + m * Tr;
+                cplx z = mk(0.0, 0.0);
+                if (active && s < in.nf_eff) {
+                    const double f0 = windowed ? in.wf[s] : 1.0, f1 = windowed ? in.wf[s + 1] : 1.0;
+                    const v2d xx = *(const SCINT_GLOBAL v2d*)(colp + 2 * s);
+                    const v2d yy = *(const SCINT_GLOBAL v2d*)(colp + 2 * (s + 1));
+                    const double d00 = sspec_d(xx.x, w0, f0, m1, m2, windowed);
+                    const double d01 = sspec_d(xx.y, w1, f0, m1, m2, windowed);
+                    const double d10 = sspec_d(yy.x, w0, f1, m1, m2, windowed);
+                    const double d11 = sspec_d(yy.y, w1, f1, m1, m2, windowed);
+                    double zy = 0.0;
+                    if (has1) {
+                        const double d02 = sspec_d(coln[2 * s], w2, f0, m1, m2, windowed);
+                        const double d12 = sspec_d(coln[2 * (s + 1)], w2, f1, m1, m2, windowed);
+                        zy = d12 - d11 - d02 + d01;
+                    }
+                    z = mk(d11 - d10 - d01 + d00, zy);
+                }
+                raw[m] = z;
+                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows' loads at a time (all sixteen: 150 spilled registers)
+            }
+        }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            cplx v[kEPT];
+            if (half == 0) {
+#pragma unroll
+                for (int m = 0; m < kEPT; ++m) v[m] = raw[m];
+            } else {
+                static_for<0, kEPT>([&](auto mc) {
+                    constexpr int m = decltype(mc)::value;
+                    v[m] = mul_w32<m>(raw[m] * wt2);
+                });
+                // the next pair into the registers this one leaves, in flight through the second transform (unconditionally: the
+                // last iteration reads its own pair again -- a conditional load is a phi, i.e. a copy and a wait right here)
+                if constexpr (!PW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    int tl = t; asm volatile("" : "+v"(tl));
+                    load_pair((tile + G < ntiles ? tile + G : tile) * SPB + i, tl, raw, w0, w1);
+                }
+            }
+            // (the thread index is opaque per transform: the LDS addresses are then recomputed instead of kept in registers)
+            int th = t; asm volatile("" : "+v"(th));
+            slot_fft_wc<R0, R1, R2, R3>(v, ldsc, th, sw);
+            // natural order in LDS; thread t separates the two real spectra at m = t + k Tr < n/2 from Z[m] and its
+            // partner Z[n - m] (even half) / Z[n - 1 - m] (odd half)
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < kEPT / LS::RL; ++q)
+#pragma unroll
+                for (int m = 0; m < LS::RL; ++m)
+                    ldsc[lds_pad(stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m))] = v[q * LS::RL + m];
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int m = th + k * Tr, pm = half ? n - 1 - m : (n - m) & (n - 1);
+                const cplx za = ldsc[lds_pad(m)], zb = ldsc[lds_pad(pm)];
+                // X_c = (Z[k] + conj Z[-k]) / 2,  X_{c+1} = (Z[k] - conj Z[-k]) / (2i); Y in tiles of (4 delay rows of one
+                // parity) x (one pair): 128 contiguous bytes from 4 consecutive threads
+                if (active) {
+                    cplx* out = a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
+                    gstore(out, mk(0.5 * (za.x + zb.x), 0.5 * (za.y - zb.y)));
+                    gstore(out + 1, mk(0.5 * (za.y + zb.y), -0.5 * (za.x - zb.x)));
+                }
+            }
+        }
     }
 }
 
@@ -546,6 +801,129 @@ sspec_rows_kernel(SspecRows a) {
     }
 }
 
+// Round 6: the row pass as a PERSISTENT, self-pipelined kernel.  What the counters of round 5 said about the kernel above
+// (profiles/r05_sspec_roofline_4096.json): its HBM floor is 93 us, its issue floor 81 us, it takes 222 -- the sum of its phases:
+// single-shot workgroups load, transform and store one after the other, and because every phase is bound by a shared resource the
+// workgroups of the chip fall into step (all load, then all compute).  Here a workgroup walks over rows and does BOTH halves of a
+// row from ONE read of it:
+//   * the 16 values a thread loaded stay in registers through the even half's transform and are the odd half's input too (times
+//     W_2n^s = W_2n^t W_32^m: one table entry per THREAD for the whole kernel, the rest are the radix-32 constants) -- the row
+//     is read once, not twice;
+//   * as soon as the odd half has taken its input, the same registers receive the NEXT row: its loads are in flight through the
+//     whole second transform (the transform's barriers wait for the LDS counter only, see xbarrier);
+//   * a thread ends up holding bins 2 mm (even half) and 2 mm + 1 (odd half) of the same mm: one 16-byte store per pair, consecutive
+//     lanes 16 bytes apart -- whole 128-byte lines (the single-half workgroups stored 8 bytes every 16 and left the merging to the
+//     L2: 315 MB written for a 268 MB output).
+// Workgroups per CU are set by registers (two waves per SIMD); logical blocks are dealt to XCDs in contiguous runs so that the four
+// rows of one parity that share the lines of a tile row meet in one L2.
+template <int R0, int R1, int R2, int R3>
+__global__ void __launch_bounds__((R0 * R1 * R2 * R3 / kEPT) >= 256 ? (R0 * R1 * R2 * R3 / kEPT) : 256, 2)
+sspec_rows2_kernel(SspecRows a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
+    static_assert(R0 == kEPT, "one radix-16 butterfly per thread in stage 0: input s = t + m n/16");
+    using LS = LastStage<R0, R1, R2, R3>;
+    const int i = (int)threadIdx.x / Tr, t = (int)threadIdx.x - i * Tr;
+    const int spb = (int)blockDim.x / Tr, G = (int)gridDim.x;
+    int lb = (int)blockIdx.x;
+    if (a.xcd_remap) lb = (lb & 7) * (G >> 3) + (lb >> 3);
+    double* lds = reinterpret_cast<double*>(smem_raw) + (size_t)i * lds_pad(n);
+    // the even half's sixteen bins of a thread wait in LDS for the odd half's (thread-private slots, lanes contiguous: no barrier,
+    // no conflict) -- in registers they cost the kernel its prefetch (spills at two waves per SIMD)
+    double* evl = reinterpret_cast<double*>(smem_raw) + (size_t)spb * lds_pad(n) + threadIdx.x;
+    const int evs = (int)blockDim.x;
+    __shared__ double tlog[128][2];                                 // ten_log10's table (visible after the transform's barriers)
+    if (threadIdx.x < 128) { tlog[threadIdx.x][0] = kTenLogTab[threadIdx.x][0]; tlog[threadIdx.x][1] = kTenLogTab[threadIdx.x][1]; }
+    const cplx wt = a.tw_2n[t];                                     // W_2n^t, t < n/16
+    StageW<R0, R1, R2, R3> sw;
+    sw.load(t, a.tw_n);
+    const int ngroups = (a.nrows + spb - 1) / spb;
+    // row k1 = 2 m + h of the tiled intermediate: element c at tile (m >> 2, c >> 1), slot h, m & 3, c & 1.  Every load is
+    // unconditional (a load under a branch makes the compiler wait for everything in flight) and goes through a buffer resource:
+    // ONE per-lane byte offset (row + thread) and sixteen scalar distances -- as global loads the compiler kept sixteen
+    // loop-carried 64-bit addresses, and spilled them.  Elements beyond the row's length read element t and are zeroed by selects.
+    const bool full = a.nt_eff == n;
+    const BufRsrc yres = make_rsrc(a.Y, (int64_t)a.nrows * a.npairs * 2 * (int64_t)sizeof(cplx));
+    constexpr int kStep = (Tr / 2) * 16 * (int)sizeof(cplx);           // from s to s + n/16: n/32 tiles on
+    // (no select and no branch between the loads and their first use in the NEXT iteration: either makes the compiler wait for
+    //  the data where it is issued.  The zeroing of a short row's tail happens where the values are consumed.)
+    auto load_row = [&](int k1, int tl, cplx (&r)[kEPT]) {
+        const int kk = k1 < a.nrows ? k1 : 0;
+        const int voff = (((kk >> 3) * a.npairs + (tl >> 1)) * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2 + (tl & 1)) * (int)sizeof(cplx);
+#pragma unroll
+        for (int m = 0; m < kEPT; ++m) r[m] = bload_c(yres, voff + ((full || tl + m * Tr < a.nt_eff) ? m * kStep : 0), 0);
+    };
+    cplx raw[kEPT];
+    int grp = lb;
+    if (grp < ngroups) load_row(grp * spb + i, t, raw);
+    for (; grp < ngroups; grp += G) {
+        const int k1 = grp * spb + i;
+        const bool active = k1 < a.nrows;
+        const double td = (a.prewhite && active) ? a.pd_td[k1] : 1.0;
+        if (!full || !active) {
+#pragma unroll
+            for (int m = 0; m < kEPT; ++m) {
+                const bool ok = active && t + m * Tr < a.nt_eff;
+                raw[m] = mk(ok ? raw[m].x : 0.0, ok ? raw[m].y : 0.0);
+            }
+        }
+        cplx v[kEPT];
+#pragma unroll
+        for (int m = 0; m < kEPT; ++m) v[m] = raw[m];
+        // the thread index of each transform is opaque to the compiler: it would otherwise keep every LDS address of the exchanges
+        // alive across both transforms and the whole loop (hundreds of registers, see the note above sspec_rows_kernel)
+        int th = t; asm volatile("" : "+v"(th));
+        slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw);
+#pragma unroll
+        for (int q = 0; q < kEPT / LS::RL; ++q) {
+#pragma unroll
+            for (int m = 0; m < LS::RL; ++m) {
+                const int e = q * LS::RL + m;
+                const int mm = stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m);
+                const int col = (2 * mm + n) & (a.C - 1);           // Doppler bin 2 mm at its fftshift-ed place (dynspec.py:3687)
+                double p = v[e].x * v[e].x + v[e].y * v[e].y;
+                if (a.prewhite) {   // post-darkening, column C/2 and row 0 forced to 1 (dynspec.py:3704-3717)
+                    const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
+                    p = p / d;
+                }
+                evl[e * evs] = ten_log10(p, tlog);
+                __builtin_amdgcn_sched_barrier(0);                  // one logarithm at a time (sixteen interleaved ones spill)
+            }
+        }
+        // the odd half: the row times W_2n^s, s = t + m n/16
+        static_for<0, kEPT>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            v[m] = mul_w32<m>(raw[m] * wt);
+        });
+        // ... and the next row into the registers this one leaves (unconditionally: the last iteration reads its own row again --
+        // a conditional load is a phi, the compiler then loads elsewhere and copies, i.e. waits, right here)
+        __builtin_amdgcn_sched_barrier(0);
+        th = t; asm volatile("" : "+v"(th));
+        load_row((grp + G < ngroups ? grp + G : grp) * spb + i, th, raw);
+        slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw);
+        if (active) {
+            double* __restrict__ orow = a.out + (int64_t)k1 * a.C;
+#pragma unroll
+            for (int q = 0; q < kEPT / LS::RL; ++q) {
+#pragma unroll
+                for (int m = 0; m < LS::RL; ++m) {
+                    const int e = q * LS::RL + m;
+                    const int mm = stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m);
+                    const int col = (2 * mm + n) & (a.C - 1);
+                    double p = v[e].x * v[e].x + v[e].y * v[e].y;
+                    if (a.prewhite) {
+                        const double d = (k1 == 0) ? 1.0 : a.pd_fd[col + 1] * td;    // (col + 1 is odd: never C/2)
+                        p = p / d;
+                    }
+                    v2d o; o.x = evl[e * evs]; o.y = ten_log10(p, tlog);
+                    *(SCINT_GLOBAL v2d*)(orow + col) = o;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+}
+
 template <int R0, int R1, int R2, int R3>
 static int32_t launch_cols(const SspecCols& a, hipStream_t stream) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
@@ -577,6 +955,65 @@ static int32_t launch_rows(const SspecRows& a, hipStream_t stream) {
     return SCINT_OK;
 }
 
+// Experiment switches of round 6 (read once per process; removed once the A/B is settled)
+struct SspecKnobs { int rows, cols, wgs_rows, wgs_cols, max_grid; };
+static const SspecKnobs& sspec_knobs() {
+    static const SspecKnobs k = [] {
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        return SspecKnobs{env_int("SCINT_SSPEC_ROWS", 2), env_int("SCINT_SSPEC_COLS", 2), env_int("SCINT_SSPEC_WGS_ROWS", 0),
+                          env_int("SCINT_SSPEC_WGS_COLS", 0), env_int("SCINT_SSPEC_MAXGRID", 0)};
+    }();
+    return k;
+}
+constexpr int kSspecCUs = 256;     // compute units of an MI355X: the persistent kernels launch (workgroups per CU) x this many
+static int persistent_grid(int units, int per_cu) {
+    int g = per_cu * kSspecCUs;
+    if (sspec_knobs().max_grid > 0 && g > sspec_knobs().max_grid) g = sspec_knobs().max_grid;   // (tests: several iterations per workgroup at small shapes)
+    if (g > units) g = units;
+    if (g >= 8) g &= ~7;           // whole XCD rounds (the logical-block remap)
+    return g < 1 ? 1 : g;
+}
+
+template <int R0, int R1, int R2, int R3>
+static int32_t launch_cols2(const SspecCols& a, hipStream_t stream) {
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
+    const int tiles = (int)ceil_div(a.npairs, SPB);
+    const int per_cu = sspec_knobs().wgs_cols > 0 ? sspec_knobs().wgs_cols : (kColsBlock >= 512 ? 1 : 2);
+    const int grid = persistent_grid(tiles, per_cu);
+    SspecCols b = a;
+    b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+    const size_t lds = (size_t)SPB * (size_t)(n + n / 16) * sizeof(cplx);      // whole complex values (68 KiB at n = 4096: two per CU)
+    if (a.in.prewhite) {
+        auto k = sspec_cols2_kernel<R0, R1, R2, R3, true>;
+        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kColsBlock), lds, stream, b);
+    } else {
+        auto k = sspec_cols2_kernel<R0, R1, R2, R3, false>;
+        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kColsBlock), lds, stream, b);
+    }
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
+template <int R0, int R1, int R2, int R3>
+static int32_t launch_rows2(const SspecRows& a, hipStream_t stream) {
+    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
+    const int block = Tr >= 256 ? Tr : 256, spb = block / Tr;
+    const int groups = (int)ceil_div((int64_t)a.nrows, spb);
+    const int per_cu = sspec_knobs().wgs_rows > 0 ? sspec_knobs().wgs_rows : (block >= 512 ? 1 : 2);
+    const int grid = persistent_grid(groups, per_cu);
+    SspecRows b = a;
+    b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+    const size_t lds = ((size_t)spb * (size_t)(n + n / 16) + (size_t)kEPT * (size_t)block) * sizeof(double);
+    auto k = sspec_rows2_kernel<R0, R1, R2, R3>;
+    if (lds > 64 * 1024)
+        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, b);
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+
 #define SCINT_SSPEC_DISPATCH(N, F, ...)                                  \
     switch (N) {                                                         \
         case 256: return F<16, 16, 1, 1>(__VA_ARGS__);                   \
@@ -588,10 +1025,12 @@ static int32_t launch_rows(const SspecRows& a, hipStream_t stream) {
         default: break;                                                  \
     }
 static int32_t dispatch_cols(int64_t n, const SspecCols& a, hipStream_t s) {
+    if (sspec_knobs().cols == 2) { SCINT_SSPEC_DISPATCH(n, launch_cols2, a, s) }
     SCINT_SSPEC_DISPATCH(n, launch_cols, a, s)
     SCINT_REQUIRE(false, "sspec: unsupported column transform length");
 }
 static int32_t dispatch_rows(int64_t n, const SspecRows& a, hipStream_t s) {
+    if (sspec_knobs().rows == 2) { SCINT_SSPEC_DISPATCH(n, launch_rows2, a, s) }
     SCINT_SSPEC_DISPATCH(n, launch_rows, a, s)
     SCINT_REQUIRE(false, "sspec: unsupported row transform length");
 }

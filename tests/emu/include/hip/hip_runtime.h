@@ -12,6 +12,8 @@
 #pragma once
 #include <math.h>
 #include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -174,6 +176,30 @@ inline int emu_update_dpp(int v, int ctrl) {
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))                 // v_rcp_f64: an approximation on the GPU, refined by its callers
 #define __builtin_amdgcn_readlane(v, lane) emu_readlane((v), (lane))
 #define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane(v)
+
+// buffer-resource accesses: base + per-lane byte offset + scalar byte offset.  The hardware's range check covers the per-lane
+// offset only (out of range reads 0) and not the scalar one, so the kernels must not rely on it: here an access beyond the
+// resource aborts the test.
+struct __amdgpu_buffer_rsrc_t { char* base; uint32_t bytes; };
+inline __amdgpu_buffer_rsrc_t emu_make_buffer_rsrc(void* p, uint32_t bytes) { return __amdgpu_buffer_rsrc_t{(char*)p, bytes}; }
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu_make_buffer_rsrc((p), (uint32_t)(bytes))
+typedef unsigned int emu_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int emu_v2u __attribute__((ext_vector_type(2)));
+template <typename V> inline V emu_buffer_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    V v = {};
+    const uint64_t o = (uint64_t)(uint32_t)voff + (uint64_t)(uint32_t)soff;
+    if (o + sizeof(V) > r.bytes) { fprintf(stderr, "emu: buffer load beyond the resource (%llu + %zu > %u)\n", (unsigned long long)o, sizeof(V), r.bytes); abort(); }
+    memcpy(&v, r.base + o, sizeof(V));
+    return v;
+}
+template <typename V> inline void emu_buffer_store(V v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const uint64_t o = (uint64_t)(uint32_t)voff + (uint64_t)(uint32_t)soff;
+    if (o + sizeof(V) > r.bytes) { fprintf(stderr, "emu: buffer store beyond the resource (%llu + %zu > %u)\n", (unsigned long long)o, sizeof(V), r.bytes); abort(); }
+    memcpy(r.base + o, &v, sizeof(V));
+}
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) emu_buffer_load<emu_v4u>((r), (voff), (soff))
+#define __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux) emu_buffer_load<emu_v2u>((r), (voff), (soff))
+#define __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, aux) emu_buffer_store<emu_v4u>((v), (r), (voff), (soff))
 
 // ---- device library bits the kernels use --------------------------------------------------------
 inline int __double2hiint(double v) { return (int)(::emu::to_bits(v) >> 32); }
