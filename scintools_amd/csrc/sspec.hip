@@ -35,6 +35,16 @@
 
 #include "fft.hpp"
 
+#ifndef SCINT_ROWS2_LOG_GROUP
+#define SCINT_ROWS2_LOG_GROUP 4
+#endif
+#ifndef SCINT_ROWS2_LOAD_PIECES
+#define SCINT_ROWS2_LOAD_PIECES 4
+#endif
+#ifndef SCINT_ROWS2_STORE_PIECES
+#define SCINT_ROWS2_STORE_PIECES 1
+#endif
+
 namespace scint {
 
 // d'(r, c) of dynspec.py:3667-3674 with NumPy's operation order (as WindowedValue / RowSource in fft.hip)
@@ -132,6 +142,8 @@ struct SspecCols {
     const cplx* tw_n;             // W_n
     const cplx* tw_2n;            // W_2n (the odd half's input twiddle)
     int xcd_remap;
+    int rowmajor;                 // experiment (round 6): Y row-major [R/2][2 npairs] instead of the 4-row tiles
+    int abl; double* dbg;         // experiment: abl & 64 -> shader clocks per phase to dbg (the row kernel is then not launched)
 };
 
 // Workgroup barrier of the transforms.  LB = true: wait for the LDS counter only (lds_barrier) -- a persistent
@@ -141,7 +153,28 @@ template <bool LB> __device__ inline void xbarrier() { if constexpr (LB) lds_bar
 
 // one Stockham exchange through n doubles of LDS per slot: real parts, then imaginary parts
 template <int RP, int RN, bool LB = false>
-__device__ inline void split_exchange(cplx (&v)[kEPT], double* ldsd, int t, int Tr, int n, int Ns) {
+__device__ inline void split_exchange(cplx (&v)[kEPT], double* ldsd, int t, int Tr, int n, int Ns, int abl = 0) {
+    if (abl & 4) return;
+    if (abl & 16) {
+#pragma unroll
+        for (int q = 0; q < kEPT / RP; ++q)
+#pragma unroll
+            for (int m = 0; m < RP; ++m) ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].x;
+        double re[kEPT];
+#pragma unroll
+        for (int q = 0; q < kEPT / RN; ++q)
+#pragma unroll
+            for (int m = 0; m < RN; ++m) re[q * RN + m] = ldsd[lds_pad(t + q * Tr + m * (n / RN))];
+#pragma unroll
+        for (int q = 0; q < kEPT / RP; ++q)
+#pragma unroll
+            for (int m = 0; m < RP; ++m) ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].y;
+#pragma unroll
+        for (int q = 0; q < kEPT / RN; ++q)
+#pragma unroll
+            for (int m = 0; m < RN; ++m) v[q * RN + m] = mk(re[q * RN + m], ldsd[lds_pad(t + q * Tr + m * (n / RN))]);
+        return;
+    }
     xbarrier<LB>();
 #pragma unroll
     for (int q = 0; q < kEPT / RP; ++q)
@@ -234,6 +267,7 @@ template <int R0, int R1, int R2, int R3>
 struct StageW {
     static_assert(R0 == kEPT && R1 == kEPT && (R3 == 1 || R2 == kEPT), "only the last stage may hold several butterflies per thread");
     cplx w[3];
+    int abl = 0;
     __device__ inline void load(int t, const cplx* __restrict__ tw) {
         constexpr int n = R0 * R1 * R2 * R3;
         w[0] = stage_w<R1>(t, n, R0, tw);
@@ -241,19 +275,29 @@ struct StageW {
         w[2] = R3 > 1 ? stage_w<R3>(t, n, R0 * R1 * R2, tw) : mk(1.0, 0.0);
     }
 };
-// slot_fft with the twiddles of StageW and LDS-only barriers
-template <int R0, int R1, int R2, int R3>
-__device__ inline void slot_fft_w(cplx (&v)[kEPT], double* lds, int t, const StageW<R0, R1, R2, R3>& sw) {
+// slot_fft with the twiddles of StageW and LDS-only barriers.  `hook(c)` runs before the first stage (c = 0) and after every
+// stage (c = 1 ..): the persistent kernels issue their memory instructions there in pieces -- a wave that issues sixteen loads
+// (or stores) in one go stands at the issue port for as long as the memory pipeline takes to accept them (4000 - 11000 clocks
+// a row, measured: profiles/r06_rows2_phase_times.txt), pieces drain while the next stage computes.
+struct NoHook { template <class C> __device__ inline void operator()(C) const {} };
+template <int R0, int R1, int R2, int R3> struct HookCount { static constexpr int value = 2 + (R2 > 1) + (R3 > 1) + 1; };
+template <int R0, int R1, int R2, int R3, class Hook = NoHook>
+__device__ inline void slot_fft_w(cplx (&v)[kEPT], double* lds, int t, const StageW<R0, R1, R2, R3>& sw, Hook&& hook = Hook()) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
+    hook(std::integral_constant<int, 0>{});
     stockham_compute<R0>(v, t, Tr, n, 1, nullptr);
-    split_exchange<R0, R1, true>(v, lds, t, Tr, n, 1);
+    hook(std::integral_constant<int, 1>{});
+    split_exchange<R0, R1, true>(v, lds, t, Tr, n, 1, sw.abl);
     stockham_compute_w<R1>(v, sw.w[0]);
+    hook(std::integral_constant<int, 2>{});
     if constexpr (R2 > 1) {
-        split_exchange<R1, R2, true>(v, lds, t, Tr, n, R0);
+        split_exchange<R1, R2, true>(v, lds, t, Tr, n, R0, sw.abl);
         stockham_compute_w<R2>(v, sw.w[1]);
+        hook(std::integral_constant<int, 3>{});
         if constexpr (R3 > 1) {
-            split_exchange<R2, R3, true>(v, lds, t, Tr, n, R0 * R1);
+            split_exchange<R2, R3, true>(v, lds, t, Tr, n, R0 * R1, sw.abl);
             stockham_compute_w<R3>(v, sw.w[2]);
+            hook(std::integral_constant<int, 4>{});
         }
     }
 }
@@ -438,6 +482,12 @@ sspec_cols2_kernel(SspecCols a) {
     double w0 = 1.0, w1 = 1.0;
     int tile = lb;
     if (!PW && tile < ntiles) load_pair(tile * SPB + i, t, raw, w0, w1);
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool timing = (a.abl & 64) != 0;
+    auto tick = [&](int ph) {
+        if (timing) { const long long now = (long long)__builtin_readcyclecounter(); tacc[ph] += now - tprev; tprev = now; }
+    };
+    if (timing) tprev = (long long)__builtin_readcyclecounter();
     for (; tile < ntiles; tile += G) {
         const int p = tile * SPB + i;
         const bool active = p < a.npairs;
@@ -498,6 +548,7 @@ sspec_cols2_kernel(SspecCols a) {
                 if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows' loads at a time (all sixteen: 150 spilled registers)
             }
         }
+        tick(0);                                                     // waited for the pair, windowed it
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             cplx v[kEPT];
@@ -519,7 +570,9 @@ sspec_cols2_kernel(SspecCols a) {
             }
             // (the thread index is opaque per transform: the LDS addresses are then recomputed instead of kept in registers)
             int th = t; asm volatile("" : "+v"(th));
+            tick(1 + 3 * half);                                      // input (odd half: + prefetch issue)
             slot_fft_wc<R0, R1, R2, R3>(v, ldsc, th, sw);
+            tick(2 + 3 * half);                                      // transform
             // natural order in LDS; thread t separates the two real spectra at m = t + k Tr < n/2 from Z[m] and its
             // partner Z[n - m] (even half) / Z[n - 1 - m] (odd half)
             lds_barrier();
@@ -536,12 +589,17 @@ sspec_cols2_kernel(SspecCols a) {
                 // X_c = (Z[k] + conj Z[-k]) / 2,  X_{c+1} = (Z[k] - conj Z[-k]) / (2i); Y in tiles of (4 delay rows of one
                 // parity) x (one pair): 128 contiguous bytes from 4 consecutive threads
                 if (active) {
-                    cplx* out = a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
+                    cplx* out = a.rowmajor ? a.Y + (int64_t)(2 * m + half) * (2 * a.npairs) + 2 * p
+                                           : a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
                     gstore(out, mk(0.5 * (za.x + zb.x), 0.5 * (za.y - zb.y)));
                     gstore(out + 1, mk(0.5 * (za.y + zb.y), -0.5 * (za.x - zb.x)));
                 }
             }
+            tick(3 + 3 * half);                                      // separation + stores
         }
+    }
+    if (timing && threadIdx.x == 0) {
+        for (int ph = 0; ph < 8; ++ph) a.dbg[(int64_t)blockIdx.x * 8 + ph] = (double)tacc[ph];
     }
 }
 
@@ -553,6 +611,8 @@ struct SspecRows {
     double* out;                  // [R/2][C] dB
     int prewhite; const double* pd_fd; const double* pd_td;
     int xcd_remap;
+    int rowmajor;                 // experiment (round 6): Y row-major [R/2][2 npairs] instead of the 4-row tiles
+    int abl;                      // experiment: ablation bits (1 no loop loads, 2 no stores, 4 no exchanges, 8 no logs, 16 no barriers)
 };
 
 // 10 log10(x), series form (round 3, first version; now the path of zero, subnormal and non-finite powers and the
@@ -837,6 +897,7 @@ sspec_rows2_kernel(SspecRows a) {
     const cplx wt = a.tw_2n[t];                                     // W_2n^t, t < n/16
     StageW<R0, R1, R2, R3> sw;
     sw.load(t, a.tw_n);
+    sw.abl = a.abl;
     const int ngroups = (a.nrows + spb - 1) / spb;
     // row k1 = 2 m + h of the tiled intermediate: element c at tile (m >> 2, c >> 1), slot h, m & 3, c & 1.  Every load is
     // unconditional (a load under a branch makes the compiler wait for everything in flight) and goes through a buffer resource:
@@ -847,15 +908,58 @@ sspec_rows2_kernel(SspecRows a) {
     constexpr int kStep = (Tr / 2) * 16 * (int)sizeof(cplx);           // from s to s + n/16: n/32 tiles on
     // (no select and no branch between the loads and their first use in the NEXT iteration: either makes the compiler wait for
     //  the data where it is issued.  The zeroing of a short row's tail happens where the values are consumed.)
-    auto load_row = [&](int k1, int tl, cplx (&r)[kEPT]) {
+    auto row_voff = [&](int k1, int tl) {
         const int kk = k1 < a.nrows ? k1 : 0;
-        const int voff = (((kk >> 3) * a.npairs + (tl >> 1)) * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2 + (tl & 1)) * (int)sizeof(cplx);
-#pragma unroll
-        for (int m = 0; m < kEPT; ++m) r[m] = bload_c(yres, voff + ((full || tl + m * Tr < a.nt_eff) ? m * kStep : 0), 0);
+        return a.rowmajor ? (kk * 2 * a.npairs + tl) * (int)sizeof(cplx)
+            : (((kk >> 3) * a.npairs + (tl >> 1)) * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2 + (tl & 1)) * (int)sizeof(cplx);
     };
+    const int step = a.rowmajor ? Tr * (int)sizeof(cplx) : kStep;
+    // elements m with m * NP / 16 == P: piece P of NP of a row's loads
+    auto load_piece = [&](auto pc, auto npc, int voff, int tl, cplx (&r)[kEPT]) {
+        constexpr int P = decltype(pc)::value, NP = decltype(npc)::value;
+#pragma unroll
+        for (int m = 0; m < kEPT; ++m)
+            if (m * NP / kEPT == P) r[m] = bload_c(yres, voff + ((full || tl + m * Tr < a.nt_eff) ? m * step : 0), 0);
+    };
+    auto load_row = [&](int k1, int tl, cplx (&r)[kEPT]) {
+        load_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, row_voff(k1, tl), tl, r);
+    };
+    // A row's bins are stored at the top of the NEXT iteration (the odd half's sixteen values ride in registers across the loop
+    // edge, where nothing else is alive; the even half's wait in LDS anyway): the wait for the prefetched row is then a wait for
+    // loads only.  Stored where they are computed, the sixteen stores sit behind the prefetch on the in-order counter and the
+    // compiler's one static wait at the loop head drains them too -- a store round trip per row, fully exposed.
+    double od[kEPT];
+    int pk = -1;
+    // bins e with e * NP / 16 == P of the previous row
+    auto flush_piece = [&](auto pc, auto npc) {
+        constexpr int P = decltype(pc)::value, NP = decltype(npc)::value;
+        if (pk >= 0) {
+            int tq = t; asm volatile("" : "+v"(tq));
+            double* __restrict__ orow = a.out + (int64_t)pk * a.C;
+#pragma unroll
+            for (int q = 0; q < kEPT / LS::RL; ++q) {
+#pragma unroll
+                for (int m = 0; m < LS::RL; ++m) {
+                    const int e = q * LS::RL + m;
+                    if (e * NP / kEPT != P) continue;
+                    const int col = (2 * stockham_out_index<LS::RL>(tq, Tr, LS::Ns, q, m) + n) & (a.C - 1);
+                    v2d o; o.x = evl[e * evs]; o.y = od[e];
+                    if (!(a.abl & 2)) *(SCINT_GLOBAL v2d*)(orow + col) = o;
+                }
+            }
+        }
+    };
+    auto flush = [&]() { flush_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); };
     cplx raw[kEPT];
     int grp = lb;
     if (grp < ngroups) load_row(grp * spb + i, t, raw);
+    // experiment (abl & 32): shader clocks spent per phase, summed over the rows of this workgroup, written by its first thread
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool timing = (a.abl & 32) != 0;
+    auto tick = [&](int ph) {
+        if (timing) { const long long now = (long long)__builtin_readcyclecounter(); tacc[ph] += now - tprev; tprev = now; }
+    };
+    if (timing) tprev = (long long)__builtin_readcyclecounter();
     for (; grp < ngroups; grp += G) {
         const int k1 = grp * spb + i;
         const bool active = k1 < a.nrows;
@@ -869,11 +973,29 @@ sspec_rows2_kernel(SspecRows a) {
         }
         cplx v[kEPT];
 #pragma unroll
-        for (int m = 0; m < kEPT; ++m) v[m] = raw[m];
+        for (int m = 0; m < kEPT; ++m) {
+            // (a use of every loaded value HERE: the wait for the row must precede the stores below, or it becomes a wait for them)
+            double rx = raw[m].x, ry = raw[m].y;
+            asm volatile("" : "+v"(rx));
+            asm volatile("" : "+v"(ry));
+            v[m] = mk(rx, ry);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tick(0);                                                    // waited for the row
+        tick(1);
         // the thread index of each transform is opaque to the compiler: it would otherwise keep every LDS address of the exchanges
         // alive across both transforms and the whole loop (hundreds of registers, see the note above sspec_rows_kernel)
         int th = t; asm volatile("" : "+v"(th));
-        slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw);
+        // the previous row's bins leave in kSP pieces, before the first stage and after the first kSP - 1 stages
+        constexpr int kSP = SCINT_ROWS2_STORE_PIECES;
+        slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw, [&](auto c) {
+            if constexpr (decltype(c)::value < kSP) {
+                __builtin_amdgcn_sched_barrier(0);
+                flush_piece(c, std::integral_constant<int, kSP>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        tick(2);                                                    // even half transformed
 #pragma unroll
         for (int q = 0; q < kEPT / LS::RL; ++q) {
 #pragma unroll
@@ -886,10 +1008,12 @@ sspec_rows2_kernel(SspecRows a) {
                     const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
                     p = p / d;
                 }
-                evl[e * evs] = ten_log10(p, tlog);
-                __builtin_amdgcn_sched_barrier(0);                  // one logarithm at a time (sixteen interleaved ones spill)
+                evl[e * evs] = (a.abl & 8) ? p : ten_log10(p, tlog);
+                if ((e % SCINT_ROWS2_LOG_GROUP) == SCINT_ROWS2_LOG_GROUP - 1)
+                    __builtin_amdgcn_sched_barrier(0);              // a few logarithms at a time: one is a chain of dependent operations (two waves per SIMD do not hide it), sixteen spill
             }
         }
+        tick(3);                                                    // even half's logarithms
         // the odd half: the row times W_2n^s, s = t + m n/16
         static_for<0, kEPT>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -899,28 +1023,39 @@ sspec_rows2_kernel(SspecRows a) {
         // a conditional load is a phi, the compiler then loads elsewhere and copies, i.e. waits, right here)
         __builtin_amdgcn_sched_barrier(0);
         th = t; asm volatile("" : "+v"(th));
-        load_row((grp + G < ngroups ? grp + G : grp) * spb + i, th, raw);
-        slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw);
-        if (active) {
-            double* __restrict__ orow = a.out + (int64_t)k1 * a.C;
+        tick(4);                                                    // odd half's input
+        constexpr int kLP = SCINT_ROWS2_LOAD_PIECES < HookCount<R0, R1, R2, R3>::value ? SCINT_ROWS2_LOAD_PIECES : HookCount<R0, R1, R2, R3>::value - 1;
+        const int nvoff = row_voff((grp + G < ngroups ? grp + G : grp) * spb + i, th);
+        slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw, [&](auto c) {
+            if constexpr (decltype(c)::value < kLP) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(a.abl & 1)) load_piece(c, std::integral_constant<int, kLP>{}, nvoff, th, raw);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+        tick(5);                                                    // odd half transformed
 #pragma unroll
-            for (int q = 0; q < kEPT / LS::RL; ++q) {
+        for (int q = 0; q < kEPT / LS::RL; ++q) {
 #pragma unroll
-                for (int m = 0; m < LS::RL; ++m) {
-                    const int e = q * LS::RL + m;
-                    const int mm = stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m);
-                    const int col = (2 * mm + n) & (a.C - 1);
-                    double p = v[e].x * v[e].x + v[e].y * v[e].y;
-                    if (a.prewhite) {
-                        const double d = (k1 == 0) ? 1.0 : a.pd_fd[col + 1] * td;    // (col + 1 is odd: never C/2)
-                        p = p / d;
-                    }
-                    v2d o; o.x = evl[e * evs]; o.y = ten_log10(p, tlog);
-                    *(SCINT_GLOBAL v2d*)(orow + col) = o;
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < LS::RL; ++m) {
+                const int e = q * LS::RL + m;
+                const int mm = stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m);
+                const int col = (2 * mm + n) & (a.C - 1);
+                double p = v[e].x * v[e].x + v[e].y * v[e].y;
+                if (a.prewhite) {
+                    const double d = (k1 == 0) ? 1.0 : a.pd_fd[col + 1] * td;    // (col + 1 is odd: never C/2)
+                    p = p / d;
                 }
+                od[e] = (a.abl & 8) ? p : ten_log10(p, tlog);
+                if ((e % SCINT_ROWS2_LOG_GROUP) == SCINT_ROWS2_LOG_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        pk = active ? k1 : -1;
+        tick(6);                                                    // odd half's logarithms
+    }
+    flush();
+    if (timing && threadIdx.x == 0) {
+        for (int ph = 0; ph < 8; ++ph) a.out[(int64_t)blockIdx.x * 8 + ph] = (double)tacc[ph];
     }
 }
 
@@ -956,12 +1091,12 @@ static int32_t launch_rows(const SspecRows& a, hipStream_t stream) {
 }
 
 // Experiment switches of round 6 (read once per process; removed once the A/B is settled)
-struct SspecKnobs { int rows, cols, wgs_rows, wgs_cols, max_grid; };
+struct SspecKnobs { int rows, cols, wgs_rows, wgs_cols, max_grid, rowmajor, abl; };
 static const SspecKnobs& sspec_knobs() {
     static const SspecKnobs k = [] {
         auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         return SspecKnobs{env_int("SCINT_SSPEC_ROWS", 2), env_int("SCINT_SSPEC_COLS", 2), env_int("SCINT_SSPEC_WGS_ROWS", 0),
-                          env_int("SCINT_SSPEC_WGS_COLS", 0), env_int("SCINT_SSPEC_MAXGRID", 0)};
+                          env_int("SCINT_SSPEC_WGS_COLS", 0), env_int("SCINT_SSPEC_MAXGRID", 0), env_int("SCINT_SSPEC_ROWMAJOR", 0), env_int("SCINT_SSPEC_ABL", 0)};
     }();
     return k;
 }
@@ -982,6 +1117,8 @@ static int32_t launch_cols2(const SspecCols& a, hipStream_t stream) {
     const int grid = persistent_grid(tiles, per_cu);
     SspecCols b = a;
     b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+    b.rowmajor = sspec_knobs().rowmajor;
+    b.abl = sspec_knobs().abl;
     const size_t lds = (size_t)SPB * (size_t)(n + n / 16) * sizeof(cplx);      // whole complex values (68 KiB at n = 4096: two per CU)
     if (a.in.prewhite) {
         auto k = sspec_cols2_kernel<R0, R1, R2, R3, true>;
@@ -1005,6 +1142,8 @@ static int32_t launch_rows2(const SspecRows& a, hipStream_t stream) {
     const int grid = persistent_grid(groups, per_cu);
     SspecRows b = a;
     b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
+    b.rowmajor = sspec_knobs().rowmajor;
+    b.abl = sspec_knobs().abl;
     const size_t lds = ((size_t)spb * (size_t)(n + n / 16) + (size_t)kEPT * (size_t)block) * sizeof(double);
     auto k = sspec_rows2_kernel<R0, R1, R2, R3>;
     if (lds > 64 * 1024)
@@ -1084,10 +1223,12 @@ int32_t sspec_fast(const double* dyn, int64_t nf, int64_t nt, const double* win_
     ca.npairs = (int)ceil_div(nt_eff, 2);
     ca.Y = (cplx*)(base + ws.Y); ca.ldY = 2 * ca.npairs;
     ca.tw_n = tw_r; ca.tw_2n = tw_2r;
+    ca.dbg = sec_out;
     const int p1 = profiler().begin(kProfSspecCols, stream);
     int32_t rc = dispatch_cols(nr, ca, stream);
     profiler().end(kProfSspecCols, p1, stream);
     if (rc != SCINT_OK) return rc;
+    if (sspec_knobs().abl & 64) return rc;
     SspecRows ra{};
     ra.Y = ca.Y; ra.npairs = ca.npairs; ra.nt_eff = (int)nt_eff; ra.nrows = (int)nr; ra.C = (int)(2 * nc);
     ra.tw_n = tw_c; ra.tw_2n = tw_2c; ra.out = sec_out;
