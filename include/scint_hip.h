@@ -172,12 +172,14 @@ int32_t scint_sweep_stats(double* out /*HOST[4]*/);
  * (csrc/packed.hpp).  For callers that size the `batch` argument of the sweeps: resident curvatures x this = workgroups per
  * launch (scintools_amd/ththmod.py: default_batch).  Returns the count (>= 1), or -SCINT_E_ARG for nb < 1. */
 int32_t scint_sweep_workgroups(int32_t nb, int32_t complex64);
-/* Environment variables the library reads (each ONCE per process; none selects another kernel family or changes a result
- * beyond what is said here):
+/* Environment variables the library reads (each ONCE per process unless said otherwise; none selects another kernel family or
+ * changes a result beyond what is said here):
  *   SCINT_SWEEP_PRECISION = f64 | mixed | mixed-all   initial value of scint_sweep_precision();
  *   SCINT_SWEEP_DEPTH, SCINT_CHECK_EVERY, SCINT_SWEEP_GROUPS   initial values of scint_sweep_schedule();
  *   SCINT_STRIP_LEN = n   column tiles per mat-vec workgroup, at most the build's maximum (csrc/packed.hpp): for the test that
  *                         proves a sweep's values do not depend on the strip shape beyond rounding (tests/test_emu_cpu.py).
+ *   SCINT_SSPEC_MAXGRID = n   (read per call) an upper bound on the workgroups of calc_sspec's persistent kernels, for the test
+ *                         that runs several rows / column pairs per workgroup at small shapes; changes no bit of the result.
  * (SCINT_CHISQ_MODEL and SCINT_SSPEC_GENERIC of round 4 are gone: no test used them; the model route of the chi^2 sweep is
  *  reached with a mask or a non-finite dspec, the generic calc_sspec route with halve = 0 or lengths outside 256..8192.) */
 /* Limits common to every sweep entry point below (eval / eigvec / chisq, single and _multi): a conjugate spectrum must hold

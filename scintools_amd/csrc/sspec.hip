@@ -14,21 +14,29 @@
 //
 //   sspec_prep_kernel   pass 0: the sums behind both means AND a pair-major copy of the input, transposed
 //                       through LDS (the column kernel then streams its two real columns contiguously).
-//   sspec_cols_kernel   axis 0 (frequency -> delay).  Two adjacent REAL columns c, c+1 ride as one complex
-//                       sequence z[r] = d'[r, c] + i d'[r, c+1]; a workgroup (n/16 threads) transforms one
-//                       such pair and one half.  The real spectra are separated from Z[k], Z[2n - k] (both
-//                       inside the same half) and stored as Y[k1][c], k1 = 2m + half < R/2: exactly the
-//                       non-redundant half, [R/2, nt] complex, in tiles of (4 rows of one parity) x (pair) =
-//                       128 bytes, so that four consecutive threads store one whole line.  Window, both
-//                       means and the prewhitening stencil are fused into the loads.
-//   sspec_rows_kernel   axis 1 (time -> Doppler) of the kept rows only: one (row, half) per workgroup, |.|^2,
-//                       post-darkening, 10 log10 (own 35-instruction form) and the fftshift fused into the stores.
+//   sspec_cols2_kernel  axis 0 (frequency -> delay), persistent.  Two adjacent REAL columns c, c+1 ride as one complex
+//                       sequence z[r] = d'[r, c] + i d'[r, c+1]; a workgroup (n/16 threads) walks over such pairs and
+//                       does BOTH halves of a pair from one read of it, the next pair on its way through the second
+//                       transform.  The real spectra are separated from Z[k], Z[2n - k] (both inside the same half)
+//                       and stored as Y[k1][c], k1 = 2m + half < R/2: exactly the non-redundant half, [R/2, nt]
+//                       complex, in tiles of (4 rows of one parity) x (pair) = 128 bytes, so that four consecutive
+//                       threads store one whole line.  Window and both means are fused into the loads.
+//                       (sspec_cols_kernel: round 5's one-shot form, one (pair, half) per workgroup; it keeps the
+//                       prewhitening stencil, whose three extra loads per value are not prefetched.)
+//   sspec_rows2_kernel  axis 1 (time -> Doppler) of the kept rows only, persistent: both halves of a row from one read,
+//                       |.|^2, post-darkening, 10 log10 (table form, branch-free in groups) and the fftshift fused into
+//                       16-byte stores of (even bin, odd bin) pairs -- whole lines.
 //
-// HBM traffic at 4096^2: 134 MB in + 134 (pair-major copy out) + 134 (in) + 268 (Y out) + 268..536 (Y in:
-// twice, the second time through the L2) + 268 (dB out) = 1.2..1.5 GB for 0.40 GB algorithmic, against
-// 2.18 GB before; 0.56 ms against 0.71 (profiles/r03_sspec_ablation.txt has the kernel-by-kernel story:
-// 32-byte stores cost the column kernel 146 of 283 us, 16-byte-per-row loads 106; what is left is the
-// fragment traffic of the row kernel -- 32-byte loads, 8-byte stores -- on top of its 136-us instruction floor).
+// HBM traffic at 4096^2: 134 MB in + 134 (pair-major copy out) + 134 (in) + 268 (Y out) + 268 (Y in) + 268 (dB out) = 1.2 GB
+// for 0.40 GB algorithmic (2.18 GB with the generic driver).  Round 6 (profiles/r06_*): the persistent kernels read every
+// row / pair once (round 5's read them once per half), store whole lines, keep their twiddles in registers and hide the load
+// latency behind the second transform: 0.443 -> 0.38 ms at 4096^2, 1.85 -> 1.55 ms at 8192^2.  What the kernels' own clocks
+// say is left (profiles/r06_rows2_phase_times*.txt, r06_cols2_phase_times.txt, r06_rows2_ablation.txt): the column kernel's
+// steady state moves 192 KB per pair and workgroup in 41 600 clocks -- 9 B per clock and CU, the chip's HBM rate -- and pays
+// its four-iteration ramp; the row kernel's waves stand at the memory-issue port a third of a row's 38 000 clocks (sixteen
+// loads of 32 bytes out of every 128-byte line of the 4-row tiles: 2048 L1 misses a row; row-major Y instead costs the column
+// kernel twice that in partial-line stores, profiles/r06_sspec_rowmajor_wgs_ab.txt), its arithmetic alone is 80 us, arithmetic +
+// exchanges 115, everything 205 -- two workgroups per CU (registers: 256 each) overlap little of it.
 // Shapes outside 256 <= R/2, C/2 <= 8192 and `halve = 0` keep the generic path (fft.hip).
 #include "sspec.hpp"
 #include "prof.hpp"
@@ -52,6 +60,7 @@ struct SspecIn {
     const double* dynp;           // pair-major copy of the dynamic spectrum: [ceil(nt/2)][nf][2] (sspec_prep_kernel)
     const double* wt; const double* wf; const double* scal;   // scal[0] = mean 1, scal[1] = mean 2
     int nf, nt, nf_eff, nt_eff, prewhite;
+    const double* partial; int npartial;                      // sspec_prep_kernel's per-tile sums (the persistent column kernel adds them itself)
 };
 
 // Pass 0: one read of the dynamic spectrum gives (a) the three sums behind both means of dynspec.py:3667-3674
@@ -142,8 +151,6 @@ struct SspecCols {
     const cplx* tw_n;             // W_n
     const cplx* tw_2n;            // W_2n (the odd half's input twiddle)
     int xcd_remap;
-    int rowmajor;                 // experiment (round 6): Y row-major [R/2][2 npairs] instead of the 4-row tiles
-    int abl; double* dbg;         // experiment: abl & 64 -> shader clocks per phase to dbg (the row kernel is then not launched)
 };
 
 // Workgroup barrier of the transforms.  LB = true: wait for the LDS counter only (lds_barrier) -- a persistent
@@ -153,28 +160,7 @@ template <bool LB> __device__ inline void xbarrier() { if constexpr (LB) lds_bar
 
 // one Stockham exchange through n doubles of LDS per slot: real parts, then imaginary parts
 template <int RP, int RN, bool LB = false>
-__device__ inline void split_exchange(cplx (&v)[kEPT], double* ldsd, int t, int Tr, int n, int Ns, int abl = 0) {
-    if (abl & 4) return;
-    if (abl & 16) {
-#pragma unroll
-        for (int q = 0; q < kEPT / RP; ++q)
-#pragma unroll
-            for (int m = 0; m < RP; ++m) ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].x;
-        double re[kEPT];
-#pragma unroll
-        for (int q = 0; q < kEPT / RN; ++q)
-#pragma unroll
-            for (int m = 0; m < RN; ++m) re[q * RN + m] = ldsd[lds_pad(t + q * Tr + m * (n / RN))];
-#pragma unroll
-        for (int q = 0; q < kEPT / RP; ++q)
-#pragma unroll
-            for (int m = 0; m < RP; ++m) ldsd[lds_pad(stockham_out_index<RP>(t, Tr, Ns, q, m))] = v[q * RP + m].y;
-#pragma unroll
-        for (int q = 0; q < kEPT / RN; ++q)
-#pragma unroll
-            for (int m = 0; m < RN; ++m) v[q * RN + m] = mk(re[q * RN + m], ldsd[lds_pad(t + q * Tr + m * (n / RN))]);
-        return;
-    }
+__device__ inline void split_exchange(cplx (&v)[kEPT], double* ldsd, int t, int Tr, int n, int Ns) {
     xbarrier<LB>();
 #pragma unroll
     for (int q = 0; q < kEPT / RP; ++q)
@@ -267,7 +253,6 @@ template <int R0, int R1, int R2, int R3>
 struct StageW {
     static_assert(R0 == kEPT && R1 == kEPT && (R3 == 1 || R2 == kEPT), "only the last stage may hold several butterflies per thread");
     cplx w[3];
-    int abl = 0;
     __device__ inline void load(int t, const cplx* __restrict__ tw) {
         constexpr int n = R0 * R1 * R2 * R3;
         w[0] = stage_w<R1>(t, n, R0, tw);
@@ -287,15 +272,15 @@ __device__ inline void slot_fft_w(cplx (&v)[kEPT], double* lds, int t, const Sta
     hook(std::integral_constant<int, 0>{});
     stockham_compute<R0>(v, t, Tr, n, 1, nullptr);
     hook(std::integral_constant<int, 1>{});
-    split_exchange<R0, R1, true>(v, lds, t, Tr, n, 1, sw.abl);
+    split_exchange<R0, R1, true>(v, lds, t, Tr, n, 1);
     stockham_compute_w<R1>(v, sw.w[0]);
     hook(std::integral_constant<int, 2>{});
     if constexpr (R2 > 1) {
-        split_exchange<R1, R2, true>(v, lds, t, Tr, n, R0, sw.abl);
+        split_exchange<R1, R2, true>(v, lds, t, Tr, n, R0);
         stockham_compute_w<R2>(v, sw.w[1]);
         hook(std::integral_constant<int, 3>{});
         if constexpr (R3 > 1) {
-            split_exchange<R2, R3, true>(v, lds, t, Tr, n, R0 * R1, sw.abl);
+            split_exchange<R2, R3, true>(v, lds, t, Tr, n, R0 * R1);
             stockham_compute_w<R3>(v, sw.w[2]);
             hook(std::integral_constant<int, 4>{});
         }
@@ -443,8 +428,8 @@ sspec_cols_kernel(SspecCols a) {
 // Round 6: the strided-axis pass as a persistent, self-pipelined kernel (the reasoning is the row kernel's, sspec_rows2_kernel below):
 // a workgroup walks over column pairs and does BOTH halves of a pair from one read of it -- the windowed values stay in registers
 // through the even half's transform, the odd half takes them times W_2n^s = W_2n^t W_32^m, and the registers then receive the next
-// pair while the second transform runs.  The prewhitening stencil (PW) needs three more loads per value and is not prefetched.
-template <int R0, int R1, int R2, int R3, bool PW>
+// pair while the second transform runs.  (With the prewhitening stencil -- three more loads per value -- round 5's kernel above runs.)
+template <int R0, int R1, int R2, int R3>
 __global__ void __launch_bounds__(ColsBlock<R0 * R1 * R2 * R3>::value, 2)
 sspec_cols2_kernel(SspecCols a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -457,7 +442,20 @@ sspec_cols2_kernel(SspecCols a) {
     if (a.xcd_remap) lb = (lb & 7) * (G >> 3) + (lb >> 3);
     const SspecIn& in = a.in;
     const bool windowed = in.wt != nullptr;
-    const double m1 = in.scal[0], m2 = in.scal[1];
+    // Both means from the per-tile sums of sspec_prep_kernel, by every workgroup for itself (the same sums in the same order: the
+    // same bits everywhere) while its first pair is on the way -- a 7-us single-workgroup kernel and its launch otherwise
+    double m1, m2;
+    {
+        __shared__ double red[8];
+        double sd = 0.0, swd = 0.0, sw = 0.0;
+        for (int j = threadIdx.x; j < in.npartial; j += kColsBlock) {
+            sd += in.partial[j]; swd += in.partial[in.npartial + j]; sw += in.partial[2 * in.npartial + j];
+        }
+        sd = block_sum(sd, red); swd = block_sum(swd, red); sw = block_sum(sw, red);
+        const double cnt = (double)in.nf * (double)in.nt;
+        m1 = sd / cnt;
+        m2 = (swd - m1 * sw) / cnt;
+    }
     const cplx wt2 = a.tw_2n[t];                                  // W_2n^t
     StageW<R0, R1, R2, R3> sw;
     sw.load(t, a.tw_n);
@@ -481,19 +479,13 @@ sspec_cols2_kernel(SspecCols a) {
     cplx raw[kEPT];
     double w0 = 1.0, w1 = 1.0;
     int tile = lb;
-    if (!PW && tile < ntiles) load_pair(tile * SPB + i, t, raw, w0, w1);
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool timing = (a.abl & 64) != 0;
-    auto tick = [&](int ph) {
-        if (timing) { const long long now = (long long)__builtin_readcyclecounter(); tacc[ph] += now - tprev; tprev = now; }
-    };
-    if (timing) tprev = (long long)__builtin_readcyclecounter();
+    if (tile < ntiles) load_pair(tile * SPB + i, t, raw, w0, w1);
     for (; tile < ntiles; tile += G) {
         const int p = tile * SPB + i;
         const bool active = p < a.npairs;
         const int c0 = 2 * p;
         const bool has1 = active && c0 + 1 < in.nt_eff;          // the pair's second column exists
-        if constexpr (!PW) {
+        {
             // the frequency window at this thread's rows: sixteen unconditional loads in one batch (under the row guard they
             // were sixteen serialised round trips to the L2 per pair)
             double f[kEPT];
@@ -513,42 +505,7 @@ sspec_cols2_kernel(SspecCols a) {
                 const double d01 = sspec_d(raw[m].y, w1, f[m], m1, m2, windowed);
                 raw[m] = mk(ok ? d00 : 0.0, (ok && has1) ? d01 : 0.0);
             }
-        } else {
-            // convolve2d([[1,-1],[-1,1]], d', 'valid')  (dynspec.py:3681): pw[r, c] =
-            // d'[r+1, c+1] - d'[r+1, c] - d'[r, c+1] + d'[r, c], same association as fft.hip
-            double w2 = 1.0;
-            if (windowed && active) {
-                w0 = in.wt[c0];
-                w1 = c0 + 1 < in.nt ? in.wt[c0 + 1] : 0.0;
-                w2 = c0 + 2 < in.nt ? in.wt[c0 + 2] : 0.0;
-            }
-            const double* __restrict__ colp = in.dynp + (int64_t)(active ? p : 0) * in.nf * 2;
-            const double* __restrict__ coln = colp + (int64_t)in.nf * 2;
-#pragma unroll
-            for (int m = 0; m < kEPT; ++m) {
-                const int s = t + m * Tr;
-                cplx z = mk(0.0, 0.0);
-                if (active && s < in.nf_eff) {
-                    const double f0 = windowed ? in.wf[s] : 1.0, f1 = windowed ? in.wf[s + 1] : 1.0;
-                    const v2d xx = *(const SCINT_GLOBAL v2d*)(colp + 2 * s);
-                    const v2d yy = *(const SCINT_GLOBAL v2d*)(colp + 2 * (s + 1));
-                    const double d00 = sspec_d(xx.x, w0, f0, m1, m2, windowed);
-                    const double d01 = sspec_d(xx.y, w1, f0, m1, m2, windowed);
-                    const double d10 = sspec_d(yy.x, w0, f1, m1, m2, windowed);
-                    const double d11 = sspec_d(yy.y, w1, f1, m1, m2, windowed);
-                    double zy = 0.0;
-                    if (has1) {
-                        const double d02 = sspec_d(coln[2 * s], w2, f0, m1, m2, windowed);
-                        const double d12 = sspec_d(coln[2 * (s + 1)], w2, f1, m1, m2, windowed);
-                        zy = d12 - d11 - d02 + d01;
-                    }
-                    z = mk(d11 - d10 - d01 + d00, zy);
-                }
-                raw[m] = z;
-                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four rows' loads at a time (all sixteen: 150 spilled registers)
-            }
         }
-        tick(0);                                                     // waited for the pair, windowed it
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             cplx v[kEPT];
@@ -562,17 +519,13 @@ sspec_cols2_kernel(SspecCols a) {
                 });
                 // the next pair into the registers this one leaves, in flight through the second transform (unconditionally: the
                 // last iteration reads its own pair again -- a conditional load is a phi, i.e. a copy and a wait right here)
-                if constexpr (!PW) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    int tl = t; asm volatile("" : "+v"(tl));
-                    load_pair((tile + G < ntiles ? tile + G : tile) * SPB + i, tl, raw, w0, w1);
-                }
+                __builtin_amdgcn_sched_barrier(0);
+                int tl = t; asm volatile("" : "+v"(tl));
+                load_pair((tile + G < ntiles ? tile + G : tile) * SPB + i, tl, raw, w0, w1);
             }
             // (the thread index is opaque per transform: the LDS addresses are then recomputed instead of kept in registers)
             int th = t; asm volatile("" : "+v"(th));
-            tick(1 + 3 * half);                                      // input (odd half: + prefetch issue)
             slot_fft_wc<R0, R1, R2, R3>(v, ldsc, th, sw);
-            tick(2 + 3 * half);                                      // transform
             // natural order in LDS; thread t separates the two real spectra at m = t + k Tr < n/2 from Z[m] and its
             // partner Z[n - m] (even half) / Z[n - 1 - m] (odd half)
             lds_barrier();
@@ -589,17 +542,12 @@ sspec_cols2_kernel(SspecCols a) {
                 // X_c = (Z[k] + conj Z[-k]) / 2,  X_{c+1} = (Z[k] - conj Z[-k]) / (2i); Y in tiles of (4 delay rows of one
                 // parity) x (one pair): 128 contiguous bytes from 4 consecutive threads
                 if (active) {
-                    cplx* out = a.rowmajor ? a.Y + (int64_t)(2 * m + half) * (2 * a.npairs) + 2 * p
-                                           : a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
+                    cplx* out = a.Y + ((int64_t)(m >> 2) * a.npairs + p) * 16 + half * 8 + (m & 3) * 2;
                     gstore(out, mk(0.5 * (za.x + zb.x), 0.5 * (za.y - zb.y)));
                     gstore(out + 1, mk(0.5 * (za.y + zb.y), -0.5 * (za.x - zb.x)));
                 }
             }
-            tick(3 + 3 * half);                                      // separation + stores
         }
-    }
-    if (timing && threadIdx.x == 0) {
-        for (int ph = 0; ph < 8; ++ph) a.dbg[(int64_t)blockIdx.x * 8 + ph] = (double)tacc[ph];
     }
 }
 
@@ -611,8 +559,6 @@ struct SspecRows {
     double* out;                  // [R/2][C] dB
     int prewhite; const double* pd_fd; const double* pd_td;
     int xcd_remap;
-    int rowmajor;                 // experiment (round 6): Y row-major [R/2][2 npairs] instead of the 4-row tiles
-    int abl;                      // experiment: ablation bits (1 no loop loads, 2 no stores, 4 no exchanges, 8 no logs, 16 no barriers)
 };
 
 // 10 log10(x), series form (round 3, first version; now the path of zero, subnormal and non-finite powers and the
@@ -786,6 +732,22 @@ __device__ const double kTenLogTab[128][2] = {
     {0x1.0182436517a37p-1, 0x1.7e0d3609846cdp+1},
     {0x1.0080402010080p-1, 0x1.803b49e9bc09dp+1},
 };
+// The table form without its branch: returns the table-form value for ANY bit pattern (garbage for zero, subnormal and non-finite
+// powers) and ORs `special` for those; the caller recomputes the flagged ones with the series form under ONE branch per group -- a
+// branch per logarithm puts every logarithm in its own scheduling region, and the sixteen of a thread then run as sixteen chains
+// of dependent operations one after the other (7500 clocks per half row where the arithmetic is 1500: profiles/r06_rows2_phase_times*.txt)
+__device__ inline double ten_log10_fast(double x, const double (*tab)[2], bool& special) {
+    const unsigned hi = (unsigned)__double2hiint(x);
+    const unsigned ef = hi >> 20;                                   // sign and exponent field
+    special = special || (ef - 1u >= 2046u);
+    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(x));
+    const unsigned i = (hi >> 13) & 127u;
+    const double r = fma(m, tab[i][0], -1.0);
+    constexpr double k = 4.3429448190325182765112891891661;         // 10 / ln 10
+    double p = k / 5.0;
+    p = fma(p, r, -k / 4.0); p = fma(p, r, k / 3.0); p = fma(p, r, -k / 2.0); p = fma(p, r, k);
+    return fma(p, r, fma((double)((int)ef - 1023), 3.0102999566398119521373889472449, tab[i][1]));
+}
 __device__ inline double ten_log10(double x, const double (*tab)[2]) {
     const unsigned hi = (unsigned)__double2hiint(x);
     const unsigned ef = hi >> 20;                                   // sign and exponent field
@@ -797,68 +759,6 @@ __device__ inline double ten_log10(double x, const double (*tab)[2]) {
     double p = k / 5.0;
     p = fma(p, r, -k / 4.0); p = fma(p, r, k / 3.0); p = fma(p, r, -k / 2.0); p = fma(p, r, k);
     return fma(p, r, fma((double)((int)ef - 1023), 3.0102999566398119521373889472449, tab[i][1]));
-}
-
-// One (delay row, half) per slot: the even Doppler bins come from the transform of the row, the odd ones
-// from the transform of the row times W_2n^s.  The two halves of a row are separate slots that run side by
-// side on one XCD (block remap), each stores its bins as 8-byte values 16 bytes apart.  Measured at 4096^2
-// (profiles/r03_sspec_ablation.txt): both halves in one workgroup with the first half's powers held in
-// registers spills at any occupancy worth having (434 us with 68 KiB of LDS and two workgroups per CU);
-// both halves in sequence, each storing as soon as it has its bins, 313 us; side by side 255 us.  The
-// instruction floor of the kernel is 136 us (no loads, no stores).
-template <int R0, int R1, int R2, int R3>
-__global__ void __launch_bounds__((R0 * R1 * R2 * R3 / kEPT) >= 256 ? (R0 * R1 * R2 * R3 / kEPT) : 256, (R0 * R1 * R2 * R3 / kEPT) >= 512 ? 2 : 3)   // three waves per SIMD: 168 registers, no spills (41 spilled at 128); 8192 points: 512 threads, 70 KiB of LDS: two workgroups per CU
-sspec_rows_kernel(SspecRows a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
-    using LS = LastStage<R0, R1, R2, R3>;
-    const int i = (int)threadIdx.x / Tr, t = (int)threadIdx.x - i * Tr;
-    const int spb = (int)blockDim.x / Tr;
-    int lb = (int)blockIdx.x;
-    if (a.xcd_remap) lb = (lb & 7) * ((int)gridDim.x >> 3) + (lb >> 3);
-    const int slot = lb * spb + i;
-    const int k1 = slot >> 1, half = slot & 1;
-    const bool active = k1 < a.nrows;
-    double* lds = reinterpret_cast<double*>(smem_raw) + (size_t)i * lds_pad(n);
-    __shared__ double tlog[128][2];                                 // ten_log10's table (visible after the transform's barriers)
-    if (threadIdx.x < 128) { tlog[threadIdx.x][0] = kTenLogTab[threadIdx.x][0]; tlog[threadIdx.x][1] = kTenLogTab[threadIdx.x][1]; }
-    // row k1 = 2 m + h of the tiled intermediate: element c at tile (m >> 2, c >> 1), slot h, m & 3, c & 1
-    const int kk = active ? k1 : 0;
-    const cplx* __restrict__ row = a.Y + (int64_t)(kk >> 3) * a.npairs * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2;
-    const double td = (a.prewhite && active) ? a.pd_td[k1] : 1.0;
-    double* __restrict__ orow = a.out + (int64_t)kk * a.C;
-    cplx v[kEPT];
-#pragma unroll
-    for (int q = 0; q < kEPT / R0; ++q) {
-#pragma unroll
-        for (int m = 0; m < R0; ++m) {
-            const int s = t + q * Tr + m * (n / R0);
-            cplx z = (active && s < a.nt_eff) ? gload(row + (s >> 1) * 16 + (s & 1)) : mk(0.0, 0.0);
-            if (half) z = z * a.tw_2n[s];
-            v[q * R0 + m] = z;
-        }
-    }
-    slot_fft<R0, R1, R2, R3>(v, lds, t, a.tw_n);
-    if (!active) return;
-#pragma unroll
-    for (int q = 0; q < kEPT / LS::RL; ++q) {
-#pragma unroll
-        for (int m = 0; m < LS::RL; ++m) {
-            const int e = q * LS::RL + m;
-            const int mm = stockham_out_index<LS::RL>(t, Tr, LS::Ns, q, m);
-            // Doppler bin 2 mm + half at its fftshift-ed place (dynspec.py:3687); C/2 = n is even
-            const int col = ((2 * mm + n) & (a.C - 1)) + half;
-            double p = v[e].x * v[e].x + v[e].y * v[e].y;
-            if (a.prewhite) {   // post-darkening, column C/2 and row 0 forced to 1 (dynspec.py:3704-3717)
-                const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
-                p = p / d;
-            }
-            *(SCINT_GLOBAL double*)(orow + col) = ten_log10(p, tlog);    // (non-temporal: same at 4096^2, 2.5 % slower at 8192^2)
-            __builtin_amdgcn_sched_barrier(0);   // one bin at a time: sixteen interleaved log sequences spill (round 5, call 6: fences every 2 / 4 / 8 / 16
-                                                 // bins instead -- 140 registers, no spill in any -- are all within 1 % at 4096^2 and 8192^2: the kernel does
-                                                 // not wait on its logarithms; profiles/r05_sspec_log_group_ab.txt)
-        }
-    }
 }
 
 // Round 6: the row pass as a PERSISTENT, self-pipelined kernel.  What the counters of round 5 said about the kernel above
@@ -883,6 +783,7 @@ sspec_rows2_kernel(SspecRows a) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
     static_assert(R0 == kEPT, "one radix-16 butterfly per thread in stage 0: input s = t + m n/16");
     using LS = LastStage<R0, R1, R2, R3>;
+    constexpr int kLG = SCINT_ROWS2_LOG_GROUP;                      // logarithms per scheduling group
     const int i = (int)threadIdx.x / Tr, t = (int)threadIdx.x - i * Tr;
     const int spb = (int)blockDim.x / Tr, G = (int)gridDim.x;
     int lb = (int)blockIdx.x;
@@ -897,7 +798,6 @@ sspec_rows2_kernel(SspecRows a) {
     const cplx wt = a.tw_2n[t];                                     // W_2n^t, t < n/16
     StageW<R0, R1, R2, R3> sw;
     sw.load(t, a.tw_n);
-    sw.abl = a.abl;
     const int ngroups = (a.nrows + spb - 1) / spb;
     // row k1 = 2 m + h of the tiled intermediate: element c at tile (m >> 2, c >> 1), slot h, m & 3, c & 1.  Every load is
     // unconditional (a load under a branch makes the compiler wait for everything in flight) and goes through a buffer resource:
@@ -910,10 +810,9 @@ sspec_rows2_kernel(SspecRows a) {
     //  the data where it is issued.  The zeroing of a short row's tail happens where the values are consumed.)
     auto row_voff = [&](int k1, int tl) {
         const int kk = k1 < a.nrows ? k1 : 0;
-        return a.rowmajor ? (kk * 2 * a.npairs + tl) * (int)sizeof(cplx)
-            : (((kk >> 3) * a.npairs + (tl >> 1)) * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2 + (tl & 1)) * (int)sizeof(cplx);
+        return (((kk >> 3) * a.npairs + (tl >> 1)) * 16 + (kk & 1) * 8 + ((kk >> 1) & 3) * 2 + (tl & 1)) * (int)sizeof(cplx);
     };
-    const int step = a.rowmajor ? Tr * (int)sizeof(cplx) : kStep;
+    constexpr int step = kStep;
     // elements m with m * NP / 16 == P: piece P of NP of a row's loads
     auto load_piece = [&](auto pc, auto npc, int voff, int tl, cplx (&r)[kEPT]) {
         constexpr int P = decltype(pc)::value, NP = decltype(npc)::value;
@@ -944,7 +843,7 @@ sspec_rows2_kernel(SspecRows a) {
                     if (e * NP / kEPT != P) continue;
                     const int col = (2 * stockham_out_index<LS::RL>(tq, Tr, LS::Ns, q, m) + n) & (a.C - 1);
                     v2d o; o.x = evl[e * evs]; o.y = od[e];
-                    if (!(a.abl & 2)) *(SCINT_GLOBAL v2d*)(orow + col) = o;
+                    *(SCINT_GLOBAL v2d*)(orow + col) = o;
                 }
             }
         }
@@ -953,13 +852,6 @@ sspec_rows2_kernel(SspecRows a) {
     cplx raw[kEPT];
     int grp = lb;
     if (grp < ngroups) load_row(grp * spb + i, t, raw);
-    // experiment (abl & 32): shader clocks spent per phase, summed over the rows of this workgroup, written by its first thread
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    const bool timing = (a.abl & 32) != 0;
-    auto tick = [&](int ph) {
-        if (timing) { const long long now = (long long)__builtin_readcyclecounter(); tacc[ph] += now - tprev; tprev = now; }
-    };
-    if (timing) tprev = (long long)__builtin_readcyclecounter();
     for (; grp < ngroups; grp += G) {
         const int k1 = grp * spb + i;
         const bool active = k1 < a.nrows;
@@ -981,8 +873,6 @@ sspec_rows2_kernel(SspecRows a) {
             v[m] = mk(rx, ry);
         }
         __builtin_amdgcn_sched_barrier(0);
-        tick(0);                                                    // waited for the row
-        tick(1);
         // the thread index of each transform is opaque to the compiler: it would otherwise keep every LDS address of the exchanges
         // alive across both transforms and the whole loop (hundreds of registers, see the note above sspec_rows_kernel)
         int th = t; asm volatile("" : "+v"(th));
@@ -995,25 +885,32 @@ sspec_rows2_kernel(SspecRows a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-        tick(2);                                                    // even half transformed
+        static_for<0, kEPT / kLG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            double pw[kLG], lg[kLG];
+            bool special = false;
 #pragma unroll
-        for (int q = 0; q < kEPT / LS::RL; ++q) {
-#pragma unroll
-            for (int m = 0; m < LS::RL; ++m) {
-                const int e = q * LS::RL + m;
-                const int mm = stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m);
+            for (int j = 0; j < kLG; ++j) {
+                constexpr int RL = LS::RL;
+                const int e = g * kLG + j, q = e / RL, m = e % RL;
+                const int mm = stockham_out_index<RL>(th, Tr, LS::Ns, q, m);
                 const int col = (2 * mm + n) & (a.C - 1);           // Doppler bin 2 mm at its fftshift-ed place (dynspec.py:3687)
                 double p = v[e].x * v[e].x + v[e].y * v[e].y;
                 if (a.prewhite) {   // post-darkening, column C/2 and row 0 forced to 1 (dynspec.py:3704-3717)
                     const double d = (col == n || k1 == 0) ? 1.0 : a.pd_fd[col] * td;
                     p = p / d;
                 }
-                evl[e * evs] = (a.abl & 8) ? p : ten_log10(p, tlog);
-                if ((e % SCINT_ROWS2_LOG_GROUP) == SCINT_ROWS2_LOG_GROUP - 1)
-                    __builtin_amdgcn_sched_barrier(0);              // a few logarithms at a time: one is a chain of dependent operations (two waves per SIMD do not hide it), sixteen spill
+                pw[j] = p;
+                lg[j] = ten_log10_fast(p, tlog, special);
             }
-        }
-        tick(3);                                                    // even half's logarithms
+            if (special) {                                          // zero, subnormal, infinite or NaN power somewhere in the group
+#pragma unroll
+                for (int j = 0; j < kLG; ++j) lg[j] = ten_log10(pw[j], tlog);
+            }
+#pragma unroll
+            for (int j = 0; j < kLG; ++j) evl[(g * kLG + j) * evs] = lg[j];
+            __builtin_amdgcn_sched_barrier(0);                      // a group of logarithms at a time (all sixteen at once spill)
+        });
         // the odd half: the row times W_2n^s, s = t + m n/16
         static_for<0, kEPT>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -1023,40 +920,44 @@ sspec_rows2_kernel(SspecRows a) {
         // a conditional load is a phi, the compiler then loads elsewhere and copies, i.e. waits, right here)
         __builtin_amdgcn_sched_barrier(0);
         th = t; asm volatile("" : "+v"(th));
-        tick(4);                                                    // odd half's input
         constexpr int kLP = SCINT_ROWS2_LOAD_PIECES < HookCount<R0, R1, R2, R3>::value ? SCINT_ROWS2_LOAD_PIECES : HookCount<R0, R1, R2, R3>::value - 1;
         const int nvoff = row_voff((grp + G < ngroups ? grp + G : grp) * spb + i, th);
         slot_fft_w<R0, R1, R2, R3>(v, lds, th, sw, [&](auto c) {
             if constexpr (decltype(c)::value < kLP) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(a.abl & 1)) load_piece(c, std::integral_constant<int, kLP>{}, nvoff, th, raw);
+                load_piece(c, std::integral_constant<int, kLP>{}, nvoff, th, raw);
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
-        tick(5);                                                    // odd half transformed
+        static_for<0, kEPT / kLG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            double pw[kLG], lg[kLG];
+            bool special = false;
 #pragma unroll
-        for (int q = 0; q < kEPT / LS::RL; ++q) {
-#pragma unroll
-            for (int m = 0; m < LS::RL; ++m) {
-                const int e = q * LS::RL + m;
-                const int mm = stockham_out_index<LS::RL>(th, Tr, LS::Ns, q, m);
+            for (int j = 0; j < kLG; ++j) {
+                constexpr int RL = LS::RL;
+                const int e = g * kLG + j, q = e / RL, m = e % RL;
+                const int mm = stockham_out_index<RL>(th, Tr, LS::Ns, q, m);
                 const int col = (2 * mm + n) & (a.C - 1);
                 double p = v[e].x * v[e].x + v[e].y * v[e].y;
                 if (a.prewhite) {
                     const double d = (k1 == 0) ? 1.0 : a.pd_fd[col + 1] * td;    // (col + 1 is odd: never C/2)
                     p = p / d;
                 }
-                od[e] = (a.abl & 8) ? p : ten_log10(p, tlog);
-                if ((e % SCINT_ROWS2_LOG_GROUP) == SCINT_ROWS2_LOG_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+                pw[j] = p;
+                lg[j] = ten_log10_fast(p, tlog, special);
             }
-        }
+            if (special) {
+#pragma unroll
+                for (int j = 0; j < kLG; ++j) lg[j] = ten_log10(pw[j], tlog);
+            }
+#pragma unroll
+            for (int j = 0; j < kLG; ++j) od[g * kLG + j] = lg[j];
+            __builtin_amdgcn_sched_barrier(0);
+        });
         pk = active ? k1 : -1;
-        tick(6);                                                    // odd half's logarithms
     }
     flush();
-    if (timing && threadIdx.x == 0) {
-        for (int ph = 0; ph < 8; ++ph) a.out[(int64_t)blockIdx.x * 8 + ph] = (double)tacc[ph];
-    }
 }
 
 template <int R0, int R1, int R2, int R3>
@@ -1073,37 +974,16 @@ static int32_t launch_cols(const SspecCols& a, hipStream_t stream) {
     return SCINT_OK;
 }
 
-template <int R0, int R1, int R2, int R3>
-static int32_t launch_rows(const SspecRows& a, hipStream_t stream) {
-    constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
-    const int block = Tr >= 256 ? Tr : 256, spb = block / Tr;
-    SspecRows b = a;
-    const int grid = (int)ceil_div((int64_t)a.nrows * 2, spb);
-    b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
-    // real / imaginary parts take turns in LDS (34 KiB per slot at n = 4096: three workgroups per CU)
-    const size_t lds = (size_t)spb * (size_t)(n + n / 16) * sizeof(double);
-    auto k = sspec_rows_kernel<R0, R1, R2, R3>;
-    if (lds > 64 * 1024)
-        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(block), lds, stream, b);
-    SCINT_LAUNCH_CHECK();
-    return SCINT_OK;
-}
-
-// Experiment switches of round 6 (read once per process; removed once the A/B is settled)
-struct SspecKnobs { int rows, cols, wgs_rows, wgs_cols, max_grid, rowmajor, abl; };
-static const SspecKnobs& sspec_knobs() {
-    static const SspecKnobs k = [] {
-        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-        return SspecKnobs{env_int("SCINT_SSPEC_ROWS", 2), env_int("SCINT_SSPEC_COLS", 2), env_int("SCINT_SSPEC_WGS_ROWS", 0),
-                          env_int("SCINT_SSPEC_WGS_COLS", 0), env_int("SCINT_SSPEC_MAXGRID", 0), env_int("SCINT_SSPEC_ROWMAJOR", 0), env_int("SCINT_SSPEC_ABL", 0)};
-    }();
-    return k;
+// SCINT_SSPEC_MAXGRID (tests; read per call): an upper bound on the workgroups of the persistent kernels, so that small
+// shapes run several iterations per workgroup on the host interpreter of the kernels (tests/test_emu_cpu.py)
+static int sspec_max_grid() {
+    const char* e = getenv("SCINT_SSPEC_MAXGRID");
+    return e ? atoi(e) : 0;
 }
 constexpr int kSspecCUs = 256;     // compute units of an MI355X: the persistent kernels launch (workgroups per CU) x this many
 static int persistent_grid(int units, int per_cu) {
     int g = per_cu * kSspecCUs;
-    if (sspec_knobs().max_grid > 0 && g > sspec_knobs().max_grid) g = sspec_knobs().max_grid;   // (tests: several iterations per workgroup at small shapes)
+    if (sspec_max_grid() > 0 && g > sspec_max_grid()) g = sspec_max_grid();
     if (g > units) g = units;
     if (g >= 8) g &= ~7;           // whole XCD rounds (the logical-block remap)
     return g < 1 ? 1 : g;
@@ -1113,22 +993,14 @@ template <int R0, int R1, int R2, int R3>
 static int32_t launch_cols2(const SspecCols& a, hipStream_t stream) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT, kColsBlock = ColsBlock<n>::value, SPB = kColsBlock / Tr;
     const int tiles = (int)ceil_div(a.npairs, SPB);
-    const int per_cu = sspec_knobs().wgs_cols > 0 ? sspec_knobs().wgs_cols : (kColsBlock >= 512 ? 1 : 2);
+    const int per_cu = kColsBlock >= 512 ? 1 : 2;      // two waves per SIMD (registers)
     const int grid = persistent_grid(tiles, per_cu);
     SspecCols b = a;
     b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
-    b.rowmajor = sspec_knobs().rowmajor;
-    b.abl = sspec_knobs().abl;
     const size_t lds = (size_t)SPB * (size_t)(n + n / 16) * sizeof(cplx);      // whole complex values (68 KiB at n = 4096: two per CU)
-    if (a.in.prewhite) {
-        auto k = sspec_cols2_kernel<R0, R1, R2, R3, true>;
-        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kColsBlock), lds, stream, b);
-    } else {
-        auto k = sspec_cols2_kernel<R0, R1, R2, R3, false>;
-        SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kColsBlock), lds, stream, b);
-    }
+    auto k = sspec_cols2_kernel<R0, R1, R2, R3>;
+    SCINT_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kColsBlock), lds, stream, b);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
@@ -1138,12 +1010,10 @@ static int32_t launch_rows2(const SspecRows& a, hipStream_t stream) {
     constexpr int n = R0 * R1 * R2 * R3, Tr = n / kEPT;
     const int block = Tr >= 256 ? Tr : 256, spb = block / Tr;
     const int groups = (int)ceil_div((int64_t)a.nrows, spb);
-    const int per_cu = sspec_knobs().wgs_rows > 0 ? sspec_knobs().wgs_rows : (block >= 512 ? 1 : 2);
+    const int per_cu = block >= 512 ? 1 : 2;           // two waves per SIMD (registers)
     const int grid = persistent_grid(groups, per_cu);
     SspecRows b = a;
     b.xcd_remap = (grid % 8 == 0) ? 1 : 0;
-    b.rowmajor = sspec_knobs().rowmajor;
-    b.abl = sspec_knobs().abl;
     const size_t lds = ((size_t)spb * (size_t)(n + n / 16) + (size_t)kEPT * (size_t)block) * sizeof(double);
     auto k = sspec_rows2_kernel<R0, R1, R2, R3>;
     if (lds > 64 * 1024)
@@ -1164,13 +1034,12 @@ static int32_t launch_rows2(const SspecRows& a, hipStream_t stream) {
         default: break;                                                  \
     }
 static int32_t dispatch_cols(int64_t n, const SspecCols& a, hipStream_t s) {
-    if (sspec_knobs().cols == 2) { SCINT_SSPEC_DISPATCH(n, launch_cols2, a, s) }
+    if (!a.in.prewhite) { SCINT_SSPEC_DISPATCH(n, launch_cols2, a, s) }
     SCINT_SSPEC_DISPATCH(n, launch_cols, a, s)
     SCINT_REQUIRE(false, "sspec: unsupported column transform length");
 }
 static int32_t dispatch_rows(int64_t n, const SspecRows& a, hipStream_t s) {
-    if (sspec_knobs().rows == 2) { SCINT_SSPEC_DISPATCH(n, launch_rows2, a, s) }
-    SCINT_SSPEC_DISPATCH(n, launch_rows, a, s)
+    SCINT_SSPEC_DISPATCH(n, launch_rows2, a, s)
     SCINT_REQUIRE(false, "sspec: unsupported row transform length");
 }
 
@@ -1214,21 +1083,21 @@ int32_t sspec_fast(const double* dyn, int64_t nf, int64_t nt, const double* win_
     const int p0 = profiler().begin(kProfSspecPrep, stream);
     hipLaunchKernelGGL(sspec_prep_kernel, dim3((unsigned)ws.tiles_x, (unsigned)ws.tiles_y), dim3(256), 0, stream, dyn, win_t,
                        win_f, (int)nf, (int)nt, dynp, partial);
-    hipLaunchKernelGGL(sspec_prep_means_kernel, dim3(1), dim3(256), 0, stream, partial, ws.tiles_x * ws.tiles_y,
-                       (double)(nf * nt), scal);
+    const bool cols_persistent = !prewhite;     // (the prewhitening stencil keeps round 5's column kernel: three more loads per value, not prefetched)
+    if (!cols_persistent)
+        hipLaunchKernelGGL(sspec_prep_means_kernel, dim3(1), dim3(256), 0, stream, partial, ws.tiles_x * ws.tiles_y,
+                           (double)(nf * nt), scal);
     profiler().end(kProfSspecPrep, p0, stream);
     SCINT_LAUNCH_CHECK();
     SspecCols ca{};
-    ca.in = SspecIn{dynp, win_t, win_f, scal, (int)nf, (int)nt, (int)nf_eff, (int)nt_eff, prewhite};
+    ca.in = SspecIn{dynp, win_t, win_f, scal, (int)nf, (int)nt, (int)nf_eff, (int)nt_eff, prewhite, partial, ws.tiles_x * ws.tiles_y};
     ca.npairs = (int)ceil_div(nt_eff, 2);
     ca.Y = (cplx*)(base + ws.Y); ca.ldY = 2 * ca.npairs;
     ca.tw_n = tw_r; ca.tw_2n = tw_2r;
-    ca.dbg = sec_out;
     const int p1 = profiler().begin(kProfSspecCols, stream);
     int32_t rc = dispatch_cols(nr, ca, stream);
     profiler().end(kProfSspecCols, p1, stream);
     if (rc != SCINT_OK) return rc;
-    if (sspec_knobs().abl & 64) return rc;
     SspecRows ra{};
     ra.Y = ca.Y; ra.npairs = ca.npairs; ra.nt_eff = (int)nt_eff; ra.nrows = (int)nr; ra.C = (int)(2 * nc);
     ra.tw_n = tw_c; ra.tw_2n = tw_2c; ra.out = sec_out;

@@ -141,6 +141,45 @@ def test_secondary_spectrum_two_trip_path(emu, nf, nt, kw):
     assert np.abs(sec - ref)[strong].max() <= 1e-8
 
 
+@pytest.mark.parametrize("grid", [1, 3, 8])
+@pytest.mark.parametrize("kw", [{}, {"prewhite": True}])
+def test_secondary_spectrum_persistent_kernels_do_not_depend_on_the_grid(emu, monkeypatch, grid, kw):
+    """calc_sspec's persistent kernels (sspec.hip: a workgroup walks over rows / column pairs, the next one prefetched into the
+    registers the current one leaves, a row's stores issued one iteration later): with 1, 3 and 8 workgroups (several iterations
+    each, with and without the XCD remap of whole rounds) the result equals the default launch's bit for bit, short rows and
+    columns (zeroed tails) included."""
+    import torch
+    from scintools_amd.dynspec import sspec_device
+    rng = np.random.default_rng(7)
+    dyn = rng.standard_normal((300, 520)) + 2.0
+    monkeypatch.delenv("SCINT_SSPEC_MAXGRID", raising=False)
+    ref = sspec_device(emu.to_device(dyn, torch.float64), **kw).cpu().numpy()
+    monkeypatch.setenv("SCINT_SSPEC_MAXGRID", str(grid))
+    got = sspec_device(emu.to_device(dyn, torch.float64), **kw).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_secondary_spectrum_zero_subnormal_and_nonfinite_powers(emu):
+    """The branch-free logarithm of the row kernel hands zero, subnormal and non-finite powers to the series form: -inf, NaN and
+    the subnormal values come out where NumPy puts them."""
+    import warnings
+    import torch
+    from oracle import sspec_oracle
+    from scintools_amd.dynspec import sspec_device
+    rng = np.random.default_rng(1)
+    nan_in = 1.0 + rng.standard_normal((130, 200))
+    nan_in[3, 177] = np.nan
+    for dyn in (np.full((130, 200), 2.5), nan_in, 1e-160 * rng.standard_normal((130, 200))):
+        sec = sspec_device(emu.to_device(dyn, torch.float64)).cpu().numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = sspec_oracle.calc_sspec(dyn, 30.0, 1.0)[2]
+        assert np.array_equal(np.isneginf(sec), np.isneginf(ref)) and np.array_equal(np.isnan(sec), np.isnan(ref))
+        fin = np.isfinite(ref)
+        if fin.any():
+            assert np.abs(sec - ref)[fin].max() <= 1e-8
+
+
 def test_device_crop_tables_equal_the_host_ones(emu, case):
     """scint_sweep_keep against the NumPy expression of thth_redmap's crop (ththmod.py:153-155): same indices,
     same counts, for curvatures from 'keeps everything' to 'keeps nothing'."""

@@ -245,3 +245,27 @@ def test_rank_deficient_theta_theta_against_lapack(env):
         for e, got in zip(etas, eigs):
             lam = np.linalg.eigvalsh(to.thth_redmap(CS, tau, fd, e, edges)[0])
             assert got == pytest.approx(abs(lam[-1]), rel=1e-9)
+
+
+def test_secondary_spectrum_zero_subnormal_and_nonfinite_powers():
+    """calc_sspec of a constant dynamic spectrum (every power exactly 0 -> -inf), of one with a NaN sample (NaN everywhere) and of
+    one whose powers are subnormal: the branch-free logarithm of sspec_rows2_kernel hands such values to the series form, and the
+    result has -inf / NaN where NumPy has them (dynspec.py:3685-3721)."""
+    import warnings
+    import torch
+    from oracle import sspec_oracle
+    from scintools_amd.device import require_gpu
+    from scintools_amd.dynspec import sspec_device
+    dev = require_gpu()
+    rng = np.random.default_rng(1)
+    nan_in = 1.0 + rng.standard_normal((300, 260))
+    nan_in[3, 177] = np.nan
+    for dyn in (np.full((300, 260), 2.5), nan_in, 1e-160 * rng.standard_normal((300, 260))):
+        sec = sspec_device(torch.from_numpy(dyn).to(dev)).cpu().numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = sspec_oracle.calc_sspec(dyn, 30.0, 1.0)[2]
+        assert np.array_equal(np.isneginf(sec), np.isneginf(ref)) and np.array_equal(np.isnan(sec), np.isnan(ref))
+        fin = np.isfinite(ref)
+        if fin.any():
+            assert np.abs(sec - ref)[fin].max() <= 1e-8
