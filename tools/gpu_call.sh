@@ -1,16 +1,11 @@
 #!/bin/bash
-# scratch (round 6, call 10): branch-free grouped logarithms, means folded into the column kernel
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-cp scintools_amd/libscint_hip.so /tmp/default.so
 {
-for rep in 1 2; do
-for v in default lg2 lg8 lg16; do
-  if [ $v = default ]; then cp /tmp/default.so scintools_amd/libscint_hip.so; else cp variants/$v.so scintools_amd/libscint_hip.so; fi
-  echo "== $v: $(timeout 100 python tools/time_fft.py 4096 8192 2048 sspec prewhite 2>&1 | grep -v amdgpu | cut -c1-40 | tr '\n' ' ')"
+for rep in 1 2; do for d in 0 1; do echo "== direct=$d: $(SCINT_SSPEC_DIRECT=$d timeout 100 python tools/time_fft.py 4096 8192 sspec 2>&1 | grep -v amdgpu | cut -c1-40 | tr '\n' ' ')"; done; done
+for d in 0 1; do
+( cd /tmp && SCINT_SSPEC_DIRECT=$d timeout 100 rocprofv3 --kernel-trace --stats -d $O/r06k_d$d -o fft -- python $R/tools/time_fft.py 4096 8192 sspec > $O/r06k_d$d.log 2>&1 )
+python tools/rocpd_summary.py $(find $O/r06k_d$d -name "*.db" | head -1) $O/r06k_d$d.csv $O/r06k_d$d.json > /dev/null 2>&1
+echo "direct=$d"; grep -E "cols2|prep" $O/r06k_d$d.csv | cut -d, -f1-5 | cut -c1-110
 done
-done
-cp /tmp/default.so scintools_amd/libscint_hip.so
-echo "== default (4 logarithms per group)"; SCINT_SSPEC_ABL=32 timeout 100 python tools/experiments/rows2_phase_times.py 4096 2>&1 | grep -v amdgpu
-} | tee $O/r06j_log_groups_ab.txt
-timeout 600 python -m pytest tests -m gpu -q -x -k "sspec or arcfit or secondary" > $O/r06j_pytest_sspec.log 2>&1; tail -2 $O/r06j_pytest_sspec.log
+} | tee $O/r06k_direct_ab.txt
