@@ -148,8 +148,10 @@ class Simulation:
                         a, cols = it.next(timeout=120 + 0.05 * self.nx * self.ny * (self.nf / len(jobs)) / 1e4)
                         spe[:, a:a + cols.shape[1]] = cols
                         done[a:a + cols.shape[1]] = True
-            except Exception:      # noqa: BLE001 -- whatever went wrong, the serial loop below still gives the same array
-                pass
+            except Exception as exc:      # noqa: BLE001 -- whatever went wrong, the serial loop below still gives the same array
+                import warnings
+                warnings.warn(f"sim_oracle: worker pool failed ({exc!r}); {int((~done).sum())} of {self.nf} frequencies fall back to "
+                              "the serial loop (same values, minutes slower)", RuntimeWarning)
             for ifreq in np.nonzero(~done)[0]:
                 spe[:, ifreq] = self._field_column(int(ifreq))
         else:

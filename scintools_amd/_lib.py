@@ -98,6 +98,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 104          # scint_version() of the library these signatures describe (csrc/capi.hip)
 
 
 def header_symbols():
@@ -127,6 +128,12 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = restype
+    # The signatures above describe ONE version of the C ABI (an argument added in the middle of a list shifts every
+    # pointer after it): a stale build must fail here, not corrupt memory in its first call.
+    got = lib.scint_version()
+    if got != ABI_VERSION:
+        raise ScintHipError(f"{LIB_PATH} implements version {got} of the C ABI, this package binds version {ABI_VERSION}: "
+                            "rebuild it with `python -m scintools_amd.build`")
     _lib = lib
     return lib
 

@@ -1497,6 +1497,17 @@ struct ChisqTail : SweepTail {
     }
 };
 
+// The shared partner table trusts the caller's crop_group (a public entry point: include/scint_hip.h): members of a group must
+// hold the SAME reduced centres.  Checked on the device before a table is shared: row `rows[b]` of th_red against row `rows[0]`,
+// n values, bit for bit; any difference clears the group's flag.
+struct RowList { int32_t rows[256]; };
+__global__ void __launch_bounds__(256) rows_equal_kernel(const double* __restrict__ th_red, int64_t ld, RowList rl, int n, int32_t* flag) {
+    const unsigned long long* a = (const unsigned long long*)(th_red + (int64_t)rl.rows[0] * ld);
+    const unsigned long long* b = (const unsigned long long*)(th_red + (int64_t)rl.rows[blockIdx.x] * ld);
+    bool diff = false;
+    for (int k = threadIdx.x; k < n; k += 256) diff |= a[k] != b[k];
+    if (diff) atomicExch(flag, 0);
+}
 constexpr int kRevWalkTables = 2;      // crops that get a partner table (the largest same-crop groups of a sweep)
 constexpr int kRevWalkMinGroup = 8;    // ... if at least this many curvatures share the crop (a table costs about one back-map's walk)
 struct ChisqSweepLayout {
@@ -1633,12 +1644,36 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
                 for (const auto& kv : groups)
                     if ((int)kv.second.size() >= kRevWalkMinGroup) big.push_back(&kv.second);
                 std::sort(big.begin(), big.end(), [](const std::vector<int64_t>* a, const std::vector<int64_t>* b) { return a->size() > b->size(); });
-                for (size_t ti = 0; ti < big.size() && ti < (size_t)kRevWalkTables; ++ti) {
+                // (1) the promise, checked: equal counts on the host, equal rows on the device (flags in the job table's space, which
+                //     is filled after them; one small read-back)
+                int32_t* flags_dev = (int32_t*)(base + L.jobs);
+                int32_t flags[kRevWalkTables];
+                size_t ntab = 0;
+                for (size_t ti = 0; ti < big.size() && ti < (size_t)kRevWalkTables; ++ti) { flags[ti] = 1; ++ntab; }
+                if (ntab) SCINT_HIP(hipMemcpyAsync(flags_dev, flags, sizeof(int32_t) * ntab, hipMemcpyHostToDevice, st));
+                for (size_t ti = 0; ti < ntab; ++ti) {
+                    const std::vector<int64_t>& members = *big[ti];
+                    const int64_t n0 = keep_n[members[0]];
+                    for (size_t m0 = 1; m0 < members.size(); m0 += 255) {
+                        RowList rl;
+                        rl.rows[0] = (int32_t)members[0];
+                        int cnt = 1;
+                        for (size_t m = m0; m < members.size() && cnt < 256; ++m) rl.rows[cnt++] = (int32_t)members[m];
+                        hipLaunchKernelGGL(rows_equal_kernel, dim3((unsigned)cnt), dim3(256), 0, st, th_red, M, rl, (int)n0, flags_dev + ti);
+                    }
+                }
+                if (ntab) {
+                    SCINT_LAUNCH_CHECK();
+                    SCINT_HIP(hipMemcpyAsync(flags, flags_dev, sizeof(int32_t) * ntab, hipMemcpyDeviceToHost, st));
+                    SCINT_HIP(hipStreamSynchronize(st));
+                }
+                // (2) one table per verified group
+                for (size_t ti = 0; ti < ntab; ++ti) {
                     const std::vector<int64_t>& members = *big[ti];
                     const int64_t e0 = members[0], n0 = keep_n[e0];
-                    bool same = true;
-                    for (int64_t e : members) same = same && keep_n[e] == n0;      // (a caller's promise, checked as far as the host can)
-                    if (!same) continue;
+                    bool same = flags[ti] != 0;
+                    for (int64_t e : members) same = same && keep_n[e] == n0;
+                    if (!same) continue;                       // (its members walk in the kernel, as without a group)
                     uint8_t* masks = (uint8_t*)(base + L.walk[ti]);
                     uint8_t* col_ok = masks + (size_t)geom->nfd * (size_t)n0;
                     rc = launch_rev_walk_table(th_red + e0 * M, n0, t.g, masks, col_ok, st);

@@ -496,7 +496,7 @@ def _reduced_centres_of_ranges(grid, first, keep_n):
     operands, the same rounding, whatever the crop -- so a crop's row is a slice of one array with its two end values and its
     own `step` (a mean over the crop's slice of diff(mid): the same numbers in the same order) put in, and the subtracted
     centre is the full grid's innermost one unless an end value is closer to zero (then the crop takes the generic path).
-    Bit-identical to the generic path (tests/test_units_cpu.py); 7.5 -> 1 ms for the 96 distinct crops of the headline sweep."""
+    Bit-identical to the generic path (tests/test_arcfit_host_cpu.py); 7.5 -> 1 ms for the 96 distinct crops of the headline sweep."""
     th = grid.th_cents
     M, neta = th.shape[0], first.shape[0]
     th_red = np.zeros((neta, M))
@@ -640,7 +640,16 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     fast = _reduced_centres_of_ranges(grid, rng[0], rng[1]) if rng is not None else None
     if fast is not None:
         keep_t, keep_n = _sweep_inputs_dev(grid, etas_v)
-        if not np.array_equal(keep_n, rng[1]):         # (the device table and the host bisection evaluate the same expression)
+        # the device table and the host bisection evaluate the same expression; th_red and crop_group below describe the host
+        # ranges, the library walks the device table: the counts AND both ends of every run must agree (a run with the same
+        # count but another start, or a mask that is not one run, would pair th_red with other centres -- ADVICE r5)
+        same = np.array_equal(keep_n, rng[1])
+        if same and neta:
+            nz = keep_n > 0
+            last = torch.from_numpy(np.maximum(keep_n.astype(np.int64) - 1, 0)).to(keep_t.device)
+            ends = torch.stack([keep_t[:, 0], keep_t.gather(1, last[:, None])[:, 0]]).cpu().numpy()
+            same = (np.array_equal(ends[0][nz], rng[0][nz]) and np.array_equal(ends[1][nz], (rng[0] + keep_n - 1)[nz]))
+        if not same:
             fast = None
     if fast is not None:
         th_red, crop_group = fast

@@ -25,7 +25,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_version_and_struct_layout(lib):
-    assert lib.scint_version() >= 100
+    assert lib.scint_version() == _lib.ABI_VERSION      # (_lib.load refuses any other build: a stale library fails at load, not in its first call)
     assert ctypes.sizeof(_lib.CsGeom) == 2 * 8 + 8 * 8
 
 

@@ -567,6 +567,36 @@ def test_chisq_sweep_shares_the_backmap_walk_between_same_crop_curvatures(emu, t
     np.testing.assert_allclose(shared[[0, 5, 9, 12]], ref, rtol=1e-9)
 
 
+def test_chisq_sweep_does_not_share_a_walk_table_on_a_false_promise(emu, to, monkeypatch):
+    """scint_chisq_sweep takes the caller's crop_group on trust only as far as it can check -- members of a group must
+    hold the same reduced centres, and the library compares their th_red rows on the device before it shares a partner table.  Here
+    the wrapper is made to lie: one member of the ten-curvature group gets other centres (same count).  With the check that member
+    (and its group) walk in the kernel, and chi^2 equals the run that shares nothing, bit for bit."""
+    from scintools_amd.synth import arc_dynspec
+    dyn, freqs, times, eta_true = arc_dynspec(300, 96, seed=23, nimg=8, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 180)
+    CS = to.conjugate_spectrum(dyn, 0)
+    th = emu._Grid(tau, fd, edges).th_cents
+    eta_full = np.abs(tau).max() / (th**2).max()
+    etas = np.concatenate([np.linspace(0.05, 0.95, 10), [1.3, 1.9, 2.6, 3.4]]) * eta_full
+    honest = emu._reduced_centres_of_ranges
+
+    def lying(grid, first, n):
+        out = honest(grid, first, n)
+        if out is None:
+            return None
+        th_red, group = out
+        th_red = np.array(th_red)
+        th_red[4, :n[4]] *= 0.75                     # member 4 of the big group: other centres, the same count, the same group
+        return th_red, group
+    monkeypatch.setattr(emu, "_reduced_centres_of_ranges", lying)
+    shared = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0)
+    alone = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, share_walk=False)
+    assert np.all(np.isfinite(shared)) and np.array_equal(shared, alone)
+
+
 def test_chunk_retrieval_in_byte_bounded_groups(emu, to, capsys):
     """the batched phase retrieval stacks conjugate spectra only up to a byte budget (groups, as the fit path
     does), and a chunk that cannot be prepared is left zero with its error printed while the others go on -- the reference's
