@@ -230,6 +230,14 @@ def parse():
                          "its Sample_Data (tests/golden/fit_thetatheta.npz); fit_arc = Dynspec.fit_arc(lamsteps=True) "
                          "(dynspec.py:970-1346)")
     ap.add_argument("--chunk", type=int, default=256, help="--workload fit_thetatheta / wavefield: cwf = cwt")
+    ap.add_argument("--workload-steps", type=int, default=2,
+                    help="N=1, default line: also time this many calls (after one warm-up) of each --workload entry point on the GPU alone "
+                         "(no CPU sample: those stay behind --workload X) -- object 'workloads' of the line; 0 = skip; skipped below "
+                         "--size 1024 (the chunked workloads need 4 x 4 chunks of --chunk)")
+    ap.add_argument("--strong-steps", type=int, default=3,
+                    help="N>1, default partitioning: after the weak-scaling region also time this many steps of --shard eta on observation 0 "
+                         "(every rank holds it): object 'strong' of the line (value, efficiency against rank 0's own one-GPU step of the "
+                         "weak region, gathered_equals_one_gpu); 0 = skip")
     ap.add_argument("--tol", type=float, default=None,
                     help="Ritz tolerance of the eigenvalue sweeps (default ththmod.DEFAULT_TOL = 1e-12, 1000x inside the 1e-9 parity "
                          "bar); for the tolerance A/Bs of profiles/ -- the headline is quoted at the default")
@@ -252,6 +260,7 @@ def parse():
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline, args.modeler_steps, args.mixed_steps, args.sim_steps, args.share_steps = True, 0, 0, 0, 0
+        args.workload_steps = 0
     return args
 
 
@@ -596,6 +605,11 @@ def workload_main(args):
     seconds per call (median of --steps calls after --warmup), the work it covers, where the GPU time goes (the library's
     hipEvent brackets: gather, mat-vec, back-map), a parity figure against the oracle on a sample, and `cpu_baseline` -- the
     oracle (kind "port") timed here on a bounded sample of the same work and scaled, sample stated."""
+    print(json.dumps(run_workload(args, with_cpu=True)))
+
+
+def run_workload(args, with_cpu=True):
+    """One --workload entry point timed on the GPU; with_cpu also times the oracle on a bounded sample (parity + cpu_baseline)."""
     import torch
     from scintools_amd import _lib, ththmod
     from scintools_amd.device import require_gpu
@@ -623,7 +637,8 @@ def workload_main(args):
                              "avg_launch_us": 1e3 * ms_sum[k] / max(1, launches[k])} for k, n in enumerate(names) if launches[k]}
 
     if args.workload in ("fit_thetatheta", "wavefield"):
-        from oracle import thth_oracle
+        if with_cpu:                     # the oracle is the checker and the CPU baseline of these lines, nothing else
+            from oracle import thth_oracle
         dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
         d = Dynspec(dyn=_Obs(dyn, freqs, times, f"arc {size}x{size}"), process=False, verbose=False)
         kw = dict(cwf=cw, cwt=cw, eta_min=0.5 * eta_true, eta_max=2.0 * eta_true, npad=args.npad if args.npad else 3)
@@ -649,7 +664,7 @@ def workload_main(args):
                               "flight; matrices this small (N ~ 1200: 11 MB) stay in the 256 MiB Infinity Cache between the passes of a "
                               "chunk of launches, so the rate may exceed what HBM alone delivers")
             # parity sample + CPU port: single_search of the oracle on a few chunks
-            sample = [(0, 0), (d.ncf_fit // 2, d.nct_fit // 2)][: max(1, args.cpu_sample // 8)]
+            sample = [(0, 0), (d.ncf_fit // 2, d.nct_fit // 2)][: max(1, args.cpu_sample // 8)] if with_cpu else []
             t_cpu, diffs = [], []
             for cf, ct in sample:
                 p_ = d._search_params(cf, ct)
@@ -661,14 +676,15 @@ def workload_main(args):
                 diffs.append(float(np.nanmax(np.abs(d.thth_eigs[cf, ct] - r[4]) / np.abs(r[4]))))
             out.update(value=med, seconds_all=ts, config=dict(cfg, chunk_eta_jobs=jobs),
                        chunk_eta_points_per_s=jobs / med, kernels=kern,
-                       eta_fit_over_true_median=float(np.nanmedian(d.eta_evo) / eta_true),
-                       parity_sample={"chunks": sample, "max_rel_diff_eta_fit_vs_oracle": float(max(diffs[0::2])),
+                       eta_fit_over_true_median=float(np.nanmedian(d.eta_evo) / eta_true))
+            if with_cpu:
+                out.update(parity_sample={"chunks": sample, "max_rel_diff_eta_fit_vs_oracle": float(max(diffs[0::2])),
                                       "max_rel_diff_eigs_vs_oracle": float(max(diffs[1::2]))},
                        cpu_baseline={"value": float(np.median(t_cpu)) * nchunk, "unit": "s", "kind": "port", "cores": int(blas_threads()),
                                      "host_cores": os.cpu_count(),
                                      "sample": f"oracle.thth_oracle.single_search on {len(sample)} of {nchunk} chunks "
                                                f"({[round(t, 1) for t in t_cpu]} s), median x {nchunk}"})
-            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+                out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
         else:
             d.fit_thetatheta()
             nret = d.ncf_ret * d.nct_ret
@@ -678,7 +694,7 @@ def workload_main(args):
                     del d.chunks
                 d.calc_wavefield()
             med, ts, kern = profiled(once)
-            sample = [(0, 0), (d.ncf_ret // 2, d.nct_ret // 2)][: max(1, args.cpu_sample // 8)]
+            sample = [(0, 0), (d.ncf_ret // 2, d.nct_ret // 2)][: max(1, args.cpu_sample // 8)] if with_cpu else []
             t_cpu, diffs = [], []
             for cf, ct in sample:
                 fs = slice(cf * (cw // 2), cf * (cw // 2) + cw)
@@ -693,15 +709,17 @@ def workload_main(args):
                 ph = np.vdot(ref, got)
                 ph /= abs(ph)
                 diffs.append(float(np.abs(got / ph - ref).max() / np.abs(ref).max()))
-            out.update(value=med, seconds_all=ts, config=dict(cfg, retrieval_chunks=nret), chunks_per_s=nret / med, kernels=kern,
-                       parity_sample={"chunks": sample, "max_rel_diff_vs_oracle_modulo_global_phase": float(max(diffs))},
-                       cpu_baseline={"value": float(np.median(t_cpu)) * nret, "unit": "s", "kind": "port", "cores": int(blas_threads()),
-                                     "host_cores": os.cpu_count(),
-                                     "sample": f"oracle.thth_oracle.single_chunk_retrieval on {len(sample)} of {nret} chunks "
-                                               f"({[round(t, 1) for t in t_cpu]} s), median x {nret} (mosaic not included: host NumPy in both)"})
-            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+            out.update(value=med, seconds_all=ts, config=dict(cfg, retrieval_chunks=nret), chunks_per_s=nret / med, kernels=kern)
+            if with_cpu:
+                out.update(parity_sample={"chunks": sample, "max_rel_diff_vs_oracle_modulo_global_phase": float(max(diffs))},
+                           cpu_baseline={"value": float(np.median(t_cpu)) * nret, "unit": "s", "kind": "port", "cores": int(blas_threads()),
+                                         "host_cores": os.cpu_count(),
+                                         "sample": f"oracle.thth_oracle.single_chunk_retrieval on {len(sample)} of {nret} chunks "
+                                                   f"({[round(t, 1) for t in t_cpu]} s), median x {nret} (mosaic not included: host NumPy in both)"})
+                out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
     elif args.workload == "tutorial_fit":
-        from oracle import thth_oracle
+        if with_cpu:                     # the oracle is the checker and the CPU baseline of these lines, nothing else
+            from oracle import thth_oracle
         with np.load(os.path.join(REPO, "tests", "golden", "fit_thetatheta.npz")) as g:
             obs = _Obs(np.array(g["dspec"], dtype=float), g["freq"], g["time"], "Sample_Data (tutorial)")
             ref_evo, ref_ththeta = np.array(g["eta_evo"]), float(g["ththeta"])
@@ -711,35 +729,37 @@ def workload_main(args):
             d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50)        # the recipe of dynspec_thth.rst:146-170
             d.fit_thetatheta()
         med, ts, kern = profiled(once)
-        p_ = d._search_params(0, 0)
-        idx = np.unique(np.linspace(0, d.neta - 1, 8).astype(int))
-        fd_, tau_ = thth_oracle.fft_axis(p_[2], 1000.0, d.npad), thth_oracle.fft_axis(p_[1], 1.0, d.npad)
-        t0 = time.perf_counter()
-        CS = thth_oracle.conjugate_spectrum(p_[0], d.npad, tau_, 0.0)
-        vals = [thth_oracle.Eval_calc(CS, tau_, fd_, p_[3][i], p_[4]) for i in idx]
-        dt_cpu = time.perf_counter() - t0
         nchunk = d.ncf_fit * d.nct_fit
-        timing = None
-        try:
-            with open(os.path.join(REPO, "tests", "golden", "reference_workload_timing.json")) as fh:
-                timing = json.load(fh).get("tutorial_fit_thetatheta")
-        except (OSError, ValueError):
-            pass
         out.update(value=med, seconds_all=ts, kernels=kern,
                    config={"workload": "the reference's tutorial: prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50) + "
                                        f"fit_thetatheta on Sample_Data ({obs.dyn.shape[0]} x {obs.dyn.shape[1]}), npad = 3", "fit_chunks": nchunk, "neta": int(d.neta),
                            "nedge": int(d.edges.shape[0])},
                    parity={"max_rel_diff_eta_evo_vs_reference_run": float(np.nanmax(np.abs(d.eta_evo - ref_evo) / np.abs(ref_evo))),
-                           "rel_diff_ththeta_vs_reference_run": abs(d.ththeta - ref_ththeta) / abs(ref_ththeta),
-                           "max_rel_diff_eigs_vs_oracle_sample": float(max(abs(d.thth_eigs[0, 0][i] - v) / abs(v) for i, v in zip(idx, vals)))},
-                   cpu_baseline={"value": dt_cpu / len(idx) * d.neta * nchunk, "unit": "s", "kind": "port", "cores": int(blas_threads()),
-                                 "host_cores": os.cpu_count(),
-                                 "sample": f"oracle CS + Eval_calc on {len(idx)} of {d.neta} curvatures of chunk 0 ({dt_cpu:.1f} s), "
-                                           f"x {d.neta} / {len(idx)} x {nchunk} chunks",
-                                 "reference_itself": timing})
-        out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+                           "rel_diff_ththeta_vs_reference_run": abs(d.ththeta - ref_ththeta) / abs(ref_ththeta)})
+        if with_cpu:
+            p_ = d._search_params(0, 0)
+            idx = np.unique(np.linspace(0, d.neta - 1, 8).astype(int))
+            fd_, tau_ = thth_oracle.fft_axis(p_[2], 1000.0, d.npad), thth_oracle.fft_axis(p_[1], 1.0, d.npad)
+            t0 = time.perf_counter()
+            CS = thth_oracle.conjugate_spectrum(p_[0], d.npad, tau_, 0.0)
+            vals = [thth_oracle.Eval_calc(CS, tau_, fd_, p_[3][i], p_[4]) for i in idx]
+            dt_cpu = time.perf_counter() - t0
+            timing = None
+            try:
+                with open(os.path.join(REPO, "tests", "golden", "reference_workload_timing.json")) as fh:
+                    timing = json.load(fh).get("tutorial_fit_thetatheta")
+            except (OSError, ValueError):
+                pass
+            out["parity"]["max_rel_diff_eigs_vs_oracle_sample"] = float(max(abs(d.thth_eigs[0, 0][i] - v) / abs(v) for i, v in zip(idx, vals)))
+            out["cpu_baseline"] = {"value": dt_cpu / len(idx) * d.neta * nchunk, "unit": "s", "kind": "port", "cores": int(blas_threads()),
+                                   "host_cores": os.cpu_count(),
+                                   "sample": f"oracle CS + Eval_calc on {len(idx)} of {d.neta} curvatures of chunk 0 ({dt_cpu:.1f} s), "
+                                             f"x {d.neta} / {len(idx)} x {nchunk} chunks",
+                                   "reference_itself": timing}
+            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
     else:   # fit_arc
-        from oracle import arcfit_oracle
+        if with_cpu:                     # the oracle is the checker and the CPU baseline of these lines, nothing else
+            from oracle import arcfit_oracle
         dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
         obs = _Obs(dyn, freqs, times, f"arc {size}x{size}")
         d = Dynspec(dyn=obs, process=False, verbose=False)
@@ -750,24 +770,25 @@ def workload_main(args):
                     delattr(d, a)
             d.fit_arc(lamsteps=True, numsteps=1e4)
         med, ts, kern = profiled(once)
-        # CPU port on the top-left quarter (size/2)^2 of the same observation: the chain is O(pixels log pixels)
-        h = size // 2
-        t0 = time.perf_counter()
-        o = arcfit_oracle.calc_sspec_lam(dyn[:h, :h], freqs[:h], obs.dt, obs.df)
-        t1 = time.perf_counter()
-        fa = arcfit_oracle.fit_arc(o["lamsspec"], o["beta"], o["tdel"], o["beta"], o["fdop"], float(np.mean(freqs[:h])),
-                                   lamsteps=True, numsteps=1e4)
-        t2 = time.perf_counter()
         out.update(value=med, seconds_all=ts, kernels=kern,
                    config={"workload": f"Dynspec.fit_arc(lamsteps=True, numsteps=1e4) from the raw {size}x{size} dynspec: cubic-spline "
                                        "resample to equal wavelength steps, secondary spectrum, norm_sspec, parabola fit"},
-                   betaeta=float(d.betaeta), betaetaerr=float(d.betaetaerr),
-                   cpu_baseline={"value": 4.0 * (t2 - t0), "unit": "s", "kind": "port", "cores": int(blas_threads()), "host_cores": os.cpu_count(),
-                                 "sample": f"oracle scale_dyn + calc_sspec ({t1 - t0:.1f} s) + fit_arc ({t2 - t1:.1f} s) on the top-left "
-                                           f"{h}x{h} quarter of the same observation, x 4 (pixel count)",
-                                 "betaeta_of_the_quarter": float(fa["sides"][0]["eta"])})
-        out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
-    print(json.dumps(out))
+                   betaeta=float(d.betaeta), betaetaerr=float(d.betaetaerr))
+        if with_cpu:
+            # CPU port on the top-left quarter (size/2)^2 of the same observation: the chain is O(pixels log pixels)
+            h = size // 2
+            t0 = time.perf_counter()
+            o = arcfit_oracle.calc_sspec_lam(dyn[:h, :h], freqs[:h], obs.dt, obs.df)
+            t1 = time.perf_counter()
+            fa = arcfit_oracle.fit_arc(o["lamsspec"], o["beta"], o["tdel"], o["beta"], o["fdop"], float(np.mean(freqs[:h])),
+                                       lamsteps=True, numsteps=1e4)
+            t2 = time.perf_counter()
+            out["cpu_baseline"] = {"value": 4.0 * (t2 - t0), "unit": "s", "kind": "port", "cores": int(blas_threads()), "host_cores": os.cpu_count(),
+                                   "sample": f"oracle scale_dyn + calc_sspec ({t1 - t0:.1f} s) + fit_arc ({t2 - t1:.1f} s) on the top-left "
+                                             f"{h}x{h} quarter of the same observation, x 4 (pixel count)",
+                                   "betaeta_of_the_quarter": float(fa["sides"][0]["eta"])}
+            out["speedup_vs_cpu_baseline"] = out["cpu_baseline"]["value"] / med
+    return out
 
 
 def main():
@@ -954,6 +975,42 @@ def main():
         cs_t = ththmod.conjugate_spectrum(dyns[0], args.npad, tau, 0.0, True)
         alone = ththmod.eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch)
         gathered_equal = bool(np.array_equal(alone, head["curves"][0], equal_nan=True))
+
+    strong = None
+    if (world > 1 and not shard_eta and args.obs_total == 0 and args.obs == 1 and args.objective == "eig" and args.precision == "f64"
+            and args.strong_steps > 0):
+        # The plain multi-GPU command is weak scaling (one observation per GPU: near-linear by construction).  So that whatever N the
+        # driver picks also yields a STRONG-scaling point, the same ranks now split ONE observation's curvatures (--shard eta's
+        # path: sweep.sharded_eval_sweep, interleaved shares, one all-gather of float64 per step).  Every rank holds observation 0
+        # (the analytic arc of seed 3 is generated on every rank); T_1 is rank 0's own step of the weak region -- the same
+        # observation, all curvatures, one GPU, in this very process.
+        from scintools_amd import sweep
+        d0 = dyns[0] if rank == 0 else ththmod.to_device(dyn, torch.float64)
+
+        def strong_step():
+            cs_t = ththmod.conjugate_spectrum(d0, args.npad, tau, 0.0, True)
+            return sweep.sharded_eval_sweep(cs_t, tau, fd, etas, edges, batch=args.batch, tol=tol)
+        strong_step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.strong_steps):
+            curve = strong_step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_w = float(tt.item()) / args.strong_steps
+        if rank == 0:
+            t_1 = neta / head["rank_rates"][0]                       # rank 0's own seconds per step of the weak region
+            strong = {"what": "--shard eta on observation 0 with the same ranks: one observation's curvatures dealt interleaved "
+                              "(etas[rank::world]), one all-gather of float64 per step",
+                      "scaling": "strong", "value": neta / t_w, "unit": "eta-points/s", "steps": args.strong_steps, "ms_per_step": 1e3 * t_w,
+                      "T1_ms": 1e3 * t_1, "speedup_vs_rank0_alone": t_1 / t_w, "efficiency": t_1 / (world * t_w),
+                      "gathered_equals_one_gpu": bool(np.array_equal(curve, head["curves"][0], equal_nan=True)),
+                      "ranks_seen": int(dist.get_world_size()), "backend": backend,
+                      "note": "efficiency = T_1 / (N x T_N), T_1 = rank 0's own step in the weak-scaling region of this run (same observation, all "
+                              "curvatures); the replicated part is the conjugate-spectrum FFT every rank repeats"}
 
     if rank == 0:
         elapsed, info, fit = head["elapsed"], head["info"], head["fit"]
@@ -1182,6 +1239,52 @@ def main():
                 del probe
             except Exception:
                 pass
+        if strong is not None:
+            out["strong"] = strong
+        if legs_ok and args.workload_steps > 0:
+            # the (f) rows end to end, GPU alone (their CPU samples and parity figures stay behind --workload X)
+            if size >= 1024 and size % args.chunk == 0 and size // args.chunk >= 4:
+                import argparse as _ap
+                wls = {}
+                for name in ("fit_thetatheta", "wavefield", "tutorial_fit", "fit_arc"):
+                    try:
+                        ns = _ap.Namespace(**dict(vars(args), workload=name, steps=args.workload_steps, warmup=1, npad=0, nedge=None))
+                        r = run_workload(ns, with_cpu=False)
+                        wls[name] = {"seconds": r["value"], "seconds_all": r["seconds_all"], "workload": r["config"]["workload"],
+                                     "kernels_busy_share_of_wall": {k: v["busy_share_of_wall"] for k, v in r.get("kernels", {}).items()}}
+                        for k in ("chunk_eta_points_per_s", "chunks_per_s", "parity", "betaeta"):
+                            if k in r:
+                                wls[name][k] = r[k]
+                    except Exception as exc:           # a reported leg must never take the headline down
+                        wls[name] = {"error": repr(exc)}
+                out["workloads"] = wls
+            else:
+                out["workloads"] = {"note": f"skipped: --size {size} gives fewer than 4 x 4 chunks of --chunk {args.chunk}"}
+        # The numbers a reader of the END of this line needs, as flat scalars (the nested objects above hold what each means)
+        def _get(*path):
+            o = out
+            for k in path:
+                if not isinstance(o, dict) or k not in o:
+                    return None
+                o = o[k]
+            return o
+        out["tail"] = "flat copies of the figures the nested objects above define"
+        out["matvec_frac_of_hbm_peak"] = _get("roofline", "frac")
+        out["gather_frac_in_sweep"] = _get("gather", "frac")
+        out["gather_frac_alone"] = _get("gather", "one_slot_group", "frac")
+        out["sim_screen_eta_per_s"] = _get("simulation_screen", "value")
+        out["sim_screen_passes"] = _get("simulation_screen", "lanczos_steps_mean")
+        out["modeler_eta_per_s"] = _get("modeler", "value")
+        out["mixed_eta_per_s"] = _get("mixed_precision", "value")
+        out["strong_scaling_pred_8"] = _get("config", "predicted_strong_scaling", "8", "efficiency")
+        out["strong_scaling_measured"] = _get("strong", "efficiency")
+        out["sspec_ms"] = _get("sspec", f"{size}x{size}", "ms")
+        out["sspec_frac_of_hbm_peak"] = _get("sspec", f"{size}x{size}", "frac_of_hbm_peak")
+        out["sspec_traffic_over_algorithmic"] = _get("sspec", f"{size}x{size}", "roofline", "traffic_over_algorithmic")
+        for name in ("fit_thetatheta", "wavefield", "tutorial_fit", "fit_arc"):
+            out[f"workload_{name}_s"] = _get("workloads", name, "seconds")
+        out["cpu_baseline_eta_per_s"] = _get("cpu_baseline", "value")
+        out["eta_per_s"] = out["value"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

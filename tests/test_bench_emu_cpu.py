@@ -51,6 +51,17 @@ def test_default_line_with_its_mixed_leg():
     assert set(pred) - {"T1_ms", "note"} == {"2"} and pred["2"]["efficiency"] > 0          # 6 curvatures: only two ranks get >= 2 each
     assert len(d["library"]["csrc_sha256"]) == 64
     assert d["roofline"]["traffic"] is None or "csrc_sha256" not in (d["roofline"]["traffic_note"] or "")
+    # round 6: the figures a reader of the END of the line needs are flat scalars after every nested object
+    keys = list(d)
+    tail = keys[keys.index("tail"):]
+    for k in ("matvec_frac_of_hbm_peak", "gather_frac_in_sweep", "gather_frac_alone", "sim_screen_eta_per_s", "sim_screen_passes",
+              "modeler_eta_per_s", "mixed_eta_per_s", "strong_scaling_pred_8", "strong_scaling_measured", "sspec_ms",
+              "workload_fit_thetatheta_s", "workload_wavefield_s", "workload_tutorial_fit_s", "workload_fit_arc_s", "eta_per_s"):
+        assert k in tail, k
+    assert keys[-1] == "eta_per_s" and d["eta_per_s"] == d["value"]
+    assert d["sim_screen_eta_per_s"] == sim["value"] and d["gather_frac_in_sweep"] == d["gather"]["frac"]
+    assert d["mixed_eta_per_s"] == mp["value"] and d["modeler_eta_per_s"] is None            # (--modeler-steps 0 here)
+    assert "skipped" in d["workloads"]["note"] and d["workload_wavefield_s"] is None          # (128^2: fewer than 4 x 4 chunks)
 
 
 @pytest.mark.timeout(900)
@@ -126,5 +137,11 @@ def test_two_ranks(extra):
     if extra:
         assert d["scaling"] == "strong" and c["sweep_precision"] == "mixed" and c["gathered_equals_one_gpu"] is True
         assert d["roofline"]["kernel"] == "pk2_matvec32_kernel"
+        assert "strong" not in d
     else:
         assert d["scaling"] == "weak" and c["sweep_precision"] == "f64" and "mixed_precision" not in d
+        # round 6: the plain N-rank command also yields a strong-scaling point (the same ranks split observation 0's curvatures)
+        st = d["strong"]
+        assert st["scaling"] == "strong" and st["ranks_seen"] == 2 and st["backend"] == "gloo" and st["gathered_equals_one_gpu"] is True
+        assert st["value"] > 0 and st["efficiency"] == pytest.approx(st["T1_ms"] / (2 * st["ms_per_step"]))
+        assert d["strong_scaling_measured"] == st["efficiency"]

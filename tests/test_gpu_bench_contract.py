@@ -43,6 +43,31 @@ def test_bench_json_contract():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["max_rel_diff_vs_gpu"] < 1e-9
+    # round 6: flat scalars after every nested object (what the driver's tail of the line shows), the value last
+    keys = list(d)
+    tail = keys[keys.index("tail"):]
+    for k in ("matvec_frac_of_hbm_peak", "gather_frac_in_sweep", "gather_frac_alone", "sim_screen_eta_per_s", "sim_screen_passes",
+              "modeler_eta_per_s", "mixed_eta_per_s", "strong_scaling_pred_8", "sspec_ms", "sspec_frac_of_hbm_peak",
+              "workload_fit_thetatheta_s", "workload_wavefield_s", "workload_tutorial_fit_s", "workload_fit_arc_s",
+              "cpu_baseline_eta_per_s", "eta_per_s"):
+        assert k in tail, k
+    assert keys[-1] == "eta_per_s" and d["eta_per_s"] == d["value"] and d["modeler_eta_per_s"] == d["modeler"]["value"]
+    assert d["gather_frac_alone"] == d["gather"]["one_slot_group"]["frac"] and d["sspec_ms"] == d["sspec"]["512x512"]["ms"]
+
+
+def test_bench_default_line_times_the_workloads():
+    """At a size with 4 x 4 chunks the default line also carries `workloads`: Dynspec.fit_thetatheta, calc_wavefield, the tutorial
+    recipe and fit_arc timed on the GPU alone (their CPU samples stay behind --workload X)."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--size", "1024", "--neta", "16", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--modeler-steps", "0", "--mixed-steps", "0", "--sim-steps", "0", "--share-steps", "0",
+                          "--workload-steps", "1"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    w = d["workloads"]
+    for name in ("fit_thetatheta", "wavefield", "tutorial_fit", "fit_arc"):
+        assert "error" not in w[name], w[name]
+        assert w[name]["seconds"] > 0 and d[f"workload_{name}_s"] == w[name]["seconds"]
+    assert w["tutorial_fit"]["parity"]["max_rel_diff_eta_evo_vs_reference_run"] < 1e-6
 
 
 def test_graft_entry_smoke():
