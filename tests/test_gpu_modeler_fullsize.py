@@ -208,3 +208,25 @@ def test_rev_map_and_modeler_are_bit_reproducible(env, case):
     dyn = c["dyn"]
     x1 = thth.chisq_calc(dyn, c["CS"], c["tau"], c["fd"], c["eta"], c["edges"], 1.0)
     assert x1 == thth.chisq_calc(dyn, c["CS"], c["tau"], c["fd"], c["eta"], c["edges"], 1.0)
+
+
+def test_chisq_sweep_tail_batches_and_band_ends_vs_oracle(env):
+    """the batched tail of the chi^2 sweep (<= 8 curvatures per tail batch, back-map and chi^2 confined to the
+    delay band a curvature can reach) directly against the ORACLE's chisq_calc (ththmod.py:330-368) at 4096^2: twelve curvatures
+    over geomspace(0.25, 4) eta_true (two tail batches at least), of which the two band ends -- 0.25 eta_true: the narrowest
+    delay band, 4 eta_true: the strongest crop -- and two in between are recomputed by the oracle (about 20 s of host time each)."""
+    thth, to = env
+    from scintools_amd.synth import arc_dynspec
+    size = 4096
+    dyn, freqs, times, eta_true = arc_dynspec(size, size, seed=3, nimg=64)
+    dyn -= dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, size)
+    etas = np.geomspace(0.25, 4.0, 12) * eta_true
+    CS = to.conjugate_spectrum(dyn, 0)
+    N = float(dyn.size)
+    chis, info = thth.chisq_sweep(dyn, thth.to_device(CS), tau, fd, etas, edges, N, return_info=True)
+    assert np.all(info["status"] == 0) and len(set(int(v) for v in info["N"])) >= 3
+    for i in (0, 4, 7, 11):
+        ref = to.chisq_calc(dyn, CS, tau, fd, etas[i], edges, N)
+        assert chis[i] == pytest.approx(ref, rel=1e-9), (i, etas[i] / eta_true)
