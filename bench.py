@@ -690,7 +690,7 @@ def run_workload(args, with_cpu=True):
             nret = d.ncf_ret * d.nct_ret
 
             def once():
-                if hasattr(d, "chunks"):
+                if type(d).chunks.present(d):              # (hasattr would copy the parked gigabyte to the host)
                     del d.chunks
                 d.calc_wavefield()
             med, ts, kern = profiled(once)

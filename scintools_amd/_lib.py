@@ -80,6 +80,10 @@ _SIGNATURES = {
     "scint_model_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_model_from_recov": ([_P, c_int64, c_int64, _P, _P, c_size_t, _P], c_int32),
     "scint_ifft2_shifted": ([_P, c_int64, c_int64, c_double, c_int64, c_int64, _P, _P, c_size_t, _P], c_int32),
+    "scint_mosaic_workspace_bytes": ([c_int64, c_int64, c_int64, POINTER(c_size_t)], c_int32),
+    "scint_mosaic_phase": ([_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int32, _P, c_size_t, _P, _P], c_int32),
+    "scint_mosaic_add": ([_P, c_int64, _P, c_int64, c_int64, _P, _P, c_int32, c_double, c_double, _P], c_int32),
+    "scint_chunk_cut": ([_P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P], c_int32),
     "scint_gs_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_gerchberg_saxton": ([_P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int32, _P, c_size_t, _P], c_int32),
     "scint_acf_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
@@ -98,7 +102,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 104          # scint_version() of the library these signatures describe (csrc/capi.hip)
+ABI_VERSION = 105          # scint_version() of the library these signatures describe (csrc/capi.hip)
 
 
 def header_symbols():

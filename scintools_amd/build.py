@@ -2,8 +2,8 @@
 
     python -m scintools_amd.build [--force]
 
-hipcc cross-compiles without a GPU.  thth.hip and arcnorm.hip are built with
--ffp-contract=off (bin decisions and np.interp arithmetic must round like NumPy);
+hipcc cross-compiles without a GPU.  thth.hip, arcnorm.hip and mosaic.hip are built with
+-ffp-contract=off (bin decisions, np.interp arithmetic and the mosaic's sums must round like NumPy);
 the other units keep the default contraction.  Objects land in scintools_amd/csrc/_obj, the shared
 library next to the package so that it travels with a repository snapshot.
 """
@@ -26,6 +26,7 @@ UNITS = {
     "eigen.hip": [],
     "eigen_packed.hip": [],
     "arcnorm.hip": ["-ffp-contract=off"],
+    "mosaic.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 # Experiment builds (tools/build_variant.sh: -DSCINT_ROWS64=4 ...).  The flag string is recorded beside the objects and every unit

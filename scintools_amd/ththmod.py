@@ -979,7 +979,7 @@ def _wavefield_from_eigpair(grid, e, keep, V, w, shape, row_t=None, th_t=None):
 RETRIEVAL_GROUP_BYTES = 8 << 30   # device bytes of conjugate spectra stacked per retrieval group (the rule of Dynspec._fit_chunks)
 
 
-def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None):
+def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None, dev_chunks=None, dev_pads=None, out_device=False):
     """Phase retrieval of MANY chunks of one shape (Dynspec.thetatheta_chunks, dynspec.py:1765-1826): the chunks'
     conjugate spectra in one device stack, all their dominant eigenpairs in ONE batched sweep
     (:func:`eigvec_sweep_multi`), then per chunk the back-map and the inverse FFT queued without a host
@@ -992,12 +992,16 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
 
     chunks: list of (dspec2[nf, nt], edges, time, freq, eta).  Returns complex [nchunk, nf, nt].  A chunk whose
     preparation, eigen-solve or back-map fails is zero and the error is printed -- what the reference's
-    single_chunk_retrieval does (ththmod.py:1471-1475) -- and the other chunks are unaffected."""
-    nf, nt = np.asarray(chunks[0][0]).shape
+    single_chunk_retrieval does (ththmod.py:1471-1475) -- and the other chunks are unaffected.
+
+    ``dev_chunks`` / ``dev_pads`` (round 6): the chunks' pixels already in HBM ([nchunk, nf, nt] float64, cut there by
+    :func:`chunk_cut_device`; the list's dspec2 entries are then ignored) and their padding values (host array);
+    ``out_device``: return the device tensor instead of copying a gigabyte of chunks to the host (the mosaic reads them there)."""
+    nf, nt = (int(v) for v in dev_chunks.shape[1:]) if dev_chunks is not None else np.asarray(chunks[0][0]).shape
     R, C = (npad + 1) * nf, (npad + 1) * nt
     per_group = max(1, int((RETRIEVAL_GROUP_BYTES if group_bytes is None else group_bytes) // (16 * R * C)))
     dev = require_gpu()
-    out = np.zeros((len(chunks), nf, nt), dtype=complex)
+    out = torch.zeros((len(chunks), nf, nt), dtype=torch.complex128, device=dev) if out_device else np.zeros((len(chunks), nf, nt), dtype=complex)
     for g0 in range(0, len(chunks), per_group):
         group = chunks[g0:g0 + per_group]
         stack = torch.empty((len(group), R, C), dtype=torch.complex128, device=dev)
@@ -1006,7 +1010,7 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
         # take turns (bench.py --workload wavefield: 1.4 ms per chunk with the mat-vec busy 4 % of the time).  The group's chunks
         # travel in ONE array each way; the padding value of a chunk (its mean, ththmod.py:783) is taken on the host.
         grids, etas, live, pads = [], [], [], []
-        d_all = np.empty((len(group), nf, nt))
+        d_all = np.empty((len(group), nf, nt)) if dev_chunks is None else None
         for k, (dspec2, edges, time, freq, eta) in enumerate(group):
             try:
                 fd = fft_axis(units.strip(time, "time2", "s", warn=False), 1000.0, npad)
@@ -1015,8 +1019,11 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
                 e = np.array([_eta_float(eta)])
                 if (grid.geom.ntau, grid.geom.nfd) != (R, C) or (grids and grid.M != grids[0].M):
                     raise ValueError("axes or edges of this chunk do not match the chunk shape (%d, %d)" % (nf, nt))
-                d_all[len(live)] = np.asarray(dspec2, dtype=float)
-                pads.append(float(d_all[len(live)].mean()))
+                if dev_chunks is None:
+                    d_all[len(live)] = np.asarray(dspec2, dtype=float)
+                    pads.append(float(np.asarray(dspec2, dtype=float).mean()))     # (the chunk's own memory order, as dspec.mean() of ththmod.py:783)
+                else:
+                    pads.append(float(dev_pads[g0 + k]))
             except Exception as exc:          # this chunk stays zero; the slot of the stack is reused by the next one
                 print("Chunk %d: %s" % (g0 + k, exc), flush=True)
                 continue
@@ -1025,9 +1032,10 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
             live.append(k)
         if not live:
             continue
-        d_t = _dv.to_device(d_all[: len(live)], torch.float64)
+        d_t = _dv.to_device(d_all[: len(live)], torch.float64) if dev_chunks is None else None
         for j in range(len(live)):
-            conjugate_spectrum(d_t[j], npad, grids[j].tau, tauMask, True, pad_value=pads[j], out=stack[j])
+            src = d_t[j] if dev_chunks is None else dev_chunks[g0 + live[j]]
+            conjugate_spectrum(src, npad, grids[j].tau, tauMask, True, pad_value=pads[j], out=stack[j])
         w_list, V_t, keeps, info = eigvec_sweep_multi(stack[: len(live)], grids, etas)
         V = V_t.cpu().numpy()
         M = grids[0].M
@@ -1060,7 +1068,10 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
                 continue
             if verbose:
                 print("Chunk %d success" % (g0 + k), flush=True)
-        out[g0 + np.asarray(live)] = out_t.cpu().numpy()
+        if out_device:
+            out[g0 + torch.as_tensor(np.asarray(live), device=dev)] = out_t
+        else:
+            out[g0 + np.asarray(live)] = out_t.cpu().numpy()
         # release this group's device buffers BEFORE the next group allocates its own: while the names are bound the caching
         # allocator cannot reuse the blocks and the peak would be two groups -- the bound is `group_bytes`, not twice it
         del stack, V_t, out_t, d_t, rows_t, th_all_t
@@ -1132,6 +1143,123 @@ def mosaic(chunks):
             rot = np.angle((chunk_old * np.conjugate(chunk_new) * mask).mean())
             E_recov[sl] += chunk_new * mask * np.exp(1j * rot)
     return E_recov
+
+
+_NUMPY_MODES = {}
+
+
+def _numpy_mosaic_modes(cwf, cwt):
+    """How THIS host's NumPy evaluates ``chunk_old * np.conjugate(chunk_new) * mask`` (ththmod.py:1550) for chunks of this
+    shape -- two properties of the host, measured on random data with the very expression, so that the device mosaic can equal
+    the host loop of :func:`mosaic` bit for bit (csrc/mosaic.hip: cmul_np):
+
+    * fused: NumPy's x86 SIMD loops (AVX2 / AVX-512 with FMA3) multiply complex128 arrays as re = fma(ar, br, -(ai bi)),
+      im = fma(ar, bi, ai br) -- one rounding fewer than the plain expressions of its scalar loop;
+    * swapped: for temporaries of 256 KiB and more NumPy reuses ``conj(chunk_new)`` as the output of the product and, the
+      operation being commutative, computes ``conj(chunk_new) * chunk_old`` -- the fused form is not symmetric in its operands.
+
+    Returns (fused, swapped), or None if neither reading reproduces the expression (an unknown NumPy: the caller then warns
+    and the device result agrees with the host loop to rounding only)."""
+    key = (cwf, cwt)
+    if key not in _NUMPY_MODES:
+        rng = np.random.default_rng(12345)
+        big = rng.standard_normal((cwf + 2, cwt + 2)) + 1j * rng.standard_normal((cwf + 2, cwt + 2))
+        a = big[1:1 + cwf, 1:1 + cwt]                                 # a window of a larger array, as E_recov[sl] is
+        b = rng.standard_normal((cwf, cwt)) + 1j * rng.standard_normal((cwf, cwt))
+        m = rng.random((cwf, cwt))
+        expr = a * np.conjugate(b) * m
+        cb = np.conjugate(b)
+
+        def plain(x, y):
+            return (x.real * y.real - x.imag * y.imag) + 1j * (x.real * y.imag + x.imag * y.real)
+        fused = not np.array_equal(np.multiply(a, cb), plain(a, cb))
+        if np.array_equal(expr, np.multiply(np.multiply(a, cb), m)):
+            _NUMPY_MODES[key] = (fused, False)
+        elif np.array_equal(expr, np.multiply(np.multiply(cb, a), m)):
+            _NUMPY_MODES[key] = (fused, True)
+        else:
+            _NUMPY_MODES[key] = None
+    return _NUMPY_MODES[key]
+
+
+def _mosaic_tapers(ncf, nct, cwf, cwt):
+    """The taper of chunk (cf, ct) as mask[r, c] = fr[r] * fc[c] (ththmod.py:1526-1546 builds it by multiplying a matrix of ones
+    by a row factor, then by a column factor: one product per element, the same bits).  Returns (rows[4, cwf], cols[4, cwt]) and
+    the index function: variant 2 * (has a neighbour before) + (has a neighbour after)."""
+    def variants(w):
+        v = np.ones((4, w))
+        mf = mask_func(w // 2)
+        for k in range(4):
+            if k & 2:
+                v[k, : w // 2] *= mf
+            if k & 1:
+                v[k, w // 2:] *= 1 - mf
+        return v
+    return variants(cwf), variants(cwt)
+
+
+def mosaic_device(chunks_t):
+    """:func:`mosaic` with the chunks and the wavefield in HBM (device tensor [ncf, nct, cwf, cwt] complex128 -> device tensor
+    [F, T]): per chunk, in the reference's order (ththmod.py:1548-1553), one kernel forms ``(chunk_old * conj(chunk_new) *
+    mask)`` and its sum in NumPy's own summation order, the 16-byte sum comes to the host where ``mean``, ``numpy.angle`` and
+    ``numpy.exp`` are NumPy's, and a second kernel adds ``chunk_new * mask * exp(1j * rot)``.  Bit-identical to the host loop on the
+    same chunks (tests); the host loop spent 0.26 s on the 961 chunks of a 4096^2 observation and needed them on the host (1 GB)."""
+    lib = _lib.load()
+    ncf, nct, cwf, cwt = (int(v) for v in chunks_t.shape)
+    if cwf % 2 or cwt % 2:
+        raise ValueError("mosaic: chunk sizes must be even (the reference's half-overlap tapers)")
+    F, T = (ncf - 1) * (cwf // 2) + cwf, (nct - 1) * (cwt // 2) + cwt
+    rows, cols = _mosaic_tapers(ncf, nct, cwf, cwt)
+    rows_t, cols_t = _dv.to_device(rows, torch.float64), _dv.to_device(cols, torch.float64)
+    E_t = torch.zeros((F, T), dtype=torch.complex128, device=chunks_t.device)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_mosaic_workspace_bytes(cwf, cwt, 1, ctypes.byref(need)), "mosaic_workspace_bytes")
+    ws = workspace.get(need.value)
+    sum_t = empty((2,), torch.float64)
+    modes = _numpy_mosaic_modes(cwf, cwt)
+    if modes is None:
+        warnings.warn("scintools_amd: this NumPy evaluates the mosaic's products in an unknown way; the device mosaic agrees with "
+                      "the reference's host loop to rounding, not bit for bit")
+        modes = (False, False)
+    fused = (1 if modes[0] else 0) | (2 if modes[1] else 0)
+    count = cwf * cwt
+    st = stream_ptr()
+    for cf in range(ncf):
+        fr = rows_t[2 * (cf > 0) + (cf < ncf - 1)]
+        for ct in range(nct):
+            fc = cols_t[2 * (ct > 0) + (ct < nct - 1)]
+            win = E_t[cf * cwf // 2:, ct * cwt // 2:]
+            _lib.check(lib.scint_mosaic_phase(win.data_ptr(), T, ptr(chunks_t[cf, ct]), cwf, cwt, ptr(fr), ptr(fc), fused,
+                                              ptr(ws), ws.numel(), ptr(sum_t), st), "scint_mosaic_phase")
+            s = sum_t.cpu().numpy()
+            tot = np.complex128(complex(s[0], s[1]))
+            mean = tot.dtype.type(tot / count)                       # numpy's _mean: umr_sum(...) / rcount
+            ph = np.exp(1j * np.angle(mean))
+            _lib.check(lib.scint_mosaic_add(win.data_ptr(), T, ptr(chunks_t[cf, ct]), cwf, cwt, ptr(fr), ptr(fc), fused,
+                                            float(ph.real), float(ph.imag), st), "scint_mosaic_add")
+    return E_t
+
+
+def chunk_cut_device(dyn_t, origins, cwf, cwt, fortran_order=False):
+    """The chunks of Dynspec.thetatheta_chunks cut on the device (dynspec.py:1782-1790: ``dspec2 = dyn[fs, ts]; dspec2 -=
+    nanmean(dspec2); dspec2 = nan_to_num(dspec2)``) and the padding value of each (its mean, ththmod.py:783), NumPy's summation
+    order restated (csrc/mosaic.hip).  dyn_t: device [nf, nt] float64; origins: [(r0, c0)].  Returns (chunks [n, cwf, cwt], pads [n]).
+    ``fortran_order``: the host array the reference would slice is Fortran-ordered (a transposed view: how psrflux files load) --
+    ``np.copy`` keeps that order and NumPy's sums walk the window column by column; the means are then formed in that order."""
+    lib = _lib.load()
+    nf, nt = (int(v) for v in dyn_t.shape)
+    n = len(origins)
+    o = np.asarray(origins, dtype=np.int32).reshape(n, 2)
+    if n < 1 or o.min() < 0 or (o[:, 0] + cwf).max() > nf or (o[:, 1] + cwt).max() > nt:
+        raise ValueError("chunk_cut_device: a window lies outside the dynamic spectrum")
+    r0_t, c0_t = _dv.to_device(np.ascontiguousarray(o[:, 0]), torch.int32), _dv.to_device(np.ascontiguousarray(o[:, 1]), torch.int32)
+    out_t, pad_t = empty((n, cwf, cwt), torch.float64), empty((n,), torch.float64)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_mosaic_workspace_bytes(cwf, cwt, n, ctypes.byref(need)), "mosaic_workspace_bytes")
+    ws = workspace.get(need.value)
+    _lib.check(lib.scint_chunk_cut(ptr(dyn_t), nf, nt, ptr(r0_t), ptr(c0_t), n, cwf, cwt, 1 if fortran_order else 0, ptr(out_t), ptr(pad_t), ptr(ws), ws.numel(),
+                                   stream_ptr()), "scint_chunk_cut")
+    return out_t, pad_t
 
 
 def gerchberg_saxton_device(wavefield, dyn, tau, niter=1):

@@ -41,6 +41,7 @@ UNITS = {
     "eigen.hip": [],
     "eigen_packed.hip": [],
     "arcnorm.hip": ["-ffp-contract=off"],
+    "mosaic.hip": ["-ffp-contract=off"],
 }
 
 

@@ -597,6 +597,43 @@ def test_chisq_sweep_does_not_share_a_walk_table_on_a_false_promise(emu, to, mon
     assert np.all(np.isfinite(shared)) and np.array_equal(shared, alone)
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 16, 12), (2, 2, 64, 150), (3, 3, 128, 128), (2, 2, 126, 130), (1, 1, 8, 8)])
+def test_device_mosaic_is_the_host_loop_bit_for_bit(emu, shape):
+    """ththmod.mosaic_device (csrc/mosaic.hip) against ththmod.mosaic (the reference's loop, ththmod.py:1492-1554; itself pinned
+    to the oracle's bit for bit): NumPy's summation order (8192-element buffer pieces, pairwise sums of <= 128-double runs) and
+    its product arithmetic (fused multiply-adds of its SIMD loops; operands swapped by temporary elision from 256 KiB on --
+    128 x 128 here) restated on the device, the scalar steps (mean, angle, exp) in NumPy itself: not a bit differs."""
+    import torch
+    rng = np.random.default_rng(sum(shape))
+    ch = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 10.0 ** rng.integers(-2, 3, shape[:2] + (1, 1))
+    assert emu._numpy_mosaic_modes(shape[2], shape[3]) is not None
+    got = emu.mosaic_device(torch.from_numpy(ch)).numpy()
+    assert np.array_equal(got, emu.mosaic(ch))
+
+
+@pytest.mark.parametrize("fortran", [False, True])
+@pytest.mark.parametrize("cw", [(64, 150), (128, 128), (16, 12), (20, 30)])
+def test_device_chunk_cut_is_numpy_bit_for_bit(emu, cw, fortran):
+    """ththmod.chunk_cut_device against the reference's three lines per chunk (dynspec.py:1782-1790: copy, subtract nanmean,
+    nan_to_num) and the padding value (the chunk's mean, ththmod.py:783), NaNs in some windows: the same bits -- also for a
+    Fortran-ordered dynamic spectrum (a transposed view, as files load), whose windows NumPy copies and sums column by column."""
+    import torch
+    rng = np.random.default_rng(5)
+    dyn = rng.standard_normal((200, 300)) * 5 + 3
+    dyn[5, 7] = np.nan
+    dyn[100:120, 40] = np.nan
+    if fortran:
+        dyn = np.asfortranarray(dyn)
+    cwf, cwt = cw
+    org = [(0, 0), (10, 20), (200 - cwf, 300 - cwt), (min(90, 200 - cwf), 30)]
+    out, pad = emu.chunk_cut_device(torch.from_numpy(np.ascontiguousarray(dyn)), org, cwf, cwt, fortran_order=fortran)
+    for k, (r, c) in enumerate(org):
+        d2 = np.copy(dyn[r:r + cwf, c:c + cwt])
+        d2 -= np.nanmean(d2)
+        d2 = np.nan_to_num(d2)
+        assert np.array_equal(out[k].numpy(), d2) and float(pad[k]) == float(d2.mean())
+
+
 def test_chunk_retrieval_in_byte_bounded_groups(emu, to, capsys):
     """the batched phase retrieval stacks conjugate spectra only up to a byte budget (groups, as the fit path
     does), and a chunk that cannot be prepared is left zero with its error printed while the others go on -- the reference's

@@ -454,6 +454,54 @@ def test_phase_retrieval_vs_reference_golden(thth, golden):
     np.testing.assert_allclose(np.abs(d.wavefield[pos]) ** 2, B.dyn[: ref.shape[0]][pos], rtol=1e-9)
 
 
+def test_retrieval_tail_on_the_device_equals_the_host_fed_path_bit_for_bit(thth, golden):
+    """Round 6: Dynspec.thetatheta_chunks cuts its chunks on the device (ththmod.chunk_cut_device: window, nanmean, nan_to_num and
+    the padding value in NumPy's summation order) and calc_wavefield mosaics them there (ththmod.mosaic_device).  Against the
+    host-fed forms on the same data -- chunk_retrieval_batch with the reference's three lines per chunk on the host
+    (dynspec.py:1782-1790), and the host loop ththmod.mosaic (ththmod.py:1492-1554) -- not a bit differs; a dynamic spectrum with
+    NaNs included."""
+    from scintools_amd.dynspec import Dynspec
+    f = golden("fit_thetatheta.npz")
+    n = 256
+    dyn = np.array(f["dspec"][:n], dtype=float)
+    dyn[17, 40:44] = np.nan
+
+    class B:
+        pass
+    B.dyn, B.freqs, B.times, B.dt, B.df = dyn, f["freq"][:n], f["time"], float(f["dt"]), float(f["df"])
+    d = Dynspec(dyn=B(), verbose=False)
+    d.prep_thetatheta(cwf=64, edges_lim=.3, eta_min=30, eta_max=50, nedge=128)
+    d.calc_wavefield()
+    chunks_dev, wf_dev = d.chunks.copy(), d.wavefield.copy()
+    pars = []
+    for cf in range(d.ncf_ret):
+        fs = slice(cf * (d.cwf // 2), cf * (d.cwf // 2) + d.cwf)
+        freq2 = np.copy(d.freqs[fs])
+        eta = d.ththeta * (d.fref / freq2.mean()) ** 2
+        for ct in range(d.nct_ret):
+            ts = slice(ct * (d.cwt // 2), ct * (d.cwt // 2) + d.cwt)
+            dspec2 = np.copy(d.dyn[fs, ts])
+            dspec2 -= np.nanmean(dspec2)
+            dspec2 = np.nan_to_num(dspec2)
+            pars.append((dspec2, d.edges * (freq2.mean() / d.fref), np.copy(d.times[ts]), freq2, eta))
+    host_fed = thth.chunk_retrieval_batch(pars, d.npad, d.thth_tau_mask).reshape(chunks_dev.shape)
+    assert np.abs(chunks_dev).max() > 0 and np.array_equal(chunks_dev, host_fed)
+    assert thth._numpy_mosaic_modes(d.cwf, d.cwt) is not None
+    assert np.array_equal(wf_dev, thth.mosaic(chunks_dev))
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 128, 128), (2, 3, 256, 256), (2, 2, 64, 150)])
+def test_device_mosaic_is_the_host_loop_bit_for_bit(thth, shape):
+    """ththmod.mosaic_device on the GPU against the host loop ththmod.mosaic (ththmod.py:1492-1554) on random chunks: shapes
+    below and above NumPy's temporary-elision threshold (256 KiB: 128 x 128 complex128), several 8192-element buffer pieces."""
+    import torch
+    from scintools_amd.device import require_gpu
+    rng = np.random.default_rng(sum(shape))
+    ch = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * 10.0 ** rng.integers(-2, 3, shape[:2] + (1, 1))
+    got = thth.mosaic_device(torch.from_numpy(ch).to(require_gpu())).cpu().numpy()
+    assert np.array_equal(got, thth.mosaic(ch))
+
+
 def test_ifft2_shifted_and_gs_kernels_vs_numpy(thth):
     import torch
     from scintools_amd.ththmod import _ifft2_shifted_dev, gerchberg_saxton_device
