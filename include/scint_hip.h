@@ -286,26 +286,32 @@ int32_t scint_ifft2_shifted(const scint_c128* in, int64_t rows, int64_t cols, do
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the mosaic of the retrieved chunks (ththmod.py:1492-1554) and the chunks themselves (dynspec.py:1782-1790) ----------
- * Replaces the host loop of `mosaic`: chunk k is rotated onto the sum of chunks 0..k-1 and added under its taper, in the
- * reference's order, with NumPy's own summation order restated on the device (csrc/mosaic.hip) so that the result equals the
- * host loop's bit for bit.  Per chunk the wrapper calls scint_mosaic_phase (sum_out[2] <- sum over the window of
- * (E * conj(chunk)) * mask, device memory), forms mean / numpy.angle / numpy.exp in NumPy, and calls scint_mosaic_add
- * (E[window] += (chunk * mask) * (ph_re + i ph_im)).  E points AT the window's first element, ldE is the wavefield's row length;
- * mask[r][c] = fr[r] * fc[c].  numpy_fused, two properties of the HOST's NumPy that the wrapper measures: bit 0 = it multiplies
- * complex arrays with fused multiply-adds (re = fma(ar, br, -(ai bi)): its x86 SIMD loops) rather than the plain expressions;
- * bit 1 = it evaluates chunk_old * conj(chunk_new) with the operands swapped (temporary elision, chunks of 256 KiB and more).
+ * Replaces the host loop of `mosaic`: a chunk is rotated onto the sum of the chunks before it and added under its taper, with
+ * NumPy's own summation order and product arithmetic restated on the device (csrc/mosaic.hip) so that the result equals the
+ * host loop's bit for bit.  The reference's loop is sequential, but chunk (cf, ct) only meets its four predecessors
+ * (cf, ct-1), (cf-1, ct-1 .. ct+1): chunks with equal 2 cf + ct are independent and their windows disjoint, so the wrapper walks
+ * 2 (ncf - 1) + nct STEPS and hands each step's chunks to one launch -- every pixel still receives its addends in the
+ * reference's order.  Per step: scint_mosaic_phase (sums_out[k][2] <- sum over chunk k's window of (E * conj(chunk)) * mask,
+ * device memory), mean / numpy.angle / numpy.exp in NumPy on the host, scint_mosaic_add (E[window] += (chunk * mask) *
+ * phases[k]).  jobs: device int64 [count][4] = (offset of the window's first element in E, chunk index in the stack `chunks`
+ * [.][cwf][cwt], row taper, column taper), count <= 64; tapers rows[4][cwf], cols[4][cwt] (variant 2 * has-a-neighbour-before +
+ * has-a-neighbour-after), mask[r][c] = rows[rv][r] * cols[cv][c]; ldE the wavefield's row length; phases: HOST [count][2].
+ * numpy_fused, two properties of the HOST's NumPy that the wrapper measures: bit 0 = it multiplies complex arrays with fused
+ * multiply-adds (re = fma(ar, br, -(ai bi)): its x86 SIMD loops) rather than the plain expressions; bit 1 = it evaluates
+ * chunk_old * conj(chunk_new) with the operands swapped (temporary elision, chunks of 256 KiB and more).
  * The library keeps one small plan per window size in device memory (as it does FFT twiddle tables).
  * scint_chunk_cut: chunks_out[k] = nan_to_num(dyn[r0[k] : r0[k] + cwf, c0[k] : c0[k] + cwt] - nanmean(that window)),
  * pad_out[k] = mean(chunks_out[k]) (the padding value of the conjugate spectrum, ththmod.py:783); r0 / c0 device int32.
  * colmajor: the host array is Fortran-ordered (numpy.copy keeps the order, NumPy's sums then walk a window column by column);
  * `dyn` itself is row-major here either way.
- * Workspace for both: scint_mosaic_workspace_bytes(cwf, cwt, nchunk) (nchunk = 1 for scint_mosaic_phase). */
+ * Workspace for both: scint_mosaic_workspace_bytes(cwf, cwt, nchunk) (nchunk = count for scint_mosaic_phase). */
 int32_t scint_mosaic_workspace_bytes(int64_t cwf, int64_t cwt, int64_t nchunk, size_t* bytes /*HOST*/);
-int32_t scint_mosaic_phase(const scint_c128* E, int64_t ldE, const scint_c128* chunk, int64_t cwf, int64_t cwt,
-                           const double* fr, const double* fc, int32_t numpy_fused, void* workspace, size_t workspace_bytes,
-                           double* sum_out, void* stream);
-int32_t scint_mosaic_add(scint_c128* E, int64_t ldE, const scint_c128* chunk, int64_t cwf, int64_t cwt,
-                         const double* fr, const double* fc, int32_t numpy_fused, double ph_re, double ph_im, void* stream);
+int32_t scint_mosaic_phase(const scint_c128* E, int64_t ldE, const scint_c128* chunks, int64_t cwf, int64_t cwt,
+                           const int64_t* jobs, int64_t count, const double* rows, const double* cols, int32_t numpy_fused,
+                           void* workspace, size_t workspace_bytes, double* sums_out, void* stream);
+int32_t scint_mosaic_add(scint_c128* E, int64_t ldE, const scint_c128* chunks, int64_t cwf, int64_t cwt,
+                         const int64_t* jobs, int64_t count, const double* rows, const double* cols, int32_t numpy_fused,
+                         const double* phases /*HOST*/, void* stream);
 int32_t scint_chunk_cut(const double* dyn, int64_t nf, int64_t nt, const int32_t* r0, const int32_t* c0, int64_t nchunk,
                         int64_t cwf, int64_t cwt, int32_t colmajor, double* chunks_out, double* pad_out, void* workspace,
                         size_t workspace_bytes, void* stream);

@@ -162,13 +162,18 @@ __device__ inline void pw_combine(const PairwisePlanDev& p, double* node_re, dou
     }
 }
 
+// One chunk of a step of the mosaic: where its window starts in the wavefield, which chunk of the stack, which of the four
+// row / column tapers (2 * has a neighbour before + has a neighbour after).  int64 [4] per job in device memory.
 struct MosaicArgs {
-    cplx* E; int64_t ldE;                 // the wavefield so far, [F][T]; this chunk's window starts at E
-    const cplx* chunk; int cwf, cwt;      // [cwf][cwt]
-    const double* fr; const double* fc;   // the taper of this chunk: mask[r][c] = fr[r] * fc[c]  (ththmod.py:1526-1546)
+    cplx* E; int64_t ldE;                 // the wavefield so far, [F][T]
+    const cplx* chunks; int cwf, cwt;     // the stack [nchunk][cwf][cwt]
+    const int64_t* jobs;                  // [.][4]: window offset into E, chunk index, row taper, column taper; this launch's first job
+    const double* rows; const double* cols;   // tapers [4][cwf], [4][cwt]: mask[r][c] = rows[rv][r] * cols[cv][c]  (ththmod.py:1526-1546)
     int fused;                            // how the HOST's numpy evaluates the products (the wrapper measures it): bit 0 fused multiply-adds
                                           // (cmul_np), bit 1 operands of chunk_old * conj(chunk_new) swapped (temporary elision)
 };
+constexpr int kMosaicStep = 64;           // most chunks per launch (their phase factors travel as kernel arguments)
+struct MosaicPhases { double re[kMosaicStep], im[kMosaicStep]; };
 // numpy's product of two complex128 ARRAY elements a * b.  Its SIMD loops (x86 with FMA3: AVX2 / AVX-512 dispatch) compute
 // re = fma(ar, br, -(ai bi)), im = fma(ar, bi, ai br) -- one rounding fewer than the plain expressions its scalar loop uses.
 // Which one a host runs is a property of that host's CPU; the wrapper measures it once (ththmod._numpy_complex_product_is_fused)
@@ -178,37 +183,50 @@ __device__ inline cplx cmul_np(cplx a, cplx b, bool fused) {
     return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// sum over the window of  (E * conj(chunk)) * mask  in numpy's order  ->  out[0..1]
-__global__ void __launch_bounds__(1024) mosaic_phase_kernel(MosaicArgs a, PairwisePlanDev p, double* node_re, double* node_im, double* out) {
+// per job of the launch (one workgroup each): sum over the window of  (E * conj(chunk)) * mask  in numpy's order  ->  out[job][0..1]
+__global__ void __launch_bounds__(1024) mosaic_phase_kernel(MosaicArgs a, PairwisePlanDev p, double* nodes, double* out) {
+    const int64_t* job = a.jobs + 4 * (int64_t)blockIdx.x;
+    const cplx* __restrict__ E = a.E + job[0];
+    const cplx* __restrict__ chunk = a.chunks + job[1] * (int64_t)a.cwf * a.cwt;
+    const double* __restrict__ fr = a.rows + job[2] * a.cwf;
+    const double* __restrict__ fc = a.cols + job[3] * a.cwt;
+    double* node_re = nodes + (size_t)blockIdx.x * 2 * (size_t)p.nnodes;
+    double* node_im = node_re + p.nnodes;
     for (int lf = (int)threadIdx.x; lf < p.nleaves; lf += (int)blockDim.x) {
         const PwLeaf L = p.leaves[lf];
         auto val = [&](int i) {
             const int d = L.start + i, e = d >> 1;             // element of the window, row-major
             const int r = e / a.cwt, c = e - r * a.cwt;
-            const cplx o = a.E[(int64_t)r * a.ldE + c], n = a.chunk[e];
+            const cplx o = E[(int64_t)r * a.ldE + c], n = chunk[e];
             // chunk_old * numpy.conjugate(chunk_new): for temporaries of 256 KiB and more numpy stores the product in the
             // conjugate's buffer and, the operation being commutative, evaluates conj(chunk_new) * chunk_old (bit 1 of `fused`)
             const cplx cn = mk(n.x, -n.y);
             const cplx t = (a.fused & 2) ? cmul_np(cn, o, (a.fused & 1) != 0) : cmul_np(o, cn, (a.fused & 1) != 0);
-            const double m = a.fr[r] * a.fc[c];                // (the real mask: numpy multiplies by m + 0j, i.e. both parts by m)
+            const double m = fr[r] * fc[c];                    // (the real mask: numpy multiplies by m + 0j, i.e. both parts by m)
             return (d & 1) ? t.y * m : t.x * m;
         };
         double rr, ri;
         pw_leaf<true>(L.len, val, rr, ri);
         node_re[lf] = rr; node_im[lf] = ri;
     }
-    pw_combine(p, node_re, node_im, true, out);
+    pw_combine(p, node_re, node_im, true, out + 2 * (size_t)blockIdx.x);
 }
 
-// E[window] += (chunk * mask) * (ph_re + i ph_im)      (ththmod.py:1551: E_recov[...] += chunk_new * mask * exp(1j * rot))
-__global__ void __launch_bounds__(256) mosaic_add_kernel(MosaicArgs a, double ph_re, double ph_im) {
+// E[window] += (chunk * mask) * phase[job]      (ththmod.py:1551: E_recov[...] += chunk_new * mask * exp(1j * rot)); blockIdx.y = job
+__global__ void __launch_bounds__(256) mosaic_add_kernel(MosaicArgs a, MosaicPhases ph) {
+    const int64_t* job = a.jobs + 4 * (int64_t)blockIdx.y;
+    cplx* __restrict__ E = a.E + job[0];
+    const cplx* __restrict__ chunk = a.chunks + job[1] * (int64_t)a.cwf * a.cwt;
+    const double* __restrict__ fr = a.rows + job[2] * a.cwf;
+    const double* __restrict__ fc = a.cols + job[3] * a.cwt;
+    const cplx phase = mk(ph.re[blockIdx.y], ph.im[blockIdx.y]);
     const int n = a.cwf * a.cwt;
     for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < n; e += (int)(gridDim.x * blockDim.x)) {
         const int r = e / a.cwt, c = e - r * a.cwt;
-        const cplx v = a.chunk[e];
-        const double m = a.fr[r] * a.fc[c];
-        const cplx y = cmul_np(mk(v.x * m, v.y * m), mk(ph_re, ph_im), (a.fused & 1) != 0);
-        cplx* dst = a.E + (int64_t)r * a.ldE + c;
+        const cplx v = chunk[e];
+        const double m = fr[r] * fc[c];
+        const cplx y = cmul_np(mk(v.x * m, v.y * m), phase, (a.fused & 1) != 0);
+        cplx* dst = E + (int64_t)r * a.ldE + c;
         const cplx o = *dst;
         *dst = mk(o.x + y.x, o.y + y.y);
     }
@@ -299,37 +317,39 @@ extern "C" int32_t scint_mosaic_workspace_bytes(int64_t cwf, int64_t cwt, int64_
     SCINT_REQUIRE(cwf >= 1 && cwt >= 1 && nchunk >= 1 && cwf * cwt < (int64_t(1) << 29), "mosaic_workspace_bytes: bad shape");
     // nodes of a plan: fewer than twice its leaves; leaves: at most ceil(2 n / 64) + one short one per buffer piece
     const int64_t n = cwf * cwt, leaves = (2 * n + 63) / 64 + n / kNpBuffer + 2;
-    *bytes = (size_t)(2 * leaves) * 2 * sizeof(double) * (size_t)nchunk + 256;
+    *bytes = (size_t)(2 * leaves) * 2 * sizeof(double) * (size_t)nchunk + 256;      // (real and imaginary node sums per chunk)
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_mosaic_phase(const scint_c128* E, int64_t ldE, const scint_c128* chunk, int64_t cwf, int64_t cwt,
-                                      const double* fr, const double* fc, int32_t numpy_fused, void* workspace, size_t workspace_bytes,
-                                      double* sum_out, void* stream_) {
+extern "C" int32_t scint_mosaic_phase(const scint_c128* E, int64_t ldE, const scint_c128* chunks, int64_t cwf, int64_t cwt,
+                                      const int64_t* jobs, int64_t count, const double* rows, const double* cols,
+                                      int32_t numpy_fused, void* workspace, size_t workspace_bytes, double* sums_out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SCINT_REQUIRE(E && chunk && fr && fc && workspace && sum_out, "mosaic_phase: null pointer");
-    SCINT_REQUIRE(cwf >= 1 && cwt >= 1 && ldE >= cwt, "mosaic_phase: bad shape");
+    SCINT_REQUIRE(E && chunks && jobs && rows && cols && workspace && sums_out, "mosaic_phase: null pointer");
+    SCINT_REQUIRE(cwf >= 1 && cwt >= 1 && ldE >= cwt && count >= 1 && count <= kMosaicStep, "mosaic_phase: bad shape or more than 64 chunks");
     size_t need = 0;
-    if (scint_mosaic_workspace_bytes(cwf, cwt, 1, &need) != SCINT_OK) return SCINT_E_ARG;
+    if (scint_mosaic_workspace_bytes(cwf, cwt, count, &need) != SCINT_OK) return SCINT_E_ARG;
     if (workspace_bytes < need) { set_error("scint: mosaic workspace too small"); return SCINT_E_WORKSPACE; }
     const PairwisePlanDev* p = pairwise_plan(cwf * cwt, 2);
     if (!p) return SCINT_E_HIP;
-    MosaicArgs a{(cplx*)E, ldE, (const cplx*)chunk, (int)cwf, (int)cwt, fr, fc, numpy_fused};
-    double* node_re = (double*)workspace;
-    double* node_im = node_re + p->nnodes;
-    hipLaunchKernelGGL(mosaic_phase_kernel, dim3(1), dim3(1024), 0, stream, a, *p, node_re, node_im, sum_out);
+    MosaicArgs a{(cplx*)E, ldE, (const cplx*)chunks, (int)cwf, (int)cwt, jobs, rows, cols, numpy_fused};
+    hipLaunchKernelGGL(mosaic_phase_kernel, dim3((unsigned)count), dim3(1024), 0, stream, a, *p, (double*)workspace, sums_out);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_mosaic_add(scint_c128* E, int64_t ldE, const scint_c128* chunk, int64_t cwf, int64_t cwt,
-                                    const double* fr, const double* fc, int32_t numpy_fused, double ph_re, double ph_im, void* stream_) {
+extern "C" int32_t scint_mosaic_add(scint_c128* E, int64_t ldE, const scint_c128* chunks, int64_t cwf, int64_t cwt,
+                                    const int64_t* jobs, int64_t count, const double* rows, const double* cols,
+                                    int32_t numpy_fused, const double* phases /*HOST [count][2]*/, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SCINT_REQUIRE(E && chunk && fr && fc, "mosaic_add: null pointer");
-    SCINT_REQUIRE(cwf >= 1 && cwt >= 1 && ldE >= cwt && cwf * cwt < (int64_t(1) << 30), "mosaic_add: bad shape");
-    MosaicArgs a{(cplx*)E, ldE, (const cplx*)chunk, (int)cwf, (int)cwt, fr, fc, numpy_fused};
-    const int blocks = (int)std::min<int64_t>(ceil_div(cwf * cwt, 256), 1024);
-    hipLaunchKernelGGL(mosaic_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, ph_re, ph_im);
+    SCINT_REQUIRE(E && chunks && jobs && rows && cols && phases, "mosaic_add: null pointer");
+    SCINT_REQUIRE(cwf >= 1 && cwt >= 1 && ldE >= cwt && cwf * cwt < (int64_t(1) << 30) && count >= 1 && count <= kMosaicStep,
+                  "mosaic_add: bad shape or more than 64 chunks");
+    MosaicArgs a{(cplx*)E, ldE, (const cplx*)chunks, (int)cwf, (int)cwt, jobs, rows, cols, numpy_fused};
+    MosaicPhases ph;
+    for (int64_t k = 0; k < count; ++k) { ph.re[k] = phases[2 * k]; ph.im[k] = phases[2 * k + 1]; }
+    const int blocks = (int)std::min<int64_t>(ceil_div(cwf * cwt, 256), 256);
+    hipLaunchKernelGGL(mosaic_add_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, stream, a, ph);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

@@ -1200,10 +1200,13 @@ def _mosaic_tapers(ncf, nct, cwf, cwt):
 
 def mosaic_device(chunks_t):
     """:func:`mosaic` with the chunks and the wavefield in HBM (device tensor [ncf, nct, cwf, cwt] complex128 -> device tensor
-    [F, T]): per chunk, in the reference's order (ththmod.py:1548-1553), one kernel forms ``(chunk_old * conj(chunk_new) *
-    mask)`` and its sum in NumPy's own summation order, the 16-byte sum comes to the host where ``mean``, ``numpy.angle`` and
-    ``numpy.exp`` are NumPy's, and a second kernel adds ``chunk_new * mask * exp(1j * rot)``.  Bit-identical to the host loop on the
-    same chunks (tests); the host loop spent 0.26 s on the 961 chunks of a 4096^2 observation and needed them on the host (1 GB)."""
+    [F, T]).  The reference's loop (ththmod.py:1548-1553) is sequential, but chunk (cf, ct) only meets its four predecessors
+    (cf, ct-1) and (cf-1, ct-1 .. ct+1): chunks with equal 2 cf + ct are independent, their windows disjoint, and every
+    overlapping pair keeps its order -- so the mosaic walks 2 (ncf - 1) + nct STEPS (91 for the 961 chunks of a 4096^2
+    observation).  Per step one kernel forms ``(chunk_old * conj(chunk_new) * mask)`` and its sum in NumPy's own summation order
+    for every chunk of the step, the sums (16 bytes each) come to the host where ``mean``, ``numpy.angle`` and ``numpy.exp``
+    are NumPy's, and a second kernel adds ``chunk_new * mask * exp(1j * rot)``.  Bit-identical to the host loop on the same
+    chunks (tests); the host loop spent 0.26 s on those 961 chunks and needed them on the host (1 GB)."""
     lib = _lib.load()
     ncf, nct, cwf, cwt = (int(v) for v in chunks_t.shape)
     if cwf % 2 or cwt % 2:
@@ -1212,31 +1215,46 @@ def mosaic_device(chunks_t):
     rows, cols = _mosaic_tapers(ncf, nct, cwf, cwt)
     rows_t, cols_t = _dv.to_device(rows, torch.float64), _dv.to_device(cols, torch.float64)
     E_t = torch.zeros((F, T), dtype=torch.complex128, device=chunks_t.device)
-    need = ctypes.c_size_t()
-    _lib.check(lib.scint_mosaic_workspace_bytes(cwf, cwt, 1, ctypes.byref(need)), "mosaic_workspace_bytes")
-    ws = workspace.get(need.value)
-    sum_t = empty((2,), torch.float64)
     modes = _numpy_mosaic_modes(cwf, cwt)
     if modes is None:
         warnings.warn("scintools_amd: this NumPy evaluates the mosaic's products in an unknown way; the device mosaic agrees with "
                       "the reference's host loop to rounding, not bit for bit")
         modes = (False, False)
     fused = (1 if modes[0] else 0) | (2 if modes[1] else 0)
+    # the jobs in step order, at most 64 per launch
+    steps = {}
+    for cf in range(ncf):
+        for ct in range(nct):
+            steps.setdefault(2 * cf + ct, []).append((cf, ct))
+    launches, table = [], []
+    for t in sorted(steps):
+        for k0 in range(0, len(steps[t]), 64):
+            part = steps[t][k0:k0 + 64]
+            launches.append((len(table), len(part)))
+            for cf, ct in part:
+                table.append(((cf * (cwf // 2)) * T + ct * (cwt // 2), cf * nct + ct, 2 * (cf > 0) + (cf < ncf - 1), 2 * (ct > 0) + (ct < nct - 1)))
+    jobs_t = _dv.to_device(np.asarray(table, dtype=np.int64), torch.int64)
+    most = max(n for _, n in launches)
+    need = ctypes.c_size_t()
+    _lib.check(lib.scint_mosaic_workspace_bytes(cwf, cwt, most, ctypes.byref(need)), "mosaic_workspace_bytes")
+    ws = workspace.get(need.value)
+    sums_t = empty((most, 2), torch.float64)
     count = cwf * cwt
     st = stream_ptr()
-    for cf in range(ncf):
-        fr = rows_t[2 * (cf > 0) + (cf < ncf - 1)]
-        for ct in range(nct):
-            fc = cols_t[2 * (ct > 0) + (ct < nct - 1)]
-            win = E_t[cf * cwf // 2:, ct * cwt // 2:]
-            _lib.check(lib.scint_mosaic_phase(win.data_ptr(), T, ptr(chunks_t[cf, ct]), cwf, cwt, ptr(fr), ptr(fc), fused,
-                                              ptr(ws), ws.numel(), ptr(sum_t), st), "scint_mosaic_phase")
-            s = sum_t.cpu().numpy()
-            tot = np.complex128(complex(s[0], s[1]))
+    chunks_c = chunks_t.contiguous()
+    ph = np.empty((most, 2))
+    for first, n in launches:
+        jp = jobs_t[first].data_ptr()
+        _lib.check(lib.scint_mosaic_phase(ptr(E_t), T, ptr(chunks_c), cwf, cwt, jp, n, ptr(rows_t), ptr(cols_t), fused,
+                                          ptr(ws), ws.numel(), ptr(sums_t), st), "scint_mosaic_phase")
+        sums = sums_t[:n].cpu().numpy()
+        for k in range(n):
+            tot = np.complex128(complex(sums[k, 0], sums[k, 1]))
             mean = tot.dtype.type(tot / count)                       # numpy's _mean: umr_sum(...) / rcount
-            ph = np.exp(1j * np.angle(mean))
-            _lib.check(lib.scint_mosaic_add(win.data_ptr(), T, ptr(chunks_t[cf, ct]), cwf, cwt, ptr(fr), ptr(fc), fused,
-                                            float(ph.real), float(ph.imag), st), "scint_mosaic_add")
+            e = np.exp(1j * np.angle(mean))
+            ph[k, 0], ph[k, 1] = e.real, e.imag
+        _lib.check(lib.scint_mosaic_add(ptr(E_t), T, ptr(chunks_c), cwf, cwt, jp, n, ptr(rows_t), ptr(cols_t), fused,
+                                        ph.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), st), "scint_mosaic_add")
     return E_t
 
 
