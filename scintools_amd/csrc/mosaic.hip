@@ -370,3 +370,60 @@ extern "C" int32_t scint_chunk_cut(const double* dyn, int64_t nf, int64_t nt, co
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
+
+// ---- the per-chunk steps of Dynspec.thetatheta_chunks in ONE call each (dynspec.py:1765-1826 maps single_chunk_retrieval over the
+// chunks; 961 of them for a 4096^2 observation): the same kernels as scint_cs / scint_rev_map / scint_ifft2_shifted, queued by a
+// C++ loop instead of a dozen Python calls per chunk (0.17 s of a 0.31-s calc_wavefield was that: profiles/r06_wavefield_host_profile_after.txt).
+extern "C" int32_t scint_cs_batch(const double* dstack, int64_t n, int64_t nf, int64_t nt, int64_t npad, const double* pads,
+                                  const int64_t* mask_lohi, int32_t incoherent, scint_c128* cs_stack, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    SCINT_REQUIRE(dstack && pads && mask_lohi && cs_stack && workspace && n >= 1, "cs_batch: null pointer or empty batch");
+    const int64_t R = (npad + 1) * nf, C = (npad + 1) * nt;
+    for (int64_t k = 0; k < n; ++k) {
+        const int32_t rc = scint_cs(dstack + k * nf * nt, nf, nt, npad, pads[k], mask_lohi[2 * k], mask_lohi[2 * k + 1], incoherent,
+                                    cs_stack + k * R * C, workspace, workspace_bytes, stream);
+        if (rc != SCINT_OK) return rc;
+    }
+    return SCINT_OK;
+}
+
+extern "C" int32_t scint_retrieval_tail_workspace_bytes(int64_t M, int64_t ntau, int64_t nfd, size_t* bytes) {
+    SCINT_REQUIRE(bytes && M >= 1 && ntau >= 1 && nfd >= 1, "retrieval_tail_workspace_bytes: bad arguments");
+    size_t fft = 0;
+    const int32_t rc = scint_fft2_workspace_bytes(ntau, nfd, &fft);
+    if (rc != SCINT_OK) return rc;
+    *bytes = align_up(sizeof(cplx) * (size_t)M * (size_t)M, 256) + align_up(sizeof(cplx) * (size_t)ntau * (size_t)nfd, 256) + align_up(fft, 256) + 512;
+    return SCINT_OK;
+}
+
+// Per chunk k with keep_n[k] >= 2 (ththmod.py:1457-1470): theta-theta of the E field = zeros with row N/2 = rows[k][:N] (the caller's
+// conj(V) sqrt(w)), its non-Hermitian back-map on the chunk's axes, scale * ifft2(ifftshift(.))[:nf, :nt] -> out[k].  Chunks with
+// keep_n[k] < 2 (failed or skipped by the caller) are left as the caller initialised them.
+extern "C" int32_t scint_retrieval_tail(const scint_c128* rows, const double* th_red, const int32_t* keep_n, const scint_cs_geom* geoms,
+                                        const double* etas, int64_t n, int64_t M, int64_t nf, int64_t nt, double scale,
+                                        scint_c128* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SCINT_REQUIRE(rows && th_red && keep_n && geoms && etas && out && workspace && n >= 1 && M >= 1, "retrieval_tail: null pointer or empty batch");
+    const int64_t ntau = geoms[0].ntau, nfd = geoms[0].nfd;
+    size_t need = 0, fft = 0;
+    if (scint_retrieval_tail_workspace_bytes(M, ntau, nfd, &need) != SCINT_OK || scint_fft2_workspace_bytes(ntau, nfd, &fft) != SCINT_OK) return SCINT_E_ARG;
+    if (workspace_bytes < need) { set_error("scint: retrieval_tail workspace too small"); return SCINT_E_WORKSPACE; }
+    char* base = (char*)workspace;
+    cplx* E = (cplx*)base;
+    cplx* recov = (cplx*)(base + align_up(sizeof(cplx) * (size_t)M * (size_t)M, 256));
+    char* fftws = (char*)recov + align_up(sizeof(cplx) * (size_t)ntau * (size_t)nfd, 256);
+    char* scratch = fftws + align_up(fft, 256);
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t N = keep_n[k];
+        if (N < 2) continue;
+        SCINT_REQUIRE(N <= M && geoms[k].ntau == ntau && geoms[k].nfd == nfd, "retrieval_tail: chunk does not match the batch's shape");
+        SCINT_HIP(hipMemsetAsync(E, 0, sizeof(cplx) * (size_t)N * (size_t)N, stream));
+        SCINT_HIP(hipMemcpyAsync(E + (N / 2) * N, (const cplx*)rows + k * M, sizeof(cplx) * (size_t)N, hipMemcpyDeviceToDevice, stream));
+        int32_t rc = scint_rev_map((const scint_c128*)E, nullptr, nullptr, 0, th_red + k * M, N, &geoms[k], etas[k], 0, (scint_c128*)recov,
+                                   scratch, 256, stream_);
+        if (rc != SCINT_OK) return rc;
+        rc = scint_ifft2_shifted((const scint_c128*)recov, ntau, nfd, scale, nf, nt, out + k * nf * nt, fftws, fft, stream_);
+        if (rc != SCINT_OK) return rc;
+    }
+    return SCINT_OK;
+}
