@@ -172,17 +172,6 @@ int32_t scint_sweep_stats(double* out /*HOST[4]*/);
  * (csrc/packed.hpp).  For callers that size the `batch` argument of the sweeps: resident curvatures x this = workgroups per
  * launch (scintools_amd/ththmod.py: default_batch).  Returns the count (>= 1), or -SCINT_E_ARG for nb < 1. */
 int32_t scint_sweep_workgroups(int32_t nb, int32_t complex64);
-/* Index-compressed passes of the float64 EIGENVALUE sweeps (scint_eval_sweep, scint_eval_sweep_multi; round 6).  A Lanczos pass
- * streams theta-theta of its curvature: 16 bytes per strict-upper element.  For a curvature whose 64-centre tiles span few delay
- * rows the sweep stores a 4-byte conjugate-spectrum offset per element instead and a pass fetches the payload from the spectrum
- * (resident in the Infinity Cache, shared by all resident curvatures) times a weight from a |j - i| table: the same float64
- * products to 1e-12 (the table assumes the uniform theta grid it has verified), 1.25-1.39x the streamed pass
- * (profiles/r06_indexed_pass_probe.txt).  Used only when the spectrum is finite, smaller than 2^30 elements and the theta grid
- * strictly increasing and uniform to 1e-12 (checked on the device per sweep); everything else, the eigenvector sweeps and the
- * mixed sweep stream as before.  mode: 0 off, 1 on (default; SCINT_SWEEP_INDEXED in the environment), -1 leave; span > 0 sets the
- * most delay rows a tile may span at the grid's edge (default 64; SCINT_SWEEP_INDEXED_SPAN).  Returns the previous mode. */
-int32_t scint_sweep_indexed(int32_t mode, double span);
-
 /* Environment variables the library reads (each ONCE per process unless said otherwise; none selects another kernel family or
  * changes a result beyond what is said here):
  *   SCINT_SWEEP_PRECISION = f64 | mixed | mixed-all   initial value of scint_sweep_precision();

@@ -50,7 +50,6 @@ _SIGNATURES = {
     "scint_sweep_schedule": ([c_int32, c_int32, c_int32], c_int32),
     "scint_sweep_stats": ([POINTER(c_double)], c_int32),
     "scint_sweep_workgroups": ([c_int32, c_int32], c_int32),
-    "scint_sweep_indexed": ([c_int32, c_double], c_int32),
     "scint_eval_sweep_workspace_bytes": ([c_int64, c_int64, c_int64, c_int32, POINTER(c_size_t)], c_int32),
     "scint_eval_sweep": ([_P, POINTER(CsGeom), _P, c_int64, _P, POINTER(c_int32), POINTER(c_double), c_int64,
                           c_double, c_int32, c_int64, _P, _P, _P, _P, c_size_t, _P], c_int32),
@@ -107,7 +106,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 106          # scint_version() of the library these signatures describe (csrc/capi.hip)
+ABI_VERSION = 105          # scint_version() of the library these signatures describe (csrc/capi.hip)
 
 
 def header_symbols():

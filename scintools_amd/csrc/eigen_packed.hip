@@ -62,21 +62,8 @@ constexpr int kFirstCheck = 8;
 constexpr int kMaxK = 512;   // upper bound on the Lanczos steps a caller may ask for
 
 // Element (row, col) of the packed Hermitian matrix, row != col blocks handled by symmetry.
-// value of an index-compressed element (packed.hpp): cs[offset] * weight, conjugated if the code says so
-__device__ inline cplx idx_value(int code, const cplx* __restrict__ cs, double w) {
-    const cplx v = gload(cs + (code >= 0 ? (code & kIdxMask) : 0));
-    const double none = code == -2 ? nan("") : 0.0;
-    const double vy = v.y * w;
-    return mk(code >= 0 ? v.x * w : none, code >= 0 ? ((code & kIdxConj) ? -vy : vy) : none);
-}
 __device__ inline cplx packed_at(const PackedJob& jb, int r, int c) {
     const int br = r / kTB, bc = c / kTB;
-    if (jb.indexed && gload(jb.idx_ok) != 0) {
-        const int32_t* __restrict__ codes = (const int32_t*)jb.tiles;
-        const double w = jb.wtab[r > c ? r - c : c - r];
-        if (bc >= br) return idx_value(codes[(tile_offset(jb.nb, br) + (bc - br)) * kTileElems + (r % kTB) * kTB + (c % kTB)], jb.cs, w);
-        return conj(idx_value(codes[(tile_offset(jb.nb, bc) + (br - bc)) * kTileElems + (c % kTB) * kTB + (r % kTB)], jb.cs, w));
-    }
     if (bc >= br) return jb.tiles[(tile_offset(jb.nb, br) + (bc - br)) * kTileElems + (r % kTB) * kTB + (c % kTB)];
     return conj(jb.tiles[(tile_offset(jb.nb, bc) + (br - bc)) * kTileElems + (c % kTB) * kTB + (r % kTB)]);
 }
@@ -319,30 +306,19 @@ __device__ __forceinline__ cplx pk2_colsum(cplx (&c1)[2], cplx (&c2)[2], int rg)
 // One block row of the strip: tiles t = t0 .. ntile-1 at tp + (t - t0) tiles; a0 holds the first half of tile t0.
 // ADD: the column partials are added to what the first row left (the tile tskip -- the second row's diagonal
 // tile -- adds nothing); else they are stored.  Then the row partials: 8 lanes by shuffles, 4 waves through LDS.
-// IDX (round 6, packed.hpp): the tiles hold int32 codes; element (row rg + 8 q, column col + 8 cc) of tile t is
-// cs[offset] * wtab[|j - i|], j - i = dj0 + 64 t + 8 cc - 8 q.  Same loop, same prefetch distance, same sums.
-struct IdxSrc { const cplx* cs; const double* wtab; int dj0; };
-template <bool IDX>
-__device__ __forceinline__ cplx pk2_fetch(const cplx* __restrict__ tc, int e, const IdxSrc& ix, int dj) {
-    if (!IDX) return gload_nt(tc + e);
-    const int code = __builtin_nontemporal_load((const SCINT_GLOBAL int32_t*)((const int32_t*)tc + e));
-    return idx_value(code, ix.cs, gload(ix.wtab + (dj < 0 ? -dj : dj)));
-}
-template <bool ADD, bool IDX>
-__device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, const IdxSrc ix, cplx (&a0)[8], int t0, int ntile, int tskip,
+template <bool ADD>
+__device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, cplx (&a0)[8], int t0, int ntile, int tskip,
                                        const cplx (*__restrict__ xs)[kTB][2], const cplx (*__restrict__ xir)[2],
                                        cplx* __restrict__ cslot, cplx* __restrict__ scratch, cplx (*__restrict__ rsum)[kTB][2],
                                        cplx* __restrict__ rowpart, int lane, int w, int col, int cg, int rg) {
     cplx a1[8], acc1[8], acc2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { acc1[j] = mk(0.0, 0.0); acc2[j] = mk(0.0, 0.0); }
-    constexpr int kTileStep = IDX ? kTileElems / 4 : kTileElems;      // (a tile of int32 codes is a quarter of a complex128 tile, in units of cplx)
 #pragma unroll 1
     for (int t = t0; t + 1 < ntile; ++t) {
-        const cplx* __restrict__ tc = tp + (int64_t)(t - t0) * kTileStep;
-        const int djt = ix.dj0 + 64 * t;
+        const cplx* __restrict__ tc = tp + (int64_t)(t - t0) * kTileElems;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a1[k] = pk2_fetch<IDX>(tc, (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1), ix, djt + 8 * (k & 1) - 8 * (4 + (k >> 1)));   // rows 32 .. 63
+        for (int k = 0; k < 8; ++k) a1[k] = gload_nt(tc + (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1));   // rows 32 .. 63
         cplx xJ1[2], xJ2[2], c1[2], c2[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -352,9 +328,7 @@ __device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, const IdxSr
         pk2_half(a0, 0, xir, xJ1, xJ2, acc1, acc2, c1, c2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)      // rows 0 .. 31 of the next tile
-            a0[k] = pk2_fetch<IDX>(IDX ? (const cplx*)((const int32_t*)tc + kTileElems) : tc + kTileElems, (8 * (k >> 1)) * kTB + 8 * (k & 1), ix,
-                                   djt + 64 + 8 * (k & 1) - 8 * (k >> 1));
+        for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tc + kTileElems + (8 * (k >> 1)) * kTB + 8 * (k & 1));   // rows 0 .. 31 of the next tile
         __builtin_amdgcn_sched_barrier(0);
         pk2_half(a1, 1, xir, xJ1, xJ2, acc1, acc2, c1, c2);
         cplx c = pk2_colsum(c1, c2, rg);
@@ -370,10 +344,9 @@ __device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, const IdxSr
     }
     {   // the last tile: nothing left to prefetch
         const int t = ntile - 1;
-        const cplx* __restrict__ tc = tp + (int64_t)(t - t0) * kTileStep;
-        const int djt = ix.dj0 + 64 * t;
+        const cplx* __restrict__ tc = tp + (int64_t)(t - t0) * kTileElems;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a1[k] = pk2_fetch<IDX>(tc, (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1), ix, djt + 8 * (k & 1) - 8 * (4 + (k >> 1)));
+        for (int k = 0; k < 8; ++k) a1[k] = gload_nt(tc + (8 * (4 + (k >> 1))) * kTB + 8 * (k & 1));
         cplx xJ1[2], xJ2[2], c1[2], c2[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -415,8 +388,7 @@ __device__ __forceinline__ void pk2_row(const cplx* __restrict__ tp, const IdxSr
 
 // (the workgroup's whole work, so that the mixed sweep can put complex128 and complex64 strips into ONE launch:
 // pk2_matvec_mixed_kernel in matvec32.hpp)
-template <bool IDX>
-__device__ __forceinline__ void pk2_matvec_body_t(const Strip* __restrict__ sp, int launch) {
+__device__ __forceinline__ void pk2_matvec_body(const Strip* __restrict__ sp, int launch) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];             // kMatvecLdsBytes = 76 KiB: two workgroups per CU
     cplx* lds = reinterpret_cast<cplx*>(smem_raw);
     cplx (*xs)[kTB][2] = reinterpret_cast<cplx (*)[kTB][2]>(lds + kLdsXs);     // [kMaxStrip]: the blocks X_J = rows of Q_j (32 KiB)
@@ -427,15 +399,13 @@ __device__ __forceinline__ void pk2_matvec_body_t(const Strip* __restrict__ sp, 
     const int cg = lane & 7, rg = lane >> 3, col = 16 * w + cg;
     const int ntile = sp->ntile;
     const int lane_off = rg * kTB + col;                                        // row rg, first column of the lane
-    // (index-compressed strips: the tile pointers address int32 codes)
-    const cplx* __restrict__ tp = IDX ? (const cplx*)((const int32_t*)sp->tiles[0] + lane_off) : sp->tiles[0] + lane_off;
-    const int I = sp->I, J0 = sp->J0, nrows = sp->nrows;
-    IdxSrc ix{sp->cs, sp->wtab, 64 * (J0 - I) + col - rg};
+    const cplx* __restrict__ tp = sp->tiles[0] + lane_off;
     cplx a0[8];                                                                 // element 2 jj + cc: row 8 (4h + jj) + rg, column col + 8 cc
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a0[k] = pk2_fetch<IDX>(tp, (8 * (k >> 1)) * kTB + 8 * (k & 1), ix, ix.dj0 + 8 * (k & 1) - 8 * (k >> 1));
+    for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tp + (8 * (k >> 1)) * kTB + 8 * (k & 1));
     const int32_t done = gload(sp->state);
     const cplx* __restrict__ X = sp->Q + (int64_t)(step % sp->qslots) * sp->qstride * 2;   // Q_j
+    const int I = sp->I, J0 = sp->J0, nrows = sp->nrows;
     // X_I of both rows and the strip's X_J blocks: contiguous copies of rows of Q_j (the first tile's loads stay in flight)
     for (int idx = threadIdx.x; idx < nrows * 2 * kTB; idx += 256) lds[kLdsXi + idx] = gload(X + 2 * I * kTB + idx);
     for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) lds[kLdsXs + idx] = gload(X + 2 * J0 * kTB + idx);
@@ -444,21 +414,19 @@ __device__ __forceinline__ void pk2_matvec_body_t(const Strip* __restrict__ sp, 
     const cplx (*__restrict__ xi)[2] = reinterpret_cast<const cplx (*)[2]>(lds + kLdsXi);
     // this lane's slot in a tile's [64][2] column partial: column col + 8 (rg >> 1 & 1), vector rg & 1
     cplx* __restrict__ cslot = lds + kLdsCol + 2 * (col + 8 * ((rg >> 1) & 1)) + (rg & 1);
-    pk2_row<false, IDX>(tp, ix, a0, 0, ntile, -1, xs, xi + rg, cslot, nullptr, rsum, sp->rowpart[0], lane, w, col, cg, rg);
+    pk2_row<false>(tp, a0, 0, ntile, -1, xs, xi + rg, cslot, nullptr, rsum, sp->rowpart[0], lane, w, col, cg, rg);
 #pragma unroll 1
     for (int r = 1; r < nrows; ++r) {
         // block row I+r over the same columns: its tiles start at column max(J0, I+r); its diagonal tile (I+r, I+r)
         // adds no column partial
         const int t0 = max(0, I + r - J0);
         if (t0 < ntile) {
-            const cplx* __restrict__ tpB = IDX ? (const cplx*)((const int32_t*)sp->tiles[r] + lane_off) : sp->tiles[r] + lane_off;
-            ix.dj0 = 64 * (J0 - (I + r)) + col - rg;
+            const cplx* __restrict__ tpB = sp->tiles[r] + lane_off;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                a0[k] = pk2_fetch<IDX>(tpB, (8 * (k >> 1)) * kTB + 8 * (k & 1), ix, ix.dj0 + 64 * t0 + 8 * (k & 1) - 8 * (k >> 1));
+            for (int k = 0; k < 8; ++k) a0[k] = gload_nt(tpB + (8 * (k >> 1)) * kTB + 8 * (k & 1));
             // (scratch elements of the upper row groups: the first row's X_I block, dead since that row's barrier)
-            pk2_row<true, IDX>(tpB, ix, a0, t0, ntile, I + r - J0, xs, xi + r * kTB + rg, cslot, lds + kLdsXi + 32 * w + (lane & 31), rsum,
-                               sp->rowpart[r], lane, w, col, cg, rg);
+            pk2_row<true>(tpB, a0, t0, ntile, I + r - J0, xs, xi + r * kTB + rg, cslot, lds + kLdsXi + 32 * w + (lane & 31), rsum,
+                          sp->rowpart[r], lane, w, col, cg, rg);
         } else if (threadIdx.x < 2 * kTB) {
             gstore(sp->rowpart[r] + threadIdx.x, mk(0.0, 0.0));   // short strips (tests): row I+r has nothing in this column range
         }
@@ -467,12 +435,6 @@ __device__ __forceinline__ void pk2_matvec_body_t(const Strip* __restrict__ sp, 
     __syncthreads();
     cplx* __restrict__ colpart = sp->colpart;
     for (int idx = threadIdx.x; idx < ntile * 2 * kTB; idx += 256) gstore_nt(colpart + idx, lds[kLdsCol + idx]);
-}
-
-// (a launch holds streamed and index-compressed strips side by side: the strip says which, its spectrum's flag whether it may)
-__device__ __forceinline__ void pk2_matvec_body(const Strip* __restrict__ sp, int launch) {
-    if (sp->indexed != 0 && gload(sp->idx_ok) != 0) pk2_matvec_body_t<true>(sp, launch);
-    else pk2_matvec_body_t<false>(sp, launch);
 }
 
 __global__ void __launch_bounds__(256, 2)
@@ -847,7 +809,7 @@ __global__ void __launch_bounds__(64) pk2_restart_kernel(const PackedJob* jobs, 
 // ------------------------------------------------------------------------------
 struct SlabLayout {
     size_t tiles, tiles32, U0, U1, Q, svec, rowpart, colpart, apart0, apart1, upart0, upart1,
-        coef, alpha, beta, result, wtab, total;
+        coef, alpha, beta, result, total;
     int qslots;
 };
 
@@ -897,7 +859,6 @@ static SlabLayout slab_layout(int nbmax, int max_steps, bool want_vec, bool mixe
     L.alpha = take(sizeof(double) * (size_t)(max_steps + 2) * sc);
     L.beta = take(sizeof(double) * (size_t)(max_steps + 3) * sc);
     L.result = take(sizeof(double) * 4);
-    L.wtab = take(sizeof(double) * (size_t)nbmax * kTB);      // weights of an index-compressed job (packed.hpp)
     L.total = align_up(off, 256);
     return L;
 }
@@ -907,7 +868,7 @@ constexpr int kTabs = 3;   // rotating copies of the per-chunk tables (job table
 struct BatchLayout {
     SlabLayout slab;
     int smax;
-    size_t jobs, strips, strips32, states, slots, fin_slots, restart, fin_eta, rs, geoms, scales, scale_bits, idx_ok, total;   // table offsets: copy 0; copies are *_stride apart
+    size_t jobs, strips, strips32, states, slots, fin_slots, restart, fin_eta, rs, geoms, scales, scale_bits, total;   // table offsets: copy 0; copies are *_stride apart
     size_t jobs_stride, strips_stride, strips32_stride, list_stride, fin_eta_stride, rs_stride;
 };
 
@@ -939,7 +900,6 @@ static BatchLayout batch_layout(int nbmax, int max_steps, int nbatch, bool want_
     B.geoms = take(sizeof(GeomDev) * (size_t)ncs);
     B.scales = take(sizeof(double) * (size_t)ncs);
     B.scale_bits = take(sizeof(unsigned long long) * (size_t)ncs);
-    B.idx_ok = take(sizeof(int32_t) * (size_t)ncs);
     B.total = align_up(off, 256);
     return B;
 }
@@ -1001,19 +961,6 @@ int32_t sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t ma
 // read ONCE per process -- until round 4 run_sweep called getenv three times per sweep).  0 = the measured default.  None
 // selects a different kernel; depth and groups change no result bit (the check cadence moves the pass a curvature stops at,
 // i.e. its value inside the tolerance): they exist for the tests that prove exactly that, and for bench.py's one-slot-group leg.
-// Index-compressed tiles (packed.hpp): scint_sweep_indexed(); initial values SCINT_SWEEP_INDEXED (0 / 1) and
-// SCINT_SWEEP_INDEXED_SPAN (delay rows a tile may span, default 64) in the environment, read once
-struct SweepIndexed { std::atomic<int> mode{1}; std::atomic<double> span{64.0}; };
-static SweepIndexed& sweep_indexed() {
-    static SweepIndexed s;
-    static const bool init = [] {
-        if (const char* e = getenv("SCINT_SWEEP_INDEXED")) s.mode.store(atoi(e) != 0 ? 1 : 0);
-        if (const char* e = getenv("SCINT_SWEEP_INDEXED_SPAN")) { const double v = atof(e); if (v > 0.0) s.span.store(v); }
-        return true;
-    }();
-    (void)init;
-    return s;
-}
 struct SweepSchedule { std::atomic<int> depth{0}, check_every{0}, groups{0}; };
 static SweepSchedule& sweep_schedule() {
     static SweepSchedule sc;
@@ -1116,19 +1063,6 @@ struct SweepProblem {
     SweepTail* tail_hook; hipStream_t tail[kTailLanes]; int tail_rr = 0;   // retired curvatures go round the tail streams
     int nbmax, steps_cap, depth, check_every;
     bool mixed = false; double tol = 0.0; const double* scales_dev = nullptr;   // the mixed sweep (see "Mixed precision" above)
-    bool indexed = false; const int32_t* idx_ok_dev = nullptr; const scint_cs_geom* geom_h = nullptr; double idx_span = 64.0;   // index-compressed tiles (packed.hpp)
-    // delay rows a tile's 64 centres span at the edge of the grid for curvature e (an upper bound from the axes alone): the gather
-    // locality of an indexed pass -- up to ~64 rows it beats the streamed pass (profiles/r06_indexed_pass_probe.txt: 1.25-1.39x at
-    // 31 rows and less, 0.94x at 122)
-    bool eta_indexed(int64_t e, int64_t c) const {
-        if (!indexed) return false;
-        const scint_cs_geom& g = geom_h[c];
-        const double eta = fabs(etas[e]);
-        double thmax = 0.5 * g.fd_max;
-        if (eta > 0.0) thmax = std::min(thmax, sqrt(g.tau_max / eta));
-        const double span = 2.0 * eta * thmax * (64.0 * g.fd_max / (double)M) / fabs(g.tau1_step);
-        return span <= idx_span;
-    }
     char* base; BatchLayout BL; const GeomDev* geoms_dev; int32_t* states_dev;
     int64_t next_eta = 0;                 // the queue of curvatures still to be started (both groups pull)
     hipEvent_t stagger_ev = nullptr;      // recorded after the first group's first pass
@@ -1225,7 +1159,6 @@ struct SweepGroup {
             J.iters_out = S.iters_out ? S.iters_out + e : nullptr;
             J.use32 = S.mixed ? 1 : 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = S.mixed ? kRows32Lg : kRows64Lg;
             J.scale32 = S.mixed ? S.scales_dev + c : nullptr;
-            J.indexed = S.eta_indexed(e, c) ? 1 : 0; J.idx_ok = S.idx_ok_dev + c;
             J.tol = S.mixed ? 0.5 * S.tol : S.tol;      // (the certificate then passes at the first attempt: measured 1.00 passes per curvature)
             slot_phase[(size_t)s] = 0;
             fresh.push_back(s);
@@ -1299,12 +1232,9 @@ struct SweepGroup {
                         st.state = J.state;
                         st.I = I; st.J0 = J0; st.ntile = std::min(J.nb, J0 + J.strip_len) - J0;
                         st.start = J.start; st.gen = J.gen; st.max_steps = J.max_steps; st.nrows = nrows;
-                        st.cs = J.cs; st.wtab = J.wtab; st.idx_ok = J.idx_ok; st.indexed = J.indexed; st.pad = 0;
                         for (int r = 0; r < kRows64; ++r) {
                             const int Ir = std::min(I + r, J.nb - 1), JB = std::max(J0, Ir);
-                            // (index-compressed: the same tile order, one int32 per element)
-                            st.tiles[r] = J.indexed ? (const cplx*)((const int32_t*)J.tiles + (tile_offset(J.nb, Ir) + (JB - Ir)) * kTileElems)
-                                                    : J.tiles + (tile_offset(J.nb, Ir) + (JB - Ir)) * kTileElems;
+                            st.tiles[r] = J.tiles + (tile_offset(J.nb, Ir) + (JB - Ir)) * kTileElems;
                             st.rowpart[r] = J.rowpart + 2 * (int64_t)(rs0[Ir] + k) * kTB;
                         }
                     }
@@ -1531,13 +1461,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     S.states_dev = (int32_t*)(S.base + S.BL.states);
     S.geoms_dev = (const GeomDev*)(S.base + S.BL.geoms);
     S.scales_dev = (const double*)(S.base + S.BL.scales);
-    S.idx_ok_dev = (const int32_t*)(S.base + S.BL.idx_ok);
-    S.geom_h = geom;
-    {   // index-compressed tiles: eigenvalue sweeps in float64 only (the eigenvector paths and the mixed sweep keep the streamed tiles)
-        const SweepIndexed& si = sweep_indexed();
-        S.indexed = si.mode.load() != 0 && !want_vec && !S.mixed;
-        S.idx_span = si.span.load();
-    }
 
     // pinned staging: geometry table + per group kTabs x {jobs, strips, fresh, fin, fin_eta, row_strip0, flags}
     auto per_tab = [&](size_t nsl) {
@@ -1589,7 +1512,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
             J.tiles = (cplx*)(sl + L.tiles);
             J.tiles32 = S.mixed ? (c32*)(sl + L.tiles32) : nullptr;
             J.scale32 = nullptr; J.use32 = 0; J.certify = 0; J.iters_base = 0; J.rowgroup_lg = kRows64Lg;
-            J.indexed = 0; J.pad2 = 0; J.wtab = (double*)(sl + L.wtab); J.idx_ok = (const int32_t*)(S.base + S.BL.idx_ok);
             J.U[0] = (cplx*)(sl + L.U0); J.U[1] = (cplx*)(sl + L.U1);
             J.Q = (cplx*)(sl + L.Q); J.qstride = (int64_t)S.nbmax * kTB; J.qslots = L.qslots;
             J.want_vec = want_vec ? 1 : 0; J.svec = (double*)(sl + L.svec);
@@ -1613,11 +1535,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
     if (rc == SCINT_OK) {
         he = hipMemcpyAsync((void*)S.geoms_dev, h_geoms, sizeof(GeomDev) * (size_t)ncs, hipMemcpyHostToDevice, stream);
         if (he == hipSuccess) he = hipMemsetAsync(S.states_dev, 0, sizeof(int32_t) * 4 * (size_t)nslots, stream);
-        if (he == hipSuccess && S.indexed) {
-            const int32_t irc = launch_idx_ok((const cplx*)cs, ncs, cs_stride, (int64_t)geom[0].ntau * geom[0].nfd, th_cents, M,
-                                              (int32_t*)(S.base + S.BL.idx_ok), stream);
-            if (irc != SCINT_OK) rc = irc;
-        }
         if (he == hipSuccess && S.mixed) {
             const int32_t src = launch_cs_scale((const cplx*)cs, ncs, cs_stride, (int64_t)geom[0].ntau * geom[0].nfd,
                                                 (unsigned long long*)(S.base + S.BL.scale_bits), (double*)(S.base + S.BL.scales), stream);
@@ -1673,15 +1590,6 @@ int32_t run_sweep(const scint_c128* cs, int64_t ncs, int64_t cs_stride, const in
 }  // namespace scint
 
 using namespace scint;
-
-extern "C" int32_t scint_sweep_indexed(int32_t mode, double span) {
-    SweepIndexed& si = sweep_indexed();
-    const int prev = si.mode.load();
-    if (mode == 0 || mode == 1) si.mode.store(mode);
-    else if (mode != -1) { set_error("scint: sweep_indexed: mode must be 0 (off), 1 (on) or -1 (leave)"); return SCINT_E_ARG; }
-    if (span > 0.0) si.span.store(span);
-    return prev;
-}
 
 extern "C" int32_t scint_sweep_precision(int32_t mode) {
     std::atomic<int>& m = sweep_mode_ref();

@@ -101,13 +101,6 @@ struct PackedJob {
     int32_t certify;        // 1: restarted on the complex128 tiles from the Ritz vectors of the iteration phase
     int32_t iters_base;     // passes of the iteration phase (certify: added to the reported count; restart: its T_k has 2 iters_base rows)
     int32_t rowgroup_lg;    // log2 of the block rows that share one column partial: kRows64Lg (complex128 strips), kRows32Lg (complex64)
-    // ---- index-compressed tiles (round 6) ------------------------------
-    int32_t indexed;        // 1: if *idx_ok, `tiles` holds one int32 CODE per element (tile stride kTileElems ints) instead of the value:
-                            //    the element's offset into `cs` (bit 30: conjugate; -1: zero; -2: NaN marker), and a Lanczos pass
-                            //    fetches cs[offset] * wtab[|j - i|] -- 4 bytes streamed per element instead of 16
-    int32_t pad2;
-    double* wtab;           // [nb * 64] weights sqrt|2 eta (theta_0 - theta_d)| of this job (written by its gather)
-    const int32_t* idx_ok;  // device word of the job's spectrum: 1 if spectrum and theta grid allow the indexed form (launch_idx_ok)
     // ---- Lanczos state -----------------------------------------------------------
     int32_t max_steps, strip_len;
     int32_t start, gen;     // launch index of this job's Lanczos step 0; generation of the slot (>= 1)
@@ -147,9 +140,6 @@ struct __attribute__((aligned(16))) Strip {
     int64_t qstride;
     int32_t I, J0, ntile, qslots;
     int32_t start, gen, max_steps, nrows;
-    // index-compressed tiles: `tiles[r]` then point at int32 codes (same tile order, kTileElems ints apart)
-    const cplx* cs; const double* wtab; const int32_t* idx_ok;
-    int32_t indexed, pad;
 };
 
 // Rows are grouped (0..R-1), (R..2R-1), ...; a short last group runs with the rows it has.  Every row of a group is
@@ -181,11 +171,6 @@ int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJo
 // maximum is 0); `bits` is scratch of ncs words.  Queued on `stream`.
 int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t nelem, unsigned long long* bits,
                         double* scale, hipStream_t stream);
-// ok[c] = 1 if spectrum c (nelem < 2^30 elements, all finite, |.| < 1e150) and its theta grid th + c M (strictly increasing, uniform to
-// 1e-12 of its step) allow index-compressed tiles: the mat-vec then multiplies cs[offset] by a weight from a |j - i| table without
-// nan_to_num (nothing to clean) and the table is exact to 1e-12.  Queued on `stream`.
-int32_t launch_idx_ok(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t nelem, const double* th, int64_t M, int32_t* ok, hipStream_t stream);
-constexpr int kIdxConj = 0x40000000, kIdxMask = 0x3fffffff;     // code of an element: offset | kIdxConj; -1 zero; -2 NaN
 
 // What the sweep does with a curvature once its eigenpair has been exported (chi^2 sweep): called
 // on the host while the sweep runs; enqueues on a tail stream that already waits for the export.

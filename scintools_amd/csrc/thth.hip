@@ -166,16 +166,6 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
     const double sq_j = th_j * th_j;
     cplx* __restrict__ tile = jp->tiles + (int64_t)t * kTileElems + lane;
     c32* __restrict__ tile32 = F32 ? jp->tiles32 + (int64_t)t * kTileElems + lane : nullptr;
-    // index-compressed job (packed.hpp): the tile leaves as one int32 code per element, nothing is read from the spectrum here
-    const bool idx = !F32 && jp->indexed != 0 && gload(jp->idx_ok) != 0;      // uniform over the launch's workgroups of this job
-    int32_t* __restrict__ tilei = (int32_t*)jp->tiles + (int64_t)t * kTileElems + lane;
-    if (idx && t == 0) {
-        // the job's weight table: w[d] = sqrt|2 eta (theta_0 - theta_d)| over its kept centres (a contiguous run of a sorted, uniform
-        // grid: launch_idx_ok) -- what gather_elem forms per element, to the grid's 1e-12
-        const int k0 = n > 0 ? gload(keep) : 0;
-        const double t0 = gload(th + k0);
-        for (int d = threadIdx.x; d < nb * kTB; d += 256) jp->wtab[d] = d < n ? sqrt(fabs(two_eta * (t0 - gload(th + k0 + d)))) : 0.0;
-    }
     const double sc32 = F32 ? gload(jp->scale32) : 1.0;
     const bool diag = (I == J);
     // the wave's 16 rows: lanes 0..15 fetch keep / theta_i once (one dependent load pair), every
@@ -213,21 +203,11 @@ thth_gather_packed_kernel(const GeomDev* __restrict__ geoms, int64_t M,
                 el[b][k] = gather_elem(g, nfd, eta, two_eta, th_i, th_j, sq_i, sq_j, i < n && jin && !anti);
             }
         }
-        if (idx) return;
 #pragma unroll
         for (int k = 0; k < 8; ++k) val[b][k] = gload(cs + (el[b][k].off >= 0 ? el[b][k].off : 0));
     };
     auto weight_and_store = [&](int b, auto diag_c) {
         constexpr bool DIAG = decltype(diag_c)::value;
-        if (idx) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const GatherElem e = el[b][k];
-                const int code = e.off >= 0 ? (e.off | ((DIAG && e.wgt < 0.0) ? kIdxConj : 0)) : e.off;
-                __builtin_nontemporal_store(code, (SCINT_GLOBAL int32_t*)(tilei + (16 * w + 8 * b + k) * kTB));
-            }
-            return;
-        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const GatherElem e = el[b][k];
@@ -263,44 +243,6 @@ int32_t launch_gather_packed(const GeomDev* geoms_dev, int64_t M, const PackedJo
     if (with32) hipLaunchKernelGGL(thth_gather_packed_kernel<true>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
     else hipLaunchKernelGGL(thth_gather_packed_kernel<false>, grid, dim3(256), 0, stream, geoms_dev, M, jobs_dev, slots_dev);
     profiler().end(kProfGather, slot, stream);
-    SCINT_LAUNCH_CHECK();
-    return SCINT_OK;
-}
-
-// Eligibility of index-compressed tiles per spectrum (packed.hpp: launch_idx_ok).  ok[c] starts at 1 and is cleared by any workgroup
-// that finds a non-finite or huge element, or a theta grid that is not strictly increasing and uniform.
-__global__ void __launch_bounds__(256) idx_ok_kernel(const cplx* __restrict__ cs, int64_t cs_stride, int64_t nelem, const double* __restrict__ th,
-                                                     int64_t M, int32_t* __restrict__ ok) {
-    const int64_t c = blockIdx.y;
-    const cplx* __restrict__ p = cs + c * cs_stride;
-    bool bad = false;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nelem; k += (int64_t)gridDim.x * 256) {
-        const cplx v = gload(p + k);
-        bad |= !(fabs(v.x) < 1e150) || !(fabs(v.y) < 1e150);           // (NaN compares false)
-    }
-    if (blockIdx.x == 0) {
-        const double* __restrict__ t = th + c * M;
-        const double step = M > 1 ? (gload(t + M - 1) - gload(t)) / (double)(M - 1) : 1.0;
-        bad |= !(step > 0.0) || !(step < 1e150);
-        for (int64_t k = threadIdx.x; k + 1 < M; k += 256) {
-            const double d = gload(t + k + 1) - gload(t + k);
-            bad |= !(d > 0.0) || !(fabs(d - step) <= 1e-12 * step);
-            bad |= !(fabs((gload(t + k) - gload(t)) - (double)k * step) <= 1e-12 * step * (double)(M > 1 ? M : 1));
-        }
-    }
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicExch(ok + c, 0);
-}
-__global__ void __launch_bounds__(64) idx_ok_init_kernel(int32_t* ok, int64_t ncs, int32_t v) {
-    for (int64_t k = threadIdx.x; k < ncs; k += 64) ok[k] = v;
-}
-int32_t launch_idx_ok(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t nelem, const double* th, int64_t M, int32_t* ok, hipStream_t stream) {
-    if (ncs <= 0) return SCINT_OK;
-    const bool fits = nelem < (int64_t(1) << 30) && ncs <= 65535;
-    hipLaunchKernelGGL(idx_ok_init_kernel, dim3(1), dim3(64), 0, stream, ok, ncs, fits ? 1 : 0);
-    if (fits) {
-        const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(nelem, 256 * 8), 2048);
-        hipLaunchKernelGGL(idx_ok_kernel, dim3(blocks, (unsigned)ncs), dim3(256), 0, stream, cs, cs_stride, nelem, th, M, ok);
-    }
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
