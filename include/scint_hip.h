@@ -320,17 +320,20 @@ int32_t scint_chunk_cut(const double* dyn, int64_t nf, int64_t nt, const int32_t
  * maps single_chunk_retrieval, ththmod.py:1390-1476, over the chunks) --------------------------------------------------------
  * scint_cs_batch: scint_cs of every chunk of dstack [n][nf][nt] into cs_stack [n][R][C]; pads (HOST [n]) the padding values,
  * mask_lohi (HOST [n][2]) the masked delay rows of each.  scint_retrieval_tail: per chunk k with keep_n[k] >= 2 the theta-theta
- * of the E field (zeros with row N/2 = rows[k][:N] = conj(V) sqrt(w), ththmod.py:1459-1461), its non-Hermitian back-map
- * (scint_rev_map) on geoms[k] / etas[k] / th_red[k][:N], and scale * ifft2(ifftshift(.))[:nf, :nt] -> out[k] (scint_ifft2_shifted);
- * chunks with keep_n[k] < 2 are left untouched.  rows [n][M] complex, th_red [n][M], out [n][nf][nt]: device; keep_n, geoms,
- * etas: HOST.  Same kernels as the single-chunk entry points, queued by one C++ loop. */
+ * of the E field (zeros with row N/2 = rows[k][:N] = conj(V) sqrt(w), ththmod.py:1459-1461), its non-Hermitian back-map on
+ * geoms[k] / etas[k] / th_red[k][:N], and scale * ifft2(ifftshift(.))[:nf, :nt] -> out[k] (scint_ifft2_shifted); chunks with
+ * keep_n[k] < 2 are left untouched.  The back-map is rev_map's arithmetic (ththmod.py:176-271, hermetian=False) without the N x N
+ * matrix: a pixel is (sum of the row's weights that fall in it, in increasing j) x 1 / (number of ALL N^2 pairs that fall in it),
+ * and those counts are formed once per CLASS -- class_id (HOST [n]): consecutive chunks with equal ids share theta grid, curvature
+ * and axes (the chunks of one frequency row of an observation).  rows [n][M] complex, th_red [n][M], out [n][nf][nt]: device;
+ * keep_n, class_id, geoms, etas: HOST. */
 int32_t scint_cs_batch(const double* dstack, int64_t n, int64_t nf, int64_t nt, int64_t npad, const double* pads /*HOST*/,
                        const int64_t* mask_lohi /*HOST*/, int32_t incoherent, scint_c128* cs_stack, void* workspace,
                        size_t workspace_bytes, void* stream);
 int32_t scint_retrieval_tail_workspace_bytes(int64_t M, int64_t ntau, int64_t nfd, size_t* bytes /*HOST*/);
-int32_t scint_retrieval_tail(const scint_c128* rows, const double* th_red, const int32_t* keep_n /*HOST*/, const scint_cs_geom* geoms /*HOST*/,
-                             const double* etas /*HOST*/, int64_t n, int64_t M, int64_t nf, int64_t nt, double scale,
-                             scint_c128* out, void* workspace, size_t workspace_bytes, void* stream);
+int32_t scint_retrieval_tail(const scint_c128* rows, const double* th_red, const int32_t* keep_n /*HOST*/, const int32_t* class_id /*HOST*/,
+                             const scint_cs_geom* geoms /*HOST*/, const double* etas /*HOST*/, int64_t n, int64_t M, int64_t nf, int64_t nt,
+                             double scale, scint_c128* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Gerchberg-Saxton iterations of Dynspec.gerchberg_saxton (dynspec.py:1868-1875) -------
  * wavefield[rows, cols] in place.  Per iteration: fft2, zero the natural-order delay rows

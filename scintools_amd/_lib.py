@@ -86,8 +86,8 @@ _SIGNATURES = {
     "scint_chunk_cut": ([_P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int64, c_int32, _P, _P, _P, c_size_t, _P], c_int32),
     "scint_cs_batch": ([_P, c_int64, c_int64, c_int64, c_int64, POINTER(c_double), POINTER(c_int64), c_int32, _P, _P, c_size_t, _P], c_int32),
     "scint_retrieval_tail_workspace_bytes": ([c_int64, c_int64, c_int64, POINTER(c_size_t)], c_int32),
-    "scint_retrieval_tail": ([_P, _P, POINTER(c_int32), POINTER(CsGeom), POINTER(c_double), c_int64, c_int64, c_int64, c_int64, c_double,
-                              _P, _P, c_size_t, _P], c_int32),
+    "scint_retrieval_tail": ([_P, _P, POINTER(c_int32), POINTER(c_int32), POINTER(CsGeom), POINTER(c_double), c_int64, c_int64, c_int64, c_int64,
+                              c_double, _P, _P, c_size_t, _P], c_int32),
     "scint_gs_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
     "scint_gerchberg_saxton": ([_P, c_int64, c_int64, _P, _P, c_int64, c_int64, c_int32, _P, c_size_t, _P], c_int32),
     "scint_acf_workspace_bytes": ([c_int64, c_int64, POINTER(c_size_t)], c_int32),
@@ -106,7 +106,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 105          # scint_version() of the library these signatures describe (csrc/capi.hip)
+ABI_VERSION = 106          # scint_version() of the library these signatures describe (csrc/capi.hip)
 
 
 def header_symbols():

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "thth.hpp"
 
 namespace scint {
 
@@ -183,16 +184,19 @@ __device__ inline cplx cmul_np(cplx a, cplx b, bool fused) {
     return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// per job of the launch (one workgroup each): sum over the window of  (E * conj(chunk)) * mask  in numpy's order  ->  out[job][0..1]
-__global__ void __launch_bounds__(1024) mosaic_phase_kernel(MosaicArgs a, PairwisePlanDev p, double* nodes, double* out) {
-    const int64_t* job = a.jobs + 4 * (int64_t)blockIdx.x;
+// per job of the launch: sum over the window of  (E * conj(chunk)) * mask  in numpy's order  ->  out[job][0..1].  Two kernels: the leaves
+// (blockIdx.y = job, kLeafBlocks workgroups of 256 threads share its leaves: one workgroup per chunk took 238 us a step, a CU each
+// for at most sixteen chunks), then the additions (one workgroup per job).
+constexpr int kLeafBlocks = 8;
+__global__ void __launch_bounds__(256) mosaic_phase_leaves_kernel(MosaicArgs a, PairwisePlanDev p, double* nodes) {
+    const int64_t* job = a.jobs + 4 * (int64_t)blockIdx.y;
     const cplx* __restrict__ E = a.E + job[0];
     const cplx* __restrict__ chunk = a.chunks + job[1] * (int64_t)a.cwf * a.cwt;
     const double* __restrict__ fr = a.rows + job[2] * a.cwf;
     const double* __restrict__ fc = a.cols + job[3] * a.cwt;
-    double* node_re = nodes + (size_t)blockIdx.x * 2 * (size_t)p.nnodes;
+    double* node_re = nodes + (size_t)blockIdx.y * 2 * (size_t)p.nnodes;
     double* node_im = node_re + p.nnodes;
-    for (int lf = (int)threadIdx.x; lf < p.nleaves; lf += (int)blockDim.x) {
+    for (int lf = (int)(blockIdx.x * 256 + threadIdx.x); lf < p.nleaves; lf += (int)gridDim.x * 256) {
         const PwLeaf L = p.leaves[lf];
         auto val = [&](int i) {
             const int d = L.start + i, e = d >> 1;             // element of the window, row-major
@@ -209,7 +213,10 @@ __global__ void __launch_bounds__(1024) mosaic_phase_kernel(MosaicArgs a, Pairwi
         pw_leaf<true>(L.len, val, rr, ri);
         node_re[lf] = rr; node_im[lf] = ri;
     }
-    pw_combine(p, node_re, node_im, true, out + 2 * (size_t)blockIdx.x);
+}
+__global__ void __launch_bounds__(256) mosaic_phase_combine_kernel(PairwisePlanDev p, double* nodes, double* out) {
+    double* node_re = nodes + (size_t)blockIdx.x * 2 * (size_t)p.nnodes;
+    pw_combine(p, node_re, node_re + p.nnodes, true, out + 2 * (size_t)blockIdx.x);
 }
 
 // E[window] += (chunk * mask) * phase[job]      (ththmod.py:1551: E_recov[...] += chunk_new * mask * exp(1j * rot)); blockIdx.y = job
@@ -333,7 +340,8 @@ extern "C" int32_t scint_mosaic_phase(const scint_c128* E, int64_t ldE, const sc
     const PairwisePlanDev* p = pairwise_plan(cwf * cwt, 2);
     if (!p) return SCINT_E_HIP;
     MosaicArgs a{(cplx*)E, ldE, (const cplx*)chunks, (int)cwf, (int)cwt, jobs, rows, cols, numpy_fused};
-    hipLaunchKernelGGL(mosaic_phase_kernel, dim3((unsigned)count), dim3(1024), 0, stream, a, *p, (double*)workspace, sums_out);
+    hipLaunchKernelGGL(mosaic_phase_leaves_kernel, dim3(kLeafBlocks, (unsigned)count), dim3(256), 0, stream, a, *p, (double*)workspace);
+    hipLaunchKernelGGL(mosaic_phase_combine_kernel, dim3((unsigned)count), dim3(256), 0, stream, *p, (double*)workspace, sums_out);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }
@@ -387,43 +395,139 @@ extern "C" int32_t scint_cs_batch(const double* dstack, int64_t n, int64_t nf, i
     return SCINT_OK;
 }
 
+// ---- the back-map of single_chunk_retrieval without its N x N matrix -------------------------------------------------------
+// ththmod.py:1457-1464 maps a theta-theta matrix that is zero except for ONE row (row N/2 = conj(V) sqrt(w)) with
+// rev_map(hermetian=False): every pixel is (sum of the weights that fall in it) / (number of ALL N^2 theta-theta pixels that
+// fall in it).  The counts depend on the chunk's theta grid, curvature and axes only -- the same for every chunk of one frequency
+// row of the observation -- so they are formed once per such class (integer atomics: exact), and a chunk costs N pairs instead
+// of N^2 and no zero matrix.  A pixel's weights are added in increasing j, NumPy's order (bincount adds in input order).
+namespace scint {
+__global__ void __launch_bounds__(256) rev_count_kernel(const double* __restrict__ th, int N, double eta, GeomDev g, uint32_t* __restrict__ cnt) {
+    const int64_t total = (int64_t)N * N;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int i = (int)(q / N), j = (int)(q - (int64_t)i * N);
+        if (i == j) continue;                                          // (the centre bin these poison is written as 0: below)
+        const double ti = th[i], tj = th[j];
+        const int64_t bx = hist_bin(tj - ti, g.fd0, g.fd1_step, g.nfd);             // fd_map[i, j]   (ththmod.py:207)
+        const int64_t by = hist_bin(eta * (tj * tj - ti * ti), g.tau0, g.tau1_step, g.ntau);   // tau_map[i, j] (:208-210)
+        if (bx >= 0 && by >= 0) atomicAdd(cnt + by * g.nfd + bx, 1u);
+    }
+}
+constexpr int kRowRun = 8;     // positions looked at either side for the same pixel (a Doppler bin holds two or three centres)
+constexpr int kTailGroup = 8;  // chunks of a class whose back-maps and zero-fills go in one launch (their images side by side)
+struct TailMembers { int32_t k[kTailGroup]; };
+// one workgroup per chunk of the class: pixel and weight of every j, then each pixel's first j adds its run and writes it
+__global__ void __launch_bounds__(256) rev_row_kernel(const cplx* __restrict__ rows, const double* __restrict__ th_red, int64_t M,
+                                                      TailMembers members, int N, double eta, GeomDev g,
+                                                      const uint32_t* __restrict__ cnt, cplx* __restrict__ recov_all, int64_t centre,
+                                                      int64_t* __restrict__ pix_all, cplx* __restrict__ val_all) {
+    const int k = members.k[blockIdx.x];
+    const cplx* __restrict__ row = rows + (int64_t)k * M;
+    const double* __restrict__ th = th_red + (int64_t)k * M;
+    cplx* __restrict__ recov = recov_all + (int64_t)blockIdx.x * g.ntau * g.nfd;
+    int64_t* __restrict__ pix = pix_all + (int64_t)blockIdx.x * M;
+    cplx* __restrict__ val = val_all + (int64_t)blockIdx.x * M;
+    const int i = N / 2;
+    const double ti = th[i], two_eta = 2 * eta;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        int64_t o = -1;
+        cplx v = mk(0.0, 0.0);
+        if (j != i) {
+            const double tj = th[j];
+            const int64_t bx = hist_bin(tj - ti, g.fd0, g.fd1_step, g.nfd);
+            const int64_t by = hist_bin(eta * (tj * tj - ti * ti), g.tau0, g.tau1_step, g.ntau);
+            if (bx >= 0 && by >= 0) {
+                o = by * g.nfd + bx;
+                const double scl = rsqrt(fabs(two_eta * (ti - tj)));      // thth / sqrt(|2 eta fd_map.T|)  (ththmod.py:226), as rev_gather_body
+                v = mk(row[j].x * scl, row[j].y * scl);
+            }
+        }
+        pix[j] = o; val[j] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const int64_t o = pix[j];
+        if (o < 0 || o == centre) continue;
+        bool head = true;
+        for (int r = 1; r <= kRowRun && j - r >= 0; ++r) head = head && pix[j - r] != o;
+        if (!head) continue;
+        double sr = val[j].x, si = val[j].y;
+        for (int r = 1; r <= kRowRun && j + r < N; ++r)
+            if (pix[j + r] == o) { sr = sr + val[j + r].x; si = si + val[j + r].y; }
+        const double scl = 1.0 / (double)cnt[o];                      // NumPy divides complex by real as v * (1 / c)
+        auto clean = [](double x) { return x != x ? 0.0 : (x == INFINITY ? 1.7976931348623157e308 : (x == -INFINITY ? -1.7976931348623157e308 : x)); };
+        recov[o] = mk(clean(sr * scl), clean(si * scl));
+    }
+}
+}  // namespace scint
+
 extern "C" int32_t scint_retrieval_tail_workspace_bytes(int64_t M, int64_t ntau, int64_t nfd, size_t* bytes) {
     SCINT_REQUIRE(bytes && M >= 1 && ntau >= 1 && nfd >= 1, "retrieval_tail_workspace_bytes: bad arguments");
     size_t fft = 0;
     const int32_t rc = scint_fft2_workspace_bytes(ntau, nfd, &fft);
     if (rc != SCINT_OK) return rc;
-    *bytes = align_up(sizeof(cplx) * (size_t)M * (size_t)M, 256) + align_up(sizeof(cplx) * (size_t)ntau * (size_t)nfd, 256) + align_up(fft, 256) + 512;
+    *bytes = align_up(sizeof(uint32_t) * (size_t)ntau * (size_t)nfd, 256) + align_up(sizeof(cplx) * (size_t)ntau * (size_t)nfd * kTailGroup, 256) +
+             align_up(fft, 256) + align_up((sizeof(int64_t) + sizeof(cplx)) * (size_t)M * kTailGroup, 256) + 512;
     return SCINT_OK;
 }
 
 // Per chunk k with keep_n[k] >= 2 (ththmod.py:1457-1470): theta-theta of the E field = zeros with row N/2 = rows[k][:N] (the caller's
-// conj(V) sqrt(w)), its non-Hermitian back-map on the chunk's axes, scale * ifft2(ifftshift(.))[:nf, :nt] -> out[k].  Chunks with
-// keep_n[k] < 2 (failed or skipped by the caller) are left as the caller initialised them.
-extern "C" int32_t scint_retrieval_tail(const scint_c128* rows, const double* th_red, const int32_t* keep_n, const scint_cs_geom* geoms,
-                                        const double* etas, int64_t n, int64_t M, int64_t nf, int64_t nt, double scale,
-                                        scint_c128* out, void* workspace, size_t workspace_bytes, void* stream_) {
+// conj(V) sqrt(w)), its non-Hermitian back-map on the chunk's axes (one-row form above), scale * ifft2(ifftshift(.))[:nf, :nt] -> out[k].
+// class_id (HOST [n]): chunks with equal ids in a row share theta grid, curvature and axes (the caller's promise: the pair counts
+// are formed from the first one's).  Chunks with keep_n[k] < 2 (failed or skipped by the caller) are left as the caller initialised them.
+extern "C" int32_t scint_retrieval_tail(const scint_c128* rows, const double* th_red, const int32_t* keep_n, const int32_t* class_id,
+                                        const scint_cs_geom* geoms, const double* etas, int64_t n, int64_t M, int64_t nf, int64_t nt,
+                                        double scale, scint_c128* out, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    SCINT_REQUIRE(rows && th_red && keep_n && geoms && etas && out && workspace && n >= 1 && M >= 1, "retrieval_tail: null pointer or empty batch");
-    const int64_t ntau = geoms[0].ntau, nfd = geoms[0].nfd;
+    SCINT_REQUIRE(rows && th_red && keep_n && class_id && geoms && etas && out && workspace && n >= 1 && M >= 1, "retrieval_tail: null pointer or empty batch");
+    const int64_t ntau = geoms[0].ntau, nfd = geoms[0].nfd, npix = ntau * nfd;
     size_t need = 0, fft = 0;
     if (scint_retrieval_tail_workspace_bytes(M, ntau, nfd, &need) != SCINT_OK || scint_fft2_workspace_bytes(ntau, nfd, &fft) != SCINT_OK) return SCINT_E_ARG;
     if (workspace_bytes < need) { set_error("scint: retrieval_tail workspace too small"); return SCINT_E_WORKSPACE; }
     char* base = (char*)workspace;
-    cplx* E = (cplx*)base;
-    cplx* recov = (cplx*)(base + align_up(sizeof(cplx) * (size_t)M * (size_t)M, 256));
-    char* fftws = (char*)recov + align_up(sizeof(cplx) * (size_t)ntau * (size_t)nfd, 256);
-    char* scratch = fftws + align_up(fft, 256);
-    for (int64_t k = 0; k < n; ++k) {
-        const int64_t N = keep_n[k];
-        if (N < 2) continue;
-        SCINT_REQUIRE(N <= M && geoms[k].ntau == ntau && geoms[k].nfd == nfd, "retrieval_tail: chunk does not match the batch's shape");
-        SCINT_HIP(hipMemsetAsync(E, 0, sizeof(cplx) * (size_t)N * (size_t)N, stream));
-        SCINT_HIP(hipMemcpyAsync(E + (N / 2) * N, (const cplx*)rows + k * M, sizeof(cplx) * (size_t)N, hipMemcpyDeviceToDevice, stream));
-        int32_t rc = scint_rev_map((const scint_c128*)E, nullptr, nullptr, 0, th_red + k * M, N, &geoms[k], etas[k], 0, (scint_c128*)recov,
-                                   scratch, 256, stream_);
-        if (rc != SCINT_OK) return rc;
-        rc = scint_ifft2_shifted((const scint_c128*)recov, ntau, nfd, scale, nf, nt, out + k * nf * nt, fftws, fft, stream_);
-        if (rc != SCINT_OK) return rc;
+    uint32_t* cnt = (uint32_t*)base;
+    cplx* recov = (cplx*)(base + align_up(sizeof(uint32_t) * (size_t)npix, 256));
+    char* fftws = (char*)recov + align_up(sizeof(cplx) * (size_t)npix * kTailGroup, 256);
+    int64_t* pix = (int64_t*)(fftws + align_up(fft, 256));
+    cplx* val = (cplx*)(pix + (size_t)M * kTailGroup);
+    int64_t k = 0;
+    while (k < n) {
+        int64_t e = k;
+        while (e < n && class_id[e] == class_id[k]) ++e;                  // the class: chunks k .. e-1
+        int64_t first = -1;
+        for (int64_t m = k; m < e; ++m) if (keep_n[m] >= 2) { first = m; break; }
+        if (first >= 0) {
+            const int64_t N = keep_n[first];
+            SCINT_REQUIRE(N <= M && geoms[first].ntau == ntau && geoms[first].nfd == nfd, "retrieval_tail: chunk does not match the batch's shape");
+            const GeomDev g = to_dev(geoms[first]);
+            const double eta = etas[first];
+            const int64_t cbx = hist_bin(0.0, g.fd0, g.fd1_step, g.nfd), cby = hist_bin(eta * 0.0, g.tau0, g.tau1_step, g.ntau);
+            const int64_t centre = (cbx >= 0 && cby >= 0) ? cby * g.nfd + cbx : -1;
+            SCINT_HIP(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)npix, stream));
+            const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(N * N, 256 * 4), 4096);
+            hipLaunchKernelGGL(rev_count_kernel, dim3(blocks), dim3(256), 0, stream, th_red + first * M, (int)N, eta, g, cnt);
+            SCINT_LAUNCH_CHECK();
+            for (int64_t m0 = k; m0 < e; m0 += kTailGroup) {
+                TailMembers members;
+                int cntm = 0;
+                for (int64_t m = m0; m < std::min(e, m0 + kTailGroup); ++m)
+                    if (keep_n[m] >= 2) {
+                        SCINT_REQUIRE(keep_n[m] == N, "retrieval_tail: chunks of one class keep different numbers of centres");
+                        members.k[cntm++] = (int32_t)m;
+                    }
+                if (cntm == 0) continue;
+                SCINT_HIP(hipMemsetAsync(recov, 0, sizeof(cplx) * (size_t)npix * (size_t)cntm, stream));
+                hipLaunchKernelGGL(rev_row_kernel, dim3((unsigned)cntm), dim3(256), 0, stream, (const cplx*)rows, th_red, M, members, (int)N, eta, g,
+                                   cnt, recov, centre, pix, val);
+                SCINT_LAUNCH_CHECK();
+                for (int q = 0; q < cntm; ++q) {
+                    const int32_t rc = scint_ifft2_shifted((const scint_c128*)(recov + (size_t)q * (size_t)npix), ntau, nfd, scale, nf, nt,
+                                                           out + (int64_t)members.k[q] * nf * nt, fftws, fft, stream_);
+                    if (rc != SCINT_OK) return rc;
+                }
+            }
+        }
+        k = e;
     }
     return SCINT_OK;
 }

@@ -299,24 +299,7 @@ int32_t launch_cs_scale(const cplx* cs, int64_t ncs, int64_t cs_stride, int64_t 
 // ------------------------------------------------------------------------------
 // rev_map
 // ------------------------------------------------------------------------------
-// np.histogram2d bin of x on the edges e(k) = (k - 0.5)*step + x0, k = 0..n:
-// searchsorted(edges, x, 'right') - 1, with x == e(n) folded into the last bin
-// (numpy/lib/_histograms_impl.py histogramdd).  Returns -1 for an outlier.
-__host__ __device__ inline int64_t hist_bin(double x, double x0, double step, int64_t n) {
-    if (!(step > 0.0) || x != x) return -1;
-    double guess = floor((x - x0) / step + 0.5);
-    if (guess < -1.0) return -1;
-    if (guess > (double)n + 1.0) return -1;
-    int64_t k = (int64_t)guess;
-    if (k < 0) k = 0;
-    if (k > n) k = n;
-    // largest k in [0, n] with e(k) <= x
-    while (k < n && (((double)(k + 1) - 0.5) * step + x0) <= x) ++k;
-    while (k >= 0 && (((double)k - 0.5) * step + x0) > x) --k;
-    if (k < 0) return -1;
-    if (k == n) return (x == (((double)n - 0.5) * step + x0)) ? n - 1 : -1;
-    return k;
-}
+// (hist_bin: thth.hpp)
 
 // The same bin for the back-map kernel, 32-bit index, the first guess from a multiplication by 1/step.  The
 // edges e(k) = (k - 0.5) step + x0 are non-decreasing in k, so the answer is the largest k in [0, n) with

@@ -159,4 +159,24 @@ int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b,
 int32_t launch_rev_walk_table(const double* th, int64_t N, const GeomDev& g, uint8_t* masks, uint8_t* col_ok, hipStream_t stream);
 enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6, kRevBandLo = 7, kRevBandHi = 8 };
 
+// np.histogram2d bin of x on the edges e(k) = (k - 0.5)*step + x0, k = 0..n:
+// searchsorted(edges, x, 'right') - 1, with x == e(n) folded into the last bin
+// (numpy/lib/_histograms_impl.py histogramdd).  Returns -1 for an outlier.
+__host__ __device__ inline int64_t hist_bin(double x, double x0, double step, int64_t n) {
+    if (!(step > 0.0) || x != x) return -1;
+    double guess = floor((x - x0) / step + 0.5);
+    if (guess < -1.0) return -1;
+    if (guess > (double)n + 1.0) return -1;
+    int64_t k = (int64_t)guess;
+    if (k < 0) k = 0;
+    if (k > n) k = n;
+    // largest k in [0, n] with e(k) <= x
+    while (k < n && (((double)(k + 1) - 0.5) * step + x0) <= x) ++k;
+    while (k >= 0 && (((double)k - 0.5) * step + x0) > x) --k;
+    if (k < 0) return -1;
+    if (k == n) return (x == (((double)n - 0.5) * step + x0)) ? n - 1 : -1;
+    return k;
+}
+
+
 }  // namespace scint

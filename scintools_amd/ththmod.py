@@ -1076,9 +1076,18 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
         out_t = torch.zeros((len(live), nf, nt), dtype=torch.complex128, device=dev)
         geoms = (_lib.CsGeom * len(live))(*[g_.geom for g_ in grids])
         etas_a = np.ascontiguousarray([float(e_[0]) for e_ in etas], dtype=np.float64)
+        # classes: consecutive chunks with the same reduced centres, curvature and axes (the chunks of one frequency row) share the
+        # pair counts of their back-maps
+        class_id, prev, cid = np.zeros(len(live), dtype=np.int32), None, -1
+        for j in range(len(live)):
+            key = (float(etas_a[j]), int(keep_n[j]), th_all[j, :keep_n[j]].tobytes(), bytes(grids[j].geom))
+            if key != prev:
+                cid, prev = cid + 1, key
+            class_id[j] = cid
         _lib.check(lib.scint_retrieval_tail_workspace_bytes(M, R, C, ctypes.byref(need)), "retrieval_tail_workspace_bytes")
         ws = workspace.get(need.value)
-        _lib.check(lib.scint_retrieval_tail(ptr(rows_t), ptr(th_all_t), keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), geoms,
+        _lib.check(lib.scint_retrieval_tail(ptr(rows_t), ptr(th_all_t), keep_n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                            class_id.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), geoms,
                                             etas_a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(live), M, nf, nt, nf * nt / 4,
                                             ptr(out_t), ptr(ws), ws.numel(), stream_ptr()), "scint_retrieval_tail")
         if verbose:

@@ -1,11 +1,7 @@
 #!/bin/bash
-# scratch (round 6): index-compressed passes in the real sweep, on / off and span thresholds
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_stopping_rule.py -m gpu -q -x -k "sweep or eval or Eval or stopping or calibrated or single_search" > $O/r06r_pytest.log 2>&1; tail -3 $O/r06r_pytest.log
-{
-for rep in 1 2; do
-for v in "SCINT_SWEEP_INDEXED=0" "SCINT_SWEEP_INDEXED=1" "SCINT_SWEEP_INDEXED=1 SCINT_SWEEP_INDEXED_SPAN=40" "SCINT_SWEEP_INDEXED=1 SCINT_SWEEP_INDEXED_SPAN=100" "SCINT_SWEEP_INDEXED=1 SCINT_SWEEP_INDEXED_SPAN=1000"; do
-  echo "== $v: $(env $v timeout 300 python bench.py --steps 5 --warmup 2 --headline-only 2>/dev/null | python tools/bench_line.py /dev/stdin 2>&1 | tr '\n' ' ' | cut -c1-300)"
-done
-done
-} | tee $O/r06r_indexed_ab.txt
+export TMPDIR=/tmp
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/r06t_prof_wf -o wf -- python $R/bench.py --workload wavefield --steps 2 --warmup 1 > $O/r06t_prof_wf.log 2>&1 )
+db=$(find $O/r06t_prof_wf -name "*.db" | head -1)
+python tools/rocpd_summary.py $db $O/r06t_wf_kernel_stats.csv $O/r06t_wf_kernel_overlap.json > /dev/null 2>&1
+head -16 $O/r06t_wf_kernel_stats.csv | cut -c1-150
