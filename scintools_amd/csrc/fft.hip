@@ -1432,6 +1432,7 @@ struct ChisqTail : SweepTail {
     const double* dspecT; int64_t nf, nt; const uint8_t* maskT; double noise_n; double* chisq_out;
     const cplx* specT = nullptr;      // fftshift(fft2(dspec^T)): set when chi^2 goes by Parseval (no model transform)
     const RevJobDev* jobs_dev = nullptr; const double* pre = nullptr; const double* suf = nullptr;   // Parseval route: per-curvature table, |D|^2 sums
+    std::vector<uint8_t> uniform;     // per curvature: its back-map takes the uniform-grid kernel (launch_rev_uniform's flags)
     int images = 1;                   // image buffers (and partial-sum sets) per tail lane
     // one set of scratch buffers per tail lane
     cplx* recovT_[kTailLanes]; double* modelT_[kTailLanes]; void* fft_ws_[kTailLanes]; size_t fft_ws_bytes;
@@ -1455,7 +1456,7 @@ struct ChisqTail : SweepTail {
         for (int k = b.n; k < kRevBatchMax; ++k) { b.job[k] = 0; b.recov[k] = nullptr; }
         if (b.n == 0) return SCINT_OK;
         const int ps = profiler().begin(kProfRevmap, tail);
-        int32_t rc = launch_rev_map_rank1_batch(jobs_dev, b, g, tail);
+        int32_t rc = launch_rev_map_rank1_batch(jobs_dev, b, g, uniform.empty() ? nullptr : uniform.data(), tail);
         profiler().end(kProfRevmap, ps, tail);
         if (rc != SCINT_OK) return rc;
         const int pm = profiler().begin(kProfModel, tail);
@@ -1513,6 +1514,7 @@ constexpr int kRevWalkMinGroup = 8;    // ... if at least this many curvatures s
 struct ChisqSweepLayout {
     size_t recov[kTailLanes], model[kTailLanes], dspecT, maskT, specT, fft[kTailLanes], partial[kTailLanes], rev[kTailLanes], sweep, total, fft_bytes, sweep_bytes;
     size_t jobs, bounds, colsum, pre, suf;     // Parseval route: RevJobDev table, per-curvature constants, |D|^2 sums along the delay axis
+    size_t uflags;                             // ... and the grid test's flag of every curvature (thth.hpp: launch_rev_uniform)
     size_t walk[kRevWalkTables];               // partner tables of the back-map for the largest groups of same-crop curvatures (thth.hpp)
     int images;                                // image buffers per tail lane (tail batches)
 };
@@ -1535,6 +1537,7 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
     const bool parseval_shape = nf == ntau && nt == nfd;
     L->jobs = take(parseval_shape ? sizeof(RevJobDev) * (size_t)neta : 0);
     L->bounds = take(parseval_shape ? sizeof(unsigned long long) * kRevWords * (size_t)neta : 0);
+    L->uflags = take(parseval_shape ? sizeof(int32_t) * (size_t)neta : 0);
     L->colsum = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) * (size_t)(kColsumChunks + 1) : 0);   // [0]: the sums; then the chunks' partials
     L->pre = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
     L->suf = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
@@ -1635,11 +1638,22 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
             for (int64_t e = 0; e < neta; ++e)
                 table[(size_t)e] = make_rev_job((const cplx*)vec_out + e * vec_stride, w_out + e, th_red + e * M, keep_n[e], t.g,
                                                 etas[e], bounds + (size_t)e * kRevWords);
-            // partner tables of the back-map for the largest groups of curvatures that keep the same theta centres (thth.hpp)
+            // which curvatures sit on a uniform theta grid (every one, on the path: centres of linspace edges, cropped to a contiguous
+            // run): their back-map is the diagonal kernel (thth.hip).  One kernel over the table, one read-back.
+            SCINT_HIP(hipMemcpyAsync(base + L.jobs, table.data(), sizeof(RevJobDev) * (size_t)neta, hipMemcpyHostToDevice, st));
+            rc = launch_rev_uniform((const RevJobDev*)(base + L.jobs), neta, t.g, (int32_t*)(base + L.uflags), st);
+            if (rc != SCINT_OK) return rc;
+            std::vector<int32_t> uflags((size_t)neta);
+            SCINT_HIP(hipMemcpyAsync(uflags.data(), base + L.uflags, sizeof(int32_t) * (size_t)neta, hipMemcpyDeviceToHost, st));
+            SCINT_HIP(hipStreamSynchronize(st));
+            t.uniform.resize((size_t)neta);
+            for (int64_t e = 0; e < neta; ++e) t.uniform[(size_t)e] = uflags[(size_t)e] != 0;
+            // partner tables of the general back-map for the largest groups of curvatures that keep the same theta centres and are
+            // NOT on a uniform grid (thth.hpp)
             if (crop_group) {
                 std::map<int32_t, std::vector<int64_t>> groups;
                 for (int64_t e = 0; e < neta; ++e)
-                    if (crop_group[e] >= 0 && keep_n[e] >= 3) groups[crop_group[e]].push_back(e);
+                    if (crop_group[e] >= 0 && keep_n[e] >= 3 && !t.uniform[(size_t)e]) groups[crop_group[e]].push_back(e);
                 std::vector<const std::vector<int64_t>*> big;
                 for (const auto& kv : groups)
                     if ((int)kv.second.size() >= kRevWalkMinGroup) big.push_back(&kv.second);

@@ -8,6 +8,7 @@
 #include <map>
 #include <type_traits>
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 
 #include "packed.hpp"
@@ -481,10 +482,19 @@ __device__ inline void rev_setup_consts(bool rank1, bool hermitian, const double
     bound[kRevThStep] = (unsigned long long)__double_as_longlong(th_step);
     bound[kRevW] = (unsigned long long)(W < 0 ? 0 : W);
 }
-__global__ void __launch_bounds__(64) rev_setup_kernel(RevParams p, GeomDev g, unsigned long long* bound) {
+__device__ inline void rev_uniform_consts(double dev, const double* th, int N, double th_step, double eta, const GeomDev& g,
+                                          unsigned long long* bound);
+__device__ inline double rev_grid_deviation(const double* th, int N, double th_step, int first, int stride);
+__global__ void __launch_bounds__(64) rev_setup_kernel(RevParams p, GeomDev g, unsigned long long* bound, int diag_enabled) {
+    // which kernel forms the image: rev_diag_kernel on a uniform grid (rank-1 Hermitian), else rev_gather_kernel
+    const bool diag = diag_enabled && p.rank1 && p.hermitian && p.N > 1;
+    const double th_step = diag ? (gload(p.th + p.N - 1) - gload(p.th)) / (double)(p.N - 1) : 0.0;
+    double dev = diag ? rev_grid_deviation(p.th, p.N, th_step, (int)threadIdx.x, 64) : INFINITY;
+    for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o, 64));
     if (threadIdx.x != 0) return;
     rev_setup_consts(p.rank1 != 0, p.hermitian != 0, p.w, p.th, p.N, p.two_eta, g, __longlong_as_double((long long)bound[0]),
                      __longlong_as_double((long long)bound[1]), bound);
+    rev_uniform_consts(dev, p.th, p.N, th_step, p.eta, g, bound);
 }
 
 // One workgroup owns the `slab` tau rows [blockIdx.y*slab, ...) of ONE fd column of recov
@@ -745,6 +755,7 @@ __device__ __forceinline__ void rev_gather_body(const RevParams& p, const GeomDe
 
 template <int kRevThreads, bool RANK1>
 __global__ void __launch_bounds__(kRevThreads) rev_gather_kernel(RevParams p, GeomDev g) {
+    if (RANK1 && p.hermitian && p.bound[kRevUniform] != 0ull) return;      // rev_diag_kernel's image
     rev_gather_body<kRevThreads, RANK1, false>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
 }
 
@@ -821,6 +832,7 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const Re
         const int64_t col = w % g.nfd;
         const int sl = (int)((w / g.nfd) % nslab), img = (int)(w / (g.nfd * (int64_t)nslab));
         const RevJobDev jb = jobs[b.job[img]];
+        if (jb.bound[kRevUniform] != 0ull) continue;                       // rev_diag_batch_kernel's image
         // slabs that miss the curvature's delay band are skipped: nothing of them is read afterwards
         const int64_t row0 = (int64_t)sl * slab;
         if (row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) continue;
@@ -836,6 +848,270 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const Re
         rev_gather_body<kRevThreadsK, true, true>(p, g, col, sl);
         __syncthreads();            // (the next item zeroes the accumulators this one has just read)
     }
+}
+
+// ---- the rank-1 Hermitian back-map on a UNIFORM theta grid: pairs along diagonals (round 6) ---------------------------------
+// rev_gather_body lets lanes run over theta_i and FINDS the partners theta_j of every lane in its Doppler column -- with one
+// partner per (theta_i, column) on the grids of the path that search (window, guards, run detection, or the partner table and its
+// ballot loop) costs more than the pair's own arithmetic, and every delay slab repeats it: 93.5 M vector instructions per 4096^2
+// image for ~13 M of pair arithmetic (profiles/r04_revmap_counters.txt).  On a uniform grid theta_k = theta_0 + k d (checked, not
+// assumed: rev_uniform_consts below; every grid of the path is one -- centres of linspace edges, and a crop keeps a contiguous
+// run of them) the pairs of a Doppler column are whole DIAGONALS j = i + s: fd_map = theta_j - theta_i is s d to within the
+// measured deviation, so the column's candidates are the s with s d within that slack of [lo, hi) -- one to three of them, each a
+// dense run of lanes with nothing to search -- and every pair still takes the column test on its own fl(theta_j - theta_i), the
+// same comparison np.histogram2d makes.  Along a diagonal the delay eta (theta_j^2 - theta_i^2) = 2 eta s d^2 i + const is LINEAR
+// in i, m = 2 |eta s| d^2 / dtau rows per step:
+//   * a slab of delay rows is a contiguous run of i (closed form, two lanes of margin; the exact bin of every pair decides);
+//   * m >= 1: consecutive pairs fall in DIFFERENT rows, so the lanes of a sweep never meet in an accumulator and the sum of a
+//     pixel has a fixed order with plain float64 adds -- diagonal after diagonal (a barrier between them);  m >= 1/P (P <= 4):
+//     P sweeps over i = p mod P, each with that property;
+//   * flatter than that a thread owns a delay ROW: the pairs that fall in it are the run [first i with y_i >= edge(r), first i
+//     with y_i >= edge(r + 1)) (closed-form guess, settled on the exact y_i: y is strictly monotone along the diagonal as
+//     computed, its step is >= 1e-6 rows against a rounding of 1e-12), summed in order, in registers.
+// No order-independent split (eight adds and three of five LDS atomics per pair), no collisions (flat curvatures: +40 % of an
+// image), no chunk pre-pass, 20 bytes of LDS per delay row instead of 36.  The histogram bin is floor((y - tau0) / dtau + 1/2)
+// whenever that argument is at least 1e-6 away from an integer (the edges of np.histogram2d round at 1e-12 of a row on any sane
+// axis; rev_uniform_consts checks the axis), else hist_bin_rcp's exact edge comparisons.  The image agrees with the reference's
+// to its rounding (each pixel is the same addends in another order; tests: 1e-9 of the peak against the oracle, bits pinned).
+constexpr int kDiagStrideMax = 4;
+#ifndef SCINT_DIAG_SLAB
+#define SCINT_DIAG_SLAB 1024
+#endif
+constexpr int kDiagSlab = SCINT_DIAG_SLAB;    // delay rows per workgroup: 20 KiB of LDS at 1024
+
+// Decides whether an image takes this kernel (rank-1, Hermitian) and leaves the slack of the column test.  `dev` is the largest
+// |theta_k - (theta_0 + k step)| over the grid (the caller's reduction; NaN counts as infinite).
+__device__ inline void rev_uniform_consts(double dev, const double* th, int N, double th_step, double eta, const GeomDev& g,
+                                          unsigned long long* bound) {
+    bool ok = N >= 2 && N < (1 << 22) && th_step > 0.0 && dev <= 1e-9 * th_step;
+    double slack = 0.0;
+    if (ok) {
+        const double tmax = fmax(fabs(gload(th)), fabs(gload(th + N - 1)));
+        slack = 2.0 * dev + 16.0 * 2.220446049250313e-16 * tmax;        // |fl(theta_j - theta_i) - s step| <= slack
+        const double m1 = 2.0 * fabs(eta) * th_step * th_step / g.tau1_step;
+        ok = tmax < INFINITY && g.tau1_step > 0.0 && g.fd1_step > 0.0 && m1 >= 1e-6 && m1 < INFINITY &&
+             fabs(g.tau0) / g.tau1_step + (double)g.ntau < 1e8 && fabs(g.fd0) / g.fd1_step + (double)g.nfd < 1e8 &&
+             tmax / th_step < 1e8;
+    }
+    bound[kRevUniform] = ok ? 1ull : 0ull;
+    bound[kRevSlack] = (unsigned long long)__double_as_longlong(slack);
+}
+__device__ inline double rev_grid_deviation(const double* th, int N, double th_step, int first, int stride) {
+    const double t0 = gload(th);
+    double dev = 0.0;
+    for (int k = first; k < N; k += stride) {
+        const double e = fabs(gload(th + k) - (t0 + (double)k * th_step));
+        dev = (e == e) ? fmax(dev, e) : INFINITY;
+    }
+    return dev;
+}
+
+template <int T>
+__device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev& g, const int64_t col_in, const int slab_index) {
+    extern __shared__ __attribute__((aligned(16))) double rev_lds[];
+    const int slab = p.slab;
+    // rev_lds[0 .. slab): real sums, [slab .. 2 slab): imaginary sums, then the counts
+    int64_t col = col_in;
+    if ((col | 31) < g.nfd) col = (col & ~(int64_t)31) + (col & 7) * 4 + ((col >> 3) & 3);      // (as rev_gather_body)
+    const int64_t row0 = (int64_t)slab_index * slab;
+    const int rows = (int)min((int64_t)slab, g.ntau - row0);
+    __shared__ double rcp_small[64];
+    if (threadIdx.x < 64) rcp_small[threadIdx.x] = 1.0 / (double)threadIdx.x;
+    for (int r = threadIdx.x; r < rows; r += T) {
+        rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0;
+        ((uint32_t*)(rev_lds + 2 * slab))[r] = 0u;
+    }
+    __syncthreads();
+
+    const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;        // histogram edges of the column
+    const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
+    const bool last = (col == g.nfd - 1);                              // last bin is closed on the right
+    const double aw = fabs(gload(p.w));
+    const int N = p.N;
+    const double d = __longlong_as_double((long long)p.bound[kRevThStep]);
+    const double slack = __longlong_as_double((long long)p.bound[kRevSlack]);
+    const double th0 = gload(p.th);
+    const double inv_tstep = p.inv_tau1_step;
+    const int ntau = (int)g.ntau;
+    auto in_column = [&](double x) { return x >= lo && (last ? x <= hi : x < hi); };
+    auto edge = [&](int k) { return ((double)k - 0.5) * g.tau1_step + g.tau0; };       // np.histogram2d's delay edges
+    auto delay = [&](int i, int j) {
+        const double a = gload(p.th + i), b = gload(p.th + j);
+        return p.eta * (b * b - a * a);                                  // tau_map[i, j] (ththmod.py:208-210)
+    };
+    // weight of pair (i, j) if it lies in the column: thth / sqrt(|2 eta fd_map.T|), thth = outer(V, conj(V)) |w| (:312-313)
+    auto weight = [&](int i, int j, double th_i, double th_j, double& wr, double& wi) {
+        const double scl = rsqrt(fabs(p.two_eta * (th_i - th_j)));
+        const cplx o = mulc(gload(p.vec + i), gload(p.vec + j));
+        wr = (o.x * aw) * scl; wi = (o.y * aw) * scl;
+    };
+    // np.histogram2d's delay bin of y, -1 off the axis
+    auto bin_of = [&](double y) {
+        const double t = (y - g.tau0) * inv_tstep + 0.5;
+        const double kf = floor(t), f = t - kf;
+        if (f >= 1e-6 && f <= 1.0 - 1e-6) return (t >= 0.0 && t < (double)ntau) ? (int)kf : -1;
+        return hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, ntau);
+    };
+    __shared__ double carry_re[T / 64], carry_im[T / 64];
+    __shared__ uint32_t carry_c[T / 64];
+    __shared__ int carry_by[T / 64];
+    // candidate diagonals: s d within `slack` of the column (one more on either side when the quotient is within 1e-9 of an integer)
+    const double qa = (lo - slack) / d, qb = (hi + slack) / d;
+    int s_lo = (int)fmax(ceil(qa - 1e-9 * (1.0 + fabs(qa))), -(double)N);
+    int s_hi = (int)fmin(floor(qb + 1e-9 * (1.0 + fabs(qb))), (double)N);
+    s_lo = max(s_lo, -(N - 1)); s_hi = min(s_hi, N - 1);
+    const double y_lo = edge((int)row0), y_hi = edge((int)row0 + rows);
+    for (int s = s_lo; s <= s_hi; ++s) {                               // uniform over the workgroup
+        if (s == 0) continue;                                          // i == j lands in the poisoned centre bin
+        const int i0 = s < 0 ? -s : 0, L = N - (s < 0 ? -s : s);       // pairs (i, i + s), i = i0 .. i0 + L - 1
+        // delay along the diagonal: y(i) ~ A i + C
+        const double A = 2.0 * p.eta * (double)s * d * d;
+        const double C = p.eta * ((double)s * d) * (2.0 * th0 + (double)s * d);
+        const bool up = A > 0.0;
+        const double m = fabs(A) * inv_tstep;                          // delay rows per step of i
+        // the lanes that can reach the slab, two of margin
+        const double fa = (y_lo - C) / A, fb = (y_hi - C) / A;
+        const double f_min = fmin(fa, fb) - 2.0, f_max = fmax(fa, fb) + 2.0;
+        const int ia = (int)fmin(fmax(floor(f_min), (double)i0), (double)(i0 + L));
+        const int ib = (int)fmin(fmax(ceil(f_max) + 1.0, (double)i0), (double)(i0 + L));       // exclusive
+        if (ia >= ib) continue;
+        const int P = (int)fmin(ceil(1.0102 / m), 1e6);
+        if (P <= kDiagStrideMax) {
+            // pairs of one sweep are P lanes apart: at least 1.01 delay rows -- no two of them in one accumulator
+            for (int pass = 0; pass < P; ++pass) {
+                int i = ia + (int)threadIdx.x * P;
+                i += ((pass - i) % P + P) % P;                         // first i >= its start with i = pass (mod P): the order of a
+                                                                       // pixel's addends does not depend on the slab
+                for (; i < ib; i += T * P) {
+                    const int j = i + s;
+                    const double th_i = gload(p.th + i), th_j = gload(p.th + j);
+                    const double x = th_j - th_i;                      // fd_map[i, j]  (ththmod.py:207)
+                    if (!in_column(x)) continue;
+                    const int by = bin_of(p.eta * (th_j * th_j - th_i * th_i)) - (int)row0;
+                    if ((unsigned)by >= (unsigned)rows) continue;
+                    double wr, wi;
+                    weight(i, j, th_i, th_j, wr, wi);
+                    atomicAdd(&rev_lds[by], wr);
+                    atomicAdd(&rev_lds[slab + by], wi);
+                    atomicAdd((uint32_t*)(rev_lds + 2 * slab) + by, 1u);
+                }
+                __syncthreads();
+            }
+        } else {
+            // flat diagonal: several pairs per delay row.  Lanes run densely over the pairs in the direction of increasing delay
+            // (u), every wavefront over one contiguous block of them; the bins of a wavefront's 64 pairs are non-decreasing, so the
+            // pairs of a row are a run of lanes: a segmented scan (fixed tree) leaves the run's sum in its last lane, which adds it
+            // to the row -- one lane per row and instruction, and a wavefront's adds to a row it meets again in its next 64 pairs
+            // are in program order.  The one row a block shares with the block before it (the bin of the pair in front of the
+            // block) is kept aside and added after a barrier, block after block: every pixel's sum has ONE order.
+            constexpr int NW = T / 64;
+            const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+            const int ua = up ? ia - i0 : (i0 + L) - ib, ub = up ? ib - i0 : (i0 + L) - ia;
+            const int B = (((ub - ua) + NW - 1) / NW + 63) & ~63;
+            const int us = ua + wave * B, ue = min(ub, us + B);
+            auto pair_i = [&](int u) { return up ? i0 + u : i0 + L - 1 - u; };
+            int k_first = INT_MIN;                                     // (no pair has this bin: the first block shares nothing)
+            if (wave > 0 && us < ue) { const int i = pair_i(us - 1); k_first = bin_of(delay(i, i + s)); }
+            if (lane == 0) { carry_re[wave] = 0.0; carry_im[wave] = 0.0; carry_c[wave] = 0u; carry_by[wave] = k_first == INT_MIN ? 0 : k_first - (int)row0; }
+            for (int u0 = us; u0 < ue; u0 += 64) {                     // uniform over the wavefront
+                const int u = u0 + lane;
+                int k = INT_MAX;
+                double wr = 0.0, wi = 0.0;
+                uint32_t c = 0u;
+                if (u < ue) {
+                    const int i = pair_i(u), j = i + s;
+                    const double th_i = gload(p.th + i), th_j = gload(p.th + j);
+                    k = bin_of(p.eta * (th_j * th_j - th_i * th_i));
+                    if (in_column(th_j - th_i) && (unsigned)(k - (int)row0) < (unsigned)rows) {
+                        weight(i, j, th_i, th_j, wr, wi);
+                        c = 1u;
+                    }
+                }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int kk = __shfl_up(k, d, 64);
+                    const double ar = __shfl_up(wr, d, 64), ai = __shfl_up(wi, d, 64);
+                    const uint32_t ac = __shfl_up(c, d, 64);
+                    if (lane >= d && kk == k) { wr += ar; wi += ai; c += ac; }
+                }
+                const int kn = __shfl_down(k, 1, 64);
+                if ((lane == 63 || kn != k) && c != 0u) {
+                    const int by = k - (int)row0;
+                    if (k == k_first) {
+                        carry_re[wave] += wr; carry_im[wave] += wi; carry_c[wave] += c;
+                    } else {
+                        atomicAdd(&rev_lds[by], wr);
+                        atomicAdd(&rev_lds[slab + by], wi);
+                        atomicAdd((uint32_t*)(rev_lds + 2 * slab) + by, c);
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int w = 1; w < NW; ++w)
+                    if (carry_c[w] != 0u) {
+                        const int by = carry_by[w];
+                        rev_lds[by] += carry_re[w]; rev_lds[slab + by] += carry_im[w];
+                        ((uint32_t*)(rev_lds + 2 * slab))[by] += carry_c[w];
+                    }
+            __syncthreads();
+        }
+    }
+    // recov = nan_to_num(sum / count), the poisoned centre 0 (as rev_gather_body)
+    for (int r = threadIdx.x; r < rows; r += T) {
+        const int64_t o = (row0 + r) * g.nfd + col;
+        cplx out = mk(0.0, 0.0);
+        if (o != p.centre) {
+            const uint32_t c = ((uint32_t*)(rev_lds + 2 * slab))[r];
+            double scl;
+            if (c < 64u) scl = rcp_small[c]; else scl = 1.0 / (double)c;
+            out = mk(nan_to_num(rev_lds[r] * scl), nan_to_num(rev_lds[slab + r] * scl));
+        }
+        gstore(p.recov + (p.transposed ? col * g.ntau + (row0 + r) : o), out);
+    }
+}
+
+__global__ void __launch_bounds__(kRevThreadsK) rev_diag_kernel(RevParams p, GeomDev g) {
+    if (p.bound[kRevUniform] == 0ull) return;                              // rev_gather_kernel's image
+    rev_diag_body<kRevThreadsK>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
+}
+__global__ void __launch_bounds__(kRevThreadsK) rev_diag_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g, int slab,
+                                                                       int nslab) {
+    const int64_t total = g.nfd * (int64_t)nslab * (int64_t)b.n;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t col = w % g.nfd;
+        const int sl = (int)((w / g.nfd) % nslab), img = (int)(w / (g.nfd * (int64_t)nslab));
+        const RevJobDev jb = jobs[b.job[img]];
+        if (jb.bound[kRevUniform] == 0ull) continue;                       // (the host sorts the jobs; this only keeps the two kernels apart)
+        const int64_t row0 = (int64_t)sl * slab;
+        if (row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) continue;
+        RevParams p;
+        p.thth = nullptr; p.ld = jb.N;
+        p.vec = jb.vec; p.w = jb.w; p.rank1 = 1;
+        p.th = jb.th; p.N = jb.N;
+        p.eta = jb.eta; p.two_eta = jb.two_eta;
+        p.hermitian = 1; p.slab = slab; p.centre = jb.centre;
+        p.recov = b.recov[img]; p.transposed = 1;
+        p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
+        p.walk = nullptr; p.walk_col = nullptr;
+        rev_diag_body<kRevThreadsK>(p, g, col, sl);
+        __syncthreads();
+    }
+}
+// the grid test of every curvature of a sweep, before it starts (the host sorts a tail batch by it)
+__global__ void __launch_bounds__(256) rev_uniform_kernel(const RevJobDev* __restrict__ jobs, GeomDev g, int32_t* __restrict__ flags, int diag_enabled) {
+    __shared__ double red[4];
+    const RevJobDev jb = jobs[blockIdx.x];
+    const int N = diag_enabled ? jb.N : 0;
+    const double th_step = N > 1 ? (gload(jb.th + N - 1) - gload(jb.th)) / (double)(N - 1) : 0.0;      // rev_setup_consts
+    double dev = N > 1 ? rev_grid_deviation(jb.th, N, th_step, (int)threadIdx.x, 256) : INFINITY;
+    for (int o = 32; o > 0; o >>= 1) dev = fmax(dev, __shfl_xor(dev, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dev;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    dev = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    rev_uniform_consts(dev, jb.th, N, th_step, jb.eta, g, jb.bound);
+    flags[blockIdx.x] = jb.bound[kRevUniform] ? 1 : 0;
 }
 
 RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, int rank1, const double* th, int N,
@@ -859,6 +1135,13 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     return p;
 }
 
+// SCINT_REV_DIAG=0 keeps every image on the general kernel (read per call: the A/B of profiles/r06_revmap_diag_ab.txt, and the
+// tests that hold the general kernel's pinned bits on uniform grids)
+static bool rev_diag_enabled() {
+    const char* e = getenv("SCINT_REV_DIAG");
+    return !(e && e[0] == '0');
+}
+
 // Enqueue the back-map: bound pre-pass (max |value|, min theta spacing) + the column gather.
 int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound /*[8] device scratch*/,
                        hipStream_t stream) {
@@ -870,12 +1153,19 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     const int64_t nvals = p.rank1 ? (int64_t)p.N : (int64_t)p.N * p.N;
     const unsigned nblk = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(nvals, 256 * 8)));
     hipLaunchKernelGGL(rev_bound_kernel, dim3(nblk), dim3(256), 0, stream, p, bound);
-    hipLaunchKernelGGL(rev_setup_kernel, dim3(1), dim3(64), 0, stream, p, g, bound);
+    hipLaunchKernelGGL(rev_setup_kernel, dim3(1), dim3(64), 0, stream, p, g, bound, rev_diag_enabled() ? 1 : 0);
     p.bound = bound;
     // equal slabs of at most kRevSlab delay rows
     p.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));
     dim3 grid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, p.slab));
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
+    if (p.rank1 && p.hermitian) {             // the uniform-grid kernel or the general one: the device decides (rev_setup_kernel), the other leaves at once
+        RevParams q = p;
+        q.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kDiagSlab));
+        dim3 qgrid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, q.slab));
+        SCINT_REQUIRE(qgrid.y <= 65535, "rev_map: ntau too large");
+        hipLaunchKernelGGL(rev_diag_kernel, qgrid, dim3(kRevThreadsK), (size_t)q.slab * 20, stream, q, g);
+    }
     if (p.rank1)
         hipLaunchKernelGGL((rev_gather_kernel<kRevThreadsK, true>), grid, dim3(kRevThreadsK), (size_t)p.slab * 36, stream, p, g);
     else
@@ -963,15 +1253,38 @@ int32_t launch_rev_walk_table(const double* th, int64_t N, const GeomDev& g, uin
     return SCINT_OK;
 }
 
-int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, hipStream_t stream) {
+int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, const uint8_t* uniform, hipStream_t stream) {
     SCINT_REQUIRE(b.n >= 1 && b.n <= kRevBatchMax, "rev_map batch: bad count");
     hipLaunchKernelGGL(rev_prep_batch_kernel, dim3((unsigned)b.n), dim3(256), 0, stream, jobs_dev, b, g);
-    const int slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kRevSlab));     // the slabs of launch_rev_map
-    const int nslab = (int)ceil_div(g.ntau, slab);
-    const int64_t total = g.nfd * (int64_t)nslab * (int64_t)b.n;
-    SCINT_REQUIRE(total < ((int64_t)1 << 31), "rev_map batch: too many work items");
-    const unsigned grid = (unsigned)(kRevCap > 0 ? std::min<int64_t>(total, kRevCap) : total);
-    hipLaunchKernelGGL(rev_gather_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, b, g, slab, nslab);
+    // the batch in two: the curvatures on a uniform grid (rev_uniform_kernel's flags, read back before the sweep) and the others
+    RevBatch part[2];
+    for (int k = 0; k < 2; ++k) {
+        part[k].n = 0; part[k].pad = 0;
+        for (int q = 0; q < kRevBatchMax; ++q) { part[k].job[q] = 0; part[k].recov[q] = nullptr; }
+    }
+    for (int q = 0; q < b.n; ++q) {
+        RevBatch& dst = part[(uniform && uniform[b.job[q]]) ? 1 : 0];
+        dst.job[dst.n] = b.job[q]; dst.recov[dst.n] = b.recov[q];
+        ++dst.n;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (part[k].n == 0) continue;
+        const int slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)(k ? kDiagSlab : kRevSlab)));     // the slabs of launch_rev_map
+        const int nslab = (int)ceil_div(g.ntau, slab);
+        const int64_t total = g.nfd * (int64_t)nslab * (int64_t)part[k].n;
+        SCINT_REQUIRE(total < ((int64_t)1 << 31), "rev_map batch: too many work items");
+        const unsigned grid = (unsigned)(kRevCap > 0 ? std::min<int64_t>(total, kRevCap) : total);
+        if (k)
+            hipLaunchKernelGGL(rev_diag_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 20, stream, jobs_dev, part[k], g, slab, nslab);
+        else
+            hipLaunchKernelGGL(rev_gather_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, part[k], g, slab, nslab);
+    }
+    SCINT_LAUNCH_CHECK();
+    return SCINT_OK;
+}
+int32_t launch_rev_uniform(const RevJobDev* jobs_dev, int64_t njobs, const GeomDev& g, int32_t* flags_dev, hipStream_t stream) {
+    SCINT_REQUIRE(jobs_dev && flags_dev && njobs >= 1 && njobs < ((int64_t)1 << 31), "rev_map grid test: bad arguments");
+    hipLaunchKernelGGL(rev_uniform_kernel, dim3((unsigned)njobs), dim3(256), 0, stream, jobs_dev, g, flags_dev, rev_diag_enabled() ? 1 : 0);
     SCINT_LAUNCH_CHECK();
     return SCINT_OK;
 }

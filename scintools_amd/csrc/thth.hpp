@@ -149,7 +149,13 @@ RevJobDev make_rev_job(const cplx* vec, const double* w, const double* th, int64
 // Only the delay rows a curvature can reach -- |tau| <= |eta| max theta^2, widened to a band that is symmetric about
 // tau = 0 -- are computed and written (whole slabs that miss the band leave at once); the band is left in
 // bound[kRevBandLo], bound[kRevBandHi] for the consumer (chisq_parseval_batch_kernel), which must not read outside it.
-int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, hipStream_t stream);
+// `uniform[job]` (host, or nullptr): the flags launch_rev_uniform left -- those curvatures take the diagonal kernel (thth.hip), the
+// others the general one; a job whose device flag disagrees with the host's copy is formed by neither (the flags are one read-back
+// of one kernel's output, so they agree).
+int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, const uint8_t* uniform, hipStream_t stream);
+// The grid test of every job of the table (rank-1 Hermitian back-map on a uniform theta grid): writes bound[kRevUniform],
+// bound[kRevSlack] of each and flags[job] = 0 / 1.  Once per sweep, before launch_rev_map_rank1_batch.
+int32_t launch_rev_uniform(const RevJobDev* jobs_dev, int64_t njobs, const GeomDev& g, int32_t* flags_dev, hipStream_t stream);
 // Which theta_j are partners of theta_i in Doppler column c does not depend on the curvature -- fd_map = theta_j - theta_i
 // (ththmod.py:207) -- only on the theta centres, i.e. on the CROP.  Curvatures that keep the same centres (161 of the 256 of
 // the headline sweep keep all 4095) can therefore share the part of the back-map that finds those partners (40 % of the
@@ -157,7 +163,7 @@ int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b,
 // window walk, k = 1 .. W <= 8), col_ok[c] = 1 iff every lane's window brackets the column (always on a near-uniform grid;
 // otherwise the column keeps the in-kernel walk).  One launch per crop; `masks` nfd * N bytes, `col_ok` nfd bytes.
 int32_t launch_rev_walk_table(const double* th, int64_t N, const GeomDev& g, uint8_t* masks, uint8_t* col_ok, hipStream_t stream);
-enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6, kRevBandLo = 7, kRevBandHi = 8 };
+enum { kRevS1 = 2, kRevS2 = 3, kRevExact = 4, kRevThStep = 5, kRevW = 6, kRevBandLo = 7, kRevBandHi = 8, kRevUniform = 9, kRevSlack = 10 };
 
 // np.histogram2d bin of x on the edges e(k) = (k - 0.5)*step + x0, k = 0..n:
 // searchsorted(edges, x, 'right') - 1, with x == e(n) folded into the last bin

@@ -232,7 +232,9 @@ def _eigh_top_dev(a_t, v0_t=None, want_vec=True, tol=DEFAULT_TOL, max_iter=DEFAU
     return float(w_t.cpu()[0]), vec_t, iters
 
 
-def _rev_map_dev(grid_geom, th_t, n, eta, hermetian, thth_t=None, vec_t=None, w_t=None):
+def _rev_map_dev(grid_geom, th_t, n, eta, hermetian, thth_t=None, vec_t=None, w_t=None, info=None):
+    """`info` (a dict, tests): receives `uniform_grid` -- word 9 of the call's scratch, 1 when the rank-1 Hermitian image was
+    formed by the uniform-grid kernel (csrc/thth.hip: rev_diag_kernel), 0 when by the general one."""
     lib = _lib.load()
     recov = empty((grid_geom.ntau, grid_geom.nfd), torch.complex128)
     rank1 = thth_t is None
@@ -241,6 +243,8 @@ def _rev_map_dev(grid_geom, th_t, n, eta, hermetian, thth_t=None, vec_t=None, w_
                            ctypes.byref(grid_geom), eta, 1 if hermetian else 0, ptr(recov),
                            ptr(scratch), scratch.numel(), stream_ptr())
     _lib.check(rc, "scint_rev_map")
+    if info is not None:
+        info["uniform_grid"] = int(scratch.cpu().numpy().view(np.uint64)[9])
     return recov
 
 

@@ -672,7 +672,7 @@ def test_rev_map_explicit_matrix(emu, to, case):
         assert np.abs(np.nan_to_num(got) - np.nan_to_num(ref)).max() <= 1e-9 * np.abs(np.nan_to_num(ref)).max()
 
 
-def test_back_map_bits_are_pinned(emu):
+def test_back_map_bits_are_pinned(emu, monkeypatch):
     """rev_map images of the interpreted kernel on 29 grids (rank-1 and explicit, Hermitian or not, irregular theta,
     several delay slabs and 256-lane chunks, pairs pushed off the delay axis; odd axis lengths and axes that are not
     symmetric about 0 -- the seven digests added in round 4) have the SHA-256 they had before the round-3 rewrite of
@@ -682,10 +682,90 @@ def test_back_map_bits_are_pinned(emu):
     not change a bit."""
     import json
     import revmap_probe
+    monkeypatch.setenv("SCINT_REV_DIAG", "0")        # round 6: rank-1 Hermitian images on a uniform grid have their own kernel (next test)
     got = revmap_probe.digests(revmap_probe.images(emu))
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "revmap_bits.json")) as fh:
         want = json.load(fh)
     assert got == want, [k for k in want if got.get(k) != want[k]]
+
+
+def test_diagonal_back_map_vs_oracle_and_pinned(emu, to):
+    """The uniform-grid kernel of round 6 (rev_diag_kernel: pairs along diagonals, plain float64 sums in a fixed order) on the
+    grids of the probe: every rank-1 image on a uniform grid is formed by it (the call's scratch says which kernel ran), equals
+    the oracle's np.histogram2d image to 1e-12 of the peak with the same set of non-zero pixels (the same pairs in the same
+    pixels; the order of a pixel's addends differs from NumPy's), and has the SHA-256 it had when the kernel was written
+    (tests/golden/revmap_diag_bits.json: the sums have a fixed order, so a schedule may not change a bit); the irregular grids
+    keep the general kernel and its pinned bits."""
+    import json
+    import hashlib
+    import torch
+    import revmap_probe
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "revmap_bits.json")) as fh:
+        general = json.load(fh)
+    with open(os.path.join(here, "golden", "revmap_diag_bits.json")) as fh:
+        pinned = json.load(fh)
+    rng = np.random.default_rng(5)
+    seen = {}
+    for name, tau, fd, edges, eta in revmap_probe.cases():
+        grid = emu._Grid(tau, fd, edges)
+        n = grid.M
+        v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.exp(-np.linspace(-2, 2, n) ** 2)
+        w = np.array([-3.7 if name == "flat" else 2.9])
+        if n <= 300:
+            rng.standard_normal((n, n)), rng.standard_normal((n, n))       # (the probe's explicit matrix: the same random stream)
+        info = {}
+        rec = emu._rev_map_dev(grid.geom, emu.to_device(grid.th_cents, torch.float64), n, eta, True, vec_t=emu.to_device(v),
+                               w_t=emu.to_device(w, torch.float64), info=info).cpu().numpy()
+        ref = np.nan_to_num(to.rev_map(np.outer(v, np.conj(v)) * np.abs(w[0]), tau, fd, eta, edges, True))
+        assert np.abs(rec - ref).max() <= 1e-12 * np.abs(ref).max(), name
+        assert np.array_equal(rec != 0, ref != 0), name
+        irregular = name in ("irregular", "chunks_and_slabs_steep", "odd_axes_slabs")
+        assert info["uniform_grid"] == (0 if irregular else 1), name
+        digest = hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest()
+        if irregular:
+            assert digest == general[name + "_rank1"], name
+        seen[name + "_rank1"] = digest
+    if os.environ.get("SCINT_WRITE_GOLDEN"):
+        with open(os.path.join(here, "golden", "revmap_diag_bits.json"), "w") as fh:
+            json.dump(seen, fh, indent=1)
+    assert seen == pinned, [k for k in seen if pinned.get(k) != seen[k]]
+
+
+def test_diagonal_back_map_fuzz_vs_oracle(emu, to):
+    """Random axes (odd lengths, shifted off 0), theta grids whose step is commensurate with the Doppler step (s * step ON a column
+    edge: the last bit of fl(theta_j - theta_i) decides, as in np.histogram2d), curvatures of either sign from 1 % of the arc's to
+    20 times it (strided sweeps, row gathers, pairs off the delay axis): the uniform-grid kernel against the oracle."""
+    import torch
+    rng = np.random.default_rng(20260930)
+    for trial in range(30):
+        ntau, nfd = int(rng.integers(16, 1300)), int(rng.integers(8, 160))
+        dt, df = 0.0137 * float(rng.uniform(0.5, 2)), 0.211 * float(rng.uniform(0.5, 2))
+        tau = (np.arange(ntau) - ntau // 2) * dt
+        fd = (np.arange(nfd) - nfd // 2) * df
+        kind = trial % 5
+        if kind == 1:
+            tau, fd = tau + float(rng.uniform(-0.5, 0.5)) * dt, fd + float(rng.uniform(-0.5, 0.5)) * df
+        nedge = 2 * int(rng.integers(3, 300))
+        lim = float(rng.uniform(0.2, 1.1)) * fd.max() / 2
+        if kind == 2:
+            lim = df / int(rng.integers(1, 4)) * (nedge - 1) / 2
+        if kind == 3:
+            lim = df * int(rng.integers(1, 3)) * (nedge - 1) / 2
+        edges = np.linspace(-lim, lim, nedge)
+        eta = float(10 ** rng.uniform(-2.0, 1.3)) * (1 if rng.uniform() < 0.8 else -1) * np.abs(tau).max() / lim ** 2
+        grid = emu._Grid(tau, fd, edges)
+        n = grid.M
+        v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        w = np.array([float(rng.uniform(-3, 3))])
+        info = {}
+        rec = emu._rev_map_dev(grid.geom, emu.to_device(grid.th_cents, torch.float64), n, eta, True, vec_t=emu.to_device(v),
+                               w_t=emu.to_device(w, torch.float64), info=info).cpu().numpy()
+        ref = np.nan_to_num(to.rev_map(np.outer(v, np.conj(v)) * np.abs(w[0]), tau, fd, eta, edges, True))
+        key = (trial, ntau, nfd, n, eta)
+        assert info["uniform_grid"] == 1, key
+        assert np.abs(rec - ref).max() <= 1e-12 * np.abs(ref).max(), key
+        assert np.array_equal(rec != 0, ref != 0), key
 
 
 def test_results_do_not_depend_on_the_schedule(tmp_path):
