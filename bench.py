@@ -171,7 +171,7 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
                      "traffic_note": (f"HBM bytes per eta = {ratio:.3f} x algorithmic (every kernel of a chi^2 step; rocprofv3 "
                                       f"PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), {src}") if ratio else stale,
                      "parts": {"pk2_matvec_kernel": part(mv, 1), "thth_gather_packed_kernel": part(ga, 0),
-                               "rev_gather_kernel (rank-1)": dict(
+                               "back-map (rev_diag_batch_kernel; rank-1)": dict(
                                    part(rv, 3), images_per_launch=images / max(1, mod["launches"][3]),
                                    avg_ms_per_image=mod["sum_ms"][3] / max(1, images),
                                    note="launches cover the <= 8 curvatures one chunk retired (tail batches); only the delay band "
@@ -632,7 +632,7 @@ def run_workload(args, with_cpu=True):
         ms, ms_sum, launches = (ctypes.c_double * NPROF)(), (ctypes.c_double * NPROF)(), (ctypes.c_int64 * NPROF)()
         lib.scint_profile_end(ms, ms_sum, launches, NPROF)
         tot = sum(ts)
-        names = ("thth_gather_packed_kernel", "pk2_matvec_kernel", "pk2_matvec32_kernel", "rev_gather_kernel", "model / chi^2 step")
+        names = ("thth_gather_packed_kernel", "pk2_matvec_kernel", "pk2_matvec32_kernel", "back-map (rev_diag / rev_gather / rev_row kernels)", "model / chi^2 step")
         return med, ts, {n: {"busy_share_of_wall": ms[k] / 1e3 / tot, "launches_per_call": launches[k] / steps,
                              "avg_launch_us": 1e3 * ms_sum[k] / max(1, launches[k])} for k, n in enumerate(names) if launches[k]}
 

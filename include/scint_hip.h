@@ -263,7 +263,14 @@ int32_t scint_eigh_top(const scint_c128* a, int64_t n, const scint_c128* v0,
  * Every pixel of recov_out is written (no zero-fill needed).  The per-pixel sums are
  * order-independent: each addend is split on a fixed binary grid so that the float64 LDS
  * accumulations are exact (thth.hip, RevSplit), hence the image is bit-reproducible from run
- * to run like np.histogram2d's.  Workspace: scint_rev_map_workspace_bytes() (a few words). */
+ * to run like np.histogram2d's.  Workspace: scint_rev_map_workspace_bytes() (a few words).
+ * Version 107: the rank-1 Hermitian image (modeler's) on a UNIFORM theta grid -- theta_k = theta_0 + k step to 1e-9 of a
+ * step, checked on the device for every call; the centres of linspace edges and any contiguous crop of them are one -- is
+ * formed by another kernel (thth.hip, rev_diag_kernel: whole diagonals j = i + s of a Doppler column instead of a search for
+ * every theta_i's partners; plain float64 sums in ONE fixed order, so equally bit-reproducible; the same pairs in the same
+ * pixels, each pixel within its rounding of the split sums').  After the call word 9 (uint64) of the workspace is 1 if that
+ * kernel formed the image, 0 if the general one did.  Environment: SCINT_REV_DIAG=0 keeps every image (also the chi^2 sweep's)
+ * on the general kernel. */
 int32_t scint_rev_map_workspace_bytes(size_t* bytes /*HOST*/);
 int32_t scint_rev_map(const scint_c128* thth, const scint_c128* vec, const double* w,
                       int32_t rank1, const double* th_cents, int64_t N,
@@ -374,7 +381,10 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
  *   crop_group HOST [neta] or NULL: curvatures with the same non-negative id keep the same theta centres (their th_red rows
  *            are equal element for element: the caller's promise); -1 = on its own.  Which theta_j pair with theta_i in a
  *            Doppler column does not depend on the curvature, so the back-maps of the two largest groups (>= 8 members)
- *            share one partner table per group instead of walking the centres per curvature (since version 103);
+ *            share one partner table per group instead of walking the centres per curvature (since version 103).  Version
+ *            107: a curvature whose th_red row is a uniform grid (tested on the device before the sweep: every grid of the
+ *            reference's path is one) takes the diagonal back-map of scint_rev_map instead, which has no partners to look
+ *            up; tables are built only for groups of curvatures that are not;
  *   mask     DEVICE uint8[nf*nt] or NULL (= isfinite(dspec));
  *   chisq_out DEVICE [neta]: sum((model[:nf,:nt]-dspec)[mask]**2)/noise_n; NaN-filled by the call, and left NaN for a
  *            curvature whose crop keeps fewer than THREE centres (two have no mean edge step: the reference's

@@ -106,7 +106,7 @@ _SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 106          # scint_version() of the library these signatures describe (csrc/capi.hip)
+ABI_VERSION = 107          # scint_version() of the library these signatures describe (csrc/capi.hip)
 
 
 def header_symbols():

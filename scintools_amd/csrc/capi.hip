@@ -47,7 +47,7 @@ extern "C" int32_t scint_profile_end(double* ms_out, double* ms_sum_out, int64_t
     return SCINT_OK;
 }
 
-extern "C" int32_t scint_version(void) { return 106; }   // 106: scint_retrieval_tail takes class_id (one-row back-map, pair counts per class); 105: scint_mosaic_* / scint_chunk_cut; 104: calc_sspec through persistent kernels (no signature change; the version binds library and package: _lib.load checks it); 101: scint_profile_end takes the length of the caller's arrays; 102: scint_sweep_workgroups; 103: scint_chisq_sweep takes crop_group
+extern "C" int32_t scint_version(void) { return 107; }   // 107: the rank-1 Hermitian back-map on a uniform theta grid is rev_diag_kernel (scint_rev_map leaves which kernel ran in word 9 of its workspace; SCINT_REV_DIAG=0 keeps the general kernel); 106: scint_retrieval_tail takes class_id (one-row back-map, pair counts per class); 105: scint_mosaic_* / scint_chunk_cut; 104: calc_sspec through persistent kernels (no signature change; the version binds library and package: _lib.load checks it); 101: scint_profile_end takes the length of the caller's arrays; 102: scint_sweep_workgroups; 103: scint_chisq_sweep takes crop_group
 
 extern "C" int32_t scint_last_error(char* buf, size_t n) {
     if (!buf || n == 0) return SCINT_E_ARG;

@@ -347,6 +347,7 @@ struct RevParams {
     double inv_tau1_step;              // 1 / tau1_step (host: the same IEEE quotient the kernel used to form per wavefront)
     const uint8_t* walk;               // partner masks of the crop (thth.hpp: launch_rev_walk_table), or nullptr
     const uint8_t* walk_col;
+    int stride_max;                    // rev_diag_body: strided sweeps up to this many passes, the segmented scan beyond
 };
 
 #ifndef SCINT_REV_SLAB
@@ -865,9 +866,12 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const Re
 //   * m >= 1: consecutive pairs fall in DIFFERENT rows, so the lanes of a sweep never meet in an accumulator and the sum of a
 //     pixel has a fixed order with plain float64 adds -- diagonal after diagonal (a barrier between them);  m >= 1/P (P <= 4):
 //     P sweeps over i = p mod P, each with that property;
-//   * flatter than that a thread owns a delay ROW: the pairs that fall in it are the run [first i with y_i >= edge(r), first i
-//     with y_i >= edge(r + 1)) (closed-form guess, settled on the exact y_i: y is strictly monotone along the diagonal as
-//     computed, its step is >= 1e-6 rows against a rounding of 1e-12), summed in order, in registers.
+//   * flatter than that lanes still run densely over the pairs, every wavefront over one contiguous block of them: the bins
+//     of 64 consecutive pairs are non-decreasing, so a row's pairs are a run of lanes, a segmented scan (a fixed tree, as
+//     deep as the longest possible run) leaves the run's sum in its last lane, and that lane alone adds it to the row; the row a
+//     block shares with the block before it is added last, block after block, behind a barrier.  (A first version gave every
+//     delay row a thread that summed its run one pair after the other: the flattest diagonals -- thousands of pairs in six
+//     rows -- made that a chain of dependent loads on six lanes, 0.36 .. 2.3 ms per image.)
 // No order-independent split (eight adds and three of five LDS atomics per pair), no collisions (flat curvatures: +40 % of an
 // image), no chunk pre-pass, 20 bytes of LDS per delay row instead of 36.  The histogram bin is floor((y - tau0) / dtau + 1/2)
 // whenever that argument is at least 1e-6 away from an integer (the edges of np.histogram2d round at 1e-12 of a row on any sane
@@ -917,11 +921,6 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
     const int rows = (int)min((int64_t)slab, g.ntau - row0);
     __shared__ double rcp_small[64];
     if (threadIdx.x < 64) rcp_small[threadIdx.x] = 1.0 / (double)threadIdx.x;
-    for (int r = threadIdx.x; r < rows; r += T) {
-        rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0;
-        ((uint32_t*)(rev_lds + 2 * slab))[r] = 0u;
-    }
-    __syncthreads();
 
     const double lo = ((double)col - 0.5) * g.fd1_step + g.fd0;        // histogram edges of the column
     const double hi = ((double)(col + 1) - 0.5) * g.fd1_step + g.fd0;
@@ -961,22 +960,43 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
     int s_hi = (int)fmin(floor(qb + 1e-9 * (1.0 + fabs(qb))), (double)N);
     s_lo = max(s_lo, -(N - 1)); s_hi = min(s_hi, N - 1);
     const double y_lo = edge((int)row0), y_hi = edge((int)row0 + rows);
-    for (int s = s_lo; s <= s_hi; ++s) {                               // uniform over the workgroup
-        if (s == 0) continue;                                          // i == j lands in the poisoned centre bin
-        const int i0 = s < 0 ? -s : 0, L = N - (s < 0 ? -s : s);       // pairs (i, i + s), i = i0 .. i0 + L - 1
-        // delay along the diagonal: y(i) ~ A i + C
-        const double A = 2.0 * p.eta * (double)s * d * d;
-        const double C = p.eta * ((double)s * d) * (2.0 * th0 + (double)s * d);
-        const bool up = A > 0.0;
-        const double m = fabs(A) * inv_tstep;                          // delay rows per step of i
-        // the lanes that can reach the slab, two of margin
-        const double fa = (y_lo - C) / A, fb = (y_hi - C) / A;
+    // Diagonal s against the slab (uniform over the workgroup): the pairs (i, i + s), i = i0 .. i0 + L - 1, have the delay
+    // y(i) ~ A i + C; [ia, ib) are the lanes that can reach the slab (two of margin) and [ra, rb) the slab's rows they can reach
+    // (two of margin: the closed form is within 1e-3 of a row of the exact delay on a grid that passed rev_uniform_consts).
+    struct Diag { int i0, L, ia, ib, ra, rb; double A, C; };
+    auto diag_of = [&](int s, Diag& q) {
+        q.i0 = s < 0 ? -s : 0; q.L = N - (s < 0 ? -s : s);
+        q.A = 2.0 * p.eta * (double)s * d * d;
+        q.C = p.eta * ((double)s * d) * (2.0 * th0 + (double)s * d);
+        const double fa = (y_lo - q.C) / q.A, fb = (y_hi - q.C) / q.A;
         const double f_min = fmin(fa, fb) - 2.0, f_max = fmax(fa, fb) + 2.0;
-        const int ia = (int)fmin(fmax(floor(f_min), (double)i0), (double)(i0 + L));
-        const int ib = (int)fmin(fmax(ceil(f_max) + 1.0, (double)i0), (double)(i0 + L));       // exclusive
-        if (ia >= ib) continue;
+        q.ia = (int)fmin(fmax(floor(f_min), (double)q.i0), (double)(q.i0 + q.L));
+        q.ib = (int)fmin(fmax(ceil(f_max) + 1.0, (double)q.i0), (double)(q.i0 + q.L));       // exclusive
+        if (s == 0 || q.ia >= q.ib) return false;                      // (i == j lands in the poisoned centre bin)
+        const double ta = ((q.A * (double)q.ia + q.C) - g.tau0) * inv_tstep, tb = ((q.A * (double)(q.ib - 1) + q.C) - g.tau0) * inv_tstep;
+        q.ra = (int)fmin(fmax(floor(fmin(ta, tb)) - 2.0 - (double)row0, 0.0), (double)rows);
+        q.rb = (int)fmin(fmax(ceil(fmax(ta, tb)) + 3.0 - (double)row0, 0.0), (double)rows);   // exclusive
+        return q.ra < q.rb;
+    };
+    // the rows of the slab this column can reach at all: only they are accumulated (the others are written as zeros)
+    int r_lo = rows, r_hi = 0;
+    for (int s = s_lo; s <= s_hi; ++s) {
+        Diag q;
+        if (diag_of(s, q)) { r_lo = min(r_lo, q.ra); r_hi = max(r_hi, q.rb); }
+    }
+    for (int r = r_lo + (int)threadIdx.x; r < r_hi; r += T) {
+        rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0;
+        ((uint32_t*)(rev_lds + 2 * slab))[r] = 0u;
+    }
+    __syncthreads();
+    for (int s = s_lo; s <= s_hi; ++s) {                               // uniform over the workgroup
+        Diag q;
+        if (!diag_of(s, q)) continue;
+        const int i0 = q.i0, L = q.L, ia = q.ia, ib = q.ib;
+        const bool up = q.A > 0.0;
+        const double m = fabs(q.A) * inv_tstep;                        // delay rows per step of i
         const int P = (int)fmin(ceil(1.0102 / m), 1e6);
-        if (P <= kDiagStrideMax) {
+        if (P <= p.stride_max) {
             // pairs of one sweep are P lanes apart: at least 1.01 delay rows -- no two of them in one accumulator
             for (int pass = 0; pass < P; ++pass) {
                 int i = ia + (int)threadIdx.x * P;
@@ -1010,6 +1030,7 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
             const int B = (((ub - ua) + NW - 1) / NW + 63) & ~63;
             const int us = ua + wave * B, ue = min(ub, us + B);
             auto pair_i = [&](int u) { return up ? i0 + u : i0 + L - 1 - u; };
+            const int run_max = (int)fmin(1.0102 / m + 2.0, 64.0);     // pairs of one row among 64 consecutive ones: <= 1 / m + 1
             int k_first = INT_MIN;                                     // (no pair has this bin: the first block shares nothing)
             if (wave > 0 && us < ue) { const int i = pair_i(us - 1); k_first = bin_of(delay(i, i + s)); }
             if (lane == 0) { carry_re[wave] = 0.0; carry_im[wave] = 0.0; carry_c[wave] = 0u; carry_by[wave] = k_first == INT_MIN ? 0 : k_first - (int)row0; }
@@ -1029,10 +1050,12 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
                 }
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
-                    const int kk = __shfl_up(k, d, 64);
-                    const double ar = __shfl_up(wr, d, 64), ai = __shfl_up(wi, d, 64);
-                    const uint32_t ac = __shfl_up(c, d, 64);
-                    if (lane >= d && kk == k) { wr += ar; wi += ai; c += ac; }
+                    if (d < run_max) {                                 // (uniform) no run is longer: lane - d is in another row
+                        const int kk = __shfl_up(k, d, 64);
+                        const double ar = __shfl_up(wr, d, 64), ai = __shfl_up(wi, d, 64);
+                        const uint32_t ac = __shfl_up(c, d, 64);
+                        if (lane >= d && kk == k) { wr += ar; wi += ai; c += ac; }
+                    }
                 }
                 const int kn = __shfl_down(k, 1, 64);
                 if ((lane == 63 || kn != k) && c != 0u) {
@@ -1061,7 +1084,7 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
     for (int r = threadIdx.x; r < rows; r += T) {
         const int64_t o = (row0 + r) * g.nfd + col;
         cplx out = mk(0.0, 0.0);
-        if (o != p.centre) {
+        if (o != p.centre && r >= r_lo && r < r_hi) {
             const uint32_t c = ((uint32_t*)(rev_lds + 2 * slab))[r];
             double scl;
             if (c < 64u) scl = rcp_small[c]; else scl = 1.0 / (double)c;
@@ -1076,7 +1099,7 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_diag_kernel(RevParams p, Geo
     rev_diag_body<kRevThreadsK>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
 }
 __global__ void __launch_bounds__(kRevThreadsK) rev_diag_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g, int slab,
-                                                                       int nslab) {
+                                                                       int nslab, int stride_max) {
     const int64_t total = g.nfd * (int64_t)nslab * (int64_t)b.n;
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         const int64_t col = w % g.nfd;
@@ -1093,7 +1116,7 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_diag_batch_kernel(const RevJ
         p.hermitian = 1; p.slab = slab; p.centre = jb.centre;
         p.recov = b.recov[img]; p.transposed = 1;
         p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
-        p.walk = nullptr; p.walk_col = nullptr;
+        p.walk = nullptr; p.walk_col = nullptr; p.stride_max = stride_max;
         rev_diag_body<kRevThreadsK>(p, g, col, sl);
         __syncthreads();
     }
@@ -1132,11 +1155,16 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     p.bound = nullptr;
     p.inv_tau1_step = 1.0 / g.tau1_step;
     p.walk = nullptr; p.walk_col = nullptr;
+    p.stride_max = kDiagStrideMax;
     return p;
 }
 
 // SCINT_REV_DIAG=0 keeps every image on the general kernel (read per call: the A/B of profiles/r06_revmap_diag_ab.txt, and the
 // tests that hold the general kernel's pinned bits on uniform grids)
+// (slabs of 512 / 1024 / 2048 rows and strided sweeps up to 1 / 2 / 4 / 8 passes were run as environment knobs, since removed:
+// profiles/r06_revmap_diag_knobs.txt -- 512 rows 902 eta/s, 2048 rows 922, 1024 rows 937-940 whatever the stride limit)
+static int diag_slab() { return kDiagSlab; }
+static int diag_stride_max() { return kDiagStrideMax; }
 static bool rev_diag_enabled() {
     const char* e = getenv("SCINT_REV_DIAG");
     return !(e && e[0] == '0');
@@ -1161,7 +1189,8 @@ int32_t launch_rev_map(RevParams p, const GeomDev& g, unsigned long long* bound 
     SCINT_REQUIRE(grid.y <= 65535, "rev_map: ntau too large");
     if (p.rank1 && p.hermitian) {             // the uniform-grid kernel or the general one: the device decides (rev_setup_kernel), the other leaves at once
         RevParams q = p;
-        q.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)kDiagSlab));
+        q.slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)diag_slab()));
+        q.stride_max = diag_stride_max();
         dim3 qgrid((unsigned)g.nfd, (unsigned)ceil_div(g.ntau, q.slab));
         SCINT_REQUIRE(qgrid.y <= 65535, "rev_map: ntau too large");
         hipLaunchKernelGGL(rev_diag_kernel, qgrid, dim3(kRevThreadsK), (size_t)q.slab * 20, stream, q, g);
@@ -1269,13 +1298,13 @@ int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b,
     }
     for (int k = 0; k < 2; ++k) {
         if (part[k].n == 0) continue;
-        const int slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)(k ? kDiagSlab : kRevSlab)));     // the slabs of launch_rev_map
+        const int slab = (int)ceil_div(g.ntau, ceil_div(g.ntau, (int64_t)(k ? diag_slab() : kRevSlab)));     // the slabs of launch_rev_map
         const int nslab = (int)ceil_div(g.ntau, slab);
         const int64_t total = g.nfd * (int64_t)nslab * (int64_t)part[k].n;
         SCINT_REQUIRE(total < ((int64_t)1 << 31), "rev_map batch: too many work items");
         const unsigned grid = (unsigned)(kRevCap > 0 ? std::min<int64_t>(total, kRevCap) : total);
         if (k)
-            hipLaunchKernelGGL(rev_diag_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 20, stream, jobs_dev, part[k], g, slab, nslab);
+            hipLaunchKernelGGL(rev_diag_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 20, stream, jobs_dev, part[k], g, slab, nslab, diag_stride_max());
         else
             hipLaunchKernelGGL(rev_gather_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, part[k], g, slab, nslab);
     }

@@ -230,3 +230,42 @@ def test_chisq_sweep_tail_batches_and_band_ends_vs_oracle(env):
     for i in (0, 4, 7, 11):
         ref = to.chisq_calc(dyn, CS, tau, fd, etas[i], edges, N)
         assert chis[i] == pytest.approx(ref, rel=1e-9), (i, etas[i] / eta_true)
+
+
+def test_diagonal_back_map_vs_general_kernel_and_oracle(env, case, monkeypatch):
+    """Round 6: the rank-1 Hermitian back-map on a uniform theta grid is rev_diag_kernel (whole diagonals of a Doppler column,
+    plain float64 sums in one fixed order) instead of rev_gather_kernel (a partner search per theta_i, order-independent split
+    sums).  At full size, for a flat, the true and a cropped steep curvature and a negative one: the call says which kernel ran;
+    the two images hold the same pixels (identical empty-bin masks) and agree to 1e-12 of the peak (each pixel is the same
+    addends in another order); a second call gives the same BITS; and at 2048^2 the image is the oracle's np.histogram2d image
+    to 1e-12 as well (the oracle at 4096^2 is covered by test_modeler_vs_oracle at one curvature)."""
+    import torch
+    thth, to = env
+    c = case
+    size = c["size"]
+    eta_true = c["eta"] / 0.93
+    grid = thth._Grid(c["tau"], c["fd"], c["edges"])
+    rng = np.random.default_rng(size)
+    for factor in (0.2, 1.0, 3.5, -0.6):
+        eta = factor * eta_true
+        keep = grid.keep(abs(eta)) if factor > 0 else np.arange(grid.M, dtype=np.int32)
+        th_red = thth._theta_centres(grid.edges_red(keep)) if factor > 0 else grid.th_cents
+        n = len(th_red)
+        v = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.exp(-np.linspace(-2, 2, n) ** 2)
+        w = np.array([3.3])
+        th_t, v_t, w_t = thth.to_device(th_red, torch.float64), thth.to_device(v), thth.to_device(w, torch.float64)
+        info = {}
+        monkeypatch.setenv("SCINT_REV_DIAG", "1")
+        a = thth._rev_map_dev(grid.geom, th_t, n, eta, True, vec_t=v_t, w_t=w_t, info=info).cpu().numpy()
+        again = thth._rev_map_dev(grid.geom, th_t, n, eta, True, vec_t=v_t, w_t=w_t).cpu().numpy()
+        assert info["uniform_grid"] == 1, factor
+        assert np.array_equal(a, again), factor
+        monkeypatch.setenv("SCINT_REV_DIAG", "0")
+        b = thth._rev_map_dev(grid.geom, th_t, n, eta, True, vec_t=v_t, w_t=w_t, info=info).cpu().numpy()
+        assert info["uniform_grid"] == 0, factor
+        assert np.count_nonzero(a) > 1000, factor
+        _assert_image_close(a, b, 1e-12, f"diagonal against general kernel, {factor} eta_true, N = {n}")
+        if size == 2048 and factor in (0.2, 3.5):
+            edges_red = grid.edges_red(keep)
+            ref = np.nan_to_num(to.rev_map(np.outer(v, np.conj(v)) * w[0], c["tau"], c["fd"], eta, edges_red, True))
+            _assert_image_close(a, ref, 1e-12, f"diagonal kernel against the oracle, {factor} eta_true")
