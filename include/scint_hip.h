@@ -391,6 +391,16 @@ int32_t scint_chisq(const double* model, int64_t ld_model, const double* dspec,
  *            rev_map raises there, ththmod.py:166) or whose eigen-solve failed (see status_out);
  *   w_out / vec_out / status_out / iters_out as in scint_eigvec_sweep.
  * Synchronous like the other sweep entry points (returns with all internal streams drained). */
+/* Version 107: when, on that route, the axes are symmetric about 0 (even lengths, x0 = -(n / 2) step to 1e-7 of a step: every
+ * fft_axis), chi^2 of a uniform-grid curvature comes from the back-map's accumulators -- the rank-1 Hermitian histogram is then
+ * mirror-symmetric, fft2(model) at an interior pixel IS recov there, and the workgroup that holds the pixel adds |recov - D|^2
+ * itself: the image is neither written nor read back (Doppler column 0 and delay row 0, whose mirrors are off the axes, still
+ * are, and take the partner formula).  A pair that sits on a bin edge with its mirrored pair NOT in the mirrored pixel raises the
+ * curvature's flag (the edges np.histogram2d computes mirror each other only to ~1e-9 of a step); flagged curvatures are done
+ * again from a written image before the call returns.  SCINT_CHISQ_FUSE=0 (environment) keeps every image written.
+ * scint_chisq_sweep_last_route: of the LAST scint_chisq_sweep of the process -- fused = 1 if it took chi^2 from the accumulators,
+ * redone = the curvatures it did again (tests, bench.py). */
+int32_t scint_chisq_sweep_last_route(int32_t* fused /*HOST*/, int64_t* redone /*HOST*/);
 int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, int64_t batch, int32_t max_iter,
                                           int64_t ntau, int64_t nfd, int64_t nf, int64_t nt,
                                           size_t* bytes /*HOST*/);

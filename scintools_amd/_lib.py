@@ -72,6 +72,7 @@ _SIGNATURES = {
     "scint_chisq_sweep": ([_P, POINTER(CsGeom), _P, c_int64, _P, POINTER(c_int32), POINTER(c_double), c_int64,
                            c_double, c_int32, c_int64, _P, POINTER(c_int32), _P, c_int64, c_int64, _P, c_double, _P, _P, _P, c_int64,
                            _P, _P, _P, c_size_t, _P], c_int32),
+    "scint_chisq_sweep_last_route": ([POINTER(c_int32), POINTER(c_int64)], c_int32),
     "scint_eigh_top_workspace_bytes": ([c_int64, c_int32, POINTER(c_size_t)], c_int32),
     "scint_eigh_top": ([_P, c_int64, _P, c_double, c_int32, _P, _P, _P, _P, _P, c_size_t, _P], c_int32),
     "scint_rev_map_workspace_bytes": ([POINTER(c_size_t)], c_int32),

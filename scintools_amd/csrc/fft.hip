@@ -1382,6 +1382,58 @@ __global__ void __launch_bounds__(256) chisq_colsum_kernel(const cplx* __restric
     }
     part[(int64_t)blockIdx.y * Q + q] = acc;
 }
+// ---- chi^2 from the back-map's accumulators (round 6; thth.hpp: RevFuse) --------------------------------------------------------
+// On axes that are symmetric about 0 (even lengths, x0 = -(n / 2) step: every fft_axis) the rank-1 Hermitian back-map is
+// mirror-symmetric -- pair (j, i) falls in pixel (P - p, Q - q) when (i, j) falls in (p, q), with the conjugate weight -- unless a
+// pair sits ON a bin edge (the back-map raises the curvature's flag then).  So for every INTERIOR pixel (p >= 1, q >= 1) the
+// Hermitian part Xs[k] of the identity above is recov itself (to its rounding: the two sums have different orders), and the
+// pixel's chi^2 term |recov - D|^2 is formed by the back-map workgroup that holds it in LDS: the image is neither written nor read
+// back (0.46 of 0.55 GB per curvature at the headline size).  What is left for this side:
+//   * the EDGE set -- Doppler column p = 0 and delay row q = 0, whose mirror pixels are not mirror images (their partners'
+//     pairs fall off the axes): the back-map still writes them, chisq_edge_batch_kernel forms their terms with the partner
+//     formula; its partners (0, Q - q) and (P - p, 0) are in the edge set;
+//   * the interior rows outside the curvature's band: sum |D|^2 from prefix / suffix sums of
+//     colsumI[q] = sum_{p >= 1} |S[p][q]|^2 (q >= 1; 0 at q = 0), formed once per sweep by the two kernels below.
+__global__ void __launch_bounds__(256) chisq_colsum_interior_kernel(const cplx* __restrict__ S, int P, int Q, double* __restrict__ part) {
+    const int q = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (q >= Q) return;
+    const int per = (P - 1 + kColsumChunks - 1) / kColsumChunks, p0 = 1 + (int)blockIdx.y * per, p1 = min(p0 + per, P);
+    double acc = 0.0;
+    for (int p = p0; p < p1; ++p) {
+        const cplx z = gload(S + (int64_t)p * Q + q);
+        acc += z.x * z.x + z.y * z.y;
+    }
+    part[(int64_t)blockIdx.y * Q + q] = q == 0 ? 0.0 : acc;
+}
+// partial[image][items .. items + 2] = the edge set's terms, the interior rows below the band, the interior rows above it
+__global__ void __launch_bounds__(256) chisq_edge_batch_kernel(RevBatch bt, const RevJobDev* __restrict__ jobs, const cplx* __restrict__ S,
+                                                               int P, int Q, const double* __restrict__ preI, const double* __restrict__ sufI,
+                                                               double* __restrict__ partial_base, int64_t partial_stride, int items) {
+    __shared__ double red[4];
+    const cplx* __restrict__ A = bt.recov[blockIdx.x];
+    const unsigned long long* __restrict__ bound = jobs[bt.job[blockIdx.x]].bound;
+    const int qlo = (int)bound[kRevBandLo], qhi = (int)bound[kRevBandHi];
+    auto at = [&](int p, int q) {                       // recov^T, 0 outside the band (not written there)
+        return (q >= qlo && q <= qhi) ? gload(A + (int64_t)p * Q + q) : mk(0.0, 0.0);
+    };
+    auto term = [&](int p, int q) {
+        const int pp = p == 0 ? 0 : P - p, qq = q == 0 ? 0 : Q - q;
+        const cplx x = at(p, q), y = at(pp, qq), z = gload(S + (int64_t)p * Q + q);
+        const double re = 0.5 * (x.x + y.x) - z.x, im = 0.5 * (x.y - y.y) - z.y;
+        return re * re + im * im;
+    };
+    double acc = 0.0;
+    for (int q = (int)threadIdx.x; q < Q; q += 256) acc += term(0, q);
+    for (int p = 1 + (int)threadIdx.x; p < P; p += 256) acc += term(p, 0);
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        double* partial = partial_base + (int64_t)blockIdx.x * partial_stride + items;
+        partial[0] = acc;
+        partial[1] = gload(preI + qlo);
+        partial[2] = gload(sufI + qhi + 1);
+    }
+}
+
 // pre[q] = sum_{q' < q} colsum[q'], suf[q] = sum_{q' >= q} colsum[q'], q = 0 .. Q: one workgroup, a contiguous segment per
 // thread, fixed order
 __global__ void __launch_bounds__(256) chisq_prefix_kernel(const double* __restrict__ part, double* __restrict__ colsum, int Q,
@@ -1433,6 +1485,8 @@ struct ChisqTail : SweepTail {
     const cplx* specT = nullptr;      // fftshift(fft2(dspec^T)): set when chi^2 goes by Parseval (no model transform)
     const RevJobDev* jobs_dev = nullptr; const double* pre = nullptr; const double* suf = nullptr;   // Parseval route: per-curvature table, |D|^2 sums
     std::vector<uint8_t> uniform;     // per curvature: its back-map takes the uniform-grid kernel (launch_rev_uniform's flags)
+    bool fuse = false;                // ... and chi^2 comes from its accumulators (RevFuse: symmetric axes)
+    const double* preI = nullptr; const double* sufI = nullptr; int32_t* asym = nullptr; int64_t partial_stride = 0;
     int images = 1;                   // image buffers (and partial-sum sets) per tail lane
     // one set of scratch buffers per tail lane
     cplx* recovT_[kTailLanes]; double* modelT_[kTailLanes]; void* fft_ws_[kTailLanes]; size_t fft_ws_bytes;
@@ -1456,16 +1510,35 @@ struct ChisqTail : SweepTail {
         for (int k = b.n; k < kRevBatchMax; ++k) { b.job[k] = 0; b.recov[k] = nullptr; }
         if (b.n == 0) return SCINT_OK;
         const int ps = profiler().begin(kProfRevmap, tail);
-        int32_t rc = launch_rev_map_rank1_batch(jobs_dev, b, g, uniform.empty() ? nullptr : uniform.data(), tail);
+        RevFuse fz{specT, partial_[lane], partial_stride, asym};
+        RevBatch general, fused;
+        int32_t rc = launch_rev_map_rank1_batch(jobs_dev, b, g, uniform.empty() ? nullptr : uniform.data(), fuse ? &fz : nullptr,
+                                                &general, &fused, tail);
         profiler().end(kProfRevmap, ps, tail);
         if (rc != SCINT_OK) return rc;
         const int pm = profiler().begin(kProfModel, tail);
         const int P = (int)g.nfd, Q = (int)g.ntau;
-        const int nblk = std::min(P / 2 + 1, kChisqPartials);
-        hipLaunchKernelGGL(chisq_parseval_batch_kernel, dim3((unsigned)nblk, (unsigned)b.n), dim3(256), 0, tail, b, jobs_dev, specT,
-                           P, Q, pre, suf, partial_[lane], kChisqPartials + 8);
-        hipLaunchKernelGGL(chisq_final_batch_kernel, dim3((unsigned)b.n), dim3(256), 0, tail, b, partial_[lane], kChisqPartials + 8,
-                           nblk + 2, 1.0 / ((double)P * (double)Q) / noise_n, chisq_out);
+        const double scale = 1.0 / ((double)P * (double)Q) / noise_n;
+        if (!fuse) {                                   // every image was written: one Parseval pass over the whole batch
+            general = b;
+            fused.n = 0;
+        }
+        if (fused.n > 0) {
+            // the uniform-grid curvatures: their interior terms are in partial[image][0 .. items) already
+            const int items = (int)rev_diag_items(g);
+            hipLaunchKernelGGL(chisq_edge_batch_kernel, dim3((unsigned)fused.n), dim3(256), 0, tail, fused, jobs_dev, specT, P, Q, preI, sufI,
+                               partial_[lane], partial_stride, items);
+            hipLaunchKernelGGL(chisq_final_batch_kernel, dim3((unsigned)fused.n), dim3(256), 0, tail, fused, partial_[lane], (int)partial_stride,
+                               items + 3, scale, chisq_out);
+        }
+        if (general.n > 0) {
+            double* part = partial_[lane] + (int64_t)fused.n * partial_stride;      // (behind the fused images' sums)
+            const int nblk = std::min(P / 2 + 1, kChisqPartials);
+            hipLaunchKernelGGL(chisq_parseval_batch_kernel, dim3((unsigned)nblk, (unsigned)general.n), dim3(256), 0, tail, general, jobs_dev, specT,
+                               P, Q, pre, suf, part, (int)partial_stride);
+            hipLaunchKernelGGL(chisq_final_batch_kernel, dim3((unsigned)general.n), dim3(256), 0, tail, general, part, (int)partial_stride,
+                               nblk + 2, scale, chisq_out);
+        }
         if (hipGetLastError() != hipSuccess) rc = SCINT_E_HIP;
         profiler().end(kProfModel, pm, tail);
         return rc;
@@ -1515,6 +1588,8 @@ struct ChisqSweepLayout {
     size_t recov[kTailLanes], model[kTailLanes], dspecT, maskT, specT, fft[kTailLanes], partial[kTailLanes], rev[kTailLanes], sweep, total, fft_bytes, sweep_bytes;
     size_t jobs, bounds, colsum, pre, suf;     // Parseval route: RevJobDev table, per-curvature constants, |D|^2 sums along the delay axis
     size_t uflags;                             // ... and the grid test's flag of every curvature (thth.hpp: launch_rev_uniform)
+    size_t colsumI, preI, sufI, asym;          // chi^2 from the back-map's accumulators (RevFuse): |D|^2 sums of the interior, per-curvature flags
+    int64_t partial_stride;                    // doubles per image of a lane's partial sums
     size_t walk[kRevWalkTables];               // partner tables of the back-map for the largest groups of same-crop curvatures (thth.hpp)
     int images;                                // image buffers per tail lane (tail batches)
 };
@@ -1538,6 +1613,11 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
     L->jobs = take(parseval_shape ? sizeof(RevJobDev) * (size_t)neta : 0);
     L->bounds = take(parseval_shape ? sizeof(unsigned long long) * kRevWords * (size_t)neta : 0);
     L->uflags = take(parseval_shape ? sizeof(int32_t) * (size_t)neta : 0);
+    L->colsumI = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) * (size_t)(kColsumChunks + 1) : 0);
+    L->preI = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
+    L->sufI = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
+    L->asym = take(parseval_shape ? sizeof(int32_t) * (size_t)neta : 0);
+    L->partial_stride = std::max<int64_t>(kChisqPartials, parseval_shape ? rev_diag_items_for(ntau, nfd) : 0) + 8;
     L->colsum = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) * (size_t)(kColsumChunks + 1) : 0);   // [0]: the sums; then the chunks' partials
     L->pre = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
     L->suf = take(parseval_shape ? sizeof(double) * (size_t)(ntau + 1) : 0);
@@ -1546,7 +1626,7 @@ static int32_t chisq_sweep_layout(int64_t M, int64_t neta, int64_t batch, int32_
         L->recov[l] = take(sizeof(cplx) * (size_t)ntau * (size_t)nfd * (size_t)L->images);
         L->model[l] = take(sizeof(double) * (size_t)nf * (size_t)nt);
         L->fft[l] = take(L->fft_bytes);
-        L->partial[l] = take(sizeof(double) * (kChisqPartials + 8) * (size_t)L->images);
+        L->partial[l] = take(sizeof(double) * (size_t)L->partial_stride * (size_t)L->images);
         L->rev[l] = take(256);
     }
     int32_t rc = sweep_workspace_bytes(M, neta, batch, max_iter, true, 1, &L->sweep_bytes);
@@ -1566,6 +1646,13 @@ extern "C" int32_t scint_chisq_sweep_workspace_bytes(int64_t M, int64_t neta, in
     const int32_t rc = chisq_sweep_layout(M, neta, batch, max_iter, ntau, nfd, nf, nt, &L);
     if (rc == SCINT_OK) *bytes = L.total + 256;
     return rc;
+}
+
+namespace scint { static int32_t g_chisq_fused = 0; static int64_t g_chisq_redone = 0; }
+extern "C" int32_t scint_chisq_sweep_last_route(int32_t* fused, int64_t* redone) {
+    SCINT_REQUIRE(fused && redone, "chisq_sweep_last_route: null output");
+    *fused = g_chisq_fused; *redone = g_chisq_redone;
+    return SCINT_OK;
 }
 
 extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* geom, const double* th_cents,
@@ -1632,6 +1719,27 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
             hipLaunchKernelGGL(chisq_prefix_kernel, dim3(1), dim3(256), 0, st, part, colsum, Q, (double*)(base + L.pre), (double*)(base + L.suf));
             SCINT_LAUNCH_CHECK();
             t.pre = (const double*)(base + L.pre); t.suf = (const double*)(base + L.suf);
+            t.partial_stride = L.partial_stride;
+            // chi^2 from the back-map's accumulators: axes symmetric about 0 to 1e-7 of a step (np.histogram2d's edges mirror each other
+            // that well; the back-map itself settles every pair that is closer to an edge), even lengths.  SCINT_CHISQ_FUSE=0: never.
+            {
+                const GeomDev& gd = t.g;
+                const char* env = getenv("SCINT_CHISQ_FUSE");
+                const bool sym = P % 2 == 0 && Q % 2 == 0 && gd.fd1_step > 0.0 && gd.tau1_step > 0.0 &&
+                                 fabs((double)P * gd.fd1_step + 2.0 * gd.fd0) <= 1e-7 * gd.fd1_step &&
+                                 fabs((double)Q * gd.tau1_step + 2.0 * gd.tau0) <= 1e-7 * gd.tau1_step;
+                if (sym && !(env && env[0] == '0')) {
+                    double* colsumI = (double*)(base + L.colsumI);
+                    double* partI = colsumI + (Q + 1);
+                    hipLaunchKernelGGL(chisq_colsum_interior_kernel, dim3((unsigned)ceil_div(Q, 256), (unsigned)kColsumChunks), dim3(256), 0, st, specT, P, Q, partI);
+                    hipLaunchKernelGGL(chisq_prefix_kernel, dim3(1), dim3(256), 0, st, partI, colsumI, Q, (double*)(base + L.preI), (double*)(base + L.sufI));
+                    SCINT_LAUNCH_CHECK();
+                    SCINT_HIP(hipMemsetAsync(base + L.asym, 0, sizeof(int32_t) * (size_t)neta, st));
+                    t.preI = (const double*)(base + L.preI); t.sufI = (const double*)(base + L.sufI);
+                    t.asym = (int32_t*)(base + L.asym);
+                    t.fuse = true;
+                }
+            }
             // the per-curvature table of the batched tail (thth.hpp): everything but the image buffer is known now
             std::vector<RevJobDev> table((size_t)neta);
             unsigned long long* bounds = (unsigned long long*)(base + L.bounds);
@@ -1701,6 +1809,25 @@ extern "C" int32_t scint_chisq_sweep(const scint_c128* cs, const scint_cs_geom* 
             t.images = L.images;
         }
     }
-    return run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,
-                     status_out, iters_out, true, (cplx*)vec_out, vec_stride, &t, base + L.sweep, L.sweep_bytes, stream);
+    rc = run_sweep(cs, 1, 0, nullptr, geom, th_cents, M, keep_idx, keep_n, etas, neta, tol, max_iter, batch, w_out,
+                   status_out, iters_out, true, (cplx*)vec_out, vec_stride, &t, base + L.sweep, L.sweep_bytes, stream);
+    g_chisq_fused = t.fuse ? 1 : 0; g_chisq_redone = 0;
+    if (rc != SCINT_OK || !t.fuse) return rc;
+    // the curvatures whose back-map met a pair ON a bin edge (their histogram may not be mirror-symmetric): chi^2 once more, from the
+    // written image (their eigenvectors are in vec_out); the sweep has drained its streams
+    std::vector<int32_t> asym((size_t)neta);
+    SCINT_HIP(hipMemcpyAsync(asym.data(), t.asym, sizeof(int32_t) * (size_t)neta, hipMemcpyDeviceToHost, st));
+    SCINT_HIP(hipStreamSynchronize(st));
+    t.fuse = false;
+    std::vector<int64_t> again;
+    for (int64_t e = 0; e < neta; ++e)
+        if (asym[(size_t)e]) again.push_back(e);
+    for (size_t k = 0; k < again.size(); k += (size_t)t.batch_max()) {
+        const int cnt = (int)std::min<size_t>((size_t)t.batch_max(), again.size() - k);
+        rc = t.retire_batch(again.data() + k, cnt, st, 0);
+        if (rc != SCINT_OK) return rc;
+    }
+    if (!again.empty()) SCINT_HIP(hipStreamSynchronize(st));
+    g_chisq_redone = (int64_t)again.size();
+    return SCINT_OK;
 }

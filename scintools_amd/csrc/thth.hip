@@ -348,6 +348,8 @@ struct RevParams {
     const uint8_t* walk;               // partner masks of the crop (thth.hpp: launch_rev_walk_table), or nullptr
     const uint8_t* walk_col;
     int stride_max;                    // rev_diag_body: strided sweeps up to this many passes, the segmented scan beyond
+    // rev_diag_body<FUSE>: chi^2 straight from the accumulators (RevFuse of thth.hpp); the image is not written
+    const cplx* spec; double* partial; int32_t* asym; int band_lo, band_hi;
 };
 
 #ifndef SCINT_REV_SLAB
@@ -910,7 +912,7 @@ __device__ inline double rev_grid_deviation(const double* th, int N, double th_s
     return dev;
 }
 
-template <int T>
+template <int T, bool FUSE>
 __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev& g, const int64_t col_in, const int slab_index) {
     extern __shared__ __attribute__((aligned(16))) double rev_lds[];
     const int slab = p.slab;
@@ -932,7 +934,27 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
     const double th0 = gload(p.th);
     const double inv_tstep = p.inv_tau1_step;
     const int ntau = (int)g.ntau;
-    auto in_column = [&](double x) { return x >= lo && (last ? x <= hi : x < hi); };
+    // FUSE relies on the histogram being mirror-symmetric -- pair (j, i) in pixel (nfd - c, ntau - r) when (i, j) is in (c, r):
+    // -x and -y are exact, but the edges np.histogram2d computes are mirror images of each other only to ~1e-9 of a step
+    // (step = fd[1] - fd[0] carries the rounding of fd[1]), and a value ON an edge belongs to one side.  Any pair within 1e-6 of
+    // a step of an edge therefore has its mirrored pair binned as well; if that does not land in the mirrored pixel the
+    // curvature's flag is raised and its chi^2 is formed again from a written image (fft.hip).  Column 0 and row 0 (whose
+    // mirrors are off the axes) are not fused at all.
+    const double col_tol = 1e-6 * g.fd1_step;
+    bool on_edge = false;
+    auto in_column = [&](double x) {
+        const bool in = x >= lo && (last ? x <= hi : x < hi);
+        if (FUSE && col != 0 && (fabs(x - lo) <= col_tol || fabs(x - hi) <= col_tol)) {
+            const int64_t mc = g.nfd - col;
+            const double mlo = ((double)mc - 0.5) * g.fd1_step + g.fd0, mhi = ((double)(mc + 1) - 0.5) * g.fd1_step + g.fd0;
+            const bool mirrored = -x >= mlo && (mc == g.nfd - 1 ? -x <= mhi : -x < mhi);
+            on_edge |= in != mirrored;
+#ifdef SCINT_DEBUG_EDGE
+            if (in != mirrored) printf("col edge: x %.17g lo %.17g hi %.17g col %d\n", x, lo, hi, (int)col);
+#endif
+        }
+        return in;
+    };
     auto edge = [&](int k) { return ((double)k - 0.5) * g.tau1_step + g.tau0; };       // np.histogram2d's delay edges
     auto delay = [&](int i, int j) {
         const double a = gload(p.th + i), b = gload(p.th + j);
@@ -949,7 +971,15 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
         const double t = (y - g.tau0) * inv_tstep + 0.5;
         const double kf = floor(t), f = t - kf;
         if (f >= 1e-6 && f <= 1.0 - 1e-6) return (t >= 0.0 && t < (double)ntau) ? (int)kf : -1;
-        return hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, ntau);
+        const int k = hist_bin_rcp(y, g.tau0, g.tau1_step, inv_tstep, ntau);
+        if (FUSE) {
+            const int km = hist_bin_rcp(-y, g.tau0, g.tau1_step, inv_tstep, ntau);
+            on_edge |= (k >= 1 && km != ntau - k) || (km >= 1 && k != ntau - km);
+#ifdef SCINT_DEBUG_EDGE
+            if ((k >= 1 && km != ntau - k) || (km >= 1 && k != ntau - km)) printf("row edge: y %.17g t %.17g f %.3g k %d km %d ntau %d\n", y, t, f, k, km, ntau);
+#endif
+        }
+        return k;
     };
     __shared__ double carry_re[T / 64], carry_im[T / 64];
     __shared__ uint32_t carry_c[T / 64];
@@ -1081,6 +1111,7 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
         }
     }
     // recov = nan_to_num(sum / count), the poisoned centre 0 (as rev_gather_body)
+    double chi = 0.0;
     for (int r = threadIdx.x; r < rows; r += T) {
         const int64_t o = (row0 + r) * g.nfd + col;
         cplx out = mk(0.0, 0.0);
@@ -1090,25 +1121,48 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
             if (c < 64u) scl = rcp_small[c]; else scl = 1.0 / (double)c;
             out = mk(nan_to_num(rev_lds[r] * scl), nan_to_num(rev_lds[slab + r] * scl));
         }
-        gstore(p.recov + (p.transposed ? col * g.ntau + (row0 + r) : o), out);
+        if (FUSE && col != 0 && row0 + r != 0) {
+            // an interior pixel: fft2(model) there IS recov (its mirror pixel holds the conjugate), so its chi^2 term is local
+            const int q = (int)row0 + r;
+            if (q >= p.band_lo && q <= p.band_hi) {
+                const cplx z = gload(p.spec + col * g.ntau + q);
+                const double re = out.x - z.x, im = out.y - z.y;
+                chi += re * re + im * im;
+            }
+        } else {
+            gstore(p.recov + (p.transposed ? col * g.ntau + (row0 + r) : o), out);
+        }
+    }
+    if (FUSE) {
+        __shared__ double chi_red[T / 64];
+        chi = block_sum(chi, chi_red);
+        if (threadIdx.x == 0) gstore(p.partial, chi);
+        if (on_edge) atomicOr(p.asym, 1);
     }
 }
 
 __global__ void __launch_bounds__(kRevThreadsK) rev_diag_kernel(RevParams p, GeomDev g) {
     if (p.bound[kRevUniform] == 0ull) return;                              // rev_gather_kernel's image
-    rev_diag_body<kRevThreadsK>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
+    rev_diag_body<kRevThreadsK, false>(p, g, (int64_t)blockIdx.x, (int)blockIdx.y);
 }
+template <bool FUSE>
 __global__ void __launch_bounds__(kRevThreadsK) rev_diag_batch_kernel(const RevJobDev* __restrict__ jobs, RevBatch b, GeomDev g, int slab,
-                                                                       int nslab, int stride_max) {
+                                                                       int nslab, int stride_max, RevFuse fz) {
     const int64_t total = g.nfd * (int64_t)nslab * (int64_t)b.n;
     for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
         const int64_t col = w % g.nfd;
         const int sl = (int)((w / g.nfd) % nslab), img = (int)(w / (g.nfd * (int64_t)nslab));
         const RevJobDev jb = jobs[b.job[img]];
-        if (jb.bound[kRevUniform] == 0ull) continue;                       // (the host sorts the jobs; this only keeps the two kernels apart)
+        double* const partial = FUSE ? fz.partial + (int64_t)img * fz.partial_stride + (col * nslab + sl) : nullptr;
         const int64_t row0 = (int64_t)sl * slab;
-        if (row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) continue;
+        if (jb.bound[kRevUniform] == 0ull ||                               // (the host sorts the jobs; this only keeps the two kernels apart)
+            row0 > (int64_t)jb.bound[kRevBandHi] || row0 + slab - 1 < (int64_t)jb.bound[kRevBandLo]) {
+            if (FUSE && threadIdx.x == 0) gstore(partial, 0.0);
+            continue;
+        }
         RevParams p;
+        p.spec = fz.spec; p.partial = partial; p.asym = FUSE ? fz.asym + b.job[img] : nullptr;
+        p.band_lo = (int)jb.bound[kRevBandLo]; p.band_hi = (int)jb.bound[kRevBandHi];
         p.thth = nullptr; p.ld = jb.N;
         p.vec = jb.vec; p.w = jb.w; p.rank1 = 1;
         p.th = jb.th; p.N = jb.N;
@@ -1117,7 +1171,7 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_diag_batch_kernel(const RevJ
         p.recov = b.recov[img]; p.transposed = 1;
         p.bound = jb.bound; p.inv_tau1_step = jb.inv_tau1_step;
         p.walk = nullptr; p.walk_col = nullptr; p.stride_max = stride_max;
-        rev_diag_body<kRevThreadsK>(p, g, col, sl);
+        rev_diag_body<kRevThreadsK, FUSE>(p, g, col, sl);
         __syncthreads();
     }
 }
@@ -1282,7 +1336,8 @@ int32_t launch_rev_walk_table(const double* th, int64_t N, const GeomDev& g, uin
     return SCINT_OK;
 }
 
-int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, const uint8_t* uniform, hipStream_t stream) {
+int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, const uint8_t* uniform, const RevFuse* fuse,
+                                   RevBatch* general_out, RevBatch* uniform_out, hipStream_t stream) {
     SCINT_REQUIRE(b.n >= 1 && b.n <= kRevBatchMax, "rev_map batch: bad count");
     hipLaunchKernelGGL(rev_prep_batch_kernel, dim3((unsigned)b.n), dim3(256), 0, stream, jobs_dev, b, g);
     // the batch in two: the curvatures on a uniform grid (rev_uniform_kernel's flags, read back before the sweep) and the others
@@ -1303,14 +1358,27 @@ int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b,
         const int64_t total = g.nfd * (int64_t)nslab * (int64_t)part[k].n;
         SCINT_REQUIRE(total < ((int64_t)1 << 31), "rev_map batch: too many work items");
         const unsigned grid = (unsigned)(kRevCap > 0 ? std::min<int64_t>(total, kRevCap) : total);
-        if (k)
-            hipLaunchKernelGGL(rev_diag_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 20, stream, jobs_dev, part[k], g, slab, nslab, diag_stride_max());
-        else
+        if (k && fuse) {
+            SCINT_REQUIRE(fuse->spec && fuse->partial && fuse->asym && fuse->partial_stride >= g.nfd * (int64_t)nslab, "rev_map batch: bad fuse arguments");
+            hipLaunchKernelGGL(rev_diag_batch_kernel<true>, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 20, stream, jobs_dev, part[k], g, slab, nslab,
+                               diag_stride_max(), *fuse);
+        } else if (k) {
+            hipLaunchKernelGGL(rev_diag_batch_kernel<false>, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 20, stream, jobs_dev, part[k], g, slab, nslab,
+                               diag_stride_max(), RevFuse{nullptr, nullptr, 0, nullptr});
+        } else {
             hipLaunchKernelGGL(rev_gather_batch_kernel, dim3(grid), dim3(kRevThreadsK), (size_t)slab * 36, stream, jobs_dev, part[k], g, slab, nslab);
+        }
     }
     SCINT_LAUNCH_CHECK();
+    if (general_out) *general_out = part[0];
+    if (uniform_out) *uniform_out = part[1];
     return SCINT_OK;
 }
+int64_t rev_diag_items_for(int64_t ntau, int64_t nfd) {
+    const int slab = (int)ceil_div(ntau, ceil_div(ntau, (int64_t)diag_slab()));
+    return nfd * ceil_div(ntau, slab);
+}
+int64_t rev_diag_items(const GeomDev& g) { return rev_diag_items_for(g.ntau, g.nfd); }
 int32_t launch_rev_uniform(const RevJobDev* jobs_dev, int64_t njobs, const GeomDev& g, int32_t* flags_dev, hipStream_t stream) {
     SCINT_REQUIRE(jobs_dev && flags_dev && njobs >= 1 && njobs < ((int64_t)1 << 31), "rev_map grid test: bad arguments");
     hipLaunchKernelGGL(rev_uniform_kernel, dim3((unsigned)njobs), dim3(256), 0, stream, jobs_dev, g, flags_dev, rev_diag_enabled() ? 1 : 0);

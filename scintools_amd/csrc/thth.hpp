@@ -152,7 +152,18 @@ RevJobDev make_rev_job(const cplx* vec, const double* w, const double* th, int64
 // `uniform[job]` (host, or nullptr): the flags launch_rev_uniform left -- those curvatures take the diagonal kernel (thth.hip), the
 // others the general one; a job whose device flag disagrees with the host's copy is formed by neither (the flags are one read-back
 // of one kernel's output, so they agree).
-int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, const uint8_t* uniform, hipStream_t stream);
+// `fuse` (or nullptr): the uniform-grid curvatures of the batch do not write their image -- every workgroup leaves the chi^2 terms
+// of its interior pixels (Doppler column >= 1, delay row >= 1, inside the band), sum |recov - spec|^2, in
+// partial[image * partial_stride + column * slabs + slab] (image = position among the batch's uniform-grid curvatures; 0 for a
+// slab outside the band), writes only Doppler column 0 and delay row 0 of recov^T (the pixels whose mirror pixel is not the
+// mirror image: the consumer forms their terms), and raises asym[job] when a pair sat on a bin edge (the histogram may then
+// not be mirror-symmetric: that curvature's chi^2 must be formed from a written image).  spec = fftshift(fft2(dspec^T)) [nfd][ntau].
+// `general_out` / `uniform_out` (or nullptr): the two halves of the batch, in the order of their images.
+struct RevFuse { const cplx* spec; double* partial; int64_t partial_stride; int32_t* asym; };
+int32_t launch_rev_map_rank1_batch(const RevJobDev* jobs_dev, const RevBatch& b, const GeomDev& g, const uint8_t* uniform, const RevFuse* fuse,
+                                   RevBatch* general_out, RevBatch* uniform_out, hipStream_t stream);
+int64_t rev_diag_items(const GeomDev& g);      // work items (Doppler columns x delay slabs) of one image of the uniform-grid kernel
+int64_t rev_diag_items_for(int64_t ntau, int64_t nfd);
 // The grid test of every job of the table (rank-1 Hermitian back-map on a uniform theta grid): writes bound[kRevUniform],
 // bound[kRevSlack] of each and flags[job] = 0 / 1.  Once per sweep, before launch_rev_map_rank1_batch.
 int32_t launch_rev_uniform(const RevJobDev* jobs_dev, int64_t njobs, const GeomDev& g, int32_t* flags_dev, hipStream_t stream);

@@ -692,7 +692,10 @@ def chisq_sweep(dspec, CS, tau, fd, etas, edges, N, mask=None, return_info=False
     if return_info:
         w = w_t.cpu().numpy()
         w[(st[0] != 0) | (keep_n < 3)] = np.nan      # as chis: no model exists for these curvatures
-        return chis, {"w": w, "N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch}
+        fused, redone = ctypes.c_int32(), ctypes.c_int64()
+        _lib.check(lib.scint_chisq_sweep_last_route(ctypes.byref(fused), ctypes.byref(redone)), "scint_chisq_sweep_last_route")
+        return chis, {"w": w, "N": keep_n.copy(), "iters": st[1].copy(), "status": st[0].copy(), "batch": batch,
+                      "fused": bool(fused.value), "redone": int(redone.value)}
     return chis
 
 

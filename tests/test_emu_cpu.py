@@ -916,3 +916,55 @@ def test_eval_sweep_multi_with_device_built_crop_tables(emu, to, case):
     g2 = emu._Grid(c["tau"], c["fd"], edges2)
     assert np.array_equal(keeps[2], g2.keep(float(etas2[0]))) and np.array_equal(vinfo["N"], [len(k) for k in keeps])
     assert np.array_equal(keeps[0], emu._Grid(c["tau"], c["fd"], c["edges"]).keep(float(c["etas"][0])))
+
+
+def test_chisq_from_the_back_map_accumulators(emu, to, monkeypatch):
+    """Round 6: on symmetric axes chi^2 of a uniform-grid curvature is formed by the back-map workgroups themselves (interior
+    pixels: fft2(model) = recov, the histogram being mirror-symmetric), the image is not written; column 0 / row 0 keep the
+    partner formula; a pair on a bin edge whose mirrored pair is not in the mirrored pixel sends its curvature through the
+    written image again.  Against SCINT_CHISQ_FUSE=0 (every image written, the Parseval pass of round 4) to 1e-12 and
+    against the oracle to 1e-9, with the route the call reports: (a) a generic grid -- fused, (almost) nothing redone -- and
+    curvatures that put delays exactly on row edges -- fused, some redone;
+    (b) theta step = half the Doppler step, i.e. every odd diagonal ON a column edge -- fused, the curvatures redone, same
+    chi^2; (c) axes shifted off 0 and (d) odd lengths -- not fused at all; and two delay slabs with bands from a few rows to the
+    whole axis (row 0 in the band) in (a)."""
+    from scintools_amd.synth import arc_dynspec
+
+    def both(dyn, CS, tau, fd, etas, edges):
+        monkeypatch.setenv("SCINT_CHISQ_FUSE", "1")
+        a, ia = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, return_info=True)
+        monkeypatch.setenv("SCINT_CHISQ_FUSE", "0")
+        b, ib = emu.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, return_info=True)
+        assert not ib["fused"] and ib["redone"] == 0
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+        return a, ia
+
+    dyn, freqs, times, eta_true = arc_dynspec(1100, 48, seed=21, nimg=8, noise=0.05)
+    dyn = dyn - dyn.mean()
+    fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+    CS = to.conjugate_spectrum(dyn, 0)
+    edges = np.linspace(-fd.max() / 2, fd.max() / 2, 60)
+    th = emu._Grid(tau, fd, edges).th_cents
+    eta_full = np.abs(tau).max() / (th**2).max()
+    etas = np.array([0.004, 0.03, 0.3, 0.49, 0.51, 0.95, 1.05, 1.6, 3.0, 0.2]) * eta_full
+    a, info = both(dyn, CS, tau, fd, etas * 1.0123456, edges)                          # (a)
+    assert info["fused"] and info["redone"] <= 1
+    # (these curvatures are rational multiples of |tau|max / theta_max^2: eta (theta_j^2 - theta_i^2) ON delay edges -- four of the ten are done again)
+    a, info = both(dyn, CS, tau, fd, etas, edges)
+    assert info["fused"] and info["redone"] >= 2
+    ref = np.array([to.chisq_calc(dyn, CS, tau, fd, etas[i], edges, 3.0) for i in (0, 3, 6, 8)])
+    np.testing.assert_allclose(a[[0, 3, 6, 8]], ref, rtol=1e-9)
+    step = fd[1] - fd[0]
+    n = 40
+    edges_c = (np.arange(n) - (n - 1) / 2) * (step / 2)                                # (b) centres at multiples of step / 2 ... the differences too
+    b_, info = both(dyn, CS, tau, fd, etas[2:7], edges_c)
+    assert info["fused"] and info["redone"] >= 1
+    np.testing.assert_allclose(b_[1], to.chisq_calc(dyn, CS, tau, fd, etas[3], edges_c, 3.0), rtol=1e-9)
+    c_, info = both(dyn, CS, tau + 0.3 * (tau[1] - tau[0]), fd, etas[2:5], edges)     # (c)
+    assert not info["fused"]
+    dyn2, freqs2, times2, _ = arc_dynspec(97, 81, seed=11, nimg=8, noise=0.05)          # (d)
+    dyn2 = dyn2 - dyn2.mean()
+    fd2, tau2 = to.fft_axis(times2, 1000.0, 0), to.fft_axis(freqs2, 1.0, 0)
+    d_, info = both(dyn2, to.conjugate_spectrum(dyn2, 0), tau2, fd2, etas[2:5] * 0 + np.array([0.7, 1.0, 1.6]) * _,
+                    np.linspace(-fd2.max() / 2, fd2.max() / 2, 70))
+    assert not info["fused"]
