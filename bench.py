@@ -158,6 +158,10 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
         "value": neta / el, "unit": "eta-points/s", "steps": msteps, "ms_per_step": 1e3 * el,
         "lanczos_steps_mean": float(minfo["iters"].mean()),
         "failed_etas": int(np.sum(minfo["status"] != 0)),
+        "chisq_route": {"from_back_map_accumulators": bool(minfo.get("fused", False)), "curvatures_redone_from_a_written_image": int(minfo.get("redone", 0)),
+                        "note": "include/scint_hip.h (version 107): on symmetric axes the back-map workgroups add |recov - fft2(dspec)|^2 of their "
+                                "interior pixels themselves; the image is neither written nor read back (the algorithmic bytes below are still "
+                                "those of the written-image formulation)"},
         "matvec_share_of_step_time": mod["busy_ms"][1] / 1e3 / mod["elapsed"],
         "matvec_GBs": mod["mv_bytes"] / (mod["busy_ms"][1] / 1e3) / 1e9 if mod["busy_ms"][1] > 0 else 0.0,
         "eta_at_min_chisq_over_true": float(etas[np.nanargmin(chis)] / eta_true),
@@ -176,7 +180,7 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
                                    avg_ms_per_image=mod["sum_ms"][3] / max(1, images),
                                    note="launches cover the <= 8 curvatures one chunk retired (tail batches); only the delay band "
                                         "a curvature reaches is computed and written, the algorithmic bytes are the full image's"),
-                               "chi^2 step (chisq_parseval_batch_kernel; model transform + sink when cropped or masked)": dict(
+                               "chi^2 step (edge terms + final sum beside the fused back-map; chisq_parseval_batch_kernel when the image is written; model transform + sink when cropped or masked)": dict(
                                    part(mt, 4), images_per_launch=images / max(1, mod["launches"][4]),
                                    avg_ms_per_image=mod["sum_ms"][4] / max(1, images))}}}
 

@@ -94,7 +94,7 @@ def test_modeler_leg_has_its_own_roofline():
     parts = r["algorithmic_bytes_per_eta_by_part"]
     assert abs(sum(parts.values()) - r["algorithmic_bytes_per_eta"]) <= 1e-9 * r["algorithmic_bytes_per_eta"]
     assert parts["back_map_write"] == 16.0 * 128 * 128 and parts["model_read_plus_dspec"] == 24.0 * 128 * 128
-    for k in ("pk2_matvec_kernel", "back-map (rev_diag_batch_kernel; rank-1)", "chi^2 step (chisq_parseval_batch_kernel; model transform + sink when cropped or masked)"):
+    for k in ("pk2_matvec_kernel", "back-map (rev_diag_batch_kernel; rank-1)", "chi^2 step (edge terms + final sum beside the fused back-map; chisq_parseval_batch_kernel when the image is written; model transform + sink when cropped or masked)"):
         assert r["parts"][k]["launches_per_step"] > 0 and r["parts"][k]["achieved"] > 0, k
     mx = m["mixed_all"]
     assert "error" not in mx, mx

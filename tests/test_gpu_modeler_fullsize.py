@@ -269,3 +269,25 @@ def test_diagonal_back_map_vs_general_kernel_and_oracle(env, case, monkeypatch):
             edges_red = grid.edges_red(keep)
             ref = np.nan_to_num(to.rev_map(np.outer(v, np.conj(v)) * w[0], c["tau"], c["fd"], eta, edges_red, True))
             _assert_image_close(a, ref, 1e-12, f"diagonal kernel against the oracle, {factor} eta_true")
+
+
+def test_chisq_from_the_back_map_accumulators_fullsize(env, case, monkeypatch):
+    """Round 6: on the symmetric axes of the path chi^2 of every uniform-grid curvature is formed by the back-map workgroups
+    (interior pixels; column 0 and row 0 by the partner formula) and the image is not written.  At full size, fifteen curvatures
+    from a narrow band to the whole axis and into the crop: the call reports the fused route, and chi^2 equals the
+    written-image route's (SCINT_CHISQ_FUSE=0: round 4's Parseval pass) to 1e-12 -- which test_chisq_sweep_vs_chisq_calc holds
+    to the oracle."""
+    thth, to = env
+    c = case
+    dyn = c["dyn"]
+    eta_true = c["eta"] / 0.93
+    etas = np.concatenate([np.linspace(0.2, 1.4, 12), [2.2, 3.0, 3.8]]) * eta_true * 1.000123
+    cs_t = thth.to_device(c["CS"])
+    monkeypatch.setenv("SCINT_CHISQ_FUSE", "1")
+    a, ia = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], etas, c["edges"], float(dyn.size), return_info=True)
+    monkeypatch.setenv("SCINT_CHISQ_FUSE", "0")
+    b, ib = thth.chisq_sweep(dyn, cs_t, c["tau"], c["fd"], etas, c["edges"], float(dyn.size), return_info=True)
+    assert ia["fused"] and not ib["fused"] and ib["redone"] == 0
+    assert ia["redone"] <= 3
+    assert np.all(ia["status"] == 0) and np.all(np.isfinite(a))
+    np.testing.assert_allclose(a, b, rtol=1e-12)
