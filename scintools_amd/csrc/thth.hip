@@ -949,9 +949,6 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
             const double mlo = ((double)mc - 0.5) * g.fd1_step + g.fd0, mhi = ((double)(mc + 1) - 0.5) * g.fd1_step + g.fd0;
             const bool mirrored = -x >= mlo && (mc == g.nfd - 1 ? -x <= mhi : -x < mhi);
             on_edge |= in != mirrored;
-#ifdef SCINT_DEBUG_EDGE
-            if (in != mirrored) printf("col edge: x %.17g lo %.17g hi %.17g col %d\n", x, lo, hi, (int)col);
-#endif
         }
         return in;
     };
@@ -975,9 +972,6 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
         if (FUSE) {
             const int km = hist_bin_rcp(-y, g.tau0, g.tau1_step, inv_tstep, ntau);
             on_edge |= (k >= 1 && km != ntau - k) || (km >= 1 && k != ntau - km);
-#ifdef SCINT_DEBUG_EDGE
-            if ((k >= 1 && km != ntau - k) || (km >= 1 && k != ntau - km)) printf("row edge: y %.17g t %.17g f %.3g k %d km %d ntau %d\n", y, t, f, k, km, ntau);
-#endif
         }
         return k;
     };
