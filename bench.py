@@ -111,6 +111,15 @@ def pmc_modeler_ratio():
     return _newest_summary("*_pmc_modeler_summary.json", lambda summ: summ.get("traffic_over_algorithmic"))
 
 
+def pmc_modeler_bytes_per_eta():
+    """The measured HBM bytes of that summary per curvature (its absolute figure: the line's own algorithmic bytes -- which depend on
+    the route chi^2 took -- are divided into it, not the summary's)."""
+    def per_eta(summ):
+        n = summ.get("steps", 1) * summ.get("curvatures_per_step", 0)
+        return summ["hbm_bytes"] / n if n and summ.get("hbm_bytes") else None
+    return _newest_summary("*_pmc_modeler_summary.json", per_eta)
+
+
 def port_vs_reference():
     """Time of the oracle ("port") over the time of the unmodified reference on the same conjugate spectrum, recorded in the
     build container by tests/golden/time_port_vs_reference.py (the bench box has no /root/reference)."""
@@ -130,7 +139,8 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
     Algorithmic bytes per curvature: eigenPAIR passes x 8 N (N + 1) (upper triangle of the packed Hermitian
     theta-theta once per two-vector pass) + 16 N^2 for the gather + 16 ntau nfd written by the rank-1 back-map (recov) +
     16 ntau nfd (recov) read back + 8 nf nt of the dynamic spectrum for chi^2 (the Parseval kernel reads fft2(dspec), 16 ntau nfd,
-    in its place: its traffic is above this floor by that difference).  `achieved` is those
+    in its place: its traffic is above this floor by that difference); when chi^2 came from the back-map's accumulators (round 6:
+    `chisq_route`) no image is written or read back -- the back-map reads fft2(dspec), 16 ntau nfd, and that is all.  `achieved` is those
     bytes over the WALL time of the step -- the mat-vecs, back-maps and model transforms of different curvatures share the
     GPU on four streams, so the objective as a whole, not one kernel, is what the fraction describes; `parts` gives each
     kernel's own bytes over the union of its launch intervals."""
@@ -139,9 +149,15 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
     mv = float(np.sum(8.0 * n_ * (n_ + 1.0) * minfo["iters"]))
     ga = float(np.sum(16.0 * n_ * n_))
     rv, mt = neta * geom_bytes, neta * (geom_bytes + dspec_bytes)
+    fused = bool(minfo.get("fused", False))
+    if fused:
+        # chi^2 from the back-map's accumulators (include/scint_hip.h, version 107): no image is written or read back; the back-map
+        # workgroups read fft2(dspec) (16 ntau nfd) once, the chi^2 step proper is the edge terms and a sum of 16 387 numbers
+        rv, mt = neta * geom_bytes, 0.0
     per_step = mv + ga + rv + mt
     el = mod["elapsed"] / msteps
-    ratio, src, stale = pmc_modeler_ratio()
+    hbm_per_eta, src, stale = pmc_modeler_bytes_per_eta()
+    ratio = hbm_per_eta / (per_step / neta) if hbm_per_eta else None
     images = neta * msteps
 
     def part(bytes_per_step, k):
@@ -160,8 +176,8 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
         "failed_etas": int(np.sum(minfo["status"] != 0)),
         "chisq_route": {"from_back_map_accumulators": bool(minfo.get("fused", False)), "curvatures_redone_from_a_written_image": int(minfo.get("redone", 0)),
                         "note": "include/scint_hip.h (version 107): on symmetric axes the back-map workgroups add |recov - fft2(dspec)|^2 of their "
-                                "interior pixels themselves; the image is neither written nor read back (the algorithmic bytes below are still "
-                                "those of the written-image formulation)"},
+                                "interior pixels themselves; the image is neither written nor read back, and the algorithmic bytes below say so "
+                                "(back-map: fft2(dspec) read once, 16 ntau nfd; chi^2 step: none)"},
         "matvec_share_of_step_time": mod["busy_ms"][1] / 1e3 / mod["elapsed"],
         "matvec_GBs": mod["mv_bytes"] / (mod["busy_ms"][1] / 1e3) / 1e9 if mod["busy_ms"][1] > 0 else 0.0,
         "eta_at_min_chisq_over_true": float(etas[np.nanargmin(chis)] / eta_true),
@@ -169,8 +185,10 @@ def modeler_objects(mod, msteps, neta, etas, eta_true, geom_bytes, dspec_bytes):
                      "achieved": per_step / el / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": per_step / el / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_eta": per_step / neta,
-                     "algorithmic_bytes_per_eta_by_part": {"eigenpair_passes": mv / neta, "gather": ga / neta,
-                                                           "back_map_write": rv / neta, "model_read_plus_dspec": mt / neta},
+                     "algorithmic_bytes_per_eta_by_part": ({"eigenpair_passes": mv / neta, "gather": ga / neta,
+                                                            "back_map_reads_fft2_dspec": rv / neta, "chisq_step": mt / neta} if fused else
+                                                           {"eigenpair_passes": mv / neta, "gather": ga / neta,
+                                                            "back_map_write": rv / neta, "model_read_plus_dspec": mt / neta}),
                      "traffic": ratio * per_step / neta if ratio else None,
                      "traffic_note": (f"HBM bytes per eta = {ratio:.3f} x algorithmic (every kernel of a chi^2 step; rocprofv3 "
                                       f"PMC, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), {src}") if ratio else stale,
