@@ -875,7 +875,12 @@ __global__ void __launch_bounds__(kRevThreadsK) rev_gather_batch_kernel(const Re
 //     delay row a thread that summed its run one pair after the other: the flattest diagonals -- thousands of pairs in six
 //     rows -- made that a chain of dependent loads on six lanes, 0.36 .. 2.3 ms per image.)
 // No order-independent split (eight adds and three of five LDS atomics per pair), no collisions (flat curvatures: +40 % of an
-// image), no chunk pre-pass, 20 bytes of LDS per delay row instead of 36.  The histogram bin is floor((y - tau0) / dtau + 1/2)
+// image), no chunk pre-pass, 20 bytes of LDS per delay row instead of 36.  Counters of one 4096^2 image (mean of 0.25 / 1 / 4
+// eta_true, profiles/r06_revmap_counters_first.txt, r06_revmap_slim_ab.txt): 89.0 M vector instructions in rev_gather_kernel,
+// 41.2 M here (55.4 M before the per-diagonal geometry was cut to one pass without IEEE divisions and the strided sweeps lost
+// their runtime `%`; r06_revmap_slim2_ab.txt); 246 -> 153 us.  What is left
+// above the pairs' own ~13 M is lanes: a slab's share of a diagonal is 1024 / m lanes plus the margin, i.e. a little over one or
+// two 256-lane sweeps with the last one mostly empty, and every wavefront repeats the uniform geometry.  The histogram bin is floor((y - tau0) / dtau + 1/2)
 // whenever that argument is at least 1e-6 away from an integer (the edges of np.histogram2d round at 1e-12 of a row on any sane
 // axis; rev_uniform_consts checks the axis), else hist_bin_rcp's exact edge comparisons.  The image agrees with the reference's
 // to its rounding (each pixel is the same addends in another order; tests: 1e-9 of the peak against the oracle, bits pinned).
@@ -984,31 +989,26 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
     int s_hi = (int)fmin(floor(qb + 1e-9 * (1.0 + fabs(qb))), (double)N);
     s_lo = max(s_lo, -(N - 1)); s_hi = min(s_hi, N - 1);
     const double y_lo = edge((int)row0), y_hi = edge((int)row0 + rows);
-    // Diagonal s against the slab (uniform over the workgroup): the pairs (i, i + s), i = i0 .. i0 + L - 1, have the delay
-    // y(i) ~ A i + C; [ia, ib) are the lanes that can reach the slab (two of margin) and [ra, rb) the slab's rows they can reach
-    // (two of margin: the closed form is within 1e-3 of a row of the exact delay on a grid that passed rev_uniform_consts).
-    struct Diag { int i0, L, ia, ib, ra, rb; double A, C; };
+    // Diagonal s against the slab (uniform over the workgroup, and every wavefront computes it for itself -- so it is kept short:
+    // the first version formed it twice per diagonal with four IEEE divisions each, and 55 M vector instructions per image were
+    // mostly this, profiles/r06_revmap_counters_first.txt): the pairs (i, i + s), i = i0 .. i0 + L - 1, have the delay
+    // y(i) ~ A i + C; [ia, ib) are the lanes that can reach the slab, two of margin -- the exact bin of every pair decides, so the
+    // reciprocal of A may be the hardware's approximation (1e-8 of 4096 lanes against a margin of two).
+    struct Diag { int i0, L, ia, ib; double A, inv_m; };
+    const double two_eta_d2 = 2.0 * p.eta * d * d;
     auto diag_of = [&](int s, Diag& q) {
         q.i0 = s < 0 ? -s : 0; q.L = N - (s < 0 ? -s : s);
-        q.A = 2.0 * p.eta * (double)s * d * d;
-        q.C = p.eta * ((double)s * d) * (2.0 * th0 + (double)s * d);
-        const double fa = (y_lo - q.C) / q.A, fb = (y_hi - q.C) / q.A;
+        q.A = two_eta_d2 * (double)s;
+        const double C = p.eta * ((double)s * d) * (2.0 * th0 + (double)s * d);
+        const double inv_a = __builtin_amdgcn_rcp(q.A);
+        q.inv_m = fabs(inv_a) * g.tau1_step;                           // steps of i per delay row
+        const double fa = (y_lo - C) * inv_a, fb = (y_hi - C) * inv_a;
         const double f_min = fmin(fa, fb) - 2.0, f_max = fmax(fa, fb) + 2.0;
         q.ia = (int)fmin(fmax(floor(f_min), (double)q.i0), (double)(q.i0 + q.L));
         q.ib = (int)fmin(fmax(ceil(f_max) + 1.0, (double)q.i0), (double)(q.i0 + q.L));       // exclusive
-        if (s == 0 || q.ia >= q.ib) return false;                      // (i == j lands in the poisoned centre bin)
-        const double ta = ((q.A * (double)q.ia + q.C) - g.tau0) * inv_tstep, tb = ((q.A * (double)(q.ib - 1) + q.C) - g.tau0) * inv_tstep;
-        q.ra = (int)fmin(fmax(floor(fmin(ta, tb)) - 2.0 - (double)row0, 0.0), (double)rows);
-        q.rb = (int)fmin(fmax(ceil(fmax(ta, tb)) + 3.0 - (double)row0, 0.0), (double)rows);   // exclusive
-        return q.ra < q.rb;
+        return s != 0 && q.ia < q.ib;                                  // (i == j lands in the poisoned centre bin)
     };
-    // the rows of the slab this column can reach at all: only they are accumulated (the others are written as zeros)
-    int r_lo = rows, r_hi = 0;
-    for (int s = s_lo; s <= s_hi; ++s) {
-        Diag q;
-        if (diag_of(s, q)) { r_lo = min(r_lo, q.ra); r_hi = max(r_hi, q.rb); }
-    }
-    for (int r = r_lo + (int)threadIdx.x; r < r_hi; r += T) {
+    for (int r = threadIdx.x; r < rows; r += T) {
         rev_lds[r] = 0.0; rev_lds[slab + r] = 0.0;
         ((uint32_t*)(rev_lds + 2 * slab))[r] = 0u;
     }
@@ -1018,15 +1018,16 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
         if (!diag_of(s, q)) continue;
         const int i0 = q.i0, L = q.L, ia = q.ia, ib = q.ib;
         const bool up = q.A > 0.0;
-        const double m = fabs(q.A) * inv_tstep;                        // delay rows per step of i
-        const int P = (int)fmin(ceil(1.0102 / m), 1e6);
-        if (P <= p.stride_max) {
+        const int P = (int)fmin(ceil(1.0102 * q.inv_m), 1e6);          // (a step of i is 1 / inv_m delay rows)
+        if (P <= kDiagStrideMax) {
             // pairs of one sweep are P lanes apart: at least 1.01 delay rows -- no two of them in one accumulator
+            // sweep `pass` takes the i = pass (mod P), whatever the slab's first lane: the order of a pixel's addends does not depend
+            // on the slab.  (ia mod P without a division: P <= 4 -- a runtime `%` was a tenth of the kernel's instructions.)
+            static_assert(kDiagStrideMax <= 4, "ia mod P below is written for P <= 4");
+            const int ia_mod = P == 1 ? 0 : (P == 2 ? (ia & 1) : (P == 3 ? ia % 3 : (ia & 3)));
             for (int pass = 0; pass < P; ++pass) {
-                int i = ia + (int)threadIdx.x * P;
-                i += ((pass - i) % P + P) % P;                         // first i >= its start with i = pass (mod P): the order of a
-                                                                       // pixel's addends does not depend on the slab
-                for (; i < ib; i += T * P) {
+                const int first = pass - ia_mod + (pass < ia_mod ? P : 0);     // ia + first = pass (mod P), 0 <= first < P
+                for (int i = ia + first + (int)threadIdx.x * P; i < ib; i += T * P) {
                     const int j = i + s;
                     const double th_i = gload(p.th + i), th_j = gload(p.th + j);
                     const double x = th_j - th_i;                      // fd_map[i, j]  (ththmod.py:207)
@@ -1054,7 +1055,7 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
             const int B = (((ub - ua) + NW - 1) / NW + 63) & ~63;
             const int us = ua + wave * B, ue = min(ub, us + B);
             auto pair_i = [&](int u) { return up ? i0 + u : i0 + L - 1 - u; };
-            const int run_max = (int)fmin(1.0102 / m + 2.0, 64.0);     // pairs of one row among 64 consecutive ones: <= 1 / m + 1
+            const int run_max = (int)fmin(1.0102 * q.inv_m + 2.0, 64.0);   // pairs of one row among 64 consecutive ones: <= 1 / m + 1
             int k_first = INT_MIN;                                     // (no pair has this bin: the first block shares nothing)
             if (wave > 0 && us < ue) { const int i = pair_i(us - 1); k_first = bin_of(delay(i, i + s)); }
             if (lane == 0) { carry_re[wave] = 0.0; carry_im[wave] = 0.0; carry_c[wave] = 0u; carry_by[wave] = k_first == INT_MIN ? 0 : k_first - (int)row0; }
@@ -1109,7 +1110,7 @@ __device__ __forceinline__ void rev_diag_body(const RevParams& p, const GeomDev&
     for (int r = threadIdx.x; r < rows; r += T) {
         const int64_t o = (row0 + r) * g.nfd + col;
         cplx out = mk(0.0, 0.0);
-        if (o != p.centre && r >= r_lo && r < r_hi) {
+        if (o != p.centre) {
             const uint32_t c = ((uint32_t*)(rev_lds + 2 * slab))[r];
             double scl;
             if (c < 64u) scl = rcp_small[c]; else scl = 1.0 / (double)c;
@@ -1204,6 +1205,7 @@ RevParams make_rev_params(const cplx* thth, const cplx* vec, const double* w, in
     p.inv_tau1_step = 1.0 / g.tau1_step;
     p.walk = nullptr; p.walk_col = nullptr;
     p.stride_max = kDiagStrideMax;
+    p.spec = nullptr; p.partial = nullptr; p.asym = nullptr; p.band_lo = 0; p.band_hi = 0;
     return p;
 }
 
