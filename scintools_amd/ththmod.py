@@ -714,20 +714,35 @@ def _multi_keep_dev(G, etas_all, th_stack):
     observation (bench.py --workload fit_thetatheta)."""
     lib = _lib.load()
     M = G[0].M
-    total = int(sum(e.shape[0] for e in etas_all))
-    keep_t = empty((total, M), torch.int32)
-    n_t = empty((total,), torch.int32)
-    off = 0
+    # (round 6) chunks that share their grid OBJECT and their curvatures (the chunks of one frequency row of the phase retrieval, where
+    # chunk_retrieval_batch makes one grid per row) share their table: one call per distinct (grid, curvatures), rows expanded on the device
+    first_of, cls_of = {}, []
     for c, (g, et) in enumerate(zip(G, etas_all)):
+        cls_of.append(first_of.setdefault((id(g), et.tobytes()), c))
+    uniq = sorted(set(cls_of))
+    off_u, off = {}, 0
+    for c in uniq:
+        off_u[c] = off
+        off += int(etas_all[c].shape[0])
+    keep_u = empty((max(off, 1), M), torch.int32)
+    n_u = empty((max(off, 1),), torch.int32)
+    for c in uniq:
+        g, et = G[c], etas_all[c]
         ne = int(et.shape[0])
         if ne == 0:
             continue
         et_c = np.ascontiguousarray(et, dtype=np.float64)
+        o = off_u[c]
         _lib.check(lib.scint_sweep_keep(th_stack[c].data_ptr(), M, et_c.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ne,
-                                        float(g.geom.tau_max), float(g.geom.fd_max / 2), keep_t[off:off + ne].data_ptr(),
-                                        n_t[off:off + ne].data_ptr(), stream_ptr()), "scint_sweep_keep")
-        off += ne
-    return keep_t, np.ascontiguousarray(n_t.cpu().numpy(), dtype=np.int32)
+                                        float(g.geom.tau_max), float(g.geom.fd_max / 2), keep_u[o:o + ne].data_ptr(),
+                                        n_u[o:o + ne].data_ptr(), stream_ptr()), "scint_sweep_keep")
+    n_host = np.ascontiguousarray(n_u.cpu().numpy(), dtype=np.int32)
+    if len(uniq) == len(G):
+        return keep_u[:off], n_host[:off]
+    rows = np.concatenate([np.arange(off_u[cls_of[c]], off_u[cls_of[c]] + etas_all[c].shape[0], dtype=np.int64) for c in range(len(G))]) \
+        if len(G) else np.zeros(0, dtype=np.int64)
+    keep_t = keep_u.index_select(0, _dv.to_device(rows, torch.int64))
+    return keep_t, np.ascontiguousarray(n_host[rows], dtype=np.int32)
 
 
 def eval_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, batch=None,
@@ -815,10 +830,12 @@ def eigvec_sweep_multi(cs_stack, grids, etas_list, tol=DEFAULT_TOL, max_iter=DEF
     keep_t, keep_cnt = _multi_keep_dev(G, etas_all, th_stack)
     # the callers want the kept indices on the host too: from the crop RANGES where the crops are ranges (sorted centres, eta >= 0:
     # the same expression at the bisection's probes), else from the device table
-    keeps, rows_host = [], None
+    keeps, rows_host, keep_cache = [], None, {}
     for g, et in zip(G, etas_all):
         if et.shape[0] == 1:                       # (one curvature per chunk, the phase retrieval's case: the mask itself is cheaper than a bisection)
-            kk = g.keep(float(et[0]))
+            kk = keep_cache.get((id(g), float(et[0])))
+            if kk is None:
+                kk = keep_cache.setdefault((id(g), float(et[0])), g.keep(float(et[0])))
             if kk.shape[0] == int(keep_cnt[len(keeps)]):
                 keeps.append(kk)
                 continue
@@ -1018,11 +1035,21 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
         # travel in ONE array each way; the padding value of a chunk (its mean, ththmod.py:783) is taken on the host.
         grids, etas, live, pads = [], [], [], []
         d_all = np.empty((len(group), nf, nt)) if dev_chunks is None else None
+        # (round 6) the chunks of one frequency row share their axes and edges: one _Grid per distinct (time step, frequency step,
+        # lengths, edges) instead of one per chunk -- 961 grid objects were 45 ms of a 0.23-s calc_wavefield, before any GPU work is
+        # queued.  The objects are read-only here (axes, centres, geometry).
+        grid_cache = {}
         for k, (dspec2, edges, time, freq, eta) in enumerate(group):
             try:
-                fd = fft_axis(units.strip(time, "time2", "s", warn=False), 1000.0, npad)
-                tau = fft_axis(units.strip(freq, "freq2", "MHz", warn=False), 1.0, npad)
-                grid = _Grid(tau, fd, units.strip(edges, "edges", "mHz", warn=False))
+                time_v = np.asarray(units.strip(time, "time2", "s", warn=False))
+                freq_v = np.asarray(units.strip(freq, "freq2", "MHz", warn=False))
+                edges_v = np.asarray(units.strip(edges, "edges", "mHz", warn=False))
+                # (fft_axis reads only the length and the first step of an axis)
+                key = (time_v.shape[0], float(time_v[1] - time_v[0]), freq_v.shape[0], float(freq_v[1] - freq_v[0]), edges_v.tobytes())
+                grid = grid_cache.get(key)
+                if grid is None:
+                    grid = _Grid(fft_axis(freq_v, 1.0, npad), fft_axis(time_v, 1000.0, npad), edges_v)
+                    grid_cache[key] = grid
                 e = np.array([_eta_float(eta)])
                 if (grid.geom.ntau, grid.geom.nfd) != (R, C) or (grids and grid.M != grids[0].M):
                     raise ValueError("axes or edges of this chunk do not match the chunk shape (%d, %d)" % (nf, nt))
@@ -1068,6 +1095,7 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
         M = grids[0].M
         rows_all, th_all = np.zeros((len(live), M), dtype=complex), np.zeros((len(live), M))
         keep_n = np.zeros(len(live), dtype=np.int32)
+        th_cache = {}                    # reduced centres per (grid, crop): shared by the chunks of a frequency row
         for j, k in enumerate(live):
             n = int(keeps[j].shape[0])
             if info["status"][j] != 0 or n < 2:
@@ -1075,7 +1103,13 @@ def chunk_retrieval_batch(chunks, npad, tauMask, verbose=False, group_bytes=None
                 continue
             try:
                 rows_all[j, :n] = np.conjugate(V[j][:n]) * np.sqrt(float(w_list[j][0]))      # ththmod.py:1459-1461
-                th_all[j, :n] = _theta_centres(grids[j].edges_red(keeps[j]))
+                tkey = (id(grids[j]), int(keeps[j][0]), n) if (n == int(keeps[j][-1]) - int(keeps[j][0]) + 1) else None
+                th_red = th_cache.get(tkey) if tkey is not None else None
+                if th_red is None:
+                    th_red = _theta_centres(grids[j].edges_red(keeps[j]))
+                    if tkey is not None:
+                        th_cache[tkey] = th_red
+                th_all[j, :n] = th_red
                 keep_n[j] = n
             except Exception as exc:
                 print("Chunk %d: %s" % (g0 + k, exc), flush=True)
