@@ -787,9 +787,15 @@ def run_workload(args, with_cpu=True):
         d = Dynspec(dyn=obs, process=False, verbose=False)
 
         def once():
+            # forget the previous call's products WITHOUT looking at them: hasattr() on a device-parked attribute is a host read, i.e. a
+            # 134-MB copy down that the timed region then paid for (50 of the 60-80 ms this line reported until the round's last closing call)
             for a in ("lamsspec", "lamdyn", "betaeta"):
-                if hasattr(d, a):
-                    delattr(d, a)
+                slot = getattr(type(d), a, None)
+                if hasattr(slot, "present"):
+                    if slot.present(d):
+                        delattr(d, a)
+                else:
+                    d.__dict__.pop(a, None)
             d.fit_arc(lamsteps=True, numsteps=1e4)
         med, ts, kern = profiled(once)
         out.update(value=med, seconds_all=ts, kernels=kern,

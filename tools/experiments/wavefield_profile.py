@@ -13,7 +13,7 @@ d = Dynspec(dyn=o, process=False, verbose=False)
 d.prep_thetatheta(cwf=cw, cwt=cw, eta_min=0.5*eta_true, eta_max=2*eta_true, npad=3)
 d.fit_thetatheta()
 def once():
-    if hasattr(d, "chunks"): del d.chunks
+    if type(d).chunks.present(d): del d.chunks      # (hasattr would copy the parked gigabyte to the host first)
     d.calc_wavefield(); torch.cuda.synchronize()
 once()
 t0 = time.perf_counter(); once(); print("calc_wavefield", time.perf_counter() - t0, "s")
