@@ -56,6 +56,15 @@ def main(out_path):
     m = ththmod.modeler(CS, tau, fd, etas[2], edges)
     res["recov"], res["model"], res["V1"] = m[2], m[3], m[6]
     res["chisq"] = ththmod.chisq_sweep(dyn, cs_t, tau, fd, etas[1:4], edges, 1.0)
+    # round 6: npad = 0 on symmetric axes -- the diagonal back-map (strided sweeps and the per-wavefront segmented scan with its
+    # carried rows) with chi^2 taken from its accumulators
+    d3, f3, t3, e3 = arc_dynspec(300, 300, seed=9, nimg=6, noise=0.05)
+    d3 = d3 - d3.mean()
+    fd3, tau3 = thth_oracle.fft_axis(t3, 1000.0, 0), thth_oracle.fft_axis(f3, 1.0, 0)
+    chis, cinfo = ththmod.chisq_sweep(d3, ththmod.conjugate_spectrum(d3, 0, pad_value=0.0), tau3, fd3, np.array([0.04, 0.3, 0.8, 1.3, 2.5]) * e3,
+                                      np.linspace(-fd3.max() / 2, fd3.max() / 2, 300), 1.0, return_info=True)
+    assert cinfo["fused"]
+    res["chisq_fused"] = chis
     rng = np.random.default_rng(0)
     a = rng.standard_normal((99, 99)) + 1j * rng.standard_normal((99, 99))
     res["rev_h"] = ththmod.rev_map(a + a.conj().T, tau, fd, etas[2], edges, True)
