@@ -594,3 +594,38 @@ def test_diagonal_back_map_fuzz_vs_oracle(thth, to):
         assert np.array_equal(rec, again), key
         assert np.abs(rec - ref).max() <= 1e-12 * np.abs(ref).max(), key
         assert np.array_equal(rec != 0, ref != 0), key
+
+
+def test_chisq_from_accumulators_fuzz(thth, to, monkeypatch):
+    """Round 6, on the hardware: chi^2 from the back-map's accumulators (symmetric axes) against the written-image route
+    (SCINT_CHISQ_FUSE=0) to 1e-12 on eight random arcs -- generic theta grids (fused, at most a few curvatures redone) and grids
+    whose step is half the Doppler step (every odd diagonal ON a column edge: fused, curvatures redone from a written image) --
+    and against the oracle's chisq_calc at two curvatures of each (1e-9)."""
+    from scintools_amd.synth import arc_dynspec
+    rng = np.random.default_rng(7)
+    for trial in range(8):
+        nf, nt = 2 * int(rng.integers(100, 700)), 2 * int(rng.integers(24, 100))
+        dyn, freqs, times, eta_true = arc_dynspec(nf, nt, seed=100 + trial, nimg=8, noise=0.05)
+        dyn = dyn - dyn.mean()
+        fd, tau = to.fft_axis(times, 1000.0, 0), to.fft_axis(freqs, 1.0, 0)
+        CS = to.conjugate_spectrum(dyn, 0)
+        if trial % 2:
+            n = 2 * int(rng.integers(10, nt // 2))
+            edges = (np.arange(n) - (n - 1) / 2) * ((fd[1] - fd[0]) / 2)
+        else:
+            edges = np.linspace(-fd.max() / 2, fd.max() / 2, 2 * int(rng.integers(20, 150)))
+        th = thth._Grid(tau, fd, edges).th_cents
+        eta_full = np.abs(tau).max() / (th ** 2).max()
+        etas = np.sort(10 ** rng.uniform(-2.0, 0.6, 12)) * eta_full * 1.00071
+        monkeypatch.setenv("SCINT_CHISQ_FUSE", "1")
+        a, ia = thth.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, return_info=True)
+        monkeypatch.setenv("SCINT_CHISQ_FUSE", "0")
+        b, ib = thth.chisq_sweep(dyn, CS, tau, fd, etas, edges, 3.0, return_info=True)
+        key = (trial, nf, nt, edges.shape[0])
+        assert ia["fused"] and not ib["fused"], key
+        assert np.all(ia["status"] == 0), key
+        if trial % 2:
+            assert ia["redone"] >= 1, key
+        np.testing.assert_allclose(a, b, rtol=1e-12, err_msg=str(key))
+        for i in (2, 9):
+            assert a[i] == pytest.approx(to.chisq_calc(dyn, CS, tau, fd, etas[i], edges, 3.0), rel=1e-9), key
