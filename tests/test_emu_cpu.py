@@ -968,3 +968,32 @@ def test_chisq_from_the_back_map_accumulators(emu, to, monkeypatch):
     d_, info = both(dyn2, to.conjugate_spectrum(dyn2, 0), tau2, fd2, etas[2:5] * 0 + np.array([0.7, 1.0, 1.6]) * _,
                     np.linspace(-fd2.max() / 2, fd2.max() / 2, 70))
     assert not info["fused"]
+
+
+def test_chunks_sharing_a_grid_object_give_the_same_retrieval(emu, to):
+    """Round 6: chunk_retrieval_batch makes ONE grid object per distinct (axes, edges) and the multi-chunk sweep builds one crop
+    table per distinct (grid object, curvatures), expanded on the device -- 961 chunks of a 31 x 31 mosaic have 31 of each.  Six
+    chunks in two 'frequency rows' (same axes, edges and curvature within a row): the batch's wavefields are bit-identical to the
+    same chunks sent one by one (a group of one has nothing to share), and eigvec_sweep_multi gives the same eigenpairs and crops
+    whether the grids of a row are one object or equal copies."""
+    import torch
+    from scintools_amd.synth import arc_dynspec
+    chunks = []
+    for row in range(2):
+        base = arc_dynspec(48, 40, seed=50 + row, nimg=8)
+        fd = to.fft_axis(base[2], 1000.0, 1)
+        edges = np.linspace(-fd.max() / 2, fd.max() / 2, 40 + 2 * row)
+        for k in range(3):
+            dyn = arc_dynspec(48, 40, seed=60 + 3 * row + k, nimg=8)[0]
+            chunks.append((dyn - dyn.mean(), edges, base[2], base[1], base[3] * (1.0 + 0.1 * row)))
+    together = emu.chunk_retrieval_batch(chunks[:3], 1, 0.0)          # one row: one grid object
+    one_by_one = np.stack([emu.chunk_retrieval_batch([c], 1, 0.0)[0] for c in chunks[:3]])
+    assert np.array_equal(together, one_by_one) and np.abs(together).max() > 0
+    stack = torch.stack([emu.conjugate_spectrum(c[0], 1, pad_value=float(c[0].mean())) for c in chunks[:3]])
+    tau, fd = to.fft_axis(chunks[0][3], 1.0, 1), to.fft_axis(chunks[0][2], 1000.0, 1)
+    shared = emu._Grid(tau, fd, chunks[0][1])
+    etas = [np.array([chunks[0][4]])] * 3
+    wa, Va, ka, ia = emu.eigvec_sweep_multi(stack, [shared] * 3, etas)
+    wb, Vb, kb, ib = emu.eigvec_sweep_multi(stack, [emu._Grid(tau, fd, chunks[0][1]) for _ in range(3)], etas)
+    assert all(np.array_equal(x, y) for x, y in zip(wa, wb)) and np.array_equal(Va.cpu().numpy(), Vb.cpu().numpy())
+    assert all(np.array_equal(x, y) for x, y in zip(ka, kb)) and np.array_equal(ia["N"], ib["N"])
